@@ -1,0 +1,171 @@
+/* l2o_abi.h -- C ABI of the MI355X-native Open-L2O inner-unroll library (libl2o_hip.so).
+ *
+ * Drop-in boundary for the ONE hot path of VITA-Group/Open-L2O that this project
+ * accelerates: the model-free inner unroll loop of the coordinate-wise LSTM
+ * optimizers (L2O-DM / L2O-RNNProp).  The reference has no FFI at all (it is
+ * Python -> TensorFlow 1.14 graph ops); each entry point below cites the
+ * reference interface (file:line under
+ * "Model_Free_L2O/L2O-DM and L2O-RNNProp/", shorthand DM/) whose work it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer documented "device" is an fp32, contiguous, row-major HIP
+ *     device pointer valid on the device of `stream`; the caller owns ALL memory
+ *     (the library never allocates, frees or keeps device state between calls);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls
+ *     are asynchronous on it and never synchronise the host;
+ *   - return value: 0 = OK, L2O_ERR_ARG (-1) bad argument, L2O_ERR_UNSUPPORTED
+ *     (-2) shape / configuration not implemented by the fused kernels (callers
+ *     fall back to the step-granular entry points), L2O_ERR_HIP (-3) HIP runtime
+ *     error; l2o_last_error() returns a thread-local message;
+ *   - no C++ exception crosses the ABI; plain pointers and sizes only.
+ */
+#ifndef L2O_ABI_H_
+#define L2O_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2O_ABI_VERSION 1
+
+#define L2O_OK 0
+#define L2O_ERR_ARG (-1)
+#define L2O_ERR_UNSUPPORTED (-2)
+#define L2O_ERR_HIP (-3)
+
+/* optimizer-network kinds: networks.CoordinateWiseDeepLSTM (DM/networks.py:239-276),
+ * networks.RNNprop (DM/networks.py:279-300) */
+#define L2O_NET_CW 0
+#define L2O_NET_RNNPROP 1
+
+/* gradient preprocessing, StandardDeepLSTM.__init__/_build (DM/networks.py:180-188, 218-221):
+ * tf.identity | preprocess.LogAndSign (DM/preprocess.py:42-70) | "fc" = ELU(Linear) */
+#define L2O_PRE_IDENTITY 0
+#define L2O_PRE_LOGSIGN 1
+#define L2O_PRE_FC_ELU 2
+
+/* optimizee kinds, the problems registry (DM/problems.py) */
+#define L2O_PROB_SIMPLE 0      /* problems.simple / simple_multi_optimizer :41-70  f = sum x^2          */
+#define L2O_PROB_QUADRATIC 1   /* problems.quadratic :73-101                                              */
+#define L2O_PROB_LASSO 2       /* problems.lasso :103-134 and lasso_fixed :137-175                         */
+#define L2O_PROB_RASTRIGIN 3   /* problems.rastrigin :177-213                                              */
+#define L2O_PROB_SQUARE_COS 4  /* problems.square_cos :959-994                                             */
+
+/* Hyper-parameters of one optimizer network: the `net_options` dict of
+ * networks.factory (DM/networks.py:34-44) as used by util.get_config
+ * (DM/util.py:99-109, 136-143, 251-263). */
+typedef struct l2o_net_cfg {
+  int32_t kind;         /* L2O_NET_*                                              */
+  int32_t preprocess;   /* L2O_PRE_*                                              */
+  int32_t n_layers;     /* len(layers): 0 (Linear only) or 2                      */
+  int32_t hidden;       /* layers[i]; the fused kernels implement 20              */
+  int32_t tanh_output;  /* StandardDeepLSTM(tanh_output=...) DM/networks.py:229   */
+  int32_t reserved;
+  double scale;         /* StandardDeepLSTM(scale=...) DM/networks.py:229-232     */
+  double logsign_k;     /* LogAndSign(k) DM/preprocess.py:48                      */
+  double beta1;         /* RNNProp MetaOptimizer(beta1, beta2) DM/meta_rnnprop_eval.py:230 */
+  double beta2;         /* (python floats in the reference: kept as doubles so that the
+                           fp32 constants are rounded exactly like TF rounds them)  */
+} l2o_net_cfg;
+
+/* One optimizee batch: the non-trainable variables that problems.<name>().build()
+ * creates through tf.get_variable (DM/problems.py:84-96, 114-126, 149-165, 186-204),
+ * sharded over GPUs by problem index.  The loss is a mean over the GLOBAL batch
+ * (DM/problems.py:99, 131, 211), hence B_global. */
+typedef struct l2o_problem {
+  int32_t kind;          /* L2O_PROB_*                                                    */
+  int32_t B_local;       /* problems held by this GPU                                     */
+  int32_t B_global;      /* batch size in the reduce_mean (== B_local on one GPU)         */
+  int32_t D;             /* optimizee parameters per problem (num_dims)                   */
+  int32_t M;             /* rows of the matrix (== D except lasso_fixed)                  */
+  int32_t reserved;
+  double l1;             /* lasso `l`                                                     */
+  double alpha;          /* rastrigin `alpha`                                             */
+  const float* W;        /* device [B_local, M, D]  quadratic w / lasso w / rastrigin A   */
+  const float* y;        /* device [B_local, M]     quadratic y / lasso y / rastrigin B   */
+  const float* C;        /* device [B_local, D] rastrigin C ; [B_local, D, D] square_cos wcos ; else NULL */
+  const float* x_scale;  /* device [B_local, D] per-coordinate scale placeholder
+                            (DM/meta_dm_train.py:336-338, 384) or NULL (== ones)          */
+} l2o_problem;
+
+/* ---- library info ------------------------------------------------------ */
+int l2o_abi_version(void);
+const char* l2o_last_error(void);
+
+/* ---- weights: networks.factory / networks.save (DM/networks.py:34-62) ---
+ * The `.l2l` dict {lstm_1:{w_gates,b_gates}, lstm_2:{...}, linear:{w,b},
+ * input_projection:{w,b}} (Sonnet layouts: w_gates [in+H, 4H] gate order i,j,f,o;
+ * Linear w [in,out]) is re-laid out on the HOST into MFMA-fragment order so that
+ * every kernel loads each weight register with one coalesced dword load.
+ * Pure host code: no device is touched. */
+size_t l2o_wpack_floats(const l2o_net_cfg* cfg);
+int l2o_wpack_host(const l2o_net_cfg* cfg,
+                   const float* w_gates1, const float* b_gates1,   /* host [P+H,4H], [4H] */
+                   const float* w_gates2, const float* b_gates2,   /* host [2H,4H], [4H]  */
+                   const float* w_lin, const float* b_lin,         /* host [H or P,1], [1] */
+                   const float* w_fc, const float* b_fc,           /* host [2,H],[H] (fc) or NULL */
+                   float* wpack_out);                              /* host [l2o_wpack_floats] */
+
+/* ---- LSTM state: net.initial_state_for_inputs (DM/networks.py:234-236, 273-276)
+ * and the `update` assign of state_T (DM/meta.py:387-389).
+ * Device state lives in a packed, tile-major layout (DESIGN.md "HBM layout"):
+ * l2o_state_floats(B, D) floats for B problems of D coordinates.  Zero-filled
+ * memory is the zero initial state.  pack/unpack convert from/to the reference
+ * layout: per layer (hidden, cell) each [B*D, H] row-major. */
+size_t l2o_state_floats(int64_t B, int64_t D);
+int l2o_state_pack(const float* h1, const float* c1, const float* h2, const float* c2,
+                   float* st, int64_t B, int64_t D, void* stream);
+int l2o_state_unpack(const float* st, float* h1, float* c1, float* h2, float* c2,
+                     int64_t B, int64_t D, void* stream);
+
+/* ---- optimizee forward + gradient: build() + tf.gradients(fx, x)
+ * (DM/meta.py:322, 344; closed forms DM/problems.py:98-99, 128-131, 206-211).
+ * f_part[b] = per-problem loss term BEFORE the 1/B_global mean (so that
+ * fx = sum_b f_part[b] / B_global); g = d fx / d x INCLUDING 1/B_global and the
+ * x_scale chain rule.  g may be NULL (forward only). */
+int l2o_problem_fg(const l2o_problem* prob, const float* x /* device [B_local,D] */,
+                   float* f_part /* device [B_local] */, float* g /* device [B_local,D] or NULL */,
+                   void* stream);
+
+/* ---- one optimizer step on a gradient panel: the closure `update`
+ * (DM/meta.py:319-336; RNNProp DM/meta_rnnprop_train.py:371-395) for ONE variable:
+ * preprocess -> 2-layer coordinate-wise LSTM -> Linear -> (tanh) * scale -> x += delta
+ * (DM/networks.py:207-232, 254-271, 287-295; DM/meta.py:353).
+ * RNNProp: m, v are updated in place and the inputs (m~, g~) are formed with the
+ * bias-correction powers beta^k, k = step + t (DM/meta_rnnprop_train.py:383-388);
+ * pass pow1 = beta1^k, pow2 = beta2^k.  m, v are ignored (may be NULL) for L2O_NET_CW. */
+int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack /* device */,
+                    const float* g /* device [B,D] */, float* m, float* v /* device [B,D] */,
+                    double pow1, double pow2,
+                    float* st /* device, packed, in-out */, float* x /* device [B,D] in-out */,
+                    int64_t B, int64_t D, void* stream);
+
+/* ---- the fused unroll: MetaOptimizer.meta_loss's tf.while_loop
+ * (DM/meta.py:338-376; RNNProp DM/meta_rnnprop_eval.py time_step) as ONE persistent
+ * launch: T x { fx_t = f(x_t*s); g = s*grad f; delta,state = net(g,state); x += delta }
+ * then fx_T.  x, st (and m, v) are updated in place == the harness' `update` op.
+ * fx_part[t*B_local + b] receives problem b's loss term at step t (t = 0..T).
+ * step0 = the harness-fed `step` (DM/util.py:59-60, 85-86); RNNProp only.
+ * Returns L2O_ERR_UNSUPPORTED when (problem size, net) has no fused kernel. */
+int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack /* device */,
+               const l2o_problem* prob, float* x /* device [B_local,D] in-out */,
+               float* st /* device, packed, in-out */, float* m, float* v,
+               int32_t T, int32_t step0,
+               float* fx_part /* device [(T+1)*B_local] */, void* stream);
+/* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0. */
+int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);
+
+/* ---- fx_array.stack() / tf.reduce_mean over the batch (DM/meta.py:345, 374-376):
+ * fx[t] = (sum_b fx_part[t*B_local + b]) / B_global, fixed summation order
+ * (bit-reproducible).  With B sharded, all-reduce(sum) fx over ranks afterwards. */
+int l2o_reduce_fx(const float* fx_part, int32_t T1, int32_t B_local, int32_t B_global,
+                  float* fx /* device [T1] */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2O_ABI_H_ */

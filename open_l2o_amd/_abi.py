@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI declared in ``include/l2o_abi.h``.
+
+This is the ONLY way the Python host reaches the compute path: there is no
+PyTorch / NumPy fallback.  If ``libl2o_hip.so`` is missing (not built) every
+entry point raises ``RuntimeError`` -- the product path must fail loudly when
+the HIP extension is absent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libl2o_hip.so")
+
+L2O_ABI_VERSION = 1
+L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
+
+NET_CW, NET_RNNPROP = 0, 1
+PRE_IDENTITY, PRE_LOGSIGN, PRE_FC_ELU = 0, 1, 2
+PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS = 0, 1, 2, 3, 4
+
+# every symbol include/l2o_abi.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
+    "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg",
+    "l2o_cwlstm_step", "l2o_unroll", "l2o_unroll_supported", "l2o_reduce_fx",
+)
+
+
+class NetCfg(C.Structure):
+    """struct l2o_net_cfg"""
+    _fields_ = [
+        ("kind", C.c_int32), ("preprocess", C.c_int32), ("n_layers", C.c_int32),
+        ("hidden", C.c_int32), ("tanh_output", C.c_int32), ("reserved", C.c_int32),
+        ("scale", C.c_double), ("logsign_k", C.c_double),
+        ("beta1", C.c_double), ("beta2", C.c_double),
+    ]
+
+
+class Problem(C.Structure):
+    """struct l2o_problem"""
+    _fields_ = [
+        ("kind", C.c_int32), ("B_local", C.c_int32), ("B_global", C.c_int32),
+        ("D", C.c_int32), ("M", C.c_int32), ("reserved", C.c_int32),
+        ("l1", C.c_double), ("alpha", C.c_double),
+        ("W", C.c_void_p), ("y", C.c_void_p), ("C", C.c_void_p), ("x_scale", C.c_void_p),
+    ]
+
+
+class L2OError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libl2o_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class L2OUnsupported(L2OError):
+    """L2O_ERR_UNSUPPORTED: no fused kernel for this configuration."""
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "open_l2o_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C open_l2o_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    fp, vp, i32, i64, dbl = C.POINTER(C.c_float), C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.l2o_abi_version.restype = C.c_int
+    L.l2o_abi_version.argtypes = []
+    L.l2o_last_error.restype = C.c_char_p
+    L.l2o_last_error.argtypes = []
+    L.l2o_wpack_floats.restype = C.c_size_t
+    L.l2o_wpack_floats.argtypes = [C.POINTER(NetCfg)]
+    L.l2o_wpack_host.restype = C.c_int
+    L.l2o_wpack_host.argtypes = [C.POINTER(NetCfg)] + [vp] * 9
+    L.l2o_state_floats.restype = C.c_size_t
+    L.l2o_state_floats.argtypes = [i64, i64]
+    L.l2o_state_pack.restype = C.c_int
+    L.l2o_state_pack.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
+    L.l2o_state_unpack.restype = C.c_int
+    L.l2o_state_unpack.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
+    L.l2o_problem_fg.restype = C.c_int
+    L.l2o_problem_fg.argtypes = [C.POINTER(Problem), vp, vp, vp, vp]
+    L.l2o_cwlstm_step.restype = C.c_int
+    L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
+    L.l2o_unroll.restype = C.c_int
+    L.l2o_unroll.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Problem), vp, vp, vp, vp, i32, i32, vp, vp]
+    L.l2o_unroll_supported.restype = C.c_int
+    L.l2o_unroll_supported.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem)]
+    L.l2o_reduce_fx.restype = C.c_int
+    L.l2o_reduce_fx.argtypes = [vp, i32, i32, i32, vp, vp]
+    if L.l2o_abi_version() != L2O_ABI_VERSION:
+        raise RuntimeError("libl2o_hip.so ABI version %d != binding version %d"
+                           % (L.l2o_abi_version(), L2O_ABI_VERSION))
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Turn a C-ABI return code into the Python exception the host layer raises."""
+    if rc == L2O_OK:
+        return
+    msg = lib().l2o_last_error().decode("utf-8", "replace")
+    if rc == L2O_ERR_UNSUPPORTED:
+        raise L2OUnsupported(rc, msg)
+    if rc == L2O_ERR_ARG:
+        raise ValueError("libl2o_hip: " + msg)
+    raise L2OError(rc, msg)

@@ -1,0 +1,194 @@
+"""Execution engine: torch tensors for device memory + streams, the HIP C-ABI
+for every bit of arithmetic on the hot path.
+
+The host layer (``meta.py``) talks to an *engine* object.  The product engine is
+:class:`HipEngine`; it needs a GPU and ``libl2o_hip.so`` and raises otherwise.
+Tests may inject a different engine (e.g. an oracle-backed one that lives under
+``tests/``) to exercise the host logic and the multi-process sharding on CPU --
+the package itself contains no CPU compute path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _abi
+
+
+@dataclasses.dataclass
+class NetSpec:
+    """The ``net_options`` of one optimizer network (DM/networks.py:157-159) in
+    the form the kernels consume."""
+    kind: int                 # _abi.NET_*
+    preprocess: int           # _abi.PRE_*
+    layers: tuple
+    scale: float = 1.0
+    tanh_output: bool = False
+    logsign_k: float = 0.0
+    beta1: float = 0.95
+    beta2: float = 0.95
+
+    def to_c(self):
+        c = _abi.NetCfg()
+        c.kind, c.preprocess = self.kind, self.preprocess
+        c.n_layers = len(self.layers)
+        c.hidden = int(self.layers[0]) if self.layers else 0
+        if len(self.layers) > 1 and any(int(h) != c.hidden for h in self.layers):
+            c.hidden = -1
+        c.tanh_output = 1 if self.tanh_output else 0
+        c.scale, c.logsign_k = float(self.scale), float(self.logsign_k)
+        c.beta1, c.beta2 = float(self.beta1), float(self.beta2)
+        return c
+
+
+@dataclasses.dataclass
+class ProblemDesc:
+    """Device-side view of one optimizee batch shard (struct l2o_problem)."""
+    kind: int
+    B_local: int
+    B_global: int
+    D: int
+    M: int = 0
+    l1: float = 0.0
+    alpha: float = 0.0
+    W: Optional[torch.Tensor] = None
+    y: Optional[torch.Tensor] = None
+    C: Optional[torch.Tensor] = None
+    x_scale: Optional[torch.Tensor] = None
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.dtype == torch.float32 and t.is_contiguous(), "C-ABI wants contiguous fp32"
+    return C.c_void_p(t.data_ptr())
+
+
+class HipEngine(object):
+    """MI355X engine: every method is one call through the C ABI."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("open_l2o_amd.HipEngine needs a ROCm GPU (torch.cuda.is_available() is "
+                               "False); there is no CPU fallback")
+        self.lib = _abi.lib()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+
+    # -- memory plumbing (torch) ------------------------------------------
+    def tensor(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- weights -------------------------------------------------------------
+    def pack_weights(self, spec: NetSpec, params: dict):
+        """.l2l dict (Sonnet layouts) -> device wpack."""
+        return self.tensor(pack_weights_host(self.lib, spec, params))
+
+    # -- state ---------------------------------------------------------------
+    def state_floats(self, B, D):
+        return int(self.lib.l2o_state_floats(B, D))
+
+    def state_alloc(self, B, D):
+        return self.zeros(self.state_floats(B, D))
+
+    def state_pack(self, h1, c1, h2, c2, B, D):
+        st = self.empty(self.state_floats(B, D))
+        _abi.check(self.lib.l2o_state_pack(_ptr(h1), _ptr(c1), _ptr(h2), _ptr(c2), _ptr(st), B, D,
+                                           self._stream()))
+        return st
+
+    def state_unpack(self, st, B, D, H=20):
+        outs = [self.empty(B * D, H) for _ in range(4)]
+        _abi.check(self.lib.l2o_state_unpack(_ptr(st), *[_ptr(o) for o in outs], B, D, self._stream()))
+        return outs
+
+    # -- compute -------------------------------------------------------------
+    def _cprob(self, p: ProblemDesc):
+        c = _abi.Problem()
+        c.kind, c.B_local, c.B_global, c.D, c.M = p.kind, p.B_local, p.B_global, p.D, p.M
+        c.l1, c.alpha = float(p.l1), float(p.alpha)
+        c.W, c.y, c.C, c.x_scale = _ptr(p.W), _ptr(p.y), _ptr(p.C), _ptr(p.x_scale)
+        return c
+
+    def problem_fg(self, p: ProblemDesc, x, f_part, g):
+        cp = self._cprob(p)
+        _abi.check(self.lib.l2o_problem_fg(C.byref(cp), _ptr(x), _ptr(f_part), _ptr(g), self._stream()))
+
+    def lstm_step(self, spec: NetSpec, wpack, g, m, v, pow1, pow2, st, x, B, D):
+        cc = spec.to_c()
+        _abi.check(self.lib.l2o_cwlstm_step(C.byref(cc), _ptr(wpack), _ptr(g), _ptr(m), _ptr(v),
+                                            float(pow1), float(pow2), _ptr(st), _ptr(x), B, D,
+                                            self._stream()))
+
+    def unroll_supported(self, spec: NetSpec, p: ProblemDesc):
+        cc, cp = spec.to_c(), self._cprob(p)
+        return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))
+
+    def unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part):
+        cc, cp = spec.to_c(), self._cprob(p)
+        _abi.check(self.lib.l2o_unroll(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
+                                       _ptr(v), int(T), int(step0), _ptr(fx_part), self._stream()))
+
+    def reduce_fx(self, fx_part, T1, B_local, B_global, fx):
+        _abi.check(self.lib.l2o_reduce_fx(_ptr(fx_part), int(T1), int(B_local), int(B_global), _ptr(fx),
+                                          self._stream()))
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+
+def pack_weights_host(lib, spec: NetSpec, params: dict):
+    """Host-only re-layout of a ``.l2l`` dict into MFMA-fragment order
+    (l2o_wpack_host).  Usable without a GPU."""
+    cc = spec.to_c()
+    n = int(lib.l2o_wpack_floats(C.byref(cc)))
+    if n == 0:
+        raise _abi.L2OUnsupported(
+            _abi.L2O_ERR_UNSUPPORTED,
+            "no HIP kernel for an optimizer net with layers=%r (implemented: (20, 20) and ())" % (spec.layers,))
+    out = np.zeros((n,), np.float32)
+
+    def arr(mod, var):
+        if mod not in params:
+            return None
+        return np.ascontiguousarray(params[mod][var], dtype=np.float32)
+
+    keep = [arr("lstm_1", "w_gates"), arr("lstm_1", "b_gates"), arr("lstm_2", "w_gates"),
+            arr("lstm_2", "b_gates"), arr("linear", "w"), arr("linear", "b"),
+            arr("input_projection", "w"), arr("input_projection", "b")]
+    ptrs = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in keep]
+    _abi.check(lib.l2o_wpack_host(C.byref(cc), *ptrs, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+_default_engine = None
+
+
+def default_engine():
+    """The process-wide HipEngine (created on first use; raises without GPU/extension)."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = HipEngine()
+    return _default_engine
+
+
+def set_default_engine(engine):
+    global _default_engine
+    _default_engine = engine

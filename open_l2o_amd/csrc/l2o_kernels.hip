@@ -1,0 +1,731 @@
+// l2o_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + the C ABI of include/l2o_abi.h.
+//
+// Reference semantics (file:line under /root/reference/Model_Free_L2O/
+// "L2O-DM and L2O-RNNProp"/, shorthand DM/):
+//   unroll loop        DM/meta.py:319-389, DM/meta_rnnprop_eval.py (time_step/update)
+//   optimizer nets     DM/networks.py:157-300
+//   preprocess         DM/preprocess.py:26-70
+//   optimizees         DM/problems.py:41-213
+// Written for gfx950 only: wave64, v_mfma_f32_16x16x4_f32, 160 KiB LDS per CU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "l2o_common.h"
+
+using namespace l2o;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) return fail(L2O_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int tiles_per_problem(int64_t D) { return (int)((D + kTile - 1) / kTile); }
+
+// ---------------------------------------------------------------------------
+// kernel parameter blocks (plain structs passed by value)
+// ---------------------------------------------------------------------------
+struct NetParams {
+  const float* wpack;
+  float scale;
+  float k_inv_ln2;   // ln2 / k   (LogAndSign: log(.)/k == log2(.) * ln2/k)
+  float exp_k;       // fp32(e^k)
+  float beta1, beta2, omb1, omb2;   // fp32(beta), fp32(1 - beta)
+  int tanh_output;
+};
+
+struct ProbParams {
+  int kind, B_local, D, M;
+  float inv_bg;      // 1 / B_global
+  float l1, alpha;
+  const float* W;
+  const float* y;
+  const float* C;
+  const float* x_scale;
+};
+
+// ---------------------------------------------------------------------------
+// K1: step-granular optimizer step on a gradient panel (state in HBM).
+// One wave per 16-coordinate tile, grid-stride over tiles; weights live in VGPRs.
+// HBM traffic per coordinate: 320 B state read + 320 B write + g + x r/w.
+// ---------------------------------------------------------------------------
+template <int PRE>
+__global__ __launch_bounds__(256) void k_cwlstm_step(NetParams np, const float* __restrict__ g,
+                                                      float* __restrict__ mbuf, float* __restrict__ vbuf,
+                                                      float om1, float om2, float* __restrict__ st,
+                                                      float* __restrict__ x, int B, int D, int tpp) {
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15, q = lane >> 4;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const int ntiles = B * tpp;
+  if (wave >= ntiles) return;
+  NetW<PRE> w;
+  load_netw<PRE>(w, np.wpack, lane);
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int b = tile / tpp, tw = tile - b * tpp;
+    const int j = tw * kTile + c;
+    const bool live = j < D;
+    const size_t idx = (size_t)b * D + j;
+    TileState s;
+    float* st_tile = st + (size_t)tile * kStateFloatsPerTile;
+    load_tile_state(s, st_tile, lane);
+    float gv = live ? g[idx] : 0.0f;
+    float in0, in1;
+    if (PRE == L2O_PRE_FC_ELU) {
+      float m = live ? mbuf[idx] : 0.0f, v = live ? vbuf[idx] : 0.0f;
+      rnnprop_inputs(gv, m, v, np.beta1, np.beta2, om1, om2, in0, in1);
+      if (!live) { in0 = 0.0f; in1 = 0.0f; }
+      if (live && q == 0) { mbuf[idx] = m; vbuf[idx] = v; }
+    } else {
+      preprocess_grad<PRE>(gv, np.k_inv_ln2, np.exp_k, in0, in1);
+    }
+    float d = lstm_tile_step<PRE>(w, s, in0, in1, q);
+    if (np.tanh_output) d = tanhf_(d);
+    d *= np.scale;
+    if (live && q == 0) x[idx] += d;
+    store_tile_state(s, st_tile, lane);
+  }
+}
+
+// layers == (): StandardDeepLSTM with no cores = Linear on the preprocessed gradient
+// (DM/networks.py:225-232 with an empty DeepRNN; used by the meta_test.py:50-69 KAT).
+// lw = {w0, w1, b}
+template <int PRE>
+__global__ void k_linear_step(NetParams np, const float* __restrict__ g, float* __restrict__ x, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float w0 = np.wpack[0], w1 = np.wpack[1], bl = np.wpack[2];
+  float in0, in1;
+  preprocess_grad<PRE>(g[i], np.k_inv_ln2, np.exp_k, in0, in1);
+  float d = __builtin_fmaf(in1, w1, in0 * w0) + bl;
+  if (np.tanh_output) d = tanhf_(d);
+  x[i] += d * np.scale;
+}
+
+// ---------------------------------------------------------------------------
+// K2: optimizee forward + gradient for arbitrary sizes (matrix streamed from HBM/L2).
+// One 256-thread workgroup per problem.
+//   pass 1  r = W xs - y      rows over waves, columns over lanes (coalesced), wave reduce
+//   pass 2  g = W^T r         columns over threads (coalesced), rows split over thread groups
+// ---------------------------------------------------------------------------
+constexpr int kFgThreads = 256;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
+  v = wave_sum64(v);
+  const int wv = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wv] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const float* __restrict__ x,
+                                                            float* __restrict__ f_part,
+                                                            float* __restrict__ gout) {
+  extern __shared__ float sm[];
+  const int D = pp.D, M = pp.M;
+  float* xs = sm;                 // [D]   scaled x
+  float* rs = xs + D;             // [M]   residual
+  float* part = rs + M;           // [kFgThreads] partial column sums
+  float* red = part + kFgThreads; // [4]
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* xb = x + (size_t)b * D;
+  const float* sb = pp.x_scale ? pp.x_scale + (size_t)b * D : nullptr;
+
+  float facc = 0.0f;   // per-thread contribution to f_b
+  for (int j = tid; j < D; j += kFgThreads) {
+    const float xv = xb[j] * (sb ? sb[j] : 1.0f);
+    xs[j] = xv;
+    if (pp.kind == L2O_PROB_SIMPLE) facc += xv * xv;
+    if (pp.kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xv);
+    if (pp.kind == L2O_PROB_RASTRIGIN)
+      facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j] * cosf(6.2831853071795864769f * xv);
+  }
+  __syncthreads();
+
+  if (pp.kind != L2O_PROB_SIMPLE) {
+    const float* Wb = pp.W + (size_t)b * M * D;
+    const float* yb = pp.y + (size_t)b * M;
+    const float coef = pp.kind == L2O_PROB_QUADRATIC ? 1.0f : 0.5f;
+    const bool vec4 = (D & 3) == 0;
+    for (int i = wv; i < M; i += kFgThreads / 64) {
+      const float* row = Wb + (size_t)i * D;
+      float acc = 0.0f;
+      if (vec4) {
+        for (int j = lane * 4; j < D; j += 256) {
+          const float4 wv4 = *reinterpret_cast<const float4*>(row + j);
+          acc = __builtin_fmaf(wv4.x, xs[j], acc);
+          acc = __builtin_fmaf(wv4.y, xs[j + 1], acc);
+          acc = __builtin_fmaf(wv4.z, xs[j + 2], acc);
+          acc = __builtin_fmaf(wv4.w, xs[j + 3], acc);
+        }
+      } else {
+        for (int j = lane; j < D; j += 64) acc = __builtin_fmaf(row[j], xs[j], acc);
+      }
+      acc = wave_sum64(acc);
+      if (lane == 0) {
+        const float r = acc - yb[i];
+        rs[i] = r;
+        facc += coef * r * r;
+      }
+    }
+  }
+  const float fb = block_sum_256(facc, red);   // contains a __syncthreads: rs is visible after it
+  if (tid == 0) f_part[b] = fb;
+  if (gout == nullptr) return;
+
+  float* gb = gout + (size_t)b * D;
+  if (pp.kind == L2O_PROB_SIMPLE) {
+    for (int j = tid; j < D; j += kFgThreads) gb[j] = 2.0f * xs[j] * pp.inv_bg * (sb ? sb[j] : 1.0f);
+    return;
+  }
+  const float* Wb = pp.W + (size_t)b * M * D;
+  const float cg = pp.kind == L2O_PROB_QUADRATIC ? 2.0f : 1.0f;
+  // column chunk of CP columns handled by RP row-groups of threads
+  const int CP = D >= kFgThreads ? kFgThreads : ((D + 63) & ~63);
+  const int RP = kFgThreads / CP;
+  const int jc = tid % CP, rp = tid / CP;
+  for (int j0 = 0; j0 < D; j0 += CP) {
+    const int j = j0 + jc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (j < D && rp < RP) {
+      int i = rp;
+      for (; i + 3 * RP < M; i += 4 * RP) {
+        a0 = __builtin_fmaf(Wb[(size_t)i * D + j], rs[i], a0);
+        a1 = __builtin_fmaf(Wb[(size_t)(i + RP) * D + j], rs[i + RP], a1);
+        a2 = __builtin_fmaf(Wb[(size_t)(i + 2 * RP) * D + j], rs[i + 2 * RP], a2);
+        a3 = __builtin_fmaf(Wb[(size_t)(i + 3 * RP) * D + j], rs[i + 3 * RP], a3);
+      }
+      for (; i < M; i += RP) a0 = __builtin_fmaf(Wb[(size_t)i * D + j], rs[i], a0);
+    }
+    __syncthreads();
+    part[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rp == 0 && j < D) {
+      float s = part[jc];
+      for (int p = 1; p < RP; ++p) s += part[p * CP + jc];
+      float gj = cg * s;
+      const float xv = xs[j];
+      if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f));
+      if (pp.kind == L2O_PROB_RASTRIGIN)
+        gj += 6.2831853071795864769f * pp.alpha * pp.C[(size_t)b * D + j] * sinf(6.2831853071795864769f * xv);
+      gb[j] = gj * pp.inv_bg * (sb ? sb[j] : 1.0f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: the fused persistent unroll.  One workgroup per problem, one wave per
+// 16-coordinate tile (<= 8 waves), T steps in ONE launch:
+//   LDS  : the problem matrix W_b (row stride S == 2 mod 32 -> both GEMV passes are
+//          bank-conflict free with ds_read_b32), y, x*s, the residual r
+//   VGPR : optimizer weights (MFMA A fragments), LSTM state, x, m, v
+//   HBM  : W_b read once; x/state/m/v read+written once; one float per (step, problem)
+// per step: xs -> barrier -> r = W xs - y, f_b -> barrier -> g = W^T r (this wave's 16
+// columns, rows split over the q lanes) -> preprocess -> 2-layer LSTM on MFMA -> x += delta.
+// ---------------------------------------------------------------------------
+struct UnrollArgs {
+  NetParams np;
+  ProbParams pp;
+  float* x;
+  float* st;
+  float* m;
+  float* v;
+  float* fx_part;
+  int T;
+  float p1_hi, p1_lo, p2_hi, p2_lo;   // beta^step0 as float-float
+  int S;        // LDS row stride of W (floats)
+  int Mpad;     // rows padded to a multiple of 32
+};
+
+template <int PRE, int KIND>
+__global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
+  extern __shared__ float sm[];
+  const ProbParams& pp = a.pp;
+  const int D = pp.D, M = pp.M, S = a.S, Mpad = a.Mpad;
+  float* Ws = sm;                           // [Mpad * S + 16]
+  float* xs = Ws + (size_t)Mpad * S + 16;   // [S + 4]
+  float* rs = xs + S + 4;                   // [Mpad]
+  float* ys = rs + Mpad;                    // [Mpad]
+  float* fpart = ys + Mpad;                 // [8]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x;
+
+  // ---- stage the problem into LDS (zero padded) -------------------------
+  const float* Wb = pp.W + (size_t)b * M * D;
+  for (int i = tid; i < Mpad * S + 16; i += blockDim.x) Ws[i] = 0.0f;
+  for (int i = tid; i < S + 4; i += blockDim.x) xs[i] = 0.0f;
+  for (int i = tid; i < Mpad; i += blockDim.x) {
+    rs[i] = 0.0f;
+    ys[i] = i < M ? pp.y[(size_t)b * M + i] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < M * D; e += blockDim.x) {
+    const int i = e / D, j = e - i * D;
+    Ws[i * S + j] = Wb[e];
+  }
+
+  // ---- per-lane persistent registers -------------------------------------
+  NetW<PRE> w;
+  load_netw<PRE>(w, a.np.wpack, lane);
+  const int j = wv * kTile + c;             // this lane's coordinate
+  const bool live = j < D;
+  const size_t idx = (size_t)b * D + j;
+  const int tile = b * nw + wv;
+  TileState s;
+  float* st_tile = a.st + (size_t)tile * kStateFloatsPerTile;
+  load_tile_state(s, st_tile, lane);
+  float xv = live ? a.x[idx] : 0.0f;
+  const float sc = (live && pp.x_scale) ? pp.x_scale[idx] : 1.0f;
+  float cj = 0.0f;
+  if (KIND == L2O_PROB_RASTRIGIN) cj = live ? pp.C[idx] : 0.0f;
+  float mv = 0.0f, vv = 0.0f;
+  if (PRE == L2O_PRE_FC_ELU) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
+  float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
+  const float coef = KIND == L2O_PROB_QUADRATIC ? 1.0f : 0.5f;
+  const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;
+  constexpr float kTwoPi = 6.2831853071795864769f;
+  const int NJ = (D + 3) >> 2;
+
+  for (int t = 0;; ++t) {
+    const float xsv = xv * sc;
+    if (live && q == 0) xs[j] = xsv;
+    __syncthreads();                                        // B1: xs complete
+    // ---- r = W xs - y for rows i0 + c ; this lane covers columns 4*jj + q -----
+    float contrib = 0.0f;
+    for (int i0 = wv * kTile; i0 < Mpad; i0 += nw * kTile) {
+      const int i = i0 + c;
+      const float* wr = Ws + i * S + q;
+      float acc0 = 0.0f, acc1 = 0.0f;
+      int jj = 0;
+      for (; jj + 1 < NJ; jj += 2) {
+        acc0 = __builtin_fmaf(wr[4 * jj], xs[4 * jj + q], acc0);
+        acc1 = __builtin_fmaf(wr[4 * jj + 4], xs[4 * jj + 4 + q], acc1);
+      }
+      if (jj < NJ) acc0 = __builtin_fmaf(wr[4 * jj], xs[4 * jj + q], acc0);
+      const float r = quad_q_sum(acc0 + acc1) - ys[i];
+      if (q == 0) {
+        rs[i] = r;                       // rows >= M: W row and y are zero -> r == 0
+        contrib = __builtin_fmaf(coef * r, r, contrib);
+      }
+    }
+    if (live && q == 0) {
+      if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
+      if (KIND == L2O_PROB_RASTRIGIN) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
+    }
+    contrib = wave_sum64(contrib);
+    if (lane == 0) fpart[wv] = contrib;
+    __syncthreads();                                        // B2: rs, fpart complete
+    if (tid == 0) {
+      float f = fpart[0];
+      for (int k = 1; k < nw; ++k) f += fpart[k];
+      a.fx_part[(size_t)t * pp.B_local + b] = f;
+    }
+    if (t == a.T) break;
+
+    // ---- g_j = cg * sum_i W[i][j] r_i ; rows i = 32*mm + 8*q + ii ----------------
+    float g0 = 0.0f, g1 = 0.0f;
+    {
+      const float* wc = Ws + (8 * q) * S + (wv * kTile + c);
+      const float* rq = rs + 8 * q;
+      for (int mm = 0; mm < Mpad; mm += 32) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii += 2) {
+          g0 = __builtin_fmaf(wc[(mm + ii) * S], rq[mm + ii], g0);
+          g1 = __builtin_fmaf(wc[(mm + ii + 1) * S], rq[mm + ii + 1], g1);
+        }
+      }
+    }
+    float gv = quad_q_sum(g0 + g1);
+    if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
+    if (KIND == L2O_PROB_RASTRIGIN) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
+    gv = live ? gv * cg * sc : 0.0f;
+
+    // ---- optimizer network ----------------------------------------------------
+    float in0, in1;
+    if (PRE == L2O_PRE_FC_ELU) {
+      // beta^k as a float-float running product (k = step0 + t)
+      rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, 1.0f - p1h, 1.0f - p2h, in0, in1);
+      if (!live) { in0 = 0.0f; in1 = 0.0f; }
+      {
+        float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
+        float lo = __builtin_fmaf(p1l, a.np.beta1, er), sum = hi + lo;
+        p1l = lo - (sum - hi); p1h = sum;
+        hi = p2h * a.np.beta2; er = __builtin_fmaf(p2h, a.np.beta2, -hi);
+        lo = __builtin_fmaf(p2l, a.np.beta2, er); sum = hi + lo;
+        p2l = lo - (sum - hi); p2h = sum;
+      }
+    } else {
+      preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
+    }
+    float d = lstm_tile_step<PRE>(w, s, in0, in1, q);
+    if (a.np.tanh_output) d = tanhf_(d);
+    xv = __builtin_fmaf(d, a.np.scale, xv);
+  }
+
+  if (live && q == 0) {
+    a.x[idx] = xv;
+    if (PRE == L2O_PRE_FC_ELU) { a.m[idx] = mv; a.v[idx] = vv; }
+  }
+  store_tile_state(s, st_tile, lane);
+}
+
+// ---------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------
+// reference layout [B*D, 20] x 4  <->  packed tile layout
+__global__ void k_state_repack(float* __restrict__ h1, float* __restrict__ c1, float* __restrict__ h2,
+                               float* __restrict__ c2, float* __restrict__ st, int B, int D, int tpp,
+                               int to_packed) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * tpp * 64 * 20;
+  if (gid >= total) return;
+  const int e = gid % 20;                 // element of the lane: 4*jv + wv
+  const int lane = (gid / 20) % 64;
+  const size_t tile = gid / (20 * 64);
+  const int b = tile / tpp, tw = tile % tpp;
+  const int c = lane & 15, q = lane >> 4;
+  const int j = tw * kTile + c;
+  const int arr = e / 5, t = e % 5, u = 4 * t + q;
+  const size_t paddr = tile * kStateFloatsPerTile + ((size_t)(e >> 2) * 64 + lane) * 4 + (e & 3);
+  float* ref = arr == 0 ? h1 : (arr == 1 ? c1 : (arr == 2 ? h2 : c2));
+  if (j < D) {
+    const size_t raddr = ((size_t)b * D + j) * kH + u;
+    if (to_packed) st[paddr] = ref[raddr];
+    else ref[raddr] = st[paddr];
+  } else if (to_packed) {
+    st[paddr] = 0.0f;
+  }
+}
+
+// fx[t] = (sum_b fx_part[t][b]) / B_global, fixed order: each wave sums a strided slice
+// sequentially, then a fixed butterfly.
+__global__ void k_reduce_fx(const float* __restrict__ fx_part, int T1, int B_local, float inv_bg,
+                            float* __restrict__ fx) {
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;   // 64 threads
+  float acc = 0.0f;
+  for (int b = lane; b < B_local; b += 64) acc += fx_part[(size_t)t * B_local + b];
+  acc = wave_sum64(acc);
+  if (lane == 0) fx[t] = acc * inv_bg;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static bool net_ok_for_mfma(const l2o_net_cfg* c) {
+  if (c->n_layers != 2 || c->hidden != kH) return false;
+  if (c->kind == L2O_NET_CW) return c->preprocess == L2O_PRE_IDENTITY || c->preprocess == L2O_PRE_LOGSIGN;
+  if (c->kind == L2O_NET_RNNPROP) return c->preprocess == L2O_PRE_FC_ELU;
+  return false;
+}
+
+static NetParams make_net_params(const l2o_net_cfg* c, const float* wpack) {
+  NetParams np;
+  np.wpack = wpack;
+  np.scale = (float)c->scale;
+  np.k_inv_ln2 = c->logsign_k != 0.0 ? (float)(0.6931471805599453 / c->logsign_k) : 0.0f;
+  np.exp_k = (float)std::exp(c->logsign_k);
+  np.beta1 = (float)c->beta1;
+  np.beta2 = (float)c->beta2;
+  np.omb1 = (float)(1.0 - c->beta1);
+  np.omb2 = (float)(1.0 - c->beta2);
+  np.tanh_output = c->tanh_output;
+  return np;
+}
+
+static ProbParams make_prob_params(const l2o_problem* p) {
+  ProbParams pp;
+  pp.kind = p->kind;
+  pp.B_local = p->B_local;
+  pp.D = p->D;
+  pp.M = p->kind == L2O_PROB_SIMPLE ? 0 : p->M;
+  pp.inv_bg = 1.0f / (float)p->B_global;
+  pp.l1 = (float)p->l1;
+  pp.alpha = (float)p->alpha;
+  pp.W = p->W;
+  pp.y = p->y;
+  pp.C = p->C;
+  pp.x_scale = p->x_scale;
+  return pp;
+}
+
+static int check_problem(const l2o_problem* p) {
+  if (!p) return fail(L2O_ERR_ARG, "problem is NULL");
+  if (p->B_local <= 0 || p->B_global < p->B_local || p->D <= 0)
+    return fail(L2O_ERR_ARG, "bad problem sizes B_local=%d B_global=%d D=%d", p->B_local, p->B_global, p->D);
+  switch (p->kind) {
+    case L2O_PROB_SIMPLE: return L2O_OK;
+    case L2O_PROB_QUADRATIC:
+    case L2O_PROB_LASSO:
+      if (!p->W || !p->y || p->M <= 0) return fail(L2O_ERR_ARG, "problem needs W, y and M > 0");
+      if (p->kind == L2O_PROB_QUADRATIC && p->M != p->D) return fail(L2O_ERR_ARG, "quadratic needs M == D");
+      return L2O_OK;
+    case L2O_PROB_RASTRIGIN:
+      if (!p->W || !p->y || !p->C || p->M != p->D) return fail(L2O_ERR_ARG, "rastrigin needs A, B, C and M == D");
+      return L2O_OK;
+    default: return fail(L2O_ERR_UNSUPPORTED, "problem kind %d has no HIP kernel", p->kind);
+  }
+}
+
+// float-float split of base^k computed in double
+static void pow_ff(double base, int k, float* hi, float* lo) {
+  const double p = std::pow((double)(float)base, (double)k);
+  *hi = (float)p;
+  *lo = (float)(p - (double)*hi);
+}
+
+struct UnrollGeom { int S, Mpad, nw; size_t lds; };
+static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
+  const int D = p->D, M = p->M;
+  g->nw = tiles_per_problem(D);
+  if (g->nw > 8) return false;
+  g->S = ((D - 2 + 31) / 32) * 32 + 2;
+  if (g->S < D) g->S += 32;
+  g->Mpad = (M + 31) / 32 * 32;
+  g->lds = sizeof(float) * ((size_t)g->Mpad * g->S + 16 + g->S + 4 + 2 * (size_t)g->Mpad + 8);
+  return g->lds <= 160 * 1024;
+}
+
+template <int PRE>
+static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind, hipStream_t s) {
+  void (*fn)(UnrollArgs) = nullptr;
+  switch (kind) {
+    case L2O_PROB_QUADRATIC: fn = k_unroll<PRE, L2O_PROB_QUADRATIC>; break;
+    case L2O_PROB_LASSO: fn = k_unroll<PRE, L2O_PROB_LASSO>; break;
+    case L2O_PROB_RASTRIGIN: fn = k_unroll<PRE, L2O_PROB_RASTRIGIN>; break;
+    default: return fail(L2O_ERR_UNSUPPORTED, "no fused kernel for problem kind %d", kind);
+  }
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)g.lds));
+  hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(64 * g.nw), g.lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+extern "C" {
+
+int l2o_abi_version(void) { return L2O_ABI_VERSION; }
+const char* l2o_last_error(void) { return g_err; }
+
+size_t l2o_wpack_floats(const l2o_net_cfg* cfg) {
+  if (!cfg) return 0;
+  if (cfg->n_layers == 0) return 4;
+  if (!net_ok_for_mfma(cfg)) return 0;
+  return (size_t)wp_rows(cfg->preprocess) * 64;
+}
+
+int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, const float* wg2,
+                   const float* bg2, const float* wl, const float* bl, const float* wfc, const float* bfc,
+                   float* out) {
+  if (!cfg || !out || !wl || !bl) return fail(L2O_ERR_ARG, "l2o_wpack_host: NULL argument");
+  if (cfg->n_layers == 0) {
+    // Linear(P -> 1) on the preprocessed gradient, P = 1 (identity) or 2 (LogAndSign)
+    if (cfg->kind != L2O_NET_CW || cfg->preprocess == L2O_PRE_FC_ELU)
+      return fail(L2O_ERR_UNSUPPORTED, "layers=() is implemented for CoordinateWiseDeepLSTM only");
+    out[0] = wl[0];
+    out[1] = cfg->preprocess == L2O_PRE_LOGSIGN ? wl[1] : 0.0f;
+    out[2] = bl[0];
+    out[3] = 0.0f;
+    return L2O_OK;
+  }
+  if (!net_ok_for_mfma(cfg))
+    return fail(L2O_ERR_UNSUPPORTED, "MFMA kernels implement layers=(20,20) (got n_layers=%d hidden=%d kind=%d pre=%d)",
+                cfg->n_layers, cfg->hidden, cfg->kind, cfg->preprocess);
+  if (!wg1 || !bg1 || !wg2 || !bg2) return fail(L2O_ERR_ARG, "l2o_wpack_host: NULL LSTM weights");
+  const int pre = cfg->preprocess;
+  const bool fc = pre == L2O_PRE_FC_ELU;
+  if (fc && (!wfc || !bfc)) return fail(L2O_ERR_ARG, "l2o_wpack_host: fc preprocess needs input_projection");
+  const int P = fc ? kH : (pre == L2O_PRE_LOGSIGN ? 2 : 1);
+  const int G = 4 * kH;
+  std::memset(out, 0, sizeof(float) * wp_rows(pre) * 64);
+  auto col = [](int t, int rho) { return (rho & 3) * kH + 4 * t + (rho >> 2); };
+  for (int l = 0; l < 64; ++l) {
+    const int rho = l & 15, kq = l >> 4;   // A-fragment view of the lane
+    const int q = l >> 4;                  // C/D + B view of the lane
+    for (int t = 0; t < kNT; ++t) {
+      const int cA = col(t, rho);
+      // layer 1
+      if (fc) {
+        for (int kk = 0; kk < 10; ++kk) {
+          const int row = kk < 5 ? 4 * kk + kq : kH + 4 * (kk - 5) + kq;   // fc features, then h1
+          out[(wp_row_a1(pre) + kk * kNT + t) * 64 + l] = wg1[row * G + cA];
+        }
+      } else {
+        for (int kk = 0; kk < 5; ++kk)
+          out[(wp_row_a1(pre) + kk * kNT + t) * 64 + l] = wg1[(P + 4 * kk + kq) * G + cA];
+        float v = 0.0f;
+        if (kq == 0) v = wg1[0 * G + cA];
+        else if (kq == 1) v = P == 2 ? wg1[1 * G + cA] : 0.0f;
+        else if (kq == 2) v = bg1[cA];
+        out[(wp_row_a1(pre) + 5 * kNT + t) * 64 + l] = v;
+      }
+      // layer 2: kk 0..4 <- h1 (rows 0..19), kk 5..9 <- h2 (rows 20..39)
+      for (int kk = 0; kk < 10; ++kk) {
+        const int row = kk < 5 ? 4 * kk + kq : kH + 4 * (kk - 5) + kq;
+        out[(wp_row_a2(pre) + kk * kNT + t) * 64 + l] = wg2[row * G + cA];
+      }
+      for (int r = 0; r < 4; ++r) {
+        const int cD = col(t, 4 * q + r);
+        out[(wp_row_b1(pre) + t * 4 + r) * 64 + l] = fc ? bg1[cD] : 0.0f;
+        out[(wp_row_b2(pre) + t * 4 + r) * 64 + l] = bg2[cD];
+      }
+      out[(wp_row_wl(pre) + t) * 64 + l] = wl[4 * t + q];
+      if (fc) {
+        out[(wp_row_fc(pre) + t) * 64 + l] = wfc[0 * kH + 4 * t + q];
+        out[(wp_row_fc(pre) + kNT + t) * 64 + l] = wfc[1 * kH + 4 * t + q];
+        out[(wp_row_fc(pre) + 2 * kNT + t) * 64 + l] = bfc[4 * t + q];
+      }
+    }
+    out[wp_row_bl(pre) * 64 + l] = bl[0];
+  }
+  return L2O_OK;
+}
+
+size_t l2o_state_floats(int64_t B, int64_t D) {
+  if (B <= 0 || D <= 0) return 0;
+  return (size_t)B * tiles_per_problem(D) * kStateFloatsPerTile;
+}
+
+static int state_repack(float* h1, float* c1, float* h2, float* c2, float* st, int64_t B, int64_t D,
+                        void* stream, int to_packed) {
+  if (!h1 || !c1 || !h2 || !c2 || !st || B <= 0 || D <= 0) return fail(L2O_ERR_ARG, "state repack: bad argument");
+  const int tpp = tiles_per_problem(D);
+  const size_t total = (size_t)B * tpp * 64 * 20;
+  hipLaunchKernelGGL(k_state_repack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h1,
+                     c1, h2, c2, st, (int)B, (int)D, tpp, to_packed);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+int l2o_state_pack(const float* h1, const float* c1, const float* h2, const float* c2, float* st, int64_t B,
+                   int64_t D, void* stream) {
+  return state_repack(const_cast<float*>(h1), const_cast<float*>(c1), const_cast<float*>(h2),
+                      const_cast<float*>(c2), st, B, D, stream, 1);
+}
+int l2o_state_unpack(const float* st, float* h1, float* c1, float* h2, float* c2, int64_t B, int64_t D,
+                     void* stream) {
+  return state_repack(h1, c1, h2, c2, const_cast<float*>(st), B, D, stream, 0);
+}
+
+int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float* g, void* stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!x || !f_part) return fail(L2O_ERR_ARG, "l2o_problem_fg: NULL x / f_part");
+  const ProbParams pp = make_prob_params(prob);
+  const size_t lds = sizeof(float) * ((size_t)pp.D + pp.M + kFgThreads + 4);
+  if (lds > 160 * 1024) return fail(L2O_ERR_UNSUPPORTED, "problem too large for k_problem_fg (D=%d M=%d)", pp.D, pp.M);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_problem_fg),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_problem_fg, dim3(pp.B_local), dim3(kFgThreads), lds, (hipStream_t)stream, pp, x, f_part, g);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, float* m, float* v, double pow1,
+                    double pow2, float* st, float* x, int64_t B, int64_t D, void* stream) {
+  if (!cfg || !wpack || !g || !x || B <= 0 || D <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: bad argument");
+  const NetParams np = make_net_params(cfg, wpack);
+  hipStream_t s = (hipStream_t)stream;
+  if (cfg->n_layers == 0) {
+    if (cfg->kind != L2O_NET_CW || cfg->preprocess == L2O_PRE_FC_ELU)
+      return fail(L2O_ERR_UNSUPPORTED, "layers=() is implemented for CoordinateWiseDeepLSTM only");
+    const size_t n = (size_t)B * D;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (cfg->preprocess == L2O_PRE_LOGSIGN)
+      hipLaunchKernelGGL(k_linear_step<L2O_PRE_LOGSIGN>, grid, dim3(256), 0, s, np, g, x, n);
+    else
+      hipLaunchKernelGGL(k_linear_step<L2O_PRE_IDENTITY>, grid, dim3(256), 0, s, np, g, x, n);
+    HIP_TRY(hipGetLastError());
+    return L2O_OK;
+  }
+  if (!net_ok_for_mfma(cfg)) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_step: only layers=(20,20) / () nets");
+  if (!st) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: NULL state");
+  const int tpp = tiles_per_problem(D);
+  const int64_t ntiles = B * tpp;
+  int blocks = (int)((ntiles + 3) / 4);
+  if (blocks > 256 * 2) blocks = 256 * 2;    // 2 x 4-wave blocks per CU, grid-stride beyond
+  const dim3 grid(blocks), block(256);
+  const float om1 = (float)(1.0 - pow1), om2 = (float)(1.0 - pow2);
+  switch (cfg->preprocess) {
+    case L2O_PRE_IDENTITY:
+      hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_IDENTITY>, grid, block, 0, s, np, g, m, v, om1, om2, st, x, (int)B,
+                         (int)D, tpp);
+      break;
+    case L2O_PRE_LOGSIGN:
+      hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_LOGSIGN>, grid, block, 0, s, np, g, m, v, om1, om2, st, x, (int)B,
+                         (int)D, tpp);
+      break;
+    default:
+      if (!m || !v) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: RNNProp needs m and v");
+      hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_FC_ELU>, grid, block, 0, s, np, g, m, v, om1, om2, st, x, (int)B,
+                         (int)D, tpp);
+  }
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
+  if (!cfg || !prob || !net_ok_for_mfma(cfg)) return 0;
+  if (prob->kind != L2O_PROB_QUADRATIC && prob->kind != L2O_PROB_LASSO && prob->kind != L2O_PROB_RASTRIGIN)
+    return 0;
+  if (prob->D <= 0 || prob->M <= 0) return 0;
+  UnrollGeom g;
+  return unroll_geom(prob, &g) ? 1 : 0;
+}
+
+int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st, float* m,
+               float* v, int32_t T, int32_t step0, float* fx_part, void* stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!cfg || !wpack || !x || !st || !fx_part || T < 0) return fail(L2O_ERR_ARG, "l2o_unroll: bad argument");
+  if (!l2o_unroll_supported(cfg, prob))
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_unroll: no fused kernel for kind=%d D=%d M=%d net(kind=%d,layers=%d)",
+                prob->kind, prob->D, prob->M, cfg->kind, cfg->n_layers);
+  UnrollGeom g;
+  unroll_geom(prob, &g);
+  UnrollArgs a;
+  a.np = make_net_params(cfg, wpack);
+  a.pp = make_prob_params(prob);
+  a.x = x; a.st = st; a.m = m; a.v = v; a.fx_part = fx_part;
+  a.T = T; a.S = g.S; a.Mpad = g.Mpad;
+  pow_ff(cfg->beta1, step0, &a.p1_hi, &a.p1_lo);
+  pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
+  hipStream_t s = (hipStream_t)stream;
+  switch (cfg->preprocess) {
+    case L2O_PRE_IDENTITY: return launch_unroll_kind<L2O_PRE_IDENTITY>(a, g, prob->kind, s);
+    case L2O_PRE_LOGSIGN: return launch_unroll_kind<L2O_PRE_LOGSIGN>(a, g, prob->kind, s);
+    default:
+      if (!m || !v) return fail(L2O_ERR_ARG, "l2o_unroll: RNNProp needs m and v");
+      return launch_unroll_kind<L2O_PRE_FC_ELU>(a, g, prob->kind, s);
+  }
+}
+
+int l2o_reduce_fx(const float* fx_part, int32_t T1, int32_t B_local, int32_t B_global, float* fx, void* stream) {
+  if (!fx_part || !fx || T1 <= 0 || B_local <= 0 || B_global < B_local)
+    return fail(L2O_ERR_ARG, "l2o_reduce_fx: bad argument");
+  hipLaunchKernelGGL(k_reduce_fx, dim3(T1), dim3(64), 0, (hipStream_t)stream, fx_part, (int)T1, (int)B_local,
+                     1.0f / (float)B_global, fx);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""CPU-side checks of the C-ABI library (no GPU compute is launched):
+ * it loads and exports every symbol include/l2o_abi.h declares;
+ * the host weight packer (l2o_wpack_host) + the documented MFMA operand layout
+   reproduce the oracle's net_apply when emulated lane by lane in NumPy;
+ * size queries and argument validation.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import ORACLE_CFGS, make_params, random_state, spec_of
+import mfma_emulator as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from open_l2o_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _abi.lib()
+
+
+def test_header_symbols_exported(lib):
+    from open_l2o_amd import _abi
+    hdr = open(os.path.join(ROOT, "include", "l2o_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(l2o_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.l2o_abi_version() == _abi.L2O_ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    from open_l2o_amd import _abi
+    # 6 int32 + 4 double ; 6 int32 + 2 double + 4 pointers
+    assert C.sizeof(_abi.NetCfg) == 6 * 4 + 4 * 8
+    assert C.sizeof(_abi.Problem) == 6 * 4 + 2 * 8 + 4 * 8
+
+
+def test_size_queries(lib):
+    assert lib.l2o_state_floats(1, 16) == 1280
+    assert lib.l2o_state_floats(3, 17) == 3 * 2 * 1280
+    assert lib.l2o_state_floats(128, 128) == 128 * 8 * 1280
+    assert lib.l2o_state_floats(0, 5) == 0
+    for name, cfg in ORACLE_CFGS.items():
+        cc = spec_of(cfg).to_c()
+        assert lib.l2o_wpack_floats(C.byref(cc)) == E.wp_rows(cc.preprocess)["total"] * 64
+
+
+def test_unsupported_layers_are_reported(lib):
+    from open_l2o_amd import _abi
+    from open_l2o_amd._engine import pack_weights_host
+    cfg = O.NetConfig("cw", (1,), "identity", None, 1.0, False)
+    params = O.init_net_params(cfg, np.random.default_rng(0))
+    with pytest.raises(_abi.L2OUnsupported):
+        pack_weights_host(lib, spec_of(cfg), params)
+
+
+def test_bad_arguments_return_error_codes(lib):
+    from open_l2o_amd import _abi
+    p = _abi.Problem()
+    p.kind, p.B_local, p.B_global, p.D = _abi.PROB_QUADRATIC, 0, 0, 4
+    rc = lib.l2o_problem_fg(C.byref(p), None, None, None, None)
+    assert rc == _abi.L2O_ERR_ARG
+    assert b"bad problem sizes" in lib.l2o_last_error()
+    with pytest.raises(ValueError):
+        _abi.check(rc)
+    cc = spec_of(O.DM_IDENTITY).to_c()
+    p.B_local = p.B_global = 2
+    p.M = 4
+    p.kind = _abi.PROB_SQUARE_COS
+    assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 0
+    p.kind = _abi.PROB_QUADRATIC
+    p.D = p.M = 128
+    assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
+    p.D = p.M = 512                                    # > 8 tiles: step-granular path
+    assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 0
+
+
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_packed_weights_reproduce_oracle_under_mfma_layout(lib, name):
+    from open_l2o_amd._engine import pack_weights_host
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=21)
+    wpack = pack_weights_host(lib, spec, params)
+    rng = np.random.default_rng(22)
+    n = 16
+    state = random_state(cfg, n, seed=23)
+    g = rng.standard_normal((n,)).astype(np.float32)
+    if cfg.kind == "rnnprop":
+        mt = rng.standard_normal((n,)).astype(np.float32)
+        inputs = (mt, g)
+        in0, in1 = mt, g
+    elif cfg.preprocess_name == "LogAndSign":
+        inputs = g
+        ls = O.log_and_sign(g[:, None].astype(np.float64), 5)
+        in0, in1 = ls[:, 0], ls[:, 1]
+    else:
+        inputs = g
+        in0, in1 = g, np.zeros_like(g)
+    f64 = lambda t: tuple((h.astype(np.float64), c.astype(np.float64)) for h, c in t)
+    p64 = {k: {v: a.astype(np.float64) for v, a in d.items()} for k, d in params.items()}
+    in64 = tuple(a.astype(np.float64) for a in inputs) if isinstance(inputs, tuple) else inputs.astype(np.float64)
+    delta, st_ref = O.net_apply(cfg, p64, in64, f64(state))
+    coords = list(range(16))
+    lanes = np.arange(64)
+    h1, c1, h2, c2 = [E.ref_to_lanes(a, coords) for a in (state[0][0], state[0][1], state[1][0], state[1][1])]
+    d, h1n, c1n, h2n, c2n = E.tile_step(wpack, spec.preprocess, h1, c1, h2, c2,
+                                        np.asarray(in0, np.float64)[lanes & 15],
+                                        np.asarray(in1, np.float64)[lanes & 15])
+    d = np.tanh(d) if cfg.tanh_output else d
+    np.testing.assert_allclose(d[:16] * cfg.scale, delta, rtol=1e-9, atol=1e-12)
+    for q in range(1, 4):                              # the four q lanes agree
+        np.testing.assert_allclose(d[16 * q:16 * q + 16], d[:16], rtol=1e-12)
+    for lane_arr, ref in ((h1n, st_ref[0][0]), (c1n, st_ref[0][1]), (h2n, st_ref[1][0]), (c2n, st_ref[1][1])):
+        back = np.zeros((16, 20))
+        E.lanes_to_ref(lane_arr, back, coords)
+        np.testing.assert_allclose(back, ref, rtol=1e-9, atol=1e-12)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from open_l2o_amd._engine import HipEngine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipEngine()

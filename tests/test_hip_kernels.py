@@ -1,0 +1,244 @@
+"""GPU parity tests of the individual HIP kernels, through the C ABI.
+
+Bar (BASELINE.json north_star): fp32, loss trajectories within 1e-5 relative of the
+reference CPU path; teacher-forced single steps within ~1e-6 absolute on O(1) state.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import (ORACLE_CFGS, device_problem, make_params, make_problem, max_abs, random_state,
+                     rel_err, spec_of)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from open_l2o_amd._engine import HipEngine
+    return HipEngine()
+
+
+def _unpack_state(eng, st, B, D):
+    h1, c1, h2, c2 = [eng.to_numpy(t) for t in eng.state_unpack(st, B, D)]
+    return ((h1, c1), (h2, c2))
+
+
+@pytest.mark.parametrize("B,D", [(1, 16), (3, 10), (2, 37), (4, 128)])
+def test_state_pack_roundtrip(eng, B, D):
+    rng = np.random.default_rng(0)
+    arrs = [rng.standard_normal((B * D, 20)).astype(np.float32) for _ in range(4)]
+    st = eng.state_pack(*[eng.tensor(a) for a in arrs], B, D)
+    assert st.numel() == eng.state_floats(B, D)
+    back = [eng.to_numpy(t) for t in eng.state_unpack(st, B, D)]
+    for a, b in zip(arrs, back):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+@pytest.mark.parametrize("B,D", [(1, 16), (5, 10), (3, 50), (2, 128)])
+def test_lstm_step_teacher_forced(eng, name, B, D):
+    """One optimizer step from a random state == oracle net_apply (+ RNNProp moments)."""
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=1)
+    rng = np.random.default_rng(2)
+    N = B * D
+    g = (rng.standard_normal((B, D)) * np.exp(rng.uniform(-6, 1, (B, D)))).astype(np.float32)
+    g.flat[0] = 0.0                                   # log(|0| + eps) path
+    x0 = rng.standard_normal((B, D)).astype(np.float32)
+    state = random_state(cfg, N, seed=3)
+    m0 = (rng.standard_normal((B, D)) * 0.1).astype(np.float32)
+    v0 = (rng.random((B, D)) * 0.1).astype(np.float32)
+    k = 7
+    # oracle
+    if cfg.kind == "rnnprop":
+        dt = np.float32
+        m = dt(0.95) * m0 + dt(1 - 0.95) * g
+        v = dt(0.95) * v0 + dt(1 - 0.95) * g * g
+        mh = m / (dt(1) - np.power(dt(0.95), dt(k)))
+        vh = v / (dt(1) - np.power(dt(0.95), dt(k)))
+        inputs = (mh / (np.sqrt(vh) + dt(1e-8)), g / (np.sqrt(vh) + dt(1e-8)))
+    else:
+        inputs, m, v = g, m0, v0
+    delta, st_ref = O.net_apply(cfg, params, inputs, state)
+    # HIP
+    wpack = eng.pack_weights(spec, params)
+    st = eng.state_pack(*[eng.tensor(a) for hc in state for a in hc], B, D)
+    xd, gd, md, vd = eng.tensor(x0), eng.tensor(g), eng.tensor(m0), eng.tensor(v0)
+    pw = float(np.float32(0.95)) ** k
+    eng.lstm_step(spec, wpack, gd, md, vd, pw, pw, st, xd, B, D)
+    x1 = eng.to_numpy(xd)
+    st_hip = _unpack_state(eng, st, B, D)
+    e_delta = max_abs(x1 - x0, delta)
+    e_state = max(max_abs(st_hip[l][i], st_ref[l][i]) for l in range(2) for i in range(2))
+    print("step %s B=%d D=%d: |d delta|=%.3g |d state|=%.3g (|delta|max=%.3g)"
+          % (name, B, D, e_delta, e_state, np.abs(delta).max()))
+    assert e_state < 3e-6
+    # x1 - x0 is formed in fp32 around |x| ~ 3: allow its rounding on top of the kernel error
+    assert e_delta < 3e-6 * max(1.0, float(np.abs(delta).max())) + 5e-7
+    if cfg.kind == "rnnprop":
+        assert max_abs(eng.to_numpy(md), m) < 1e-7 and max_abs(eng.to_numpy(vd), v) < 1e-7
+
+
+def test_linear_only_net(eng):
+    from open_l2o_amd import _abi
+    from open_l2o_amd._engine import ProblemDesc
+    cfg = O.NetConfig("cw", (), "identity", None, 1.0, False)
+    params = {"linear": {"w": np.full((1, 1), -0.01, np.float32), "b": np.full((1,), -0.01, np.float32)}}
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    x = eng.tensor(np.ones((1, 1), np.float32))
+    f = eng.zeros(1)
+    g = eng.zeros(1, 1)
+    pd = ProblemDesc(_abi.PROB_SIMPLE, 1, 1, 1)
+    for _ in range(5):                                  # the meta_test.py:64-69 trajectory
+        eng.problem_fg(pd, x, f, g)
+        eng.lstm_step(spec, wpack, g, None, None, 0.0, 0.0, None, x, 1, 1)
+    eng.problem_fg(pd, x, f, None)
+    assert abs(float(eng.to_numpy(x)[0, 0]) - 0.8558813) < 1e-6
+    assert abs(float(eng.to_numpy(f)[0]) - 0.7325327) < 5e-5
+
+
+@pytest.mark.parametrize("kind,B,D,M", [("quadratic", 4, 10, None), ("quadratic", 3, 128, None),
+                                        ("quadratic", 2, 300, None), ("lasso", 4, 10, None),
+                                        ("lasso", 3, 50, 25), ("lasso", 2, 512, 256),
+                                        ("rastrigin", 4, 2, None), ("rastrigin", 3, 100, None)])
+def test_problem_fg(eng, kind, B, D, M):
+    prob, x0, arrays = make_problem(kind, B, D, seed=4, M=M, stddev=0.5)
+    Bg = 2 * B                                         # exercise the global-batch factor
+    prob.batch_global = Bg
+    rng = np.random.default_rng(5)
+    xs = np.exp(rng.uniform(-1, 1, (B, D))).astype(np.float32)
+    x2 = x0.reshape(B, D)
+    pd = device_problem(eng, arrays, B, D, B_global=Bg, x_scale=xs)
+    f = eng.zeros(B)
+    g = eng.zeros(B, D)
+    eng.problem_fg(pd, eng.tensor(x2), f, g)
+    xin = (x2 * xs).reshape(x0.shape)
+    f_ref = prob.f_per_problem(xin)
+    g_ref = prob.grad(xin).reshape(B, D) * xs
+    e_f, e_g = rel_err(eng.to_numpy(f), f_ref), max_abs(eng.to_numpy(g), g_ref) / np.abs(g_ref).max()
+    print("fg %s B=%d D=%d: rel f=%.3g, g=%.3g" % (kind, B, D, e_f, e_g))
+    assert e_f < 2e-5 and e_g < 5e-6
+    fx = eng.zeros(1)
+    eng.reduce_fx(f, 1, B, Bg, fx)
+    assert rel_err(eng.to_numpy(fx)[0], prob.f(xin)) < 1e-5
+
+
+def _run_fused(eng, cfg, params, arrays, x0, B, D, T, state=None, step0=1, Bg=None, x_scale=None):
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D, B_global=Bg, x_scale=x_scale)
+    assert eng.unroll_supported(spec, pd)
+    if state is None:
+        st = eng.state_alloc(B, D)
+    else:
+        st = eng.state_pack(*[eng.tensor(a) for hc in state for a in hc], B, D)
+    x = eng.tensor(x0.reshape(B, D))
+    m, v = eng.zeros(B, D), eng.zeros(B, D)
+    fx_part = eng.zeros((T + 1) * B)
+    eng.unroll(spec, wpack, pd, x, st, m, v, T, step0, fx_part)
+    fx = eng.zeros(T + 1)
+    eng.reduce_fx(fx_part, T + 1, B, pd.B_global, fx)
+    return eng.to_numpy(fx), eng.to_numpy(x), _unpack_state(eng, st, B, D), eng.to_numpy(m), eng.to_numpy(v)
+
+
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+@pytest.mark.parametrize("kind,B,D,M", [("quadratic", 4, 10, None), ("quadratic", 3, 32, None),
+                                        ("lasso", 4, 10, None), ("lasso", 3, 50, 25),
+                                        ("rastrigin", 4, 2, None), ("rastrigin", 3, 20, None)])
+def test_fused_unroll_vs_oracle(eng, name, kind, B, D, M):
+    cfg = ORACLE_CFGS[name]
+    params = make_params(cfg, seed=6, trained_like=True)
+    prob, x0, arrays = make_problem(kind, B, D, seed=7, M=M)
+    T = 20
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=1)
+    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
+    e_fx = rel_err(fx, res.fx)
+    e_x = max_abs(x, res.x.reshape(B, D))
+    print("fused %s/%s B=%d D=%d: rel fx=%.3g |dx|=%.3g fx0=%.4g fxT=%.4g"
+          % (name, kind, B, D, e_fx, e_x, res.fx[0], res.fx[-1]))
+    assert e_fx < 1e-5
+    assert e_x < 1e-5 * max(1.0, float(np.abs(res.x).max()))
+    for l in range(2):
+        for i in range(2):
+            assert max_abs(st[l][i], res.state[l][i]) < 2e-5
+    if cfg.kind == "rnnprop":
+        assert max_abs(m, res.m.reshape(B, D)) < 1e-6 * max(1.0, np.abs(res.m).max())
+
+
+def test_fused_unroll_continuation_and_scale(eng):
+    """Two T=10 launches carrying x/state/m/v (the harness' `update`) == one T=20 launch;
+    x_scale placeholder chain rule; B_global > B_local."""
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=8, trained_like=True)
+    B, D = 3, 24
+    prob, x0, arrays = make_problem("quadratic", B, D, seed=9)
+    prob.batch_global = 2 * B
+    rng = np.random.default_rng(10)
+    xs = np.exp(rng.uniform(-0.5, 0.5, (B, D))).astype(np.float32)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), 20, x_scale=xs, step0=1)
+    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, 20, Bg=2 * B, x_scale=xs)
+    assert rel_err(fx, res.fx) < 1e-5
+    # continuation
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D, B_global=2 * B, x_scale=xs)
+    xd, std = eng.tensor(x0), eng.state_alloc(B, D)
+    md, vd = eng.zeros(B, D), eng.zeros(B, D)
+    fxs = []
+    for seg in range(2):
+        fp = eng.zeros(11 * B)
+        eng.unroll(spec, wpack, pd, xd, std, md, vd, 10, 1 + 10 * seg, fp)
+        f = eng.zeros(11)
+        eng.reduce_fx(fp, 11, B, 2 * B, f)
+        fxs.append(eng.to_numpy(f))
+    np.testing.assert_allclose(fxs[0][:10], fx[:10], rtol=1e-6)
+    np.testing.assert_allclose(fxs[0][10], fxs[1][0], rtol=0, atol=0)
+    np.testing.assert_allclose(fxs[1], fx[10:], rtol=2e-6)
+    np.testing.assert_allclose(eng.to_numpy(xd), x, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["dm", "rnnprop"])
+def test_fused_equals_step_path_at_full_size(eng, name):
+    """BASELINE config 2 shape (Quadratic d=128, B=128, T=100): the fused persistent
+    kernel and the step-granular kernels (problem_fg + lstm_step) are two independent
+    HIP implementations of the same recurrence and must agree."""
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=11, trained_like=True)
+    B, D, T = 128, 128, 100
+    prob, x0, arrays = make_problem("quadratic", B, D, seed=12)
+    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D)
+    xd, std, md, vd = eng.tensor(x0), eng.state_alloc(B, D), eng.zeros(B, D), eng.zeros(B, D)
+    f, g = eng.zeros(B), eng.zeros(B, D)
+    fx2 = eng.zeros(T + 1)
+    b95 = float(np.float32(0.95))
+    for t in range(T):
+        eng.problem_fg(pd, xd, f, g)
+        eng.reduce_fx(f, 1, B, B, fx2[t:t + 1])
+        eng.lstm_step(spec, wpack, g, md, vd, b95 ** (1 + t), b95 ** (1 + t), std, xd, B, D)
+    eng.problem_fg(pd, xd, f, None)
+    eng.reduce_fx(f, 1, B, B, fx2[T:T + 1])
+    fx2 = eng.to_numpy(fx2)
+    e = rel_err(fx, fx2)
+    print("fused vs step path %s: rel fx=%.3g, fx0=%.5g fxT=%.5g" % (name, e, fx[0], fx[-1]))
+    assert np.all(np.isfinite(fx))
+    assert e < 1e-5
+    assert max_abs(x, eng.to_numpy(xd)) < 1e-5 * max(1.0, np.abs(x).max())
+
+
+def test_fused_c2_vs_oracle_trajectory(eng):
+    """Config 2 (L2O-DM, Quadratic d=128, B=128, T=100) against the oracle itself."""
+    cfg = O.DM_IDENTITY
+    params = make_params(cfg, seed=13, trained_like=True)
+    B, D, T = 128, 128, 100
+    prob, x0, arrays = make_problem("quadratic", B, D, seed=14)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
+    e = rel_err(fx, res.fx)
+    print("C2 fused vs oracle: rel fx=%.3g  fx0=%.5g fxT=%.5g" % (e, res.fx[0], res.fx[-1]))
+    assert e < 1e-5
