@@ -248,10 +248,12 @@ __device__ __forceinline__ void preprocess_grad(float g, float k_inv_ln2, float 
 }
 
 // RNNProp inputs, DM/meta_rnnprop_train.py:383-388.  om1 = 1 - beta1^k, om2 = 1 - beta2^k.
+//  omb1 = fp32(1 - beta1) rounded from the python double like TF rounds the constant.
 __device__ __forceinline__ void rnnprop_inputs(float g, float& m, float& v, float beta1, float beta2,
-                                               float om1, float om2, float& m_tilde, float& g_tilde) {
-  m = beta1 * m + (1.0f - beta1) * g;
-  v = beta2 * v + (1.0f - beta2) * g * g;
+                                               float omb1, float omb2, float om1, float om2,
+                                               float& m_tilde, float& g_tilde) {
+  m = beta1 * m + omb1 * g;
+  v = beta2 * v + omb2 * g * g;
   const float m_hat = m / om1;
   const float v_hat = v / om2;
   const float den = __builtin_sqrtf(v_hat) + 1e-8f;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_step(NetParams np, const float* 
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
       float m = live ? mbuf[idx] : 0.0f, v = live ? vbuf[idx] : 0.0f;
-      rnnprop_inputs(gv, m, v, np.beta1, np.beta2, om1, om2, in0, in1);
+      rnnprop_inputs(gv, m, v, np.beta1, np.beta2, np.omb1, np.omb2, om1, om2, in0, in1);
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       if (live && q == 0) { mbuf[idx] = m; vbuf[idx] = v; }
     } else {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
       // beta^k as a float-float running product (k = step0 + t)
-      rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, 1.0f - p1h, 1.0f - p2h, in0, in1);
+      rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, 1.0f - p1h, 1.0f - p2h, in0, in1);
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       {
         float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);

@@ -59,7 +59,8 @@ def log_and_sign(g, k):
 # ----------------------------------------------------------------------------
 def sigmoid(x):
     one = x.dtype.type(1.0)
-    return one / (one + np.exp(-x))
+    with np.errstate(over="ignore"):          # exp(+large) -> inf -> sigmoid 0, as in TF
+        return one / (one + np.exp(-x))
 
 
 def elu(x):

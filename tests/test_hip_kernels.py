@@ -78,7 +78,8 @@ def test_lstm_step_teacher_forced(eng, name, B, D):
     # x1 - x0 is formed in fp32 around |x| ~ 3: allow its rounding on top of the kernel error
     assert e_delta < 3e-6 * max(1.0, float(np.abs(delta).max())) + 5e-7
     if cfg.kind == "rnnprop":
-        assert max_abs(eng.to_numpy(md), m) < 1e-7 and max_abs(eng.to_numpy(vd), v) < 1e-7
+        # fma contraction on the GPU vs separately rounded mul/add in NumPy: 1 ulp
+        assert max_abs(eng.to_numpy(md), m) < 1.5e-7 and max_abs(eng.to_numpy(vd), v) < 1.5e-7
 
 
 def test_linear_only_net(eng):
@@ -163,7 +164,7 @@ def test_fused_unroll_vs_oracle(eng, name, kind, B, D, M):
     assert e_x < 1e-5 * max(1.0, float(np.abs(res.x).max()))
     for l in range(2):
         for i in range(2):
-            assert max_abs(st[l][i], res.state[l][i]) < 2e-5
+            assert max_abs(st[l][i], res.state[l][i]) < 1e-5 * max(1.0, float(np.abs(res.state[l][i]).max()))
     if cfg.kind == "rnnprop":
         assert max_abs(m, res.m.reshape(B, D)) < 1e-6 * max(1.0, np.abs(res.m).max())
 
