@@ -1,0 +1,545 @@
+"""Learning to learn (meta) optimizer -- the reference's ``DM/meta.py`` API
+(DM = /root/reference/Model_Free_L2O/"L2O-DM and L2O-RNNProp"/), session-less.
+
+``MetaOptimizer(**net_config).meta_loss(make_loss, len_unroll, net_assignments)``
+returns ``MetaLoss(loss, update, reset, fx, x)`` exactly like DM/meta.py:269-396;
+the members are *fetch handles* that ``session.Session.run`` evaluates, so the
+reference's harness (``util.run_epoch`` / ``run_eval_epoch``,
+``evaluate_dm.main``) runs unchanged in structure:
+
+    sess.run(reset)                    re-initialise x, problem data, LSTM state
+    sess.run([fx, update])             one unroll of ``len_unroll`` steps from the
+                                       current variables; ``update`` carries x_T and
+                                       the LSTM state (and RNNProp m, v) over
+
+One ``sess.run`` = ONE launch of the fused persistent HIP kernel ``l2o_unroll``
+when the (problem, net) pair has one (Quadratic / Lasso / Rastrigin with up to
+128 parameters per problem and a (20, 20) coordinate-wise LSTM), otherwise
+``len_unroll`` x {``l2o_problem_fg``, ``l2o_cwlstm_step``} launches.  Either way
+every flop of the path runs in HIP kernels behind the C ABI of
+``include/l2o_abi.h``; this module only owns buffers and control flow.
+
+Multi-GPU: with ``torch.distributed`` initialised the problem batch is sharded
+by contiguous slices over ranks, the 1/B of the loss mean stays the GLOBAL batch
+(DM/problems.py:99, 131, 211) and the only collective is one all-reduce (RCCL)
+of the ``len_unroll + 1`` partial losses per unroll.
+"""
+from __future__ import annotations
+
+import collections
+import os
+
+import numpy as np
+import torch
+
+from . import _abi, _engine, networks
+from ._engine import ProblemDesc
+
+MetaLoss = collections.namedtuple("MetaLoss", "loss, update, reset, fx, x")     # DM/meta.py:158
+MetaStep = collections.namedtuple("MetaStep", "step, update, reset, fx, x")     # DM/meta.py:159
+
+_rng = np.random.default_rng(0)
+
+
+def set_random_seed(seed):
+    """Seed for the optimizee initialisers (x0, W, y ...) and the network weights --
+    the analogue of ``tf.set_random_seed`` (DM/evaluate_dm.py:51-52)."""
+    global _rng
+    _rng = np.random.default_rng(seed)
+    networks.set_random_seed(None if seed is None else seed + 1)
+
+
+# ---------------------------------------------------------------------------
+# handles
+# ---------------------------------------------------------------------------
+class Fetch(object):
+    """Something ``Session.run`` can evaluate: (graph, key)."""
+
+    def __init__(self, graph, key, name=None):
+        self.graph, self.key, self.name = graph, key, name or key
+
+    def __repr__(self):
+        return "<Fetch %s>" % self.name
+
+
+class Placeholder(object):
+    """``tf.placeholder`` / ``placeholder_with_default`` analogue (scale, step)."""
+
+    def __init__(self, name, shape, default=None, dtype="float32"):
+        self.name, self.shape, self.default, self.dtype = name, tuple(shape), default, dtype
+
+    def __repr__(self):
+        return "<Placeholder %s %s>" % (self.name, self.shape)
+
+
+class Variable(object):
+    """An optimizee variable (``tf.Variable`` analogue): ``name`` ("x:0"), ``shape`` (the
+    GLOBAL shape), ``value`` (device tensor holding this rank's batch shard)."""
+
+    def __init__(self, decl, graph, sharded):
+        self.decl = decl
+        self.name = decl.name + ":0"
+        self.shape = decl.shape
+        self.trainable = decl.trainable
+        self._graph = graph
+        self.sharded = sharded
+        self.value = None
+
+    def _local(self, arr):
+        arr = np.asarray(arr, np.float32).reshape(self.shape)
+        if self.sharded:
+            lo, hi = self._graph.shard
+            arr = arr[lo:hi]
+        return np.ascontiguousarray(arr)
+
+    def initial_value(self):
+        init = self.decl.initializer
+        shape = self.shape
+        if init is None or init[0] == "zeros":
+            arr = np.zeros(shape, np.float32)
+        elif init[0] == "ones":
+            arr = np.ones(shape, np.float32)
+        elif init[0] == "normal":
+            arr = (_rng.standard_normal(shape) * init[2] + init[1]).astype(np.float32)
+        elif init[0] == "uniform":
+            arr = (_rng.random(shape) * (init[2] - init[1]) + init[1]).astype(np.float32)
+        elif init[0] == "constant":
+            arr = np.broadcast_to(init[1], shape).astype(np.float32)
+        else:
+            raise ValueError("unknown initializer %r" % (init,))
+        return arr
+
+    def initialize(self):
+        self.value = self._graph.engine.tensor(self._local(self.initial_value()))
+
+    def load(self, value, session=None):
+        """tf.Variable.load: assign a (global-shape) value."""
+        self.value = self._graph.engine.tensor(self._local(value))
+
+    def eval(self, session=None):
+        """This rank's shard as an ndarray."""
+        return self._graph.engine.to_numpy(self.value)
+
+    def __repr__(self):
+        return "<Variable %s %s>" % (self.name, self.shape)
+
+
+class PackedState(object):
+    """LSTM state of one variable in the packed tile-major device layout
+    (``l2o_state_floats``); ``unpack()`` gives the reference structure
+    ``((hidden_1, cell_1), (hidden_2, cell_2))`` with [N, H] arrays
+    (DM/networks.py:234-236; index [l][0] = hidden, [l][1] = cell)."""
+
+    def __init__(self, engine, packed, B, D, layers):
+        self.engine, self.packed, self.B, self.D, self.layers = engine, packed, B, D, tuple(layers)
+
+    @classmethod
+    def zeros(cls, engine, B, D, layers):
+        layers = tuple(layers)
+        if len(layers) == 0:
+            return cls(engine, None, B, D, layers)
+        return cls(engine, engine.state_alloc(B, D), B, D, layers)
+
+    def clone(self):
+        return PackedState(self.engine, None if self.packed is None else self.packed.clone(), self.B, self.D,
+                           self.layers)
+
+    def zero_(self):
+        if self.packed is not None:
+            self.packed.zero_()
+
+    def unpack(self):
+        if self.packed is None:
+            return ()
+        h1, c1, h2, c2 = self.engine.state_unpack(self.packed, self.B, self.D)
+        return ((h1, c1), (h2, c2))
+
+    def load(self, state):
+        (h1, c1), (h2, c2) = state
+        t = self.engine.tensor
+        self.packed = self.engine.state_pack(t(h1), t(c1), t(h2), t(c2), self.B, self.D)
+
+
+# ---------------------------------------------------------------------------
+# net construction, DM/meta.py:162-216
+# ---------------------------------------------------------------------------
+def _make_nets(variables, config, net_assignments):
+    """Creates the optimizer networks; returns (nets, keys, subsets).  DM/meta.py:162-216."""
+    name_to_index = dict((v.name.split(":")[0], i) for i, v in enumerate(variables))
+    if net_assignments is None:
+        if len(config) != 1:
+            raise ValueError("Default net_assignments can only be used if there is "
+                             "a single net config.")
+        key = next(iter(config))
+        kwargs = config[key]
+        net = networks.factory(**kwargs)
+        nets = {key: net}
+        keys = [key]
+        subsets = [list(range(len(variables)))]
+    else:
+        nets = {}
+        keys = []
+        subsets = []
+        for key, names in net_assignments:
+            if key in nets:
+                raise ValueError("Repeated netid in net_assigments.")
+            nets[key] = networks.factory(**config[key])
+            subset = [name_to_index[name] for name in names]
+            keys.append(key)
+            subsets.append(subset)
+    return nets, keys, subsets
+
+
+_DEFAULT_CONFIG = {
+    "coordinatewise": {
+        "net": "CoordinateWiseDeepLSTM",
+        "net_options": {
+            "layers": (20, 20),
+            "preprocess_name": "LogAndSign",
+            "preprocess_options": {"k": 5},
+            "scale": 0.01,
+        }}}
+
+
+def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+# ---------------------------------------------------------------------------
+# the unroll "graph"
+# ---------------------------------------------------------------------------
+class _Slot(object):
+    """One (net, variable) pairing: the LSTM state (and RNNProp moments) of a variable."""
+
+    def __init__(self, key, net, var_index):
+        self.key, self.net, self.var_index = key, net, var_index
+        self.state = None      # PackedState | Adam tuple | []
+        self.m = None
+        self.v = None
+
+
+class UnrollGraph(object):
+    """Everything one ``meta_loss`` call builds (DM/meta.py:293-394)."""
+
+    def __init__(self, optimizer, make_loss, len_unroll, net_assignments, rnnprop=False, beta1=0.95,
+                 beta2=0.95, engine=None):
+        self.engine = engine or _engine.default_engine()
+        self.len_unroll = int(len_unroll)
+        self.rnnprop = rnnprop
+        self.beta1, self.beta2 = float(beta1), float(beta2)
+        self.rank, self.world = _world()
+
+        loss = make_loss()                                            # _get_variables, :293
+        self.terms = list(loss.terms)
+        decls = list(loss.variables)
+        batched_kinds = (_abi.PROB_QUADRATIC, _abi.PROB_LASSO, _abi.PROB_RASTRIGIN)
+        self.sharded = self.world > 1 and all(t.kind in batched_kinds for t in self.terms)
+        B_global = decls[0].shape[0] if self.sharded else None
+        if self.sharded:
+            if any(d.shape[0] != B_global for d in decls):
+                raise ValueError("cannot shard: variables disagree on the batch dimension")
+            if B_global % self.world:
+                raise ValueError("batch_size %d is not divisible by world size %d" % (B_global, self.world))
+            per = B_global // self.world
+            self.shard = (self.rank * per, (self.rank + 1) * per)
+        else:
+            self.shard = None
+        by_name = {}
+        self.x, self.constants = [], []
+        for d in decls:
+            v = Variable(d, self, self.sharded)
+            by_name[d.name] = v
+            (self.x if d.trainable else self.constants).append(v)
+        self._by_name = by_name
+
+        self.nets, self.net_keys, self.subsets = _make_nets(self.x, optimizer._config, net_assignments)
+        optimizer._nets = self.nets
+        for net in self.nets.values():
+            if isinstance(net, networks.StandardDeepLSTM):
+                net.spec.beta1, net.spec.beta2 = self.beta1, self.beta2
+                if rnnprop != (net.spec.kind == _abi.NET_RNNPROP):
+                    raise ValueError("RNNprop networks need the RNNProp MetaOptimizer (meta_rnnprop_eval / "
+                                     "meta_rnnprop_train) and vice versa")
+
+        # placeholders of the train / RNNProp forks (DM/meta_dm_train.py:336-338,
+        # DM/meta_rnnprop_eval.py: scale + step)
+        self.scale = [Placeholder(v.name[:-2] + "_scale", v.shape, default=None) for v in self.x]
+        self.step = Placeholder("step", (), default=None, dtype="int32")
+
+        # term of each trainable variable
+        self.term_of = {}
+        for t in self.terms:
+            if t.var.name in self.term_of:
+                raise ValueError("variable %s appears in two loss terms" % t.var.name)
+            self.term_of[t.var.name] = t
+        for v in self.x:
+            if v.decl.name not in self.term_of:
+                raise ValueError("no loss term for variable %s" % v.name)
+
+        self.slots = []
+        for subset, key in zip(self.subsets, self.net_keys):
+            for j in subset:
+                self.slots.append(_Slot(key, self.nets[key], j))
+        self._initialized = False
+        self._fx_cache = {}
+        self.last_path = None
+
+    # -- geometry helpers ----------------------------------------------------
+    def _panel_shape(self, var):
+        """[B_local, D] view of a variable for the kernels."""
+        term = self.term_of[var.decl.name]
+        if term.kind == _abi.PROB_SIMPLE:
+            return 1, int(np.prod(var.shape)) if len(var.shape) else 1
+        B = var.shape[0]
+        if self.sharded:
+            B = self.shard[1] - self.shard[0]
+        return B, int(np.prod(var.shape[1:]))
+
+    def _desc(self, var, x_scale):
+        term = self.term_of[var.decl.name]
+        B, D = self._panel_shape(var)
+        if term.kind == _abi.PROB_SIMPLE:
+            return ProblemDesc(_abi.PROB_SIMPLE, 1, 1, D, x_scale=x_scale)
+        Bg = var.shape[0]
+        W = self._by_name[term.consts["W"].name].value
+        y = self._by_name[term.consts["y"].name].value
+        C = self._by_name[term.consts["C"].name].value if "C" in term.consts else None
+        M = term.consts["W"].shape[1]
+        return ProblemDesc(term.kind, B, Bg, D, M=M, l1=term.hyper.get("l1", 0.0),
+                           alpha=term.hyper.get("alpha", 0.0), W=W, y=y, C=C, x_scale=x_scale)
+
+    # -- reset / init (DM/meta.py:379-383; RNNProp :559-566) -------------------
+    def reset(self):
+        eng = self.engine
+        for v in self.x + self.constants:
+            v.initialize()
+        for s in self.slots:
+            var = self.x[s.var_index]
+            B, D = self._panel_shape(var)
+            if isinstance(s.net, networks.StandardDeepLSTM):
+                s.state = PackedState.zeros(eng, B, D, s.net.spec.layers)
+                if self.rnnprop:
+                    s.m, s.v = eng.zeros(B, D), eng.zeros(B, D)
+            else:
+                s.state = s.net.initial_state_for_inputs(var.value)
+        self._initialized = True
+
+    def _ensure_init(self):
+        if not self._initialized:
+            self.reset()
+
+    # -- execution -------------------------------------------------------------
+    def _fused_ok(self, descs):
+        if len(self.x) != 1 or len(self.slots) != 1 or len(self.terms) != 1:
+            return False
+        s = self.slots[0]
+        if not isinstance(s.net, networks.StandardDeepLSTM) or self.terms[0].weight != 1.0:
+            return False
+        if os.environ.get("L2O_DISABLE_FUSED"):
+            return False
+        return self.engine.unroll_supported(s.net.spec, descs[0])
+
+    def execute(self, feed, commit):
+        """Run one unroll from the current variables.  Returns dict(loss, fx, x)."""
+        self._ensure_init()
+        eng = self.engine
+        T = self.len_unroll
+        feed = feed or {}
+        # placeholders
+        scales = []
+        for ph, var in zip(self.scale, self.x):
+            if ph in feed:
+                arr = var._local(feed[ph])
+                B, D = self._panel_shape(var)
+                scales.append(eng.tensor(arr.reshape(B, D)))
+            else:
+                scales.append(None)
+        step0 = 1
+        if self.rnnprop:
+            if self.step not in feed:
+                raise ValueError("You must feed a value for placeholder 'step' (DM/util.py:59-60)")
+            step0 = int(feed[self.step])
+
+        # buffers: run in place on the live tensors when `update` is fetched, on copies otherwise
+        xs = [v.value if commit else v.value.clone() for v in self.x]
+        slots = self.slots
+        states, ms, vs = [], [], []
+        for s in slots:
+            if isinstance(s.state, PackedState):
+                states.append(s.state if commit else s.state.clone())
+            else:
+                states.append(s.state)
+            ms.append(s.m if (commit or s.m is None) else s.m.clone())
+            vs.append(s.v if (commit or s.v is None) else s.v.clone())
+
+        descs = [self._desc(v, sc) for v, sc in zip(self.x, scales)]
+        panels = []
+        for xv, var in zip(xs, self.x):
+            B, D = self._panel_shape(var)
+            panels.append(xv.view(B, D))
+
+        key = T
+        if key not in self._fx_cache:
+            self._fx_cache[key] = eng.zeros(T + 1)
+        fx = self._fx_cache[key]
+
+        if self._fused_ok(descs):
+            self.last_path = "fused"
+            s, d = slots[0], descs[0]
+            fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
+            eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
+                       fx_part)
+            eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
+        else:
+            self.last_path = "steps"
+            self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx)
+
+        if self.sharded:
+            import torch.distributed as dist
+            dist.all_reduce(fx)
+        fx_host = eng.to_numpy(fx)
+
+        if commit:
+            for s, st in zip(slots, states):
+                s.state = st
+        x_out = [eng.to_numpy(xv).reshape(self._local_shape(var)) for xv, var in zip(xs, self.x)]
+        return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
+                "x": x_out, "fx_array": fx_host}
+
+    def _local_shape(self, var):
+        if self.sharded:
+            return (self.shard[1] - self.shard[0],) + tuple(var.shape[1:])
+        return var.shape
+
+    def _scratch(self, name, n):
+        buf = getattr(self, "_scr_" + name, None)
+        if buf is None or buf.numel() < n:
+            buf = self.engine.zeros(n)
+            setattr(self, "_scr_" + name, buf)
+        return buf[:n]
+
+    def _run_steps(self, T, step0, descs, panels, slots, states, ms, vs, fx):
+        """Step-granular path: per step one l2o_problem_fg per term and one
+        l2o_cwlstm_step per (net, variable)."""
+        eng = self.engine
+        nvar = len(self.x)
+        f_parts = [self._scratch("f%d" % j, descs[j].B_local) for j in range(nvar)]
+        grads = [self._scratch("g%d" % j, descs[j].B_local * descs[j].D).view(descs[j].B_local, descs[j].D)
+                 for j in range(nvar)]
+        tmp = self._scratch("fx1", 1)
+        weights = [self.term_of[v.decl.name].weight for v in self.x]
+        simple_single = nvar == 1 and weights[0] == 1.0
+        b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
+
+        def forward(t, want_grad):
+            if not simple_single:
+                fx[t:t + 1].zero_()
+            for j in range(nvar):
+                eng.problem_fg(descs[j], panels[j], f_parts[j], grads[j] if want_grad else None)
+                if simple_single:
+                    eng.reduce_fx(f_parts[j], 1, descs[j].B_local, descs[j].B_global, fx[t:t + 1])
+                else:
+                    eng.reduce_fx(f_parts[j], 1, descs[j].B_local, descs[j].B_global, tmp)
+                    fx[t:t + 1].add_(tmp, alpha=float(weights[j]))
+                    if want_grad and weights[j] != 1.0:
+                        grads[j].mul_(float(weights[j]))
+
+        for t in range(T):
+            forward(t, True)
+            k = step0 + t
+            for si, s in enumerate(slots):
+                j = s.var_index
+                B, D = descs[j].B_local, descs[j].D
+                if isinstance(s.net, networks.StandardDeepLSTM):
+                    eng.lstm_step(s.net.spec, s.net.wpack(eng), grads[j], ms[si], vs[si], b1 ** k, b2 ** k,
+                                  None if states[si].packed is None else states[si].packed, panels[j], B, D)
+                else:                                    # Sgd / Adam baseline nets
+                    delta, states[si] = s.net(grads[j], states[si])
+                    panels[j].add_(delta.view(B, D))
+        forward(T, False)
+
+
+# ---------------------------------------------------------------------------
+# MetaOptimizer
+# ---------------------------------------------------------------------------
+class MetaOptimizer(object):
+    """Learning to learn (meta) optimizer.  DM/meta.py:219-414.
+
+    Optimizer which has an internal RNN which takes as input, at each iteration,
+    the gradient of the function being minimized and returns a step direction.
+    """
+
+    _rnnprop = False
+
+    def __init__(self, **kwargs):
+        """``**kwargs`` maps network identifiers to ``networks.factory`` parameters
+        (DM/meta.py:228-253); no kwargs = the default coordinate-wise LogAndSign net."""
+        self._nets = None
+        self._graph = None
+        self.beta1 = self.beta2 = 0.95
+        if not kwargs:
+            self._config = {k: dict(v) for k, v in _DEFAULT_CONFIG.items()}
+        else:
+            self._config = kwargs
+
+    # -- checkpoints: DM/meta.py:255-267, DM/meta_dm_train.py:257-302 ----------
+    def save(self, sess=None, path=None, index=None):
+        """Save meta-optimizer: ``{path}/{k}.l2l`` (or ``.l2l-{index}``), dill pickles of
+        {module: {variable: ndarray}}."""
+        result = {}
+        for k, net in self._nets.items():
+            if path is None:
+                filename = None
+                key = k
+            elif index is not None:
+                filename = os.path.join(path, "{}.l2l-{}".format(k, index))
+                key = filename
+            else:
+                filename = os.path.join(path, "{}.l2l".format(k))
+                key = filename
+            net_vars = networks.save(net, sess, filename=filename)
+            result[key] = net_vars
+        return result
+
+    def restorer(self):
+        """DM/meta_dm_train.py:274-287 builds assign placeholders; nothing to build here."""
+
+    def restore(self, sess, path, index):
+        """DM/meta_dm_train.py:289-302: load ``{k}.l2l-{index}`` back into the live nets."""
+        import dill as pickle
+        for k, net in self._nets.items():
+            filename = os.path.join(path, "{}.l2l-{}".format(k, index))
+            with open(filename, "rb") as f:
+                data = pickle.load(f)
+            for module_name, variables in net.variables.items():
+                for variable_name in variables:
+                    net.assign(module_name, variable_name, data[module_name][variable_name])
+
+    # -- the unroll ------------------------------------------------------------
+    def _build_graph(self, make_loss, len_unroll, net_assignments, second_derivatives):
+        if second_derivatives:
+            raise NotImplementedError("second_derivatives=True needs the meta-gradient path (SURVEY.md 8f)")
+        graph = UnrollGraph(self, make_loss, len_unroll, net_assignments, rnnprop=self._rnnprop,
+                            beta1=self.beta1, beta2=self.beta2)
+        self._graph = graph
+        return graph
+
+    @staticmethod
+    def _handles(graph):
+        return MetaLoss(Fetch(graph, "loss"), [Fetch(graph, "update")], [Fetch(graph, "reset")],
+                        Fetch(graph, "fx"), [Fetch(graph, ("x", j), "x_final_%d" % j) for j in range(len(graph.x))])
+
+    def meta_loss(self, make_loss, len_unroll, net_assignments=None, second_derivatives=False):
+        """Returns handles computing the meta-loss: namedtuple (loss, update, reset, fx, x).
+        DM/meta.py:269-396."""
+        return self._handles(self._build_graph(make_loss, len_unroll, net_assignments, second_derivatives))
+
+    def meta_minimize(self, make_loss, len_unroll, learning_rate=0.01, **kwargs):
+        """DM/meta.py:398-414 (Adam on the meta-loss through BPTT).  The meta-gradient is
+        not part of this build's hot path."""
+        raise NotImplementedError(
+            "meta_minimize needs the meta-gradient (BPTT through the unroll), which is the next scope row "
+            "(SURVEY.md 8f rank 2); this build accelerates the forward unroll (meta_loss)")

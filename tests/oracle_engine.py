@@ -1,0 +1,183 @@
+"""An engine with the interface of open_l2o_amd._engine.HipEngine whose arithmetic is the
+NumPy oracle, on CPU torch tensors.  TEST INFRASTRUCTURE ONLY: it lets the CPU suite
+exercise the host logic of open_l2o_amd.meta (session semantics, net assignments,
+checkpoints, batch sharding + all-reduce under gloo) without a GPU.  It lives under
+tests/ -- the package has no CPU compute path."""
+import numpy as np
+import torch
+
+import oracle as O
+from open_l2o_amd import _abi
+from open_l2o_amd._engine import pack_weights_host
+
+
+def _cfg_of(spec):
+    if spec.kind == _abi.NET_RNNPROP:
+        return O.NetConfig("rnnprop", tuple(spec.layers), "fc", {"dim": 20}, spec.scale, spec.tanh_output)
+    if spec.preprocess == _abi.PRE_LOGSIGN:
+        return O.NetConfig("cw", tuple(spec.layers), "LogAndSign", {"k": spec.logsign_k}, spec.scale,
+                           spec.tanh_output)
+    return O.NetConfig("cw", tuple(spec.layers), "identity", None, spec.scale, spec.tanh_output)
+
+
+def pack_state(h1, c1, h2, c2, B, D):
+    """The documented packed layout, vectorised."""
+    tpp = (D + 15) // 16
+    ref = np.zeros((4, B, tpp * 16, 20), np.float32)
+    for a, arr in enumerate((h1, c1, h2, c2)):
+        ref[a, :, :D] = np.asarray(arr, np.float32).reshape(B, D, 20)
+    p = ref.reshape(4, B, tpp, 16, 5, 4)                 # a, b, tw, c, t, q
+    p = p.transpose(1, 2, 0, 4, 5, 3)                    # b, tw, a, t, q, c
+    p = p.reshape(B, tpp, 20, 64)                        # e = a*5+t ; lane = q*16+c
+    p = p.reshape(B, tpp, 5, 4, 64).transpose(0, 1, 2, 4, 3)   # b, tw, j, lane, w
+    return np.ascontiguousarray(p).reshape(-1)
+
+
+def unpack_state(st, B, D):
+    tpp = (D + 15) // 16
+    p = np.asarray(st, np.float32).reshape(B, tpp, 5, 64, 4).transpose(0, 1, 2, 4, 3)
+    p = p.reshape(B, tpp, 4, 5, 4, 16)                   # b, tw, a, t, q, c
+    p = p.transpose(2, 0, 1, 5, 3, 4).reshape(4, B, tpp * 16, 20)
+    return [np.ascontiguousarray(p[a, :, :D]).reshape(B * D, 20) for a in range(4)]
+
+
+class OracleEngine(object):
+    name = "oracle"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.lib = _abi.lib()
+        self.calls = []
+
+    def tensor(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).copy())
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32)
+
+    def empty(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32)
+
+    def to_numpy(self, t):
+        return t.detach().numpy().copy()
+
+    def pack_weights(self, spec, params):
+        # run the real host packer (validates shapes) but keep the .l2l dict for the oracle
+        t = self.tensor(pack_weights_host(self.lib, spec, params))
+        t._l2l = {k: {v: np.array(a, np.float32) for v, a in d.items()} for k, d in params.items()}
+        return t
+
+    def state_floats(self, B, D):
+        return int(self.lib.l2o_state_floats(B, D))
+
+    def state_alloc(self, B, D):
+        return self.zeros(self.state_floats(B, D))
+
+    def state_pack(self, h1, c1, h2, c2, B, D):
+        return self.tensor(pack_state(h1.numpy(), c1.numpy(), h2.numpy(), c2.numpy(), B, D))
+
+    def state_unpack(self, st, B, D, H=20):
+        return [self.tensor(a) for a in unpack_state(st.numpy(), B, D)]
+
+    # ------------------------------------------------------------------ compute
+    def _oracle_problem(self, p):
+        n = lambda t: None if t is None else t.numpy()
+        if p.kind == _abi.PROB_SIMPLE:
+            return O.SimpleMulti(p.D), (p.D,)
+        if p.kind == _abi.PROB_QUADRATIC:
+            return O.Quadratic(n(p.W).reshape(p.B_local, p.M, p.D), n(p.y).reshape(p.B_local, p.M),
+                               batch_global=p.B_global), (p.B_local, p.D)
+        if p.kind == _abi.PROB_LASSO:
+            return O.Lasso(n(p.W).reshape(p.B_local, p.M, p.D), n(p.y).reshape(p.B_local, p.M, 1), p.l1,
+                           batch_global=p.B_global), (p.B_local, p.D)
+        if p.kind == _abi.PROB_RASTRIGIN:
+            return O.Rastrigin(n(p.W).reshape(p.B_local, p.D, p.D), n(p.y).reshape(p.B_local, p.D, 1),
+                               n(p.C).reshape(p.B_local, p.D, 1), p.alpha,
+                               batch_global=p.B_global), (p.B_local, p.D, 1)
+        raise _abi.L2OUnsupported(-2, "kind %d" % p.kind)
+
+    def problem_fg(self, p, x, f_part, g):
+        self.calls.append("problem_fg")
+        prob, shape = self._oracle_problem(p)
+        xs = x.numpy().reshape(p.B_local, p.D)
+        s = None if p.x_scale is None else p.x_scale.numpy().reshape(p.B_local, p.D)
+        xin = (xs if s is None else xs * s).reshape(shape)
+        if p.kind == _abi.PROB_SIMPLE:
+            f_part.copy_(torch.from_numpy(np.array([prob.f(xin)], np.float32)))
+            gr = prob.grad(xin)
+        else:
+            f_part.copy_(torch.from_numpy(prob.f_per_problem(xin).astype(np.float32)))
+            gr = prob.grad(xin)
+        if g is not None:
+            gr = gr.reshape(p.B_local, p.D)
+            if s is not None:
+                gr = gr * s
+            g.copy_(torch.from_numpy(gr.astype(np.float32)).view_as(g))
+
+    def lstm_step(self, spec, wpack, g, m, v, pow1, pow2, st, x, B, D):
+        self.calls.append("lstm_step")
+        cfg = _cfg_of(spec)
+        params = wpack._l2l
+        gn = g.numpy().reshape(B, D)
+        if len(cfg.layers):
+            h1, c1, h2, c2 = unpack_state(st.numpy(), B, D)
+            state = ((h1, c1), (h2, c2))
+        else:
+            state = ()
+        dt = np.float32
+        if cfg.kind == "rnnprop":
+            mn = dt(spec.beta1) * m.numpy() + dt(1.0 - spec.beta1) * gn
+            vn = dt(spec.beta2) * v.numpy() + dt(1.0 - spec.beta2) * gn * gn
+            mh = mn / (dt(1) - dt(pow1))
+            vh = vn / (dt(1) - dt(pow2))
+            inputs = (mh / (np.sqrt(vh) + dt(1e-8)), gn / (np.sqrt(vh) + dt(1e-8)))
+            m.copy_(torch.from_numpy(mn))
+            v.copy_(torch.from_numpy(vn))
+        else:
+            inputs = gn
+        delta, nstate = O.net_apply(cfg, params, inputs, state)
+        x.add_(torch.from_numpy(delta.astype(np.float32)).view_as(x))
+        if len(cfg.layers):
+            st.copy_(torch.from_numpy(pack_state(nstate[0][0], nstate[0][1], nstate[1][0], nstate[1][1], B, D)))
+
+    def unroll_supported(self, spec, p):
+        cc = spec.to_c()
+        import ctypes as C
+        cp = _abi.Problem()
+        cp.kind, cp.B_local, cp.B_global, cp.D, cp.M = p.kind, p.B_local, p.B_global, p.D, p.M
+        return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))
+
+    def unroll(self, spec, wpack, p, x, st, m, v, T, step0, fx_part):
+        self.calls.append("unroll")
+        cfg = _cfg_of(spec)
+        prob, shape = self._oracle_problem(p)
+        B, D = p.B_local, p.D
+        h1, c1, h2, c2 = unpack_state(st.numpy(), B, D)
+        s = None if p.x_scale is None else p.x_scale.numpy().reshape(shape)
+        xcur = x.numpy().reshape(shape).copy()
+        state = ((h1, c1), (h2, c2))
+        mm = None if m is None else m.numpy().reshape(shape).copy()
+        vv = None if v is None else v.numpy().reshape(shape).copy()
+        fparts = np.zeros((T + 1, B), np.float32)
+        # step-by-step so that per-problem losses are available
+        for t in range(T + 1):
+            xin = xcur if s is None else xcur * s
+            fparts[t] = prob.f_per_problem(xin)
+            if t == T:
+                break
+            res = O.unroll(prob, cfg, wpack._l2l, xcur, state, 1, x_scale=s, m0=mm, v0=vv,
+                           step0=step0 + t, beta1=spec.beta1, beta2=spec.beta2)
+            xcur, state, mm, vv = res.x, res.state, res.m, res.v
+        x.copy_(torch.from_numpy(xcur.reshape(B, D)))
+        st.copy_(torch.from_numpy(pack_state(state[0][0], state[0][1], state[1][0], state[1][1], B, D)))
+        if mm is not None and m is not None:
+            m.copy_(torch.from_numpy(mm.reshape(B, D)))
+            v.copy_(torch.from_numpy(vv.reshape(B, D)))
+        fx_part.copy_(torch.from_numpy(fparts.reshape(-1)))
+
+    def reduce_fx(self, fx_part, T1, B_local, B_global, fx):
+        fp = fx_part.numpy().reshape(T1, B_local)
+        fx.copy_(torch.from_numpy((fp.sum(axis=1, dtype=np.float32) / np.float32(B_global)).astype(np.float32)))
+
+    def synchronize(self):
+        pass

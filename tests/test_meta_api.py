@@ -1,0 +1,356 @@
+"""Host-API tests: the reference's MetaOptimizer / networks / problems / util surface.
+
+Every test runs twice: with the oracle-backed engine on CPU (host logic only) and --
+marked ``gpu`` -- with the product HipEngine on the MI355X, where it is a parity test
+of the whole stack against the oracle.  Mirrors the reference's own tests
+(/root/reference/Model_Free_L2O/L2O-Swarm/src/meta_test.py, networks_test.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import ORACLE_CFGS, make_params, make_problem, rel_err
+from open_l2o_amd import (_engine, meta, meta_dm_train, meta_rnnprop_eval, meta_rnnprop_train, networks,
+                          problems, util)
+from open_l2o_amd.session import Session
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def engine(request):
+    if request.param == "oracle":
+        from oracle_engine import OracleEngine
+        eng = OracleEngine()
+    else:
+        eng = _engine.HipEngine()
+    old = _engine._default_engine
+    _engine.set_default_engine(eng)
+    yield eng
+    _engine.set_default_engine(old)
+
+
+def _net_config(cfg, params, key="cw"):
+    opts = {"layers": cfg.layers, "initializer": params}
+    if cfg.kind == "rnnprop":
+        opts.update(preprocess_name="fc", preprocess_options={"dim": 20}, scale=cfg.scale, tanh_output=True)
+        return {key: {"net": "RNNprop", "net_options": opts}}
+    if cfg.preprocess_name == "LogAndSign":
+        opts.update(preprocess_name="LogAndSign", preprocess_options=dict(cfg.preprocess_options),
+                    scale=cfg.scale)
+    return {key: {"net": "CoordinateWiseDeepLSTM", "net_options": opts}}
+
+
+# ------------------------------------------------------------- meta_test.py:50-69
+def test_results_golden(engine):
+    """Reproducibility of the Torch results quoted by the reference test: cost 0.7325327,
+    final_x 0.8559.  Unroll 1 runs the all-zero net ("initializer": "zeros"); Adam's first
+    meta-step makes w = b = -0.01 (derivation in tests/test_oracle_kat.py); unroll 2."""
+    problem = problems.simple()
+    optimizer = meta.MetaOptimizer(net=dict(net="CoordinateWiseDeepLSTM",
+                                            net_options={"layers": (), "initializer": "zeros"}))
+    loss, update, reset, fx, x = optimizer.meta_loss(problem, 5)
+    with Session() as sess:
+        sess.run(reset)
+        cost, final_x, _ = sess.run([fx, x, update])
+        assert cost == 1.0 and final_x[0] == 1.0
+        net = optimizer._nets["net"]
+        net.assign("linear", "w", np.full((1, 1), -0.01))       # what tf.train.AdamOptimizer(0.01) does
+        net.assign("linear", "b", np.full((1,), -0.01))
+        cost, final_x, _ = sess.run([fx, x, update])
+    assert abs(float(cost) - 0.7325327) < 5e-5                    # assertAlmostEqual(places=4)
+    assert abs(float(final_x[0]) - 0.8559) < 5e-5
+
+
+# ------------------------------------------------------------- meta_test.py:71-126
+@pytest.mark.parametrize("net_assignments,net_config", [
+    (None, {"net": {"net": "CoordinateWiseDeepLSTM", "net_options": {"layers": (20, 20)}}}),
+    ([("net", ["x_0", "x_1"])], {"net": {"net": "CoordinateWiseDeepLSTM", "net_options": {"layers": (20, 20)}}}),
+    ([("net1", ["x_0"]), ("net2", ["x_1"])],
+     {"net1": {"net": "CoordinateWiseDeepLSTM", "net_options": {"layers": (20, 20)}}, "net2": {"net": "Adam"}}),
+    ([("net1", ["x_0"]), ("net2", ["x_0"])],
+     {"net1": {"net": "CoordinateWiseDeepLSTM", "net_options": {"layers": (20, 20)}},
+      "net2": {"net": "CoordinateWiseDeepLSTM", "net_options": {"layers": ()}}}),
+])
+def test_multi_optimizer(engine, net_assignments, net_config):
+    """Different variable->net mappings in the multi-optimizer problem run and agree with
+    a direct oracle evaluation of the same wiring."""
+    problem = problems.simple_multi_optimizer(num_dims=2)
+    optimizer = meta.MetaOptimizer(**net_config)
+    ml = optimizer.meta_loss(problem, 3, net_assignments=net_assignments)
+    with Session() as sess:
+        sess.run(ml.reset)
+        cost, xs, _ = sess.run([ml.fx, ml.x, ml.update])
+        cost2, xs2, _ = sess.run([ml.fx, ml.x, ml.update])
+    assert np.isfinite(cost) and np.isfinite(cost2)
+    assert len(xs) == 2
+    # oracle: replay with the same nets
+    nets = optimizer._nets
+    x = [np.ones((), np.float32), np.ones((), np.float32)]
+    assign = net_assignments or [(next(iter(nets)), ["x_0", "x_1"])]
+    state = {}
+    for t in range(3):
+        g = [np.float32(2) * xi for xi in x]
+        deltas = [np.float32(0), np.float32(0)]
+        for key, names in assign:
+            net = nets[key]
+            for nm in names:
+                j = int(nm[-1])
+                sk = (key, j)
+                if isinstance(net, networks.Adam):
+                    st = state.get(sk, (np.float32(0), np.zeros((1, 1), np.float32), np.zeros((1, 1), np.float32)))
+                    d, state[sk] = O.adam_net(g[j].reshape(1), st, 1e-3)
+                    deltas[j] = deltas[j] + d[0]
+                else:
+                    cfg = O.NetConfig("cw", net.spec.layers, "identity", None, 1.0, False)
+                    st = state.get(sk, O.net_initial_state(cfg, 1))
+                    d, state[sk] = O.net_apply(cfg, net.variables, g[j].reshape(1), st)
+                    deltas[j] = deltas[j] + d[0]
+        x = [xi + di for xi, di in zip(x, deltas)]
+    np.testing.assert_allclose([float(v) for v in xs], [float(v) for v in x], rtol=2e-6)
+    assert rel_err(cost, float(x[0]) ** 2 + float(x[1]) ** 2) < 1e-5
+
+
+def test_default_assignment_needs_single_net(engine):
+    optimizer = meta.MetaOptimizer(a={"net": "Adam"}, b={"net": "Sgd"})
+    with pytest.raises(ValueError, match="single net config"):
+        optimizer.meta_loss(problems.simple(), 2)
+    optimizer = meta.MetaOptimizer(a={"net": "Sgd"})
+    with pytest.raises(ValueError, match="Repeated netid"):
+        optimizer.meta_loss(problems.simple_multi_optimizer(), 2,
+                            net_assignments=[("a", ["x_0"]), ("a", ["x_1"])])
+
+
+# ------------------------------------------------------------- the harness path
+@pytest.mark.parametrize("name", ["dm", "dm_logsign"])
+@pytest.mark.parametrize("kind", ["quadratic", "lasso", "rastrigin"])
+def test_meta_loss_matches_oracle(engine, name, kind):
+    """MetaLoss(loss, update, reset, fx, x) on the registry problems == oracle unroll."""
+    cfg = ORACLE_CFGS[name]
+    params = make_params(cfg, seed=30, trained_like=True)
+    B, D, T = 6, 10, 12
+    prob, x0, arrays = make_problem(kind, B, D, seed=31)
+    if kind == "quadratic":
+        problem = problems.quadratic(batch_size=B, num_dims=D, data={"w": prob.w, "y": prob.y, "x": x0})
+    elif kind == "lasso":
+        problem = problems.lasso(batch_size=B, num_dims=D, l=prob.l, data={"w": prob.w, "y": prob.y, "x": x0})
+    else:
+        problem = problems.rastrigin(batch_size=B, num_dims=D,
+                                     data={"A": prob.A, "B": prob.B, "C": prob.C, "x": x0})
+    optimizer = meta.MetaOptimizer(**_net_config(cfg, params))
+    ml = optimizer.meta_loss(problem, T)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    res2 = O.unroll(prob, cfg, params, res.x, res.state, T)
+    with Session() as sess:
+        sess.run(ml.reset)
+        # fetching without `update` must not move the variables
+        l0, f0 = sess.run([ml.loss, ml.fx])
+        l1, f1, x1, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
+        assert l0 == l1 and f0 == f1
+        l2, f2, x2, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
+    assert optimizer._graph.last_path == "fused"
+    assert rel_err(l1, res.loss) < 1e-5 and rel_err(f1, res.fx[-1]) < 1e-5
+    assert rel_err(l2, res2.loss) < 2e-5 and rel_err(f2, res2.fx[-1]) < 2e-5
+    np.testing.assert_allclose(x1[0], res.x, rtol=1e-4, atol=1e-6)
+    assert x1[0].shape == x0.shape
+
+
+def test_fused_and_step_paths_agree(engine, monkeypatch):
+    cfg = O.DM_IDENTITY
+    params = make_params(cfg, seed=32, trained_like=True)
+    B, D, T = 5, 20, 10
+    prob, x0, _ = make_problem("quadratic", B, D, seed=33)
+    out = {}
+    for mode in ("fused", "steps"):
+        if mode == "steps":
+            monkeypatch.setenv("L2O_DISABLE_FUSED", "1")
+        optimizer = meta.MetaOptimizer(**_net_config(cfg, params))
+        ml = optimizer.meta_loss(problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0}), T)
+        with Session() as sess:
+            sess.run(ml.reset)
+            out[mode] = sess.run([ml.loss, ml.fx, ml.update])[:2]
+        assert optimizer._graph.last_path == mode
+    assert rel_err(out["fused"][0], out["steps"][0]) < 1e-5
+    assert rel_err(out["fused"][1], out["steps"][1]) < 1e-5
+
+
+def test_evaluate_dm_flow(engine):
+    """DM/evaluate_dm.py:70-91: util.get_config -> meta_loss(problem, 1) -> reset ->
+    run_eval_epoch: the loss record is [f(x_1), ..., f(x_K)]."""
+    meta.set_random_seed(5)
+    problem, net_config, net_assignments = util.get_config("quadratic",
+                                                           problem_options={"batch_size": 8, "num_dims": 6})
+    optimizer = meta.MetaOptimizer(**net_config)
+    meta_loss = optimizer.meta_loss(problem, 1, net_assignments=net_assignments)
+    _, update, reset, cost_op, _ = meta_loss
+    K = 7
+    with Session() as sess:
+        sess.run(reset)
+        g = optimizer._graph
+        w, y, x0 = g._by_name["w"].eval(), g._by_name["y"].eval(), g._by_name["x"].eval()
+        time, cost = util.run_eval_epoch(sess, cost_op, [update], K)
+    assert len(cost) == K and time > 0
+    cfg = O.DM_IDENTITY
+    res = O.unroll(O.Quadratic(w, y), cfg, optimizer._nets["cw"].variables, x0,
+                   O.net_initial_state(cfg, x0.size), K)
+    assert rel_err(np.array(cost), res.fx[1:]) < 1e-5
+    util.print_stats("Epoch 1", sum(cost) / K, time, 1)
+
+
+def test_reset_resamples_problem(engine):
+    meta.set_random_seed(6)
+    problem, net_config, _ = util.get_config("quadratic", problem_options={"batch_size": 4, "num_dims": 5})
+    optimizer = meta.MetaOptimizer(**net_config)
+    ml = optimizer.meta_loss(problem, 2)
+    with Session() as sess:
+        sess.run(ml.reset)
+        w1 = optimizer._graph._by_name["w"].eval()
+        t, c = util.run_epoch(sess, ml.fx, [ml.update], ml.reset, 3)
+        w2 = optimizer._graph._by_name["w"].eval()
+    assert np.isfinite(c) and not np.array_equal(w1, w2)
+    assert w1.shape == (4, 5, 5) and w1.min() >= 0 and w1.max() < 1
+
+
+def test_get_config_registry():
+    for name in ("simple", "simple-multi", "quadratic", "rastrigin", "lasso"):
+        problem, net_config, _ = util.get_config(name)
+        assert callable(problem)
+        loss = problem()
+        assert len(loss.variables) >= 1
+    problem, net_config, _ = util.get_config("quadratic", net_name="RNNprop")
+    assert net_config["rp"]["net"] == "RNNprop" and net_config["rp"]["net_options"]["tanh_output"]
+    loss = util.get_config("quadratic")[0]()
+    assert [v.shape for v in loss.variables] == [(128, 10), (128, 10, 10), (128, 10)]
+    assert [v.shape for v in util.get_config("rastrigin")[0]().variables][0] == (128, 2, 1)
+    with pytest.raises(ValueError, match="is not a valid problem"):
+        util.get_config("no-such-problem")
+    with pytest.raises(NotImplementedError):
+        util.get_config("mnist")
+    cfgd = util.get_default_net_config("p")
+    assert cfgd["net_options"]["preprocess_options"] == {"k": 5} and cfgd["net_path"] == "p"
+
+
+# ------------------------------------------------------------- RNNProp
+def test_rnnprop_eval_flow(engine):
+    """DM/evaluate_rnnprop.py:73-92 with DM/util.py:78-89 feeding step = i + 1."""
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=34, trained_like=True)
+    B, D, K = 4, 12, 9
+    prob, x0, _ = make_problem("lasso", B, D, seed=35)
+    problem = problems.lasso(batch_size=B, num_dims=D, l=prob.l, data={"w": prob.w, "y": prob.y, "x": x0})
+    optimizer = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+    meta_loss, scale, xvars, step = optimizer.meta_loss(problem, 1)
+    _, update, reset, cost_op, _ = meta_loss
+    assert len(scale) == 1 and len(xvars) == 1 and step.name == "step"
+    with Session() as sess:
+        sess.run(reset)
+        with pytest.raises(ValueError, match="step"):
+            sess.run([cost_op])
+        _, cost = util.run_eval_epoch(sess, cost_op, [update], K, step=step, unroll_len=1)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), K, step0=1)
+    assert rel_err(np.array(cost), res.fx[1:]) < 1e-5
+    # one 9-step unroll == nine 1-step unrolls
+    optimizer2 = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+    ml2, _, _, step2 = optimizer2.meta_loss(problem, K)
+    with Session() as sess:
+        sess.run(ml2.reset)
+        fxK = sess.run([ml2.fx, ml2.update], feed_dict={step2: 1})[0]
+    assert rel_err(fxK, cost[-1]) < 1e-5
+
+
+def test_train_fork_arities_and_scale_placeholder(engine):
+    cfg = O.DM_LOGSIGN
+    params = make_params(cfg, seed=36, trained_like=True)
+    B, D, T = 3, 8, 6
+    prob, x0, _ = make_problem("quadratic", B, D, seed=37)
+    problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+    optimizer = meta_dm_train.MetaOptimizer(0, **_net_config(cfg, params))
+    out = optimizer.meta_loss(problem, T)
+    assert len(out) == 10                                          # DM/meta_dm_train.py:526-527
+    ml, scale, x, constants, subsets = out[:5]
+    assert [c.name for c in constants] == ["w:0", "y:0"] and subsets == [[0]]
+    rng = np.random.default_rng(38)
+    xs = np.exp(rng.uniform(-1, 1, (B, D))).astype(np.float32)
+    with Session() as sess:
+        sess.run(ml.reset)
+        fx = sess.run([ml.fx, ml.update], feed_dict={scale[0]: xs})[0]
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, x_scale=xs)
+    assert rel_err(fx, res.fx[-1]) < 1e-5
+    out = meta_rnnprop_train.MetaOptimizer(0, 0.95, 0.95, **_net_config(O.RNNPROP, make_params(O.RNNPROP, 1),
+                                                                        key="rp")).meta_loss(problem, 2)
+    assert len(out) == 11
+    with pytest.raises(NotImplementedError):
+        meta_dm_train.MetaOptimizer(1, **_net_config(cfg, params))
+    with pytest.raises(NotImplementedError):
+        optimizer.meta_minimize(problem, T)
+
+
+# ------------------------------------------------------------- meta_test.py:190-236
+def test_save_and_restore(engine, tmp_path):
+    """Saving and restoring a meta-optimizer (.l2l dill files, networks.save / factory(net_path))."""
+    layers = (20, 20)
+    networks.set_random_seed(7)
+    problem = problems.quadratic(batch_size=4, num_dims=5,
+                                 data={k: v for k, v in zip(("w", "y", "x"), _quad_data(4, 5))})
+    optimizer = meta.MetaOptimizer(net=dict(net="CoordinateWiseDeepLSTM", net_options={"layers": layers}))
+    ml = optimizer.meta_loss(problem, 3)
+    with Session() as sess:
+        sess.run(ml.reset)
+        cost, x, _ = sess.run([ml.fx, ml.x, ml.update])
+        result = optimizer.save(sess)
+        net_vars = result["net"]
+        assert set(net_vars) == {"lstm_1", "lstm_2", "linear"}
+        assert net_vars["lstm_1"]["w_gates"].shape == (21, 80) and net_vars["linear"]["w"].shape == (20, 1)
+        saved = optimizer.save(sess, path=str(tmp_path))
+    net_path = next(iter(saved))
+    assert net_path == os.path.join(str(tmp_path), "net.l2l") and os.path.exists(net_path)
+    import dill
+    on_disk = dill.load(open(net_path, "rb"))
+    np.testing.assert_array_equal(on_disk["lstm_2"]["b_gates"], net_vars["lstm_2"]["b_gates"])
+    # restore through net_path
+    optimizer2 = meta.MetaOptimizer(net=dict(net="CoordinateWiseDeepLSTM", net_options={"layers": layers},
+                                             net_path=net_path))
+    ml2 = optimizer2.meta_loss(problem, 3)
+    with Session() as sess:
+        sess.run(ml2.reset)
+        cost2, x2, _ = sess.run([ml2.fx, ml2.x, ml2.update])
+    assert abs(float(cost) - float(cost2)) <= 1e-3 * abs(float(cost))      # places=3 in the reference
+    np.testing.assert_allclose(x[0], x2[0], rtol=1e-6)
+    # indexed save + restore() (DM/meta_dm_train.py:257-302)
+    opt3 = meta_dm_train.MetaOptimizer(0, net=dict(net="CoordinateWiseDeepLSTM", net_options={"layers": layers}))
+    opt3.meta_loss(problem, 3)
+    optimizer.save(None, path=str(tmp_path), index=4)
+    opt3.restore(None, str(tmp_path), 4)
+    np.testing.assert_array_equal(opt3._nets["net"].variables["lstm_1"]["w_gates"], net_vars["lstm_1"]["w_gates"])
+
+
+def _quad_data(B, D):
+    rng = np.random.default_rng(40)
+    return (rng.random((B, D, D)).astype(np.float32), rng.random((B, D)).astype(np.float32),
+            (rng.standard_normal((B, D)) * 0.01).astype(np.float32))
+
+
+# ------------------------------------------------------------- networks_test.py
+def test_network_shapes_and_zero_init(engine):
+    """networks_test.py:29-69: output shape == input shape; zero Linear => update exactly 0."""
+    import torch
+    for init in ("zeros", {"linear": {"w": "zeros", "b": "zeros"}}, {"linear": "zeros"}):
+        net = networks.CoordinateWiseDeepLSTM(layers=(20, 20), initializer=init)
+        g = engine.tensor(np.random.default_rng(41).standard_normal((3, 3)))
+        state = net.initial_state_for_inputs(g, engine=engine)
+        update, nxt = net(g, state)
+        assert tuple(update.shape) == (3, 3)
+        assert np.all(engine.to_numpy(update) == 0)
+        assert len(nxt.unpack()) == 2 and tuple(nxt.unpack()[0][0].shape) == (9, 20)
+    net = networks.CoordinateWiseDeepLSTM(layers=(20, 20))
+    assert sum(len(v) for v in net.variables.values()) == 6
+    lr = 0.25
+    sgd = networks.Sgd(learning_rate=lr)
+    g = engine.tensor(np.ones((2, 2)))
+    upd, _ = sgd(g, sgd.initial_state_for_inputs(g))
+    np.testing.assert_allclose(engine.to_numpy(upd), -lr * np.ones((2, 2)))
+    adam = networks.Adam(learning_rate=0.0)
+    upd, st = adam(g, adam.initial_state_for_inputs(g))
+    assert np.all(engine.to_numpy(upd) == 0) and tuple(st[1].shape) == (4, 1)
+    with pytest.raises(_engine._abi.L2OUnsupported):
+        networks.CoordinateWiseDeepLSTM(layers=(1,)).wpack(engine)
