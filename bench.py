@@ -33,43 +33,60 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # algorithmic bytes per coordinate-step, SURVEY.md section 8(d): x r+w (8) + LSTM state
 # r+w (640) + optimizee row+column+y (8*D + 4)
-def alg_bytes_per_coord_step(D):
-    return 8 + 640 + 8 * D + 4
+def alg_bytes_per_coord_step(problem, net, D, M):
+    """x r+w + LSTM state r+w (+ RNNProp m, v r+w) + the optimizee's matrix
+    streamed for the forward and for the gradient."""
+    base = 8 + 640 + (16 if net == "rnnprop" else 0)
+    if problem == "quadratic":
+        return base + 8 * D + 4
+    if problem == "lasso":
+        return base + 8 * M + 4.0 * M / D
+    return base + 8 * D + 8                      # rastrigin
+
+
+def alg_flops_per_coord_step(problem, net, D, M):
+    lstm = {"dm": 9800, "dm_logsign": 9960, "rnnprop": 12920 + 15}[net]
+    return lstm + 4 * (M if problem == "lasso" else D)
 
 
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK = 157.3e12
 
 
-def cpu_baseline(D, B, T, max_seconds=25.0):
-    """The NumPy fp32 oracle (the CPU restatement of the reference path) timed on this
-    host: whole unrolls of the same workload until ~max_seconds are spent."""
+def cpu_baseline(problem, net, D, M, B, T, max_seconds=20.0):
+    """The reference path restated for the CPU, timed on this host's cores on the SAME
+    workload (whole unrolls, bounded to ~max_seconds): the plain-C + OpenMP port
+    (oracle/l2o_oracle.c, one problem per thread) is the reported baseline; the NumPy
+    oracle (multi-threaded BLAS gate matmuls, single-threaded elementwise) is timed once
+    next to it for reference."""
     import oracle as O
     from helpers import make_params, make_problem
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count()
-    cfg = O.DM_IDENTITY
+    from oracle.c_oracle import c_unroll
+    from helpers import ORACLE_CFGS
+    cfg = ORACLE_CFGS[net]
     params = make_params(cfg, seed=0, trained_like=True)
-    prob, x0, _ = make_problem("quadratic", B, D, seed=1)
-    st0 = O.net_initial_state(cfg, B * D)
-    O.unroll(prob, cfg, params, x0, st0, 2)            # warm-up
+    prob, x0, arrays = make_problem(problem, B, D, seed=1, M=M)
+    c_unroll(problem, cfg, params, arrays, x0, 2)                # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
     n = 0
-    fxT = None
     while True:
-        res = O.unroll(prob, cfg, params, x0, st0, T)
-        fxT = float(res.fx[-1])
+        fx, _, _, _, _, threads = c_unroll(problem, cfg, params, arrays, x0, T)
         n += 1
-        if time.perf_counter() - t0 > max_seconds or n >= 3:
+        if time.perf_counter() - t0 > max_seconds or n >= 20:
             break
     dt = time.perf_counter() - t0
-    return {"value": B * D * T * n / dt, "unit": "coordinate-steps/s", "cores": int(threads),
-            "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": "%d full unroll(s) of the same workload (NumPy fp32 oracle, B=%d D=%d T=%d), %.1f s"
-                      % (n, B, D, T, dt), "fx_T": fxT}
+    out = {"value": B * D * T * n / dt, "unit": "coordinate-steps/s", "cores": int(threads),
+           "host_cpus": os.cpu_count(), "kind": "port",
+           "sample": "%d full unroll(s) of the same workload (C99+OpenMP port oracle/l2o_oracle.c, "
+                     "%s/%s B=%d D=%d T=%d), %.1f s" % (n, net, problem, B, D, T, dt), "fx_T": float(fx[-1])}
+    if B * D * T <= 2_000_000:
+        st0 = O.net_initial_state(cfg, B * D)
+        t0 = time.perf_counter()
+        res = O.unroll(prob, cfg, params, x0, st0, T)
+        dt = time.perf_counter() - t0
+        out["numpy_oracle"] = {"value": B * D * T / dt, "unit": "coordinate-steps/s",
+                               "sample": "1 unroll, %.1f s" % dt, "fx_T": float(res.fx[-1])}
+    return out
 
 
 def main():
@@ -81,6 +98,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="problems per GPU")
     ap.add_argument("--unroll", type=int, default=100, help="T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin"])
+    ap.add_argument("--rows", type=int, default=None, help="lasso rows M (default: dims)")
+    ap.add_argument("--net", default="dm", choices=["dm", "dm_logsign", "rnnprop"])
     args = ap.parse_args()
 
     import torch
@@ -102,17 +122,20 @@ def main():
 
     D, B, T = args.dims, args.batch, args.unroll
     Bg = B * world
-    cfg = O.DM_IDENTITY
+    from helpers import ORACLE_CFGS
+    cfg = ORACLE_CFGS[args.net]
     spec = spec_of(cfg)
     # random-init Sonnet-default weights (output Linear x0.1 so that the untrained optimizer
     # takes small steps and the trajectory stays finite); same weights on every rank
     params = make_params(cfg, seed=0, trained_like=True)
-    prob, x0, arrays = make_problem("quadratic", B, D, seed=1 + rank)   # rank's own problems
+    prob, x0, arrays = make_problem(args.problem, B, D, seed=1 + rank, M=args.rows)   # rank's own problems
     wpack = eng.pack_weights(spec, params)
     pd = device_problem(eng, arrays, B, D, B_global=Bg)
     fused = eng.unroll_supported(spec, pd)
-    x0d = eng.tensor(x0)
+    x0d = eng.tensor(x0.reshape(B, D))
     x, st = eng.empty(B, D), eng.state_alloc(B, D)
+    mm, vv = eng.zeros(B, D), eng.zeros(B, D)
+    b95 = float(np.float32(0.95))
     fx_part, fx = eng.zeros((T + 1) * B), eng.zeros(T + 1)
     f1, g = eng.zeros(B), eng.zeros(B, D)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -121,14 +144,17 @@ def main():
     def one_unroll(i=None):
         x.copy_(x0d)                                       # reset (DM/meta.py:379-383)
         st.zero_()
+        if args.net == "rnnprop":
+            mm.zero_()
+            vv.zero_()
         if i is not None:
             ev[i][0].record()
         if fused:
-            eng.unroll(spec, wpack, pd, x, st, None, None, T, 1, fx_part)
+            eng.unroll(spec, wpack, pd, x, st, mm, vv, T, 1, fx_part)
         else:
             for t in range(T):
                 eng.problem_fg(pd, x, fx_part[t * B:(t + 1) * B], g)
-                eng.lstm_step(spec, wpack, g, None, None, 0.0, 0.0, st, x, B, D)
+                eng.lstm_step(spec, wpack, g, mm, vv, b95 ** (1 + t), b95 ** (1 + t), st, x, B, D)
             eng.problem_fg(pd, x, fx_part[T * B:(T + 1) * B], None)
         if i is not None:
             ev[i][1].record()
@@ -161,22 +187,30 @@ def main():
     if rank == 0:
         coord_steps = B * D * T                            # per GPU per unroll
         value = world * coord_steps * args.steps / dt
-        alg = alg_bytes_per_coord_step(D) * coord_steps    # algorithmic bytes per launch
+        Mrows = args.rows or D
+        bpc = alg_bytes_per_coord_step(args.problem, args.net, D, Mrows)
+        alg = bpc * coord_steps                            # algorithmic bytes per unroll
         achieved = alg / (kern_ms * 1e-3)
-        flops = (9800 + 4 * D) * coord_steps
+        flops = alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps
+        netname = {"dm": "L2O-DM CoordinateWiseDeepLSTM(20,20)", "dm_logsign": "L2O-DM (LogAndSign k=5)",
+                   "rnnprop": "L2O-RNNProp (fc+ELU, tanh, 0.01)"}[args.net]
+        probname = {"quadratic": "Quadratic d=%d" % D, "lasso": "Lasso A in R^{%dx%d} l=0.1" % (Mrows, D),
+                    "rastrigin": "Rastrigin d=%d" % D}[args.problem]
         out = {
-            "metric": "unroll-steps/sec (batch x params x T), L2O-DM on Quadratic d=%d" % D,
+            "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
             "value": value, "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "L2O-DM CoordinateWiseDeepLSTM(20,20) on Quadratic d=%d, batch=%d per GPU "
-                                   "(global %d), T=%d, BASELINE.json configs[1]" % (D, B, Bg, T),
+            "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
+                                   % (netname, probname, B, Bg, T,
+                                      ", BASELINE.json configs[1]" if (args.problem, args.net, D, B, T) ==
+                                      ("quadratic", "dm", 128, 128, 100) else ""),
                        "kernel": "k_unroll (fused persistent)" if fused else "k_problem_fg + k_cwlstm_step per step",
                        "parallelism": "problem-batch sharding x%d, all-reduce of T+1 floats" % world},
             "final_loss_fx_T": float(fx_host[-1]), "fx_0": float(fx_host[0]),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "alg_bytes_per_coord_step": alg_bytes_per_coord_step(D),
+                         "alg_bytes_per_coord_step": bpc,
                          "kernel_ms_avg": kern_ms, "kernel_ms_min": kern_ms_min,
                          "fp32_tflops": flops / (kern_ms * 1e-3) / 1e12,
                          "fp32_frac_of_157.3TF": flops / (kern_ms * 1e-3) / FP32_PEAK,
@@ -185,7 +219,7 @@ def main():
                                  "kernel is matrix-core/VALU bound -- see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(D, B, T)
+            out["cpu_baseline"] = cpu_baseline(args.problem, args.net, D, args.rows, B, T)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

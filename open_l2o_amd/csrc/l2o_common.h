@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/l2o_abi.h"
 
 namespace l2o {
@@ -53,15 +55,26 @@ __host__ __device__ constexpr int wp_rows(int pre) { return wp_row_fc(pre) + 3 *
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// (L2O_ABLATE_* macros exist only for the timing ablations of scripts/ablate.sh; they
+// produce wrong numbers on purpose and are never defined in the shipped library.)
 __device__ __forceinline__ float sigmoidf_(float x) {
+#ifdef L2O_ABLATE_TRANS
+  return x * 0.25f + 0.5f;
+#endif
   // 1 / (1 + e^-x) ; e^-x = 2^(-x*log2e)
   return fast_rcp(1.0f + fast_exp2(x * -1.4426950408889634f));
 }
 // sigmoid(x + 1)  (snt.LSTM forget_bias = 1.0) with the +1 folded into the FMA
 __device__ __forceinline__ float sigmoid_p1f_(float x) {
+#ifdef L2O_ABLATE_TRANS
+  return x * 0.25f + 0.75f;
+#endif
   return fast_rcp(1.0f + fast_exp2(__builtin_fmaf(x, -1.4426950408889634f, -1.4426950408889634f)));
 }
 __device__ __forceinline__ float tanhf_(float x) {
+#ifdef L2O_ABLATE_TRANS
+  return x * 0.5f;
+#endif
   // tanh|x| = (1 - e)/(1 + e), e = e^(-2|x|) in (0, 1]: no overflow, abs err ~1e-7
   float e = fast_exp2(__builtin_fabsf(x) * -2.8853900817779268f);
   float t = (1.0f - e) * fast_rcp(1.0f + e);
@@ -73,20 +86,44 @@ __device__ __forceinline__ float eluf_(float x) {
   return x > 0.0f ? x : e;
 }
 
-__device__ __forceinline__ float wave_sum64(float v) {
-  v += __shfl_xor(v, 32);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
+// ---- cross-lane sums without LDS traffic ------------------------------------
+// DPP row operations (quad_perm / row_half_mirror / row_mirror) inside a 16-lane row and
+// the gfx950 v_permlane16_swap / v_permlane32_swap across rows: all VALU-rate, no
+// ds_bpermute latency on the per-step critical path.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// v[l] + v[l ^ 16]: swap odd rows of a copy with even rows of the other copy
+__device__ __forceinline__ float xor16_add(float v) {
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// v[l] + v[l ^ 32]
+__device__ __forceinline__ float xor32_add(float v) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the 4 lanes of a quad (lanes 4k..4k+3); result in all 4
+__device__ __forceinline__ float quad_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
   return v;
+}
+// sum over a 16-lane row; result in all 16
+__device__ __forceinline__ float row_sum16(float v) {
+  v = quad_sum(v);
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+  return xor32_add(xor16_add(row_sum16(v)));
 }
 // sum over the four q lanes that share a coordinate c (lanes c, c+16, c+32, c+48)
 __device__ __forceinline__ float quad_q_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+  return xor32_add(xor16_add(v));
 }
 
 // ---- weights in registers --------------------------------------------------
@@ -161,76 +198,134 @@ __device__ __forceinline__ void store_tile_state(const TileState& s, float* __re
 }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef L2O_ABLATE_MFMA
+  c[0] = __builtin_fmaf(a, b, c[0]);
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// LSTM nonlinearity for the 5 units a lane owns (snt.LSTM: i, j, f, o; forget_bias 1).
-__device__ __forceinline__ void lstm_gates(const f32x4 (&acc)[kNT], float (&c)[kNT], float (&h)[kNT]) {
-#pragma unroll
-  for (int t = 0; t < kNT; ++t) {
-    const float gi = acc[t][0], gj = acc[t][1], gf = acc[t][2], go = acc[t][3];
-    const float cn = sigmoid_p1f_(gf) * c[t] + sigmoidf_(gi) * tanhf_(gj);
-    c[t] = cn;
-    h[t] = tanhf_(cn) * sigmoidf_(go);
+// ---- the optimizer network, split so that the matrix work that depends only on the
+// PREVIOUS step's state can be issued early (interleaved with the optimizee GEMV) ----
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
   }
 }
 
-// One optimizer-network evaluation for a 16-coordinate tile.
+template <int PRE>
+__device__ __forceinline__ void lstm_acc_init(const NetW<PRE>& w, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    acc2[t] = w.b2[t];
+    if (PRE == L2O_PRE_FC_ELU) acc1[t] = w.b1[t];
+    else acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+// slots LO..HI-1 of the 25 layer-2 MFMAs fed by the previous h2 (slot i: k-step i/5, slice i%5)
+template <int PRE, int LO, int HI>
+__device__ __forceinline__ void lstm_issue_l2_prev(const NetW<PRE>& w, const TileState& s, f32x4 (&acc2)[kNT]) {
+  static_for<LO, HI>([&](auto ic) {
+    constexpr int i = decltype(ic)::value, kk = i / kNT, t = i % kNT;
+    acc2[t] = mfma16(w.a2[5 + kk][t], s.h2[kk], acc2[t]);
+  });
+}
+// slots LO..HI-1 of the 25 layer-1 MFMAs fed by the previous h1
+template <int PRE, int LO, int HI>
+__device__ __forceinline__ void lstm_issue_l1_prev(const NetW<PRE>& w, const TileState& s, f32x4 (&acc1)[kNT]) {
+  static_for<LO, HI>([&](auto ic) {
+    constexpr int i = decltype(ic)::value, kk = i / kNT, t = i % kNT;
+    constexpr int ka = (PRE == L2O_PRE_FC_ELU) ? 5 + kk : kk;
+    acc1[t] = mfma16(w.a1[ka][t], s.h1[kk], acc1[t]);
+  });
+}
+// LSTM nonlinearity of ONE unit slice (snt.LSTM: gates i, j, f, o; forget_bias 1):
+//   c' = sigmoid(f + 1) * c + sigmoid(i) * tanh(j) ;  h' = tanh(c') * sigmoid(o)
+// written with e_x = 2^(-x log2e) so that sigmoid(x) = 1/(1+e_x), tanh|x| = (1-E_x)/(1+E_x),
+// E_x = e^(-2|x|) <= 1, and the two quotients of each product share ONE v_rcp_f32:
+//   sigmoid(i) tanh(j) = sgn(j) (1-E_j) / ((1+e_i)(1+E_j))
+// (5 v_exp + 3 v_rcp per unit instead of 5 + 5; no overflow: e_i = inf -> rcp(inf) = 0).
+__device__ __forceinline__ void lstm_gate_unit(const f32x4 acc, float& c, float& h) {
+#ifdef L2O_ABLATE_TRANS
+  const float cn = sigmoid_p1f_(acc[2]) * c + sigmoidf_(acc[0]) * tanhf_(acc[1]);
+  c = cn;
+  h = tanhf_(cn) * sigmoidf_(acc[3]);
+  return;
+#endif
+  constexpr float kL2E = 1.4426950408889634f;
+  const float e_i = fast_exp2(acc[0] * -kL2E);
+  const float E_j = fast_exp2(__builtin_fabsf(acc[1]) * (-2.0f * kL2E));
+  const float e_f = fast_exp2(__builtin_fmaf(acc[2], -kL2E, -kL2E));
+  const float e_o = fast_exp2(acc[3] * -kL2E);
+  const float ij = __builtin_copysignf((1.0f - E_j) * fast_rcp((1.0f + e_i) * (1.0f + E_j)), acc[1]);
+  const float cn = __builtin_fmaf(fast_rcp(1.0f + e_f), c, ij);
+  const float E_c = fast_exp2(__builtin_fabsf(cn) * (-2.0f * kL2E));
+  c = cn;
+  h = __builtin_copysignf((1.0f - E_c) * fast_rcp((1.0f + E_c) * (1.0f + e_o)), cn);
+}
+
+// everything that needs this step's gradient:
 //   PRE = IDENTITY : in0 = g
 //   PRE = LOGSIGN  : in0 = clamped log, in1 = clamped sign  (computed by the caller)
 //   PRE = FC_ELU   : in0 = m~, in1 = g~  (RNNProp)
+// acc1 must already hold bias + the h1(t-1) part, acc2 bias + the h2(t-1) part.
+// With NEXT = true the layer-1 MFMAs of the NEXT step (fed by the h1 just produced) are
+// issued into acc1 interleaved with the layer-2 gate math, so that the matrix pipe has
+// work while the VALU does the transcendental-heavy part (acc1 is dead by then).
 // Returns the Linear output (before tanh / scale), identical on the four q lanes.
-template <int PRE>
-__device__ __forceinline__ float lstm_tile_step(const NetW<PRE>& w, TileState& s, float in0, float in1, int q) {
-  f32x4 acc1[kNT], acc2[kNT];
-  // layer-2 contribution of the PREVIOUS h2: independent of layer 1, issue first
-#pragma unroll
-  for (int t = 0; t < kNT; ++t) acc2[t] = w.b2[t];
-#pragma unroll
-  for (int kk = 0; kk < kNT; ++kk)
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) acc2[t] = mfma16(w.a2[5 + kk][t], s.h2[kk], acc2[t]);
-
+template <int PRE, bool NEXT>
+__device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f32x4 (&acc1)[kNT],
+                                             f32x4 (&acc2)[kNT], float in0, float in1, int q) {
   if (PRE == L2O_PRE_FC_ELU) {
     float fc[kNT];
 #pragma unroll
     for (int t = 0; t < kNT; ++t)
       fc[t] = eluf_(__builtin_fmaf(w.fcw1[t], in1, __builtin_fmaf(w.fcw0[t], in0, w.fcb[t])));
 #pragma unroll
-    for (int t = 0; t < kNT; ++t) acc1[t] = w.b1[t];
-#pragma unroll
-    for (int kk = 0; kk < kNT; ++kk)
-#pragma unroll
-      for (int t = 0; t < kNT; ++t) acc1[t] = mfma16(w.a1[5 + kk][t], s.h1[kk], acc1[t]);
-#pragma unroll
     for (int kk = 0; kk < kNT; ++kk)
 #pragma unroll
       for (int t = 0; t < kNT; ++t) acc1[t] = mfma16(w.a1[kk][t], fc[kk], acc1[t]);
   } else {
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < kNT; ++kk)
-#pragma unroll
-      for (int t = 0; t < kNT; ++t) acc1[t] = mfma16(w.a1[kk][t], s.h1[kk], acc1[t]);
     // last k-step: q=0 -> feature 0, q=1 -> feature 1, q=2 -> bias (x 1.0), q=3 -> unused
     const float bv = q == 0 ? in0 : (q == 1 ? in1 : (q == 2 ? 1.0f : 0.0f));
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc1[t] = mfma16(w.a1[5][t], bv, acc1[t]);
   }
-  lstm_gates(acc1, s.c1, s.h1);
-
+  // layer-1 gates, unit slice by unit slice; the layer-2 MFMAs of k-step kk only need h1[kk]
 #pragma unroll
-  for (int kk = 0; kk < kNT; ++kk)
+  for (int kk = 0; kk < kNT; ++kk) {
+    lstm_gate_unit(acc1[kk], s.c1[kk], s.h1[kk]);
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc2[t] = mfma16(w.a2[kk][t], s.h1[kk], acc2[t]);
-  lstm_gates(acc2, s.c2, s.h2);
-
-  float d = 0.0f;
+  }
+  if (NEXT) {
 #pragma unroll
-  for (int t = 0; t < kNT; ++t) d = __builtin_fmaf(s.h2[t], w.wl[t], d);
+    for (int t = 0; t < kNT; ++t) {
+      if (PRE == L2O_PRE_FC_ELU) acc1[t] = w.b1[t];
+      else acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float d = 0.0f;
+  static_for<0, kNT>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    lstm_gate_unit(acc2[t], s.c2[t], s.h2[t]);
+    d = __builtin_fmaf(s.h2[t], w.wl[t], d);
+    if constexpr (NEXT) lstm_issue_l1_prev<PRE, 5 * t, 5 * t + 5>(w, s, acc1);
+  });
   d = quad_q_sum(d);
   return d + w.bl;
+}
+
+// One optimizer-network evaluation for a 16-coordinate tile (step-granular kernel).
+template <int PRE>
+__device__ __forceinline__ float lstm_tile_step(const NetW<PRE>& w, TileState& s, float in0, float in1, int q) {
+  f32x4 acc1[kNT], acc2[kNT];
+  lstm_acc_init<PRE>(w, acc1, acc2);
+  lstm_issue_l2_prev<PRE, 0, 25>(w, s, acc2);
+  lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
+  return lstm_finish<PRE, false>(w, s, acc1, acc2, in0, in1, q);
 }
 
 // Gradient preprocessing -> the (in0, in1) pair fed to lstm_tile_step.

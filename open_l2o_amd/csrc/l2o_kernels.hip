@@ -234,13 +234,21 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
 
 // ---------------------------------------------------------------------------
 // K3: the fused persistent unroll.  One workgroup per problem, one wave per
-// 16-coordinate tile (<= 8 waves), T steps in ONE launch:
-//   LDS  : the problem matrix W_b (row stride S == 2 mod 32 -> both GEMV passes are
-//          bank-conflict free with ds_read_b32), y, x*s, the residual r
+// 16-coordinate tile (<= 8 waves), T steps in ONE launch.
+//   LDS  : the problem matrix TWICE -- W_b row-major and W_b^T row-major, row stride
+//          S = SQ + 16 floats (S/4 == 4 or 12 mod 16 -> ds_read_b128 of a (row, 16-byte
+//          column chunk) per lane is bank-conflict free) -- plus y, x*s and the residual r
 //   VGPR : optimizer weights (MFMA A fragments), LSTM state, x, m, v
-//   HBM  : W_b read once; x/state/m/v read+written once; one float per (step, problem)
-// per step: xs -> barrier -> r = W xs - y, f_b -> barrier -> g = W^T r (this wave's 16
-// columns, rows split over the q lanes) -> preprocess -> 2-layer LSTM on MFMA -> x += delta.
+//   HBM  : W_b read once per launch; x/state/m/v read+written once; one float per
+//          (step, problem)
+// Per step and wave (lane l also plays the GEMV role (row = 16*wave + l/4, chunk = l%4)):
+//   xs <- x*s ; barrier
+//   r  = W xs - y           || the 25 layer-2 MFMAs fed by the previous h2
+//   f_b partial ; barrier
+//   g  = W^T r (own 16 coordinates) || the 25 layer-1 MFMAs fed by the previous h1
+//   preprocess(g) -> input MFMAs -> gates -> layer-2 MFMAs -> gates -> Linear -> x += delta
+// i.e. 50 of the 80 MFMAs of a step depend only on the previous step's state and are
+// issued interleaved with the GEMV's LDS reads and FMAs (separate pipes).
 // ---------------------------------------------------------------------------
 struct UnrollArgs {
   NetParams np;
@@ -252,42 +260,59 @@ struct UnrollArgs {
   float* fx_part;
   int T;
   float p1_hi, p1_lo, p2_hi, p2_lo;   // beta^step0 as float-float
-  int S;        // LDS row stride of W (floats)
-  int Mpad;     // rows padded to a multiple of 32
 };
 
-template <int PRE, int KIND>
+#ifdef L2O_ABLATE_BARRIER
+#define L2O_SYNC() ((void)0)
+#else
+#define L2O_SYNC() __syncthreads()
+#endif
+__device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
+#ifdef L2O_ABLATE_GEMV
+  return acc + a.x;
+#endif
+  acc = __builtin_fmaf(a.x, b.x, acc);
+  acc = __builtin_fmaf(a.y, b.y, acc);
+  acc = __builtin_fmaf(a.z, b.z, acc);
+  acc = __builtin_fmaf(a.w, b.w, acc);
+  return acc;
+}
+
+template <int PRE, int KIND, int CH>
 __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
+  constexpr int SQ = 16 * CH;      // padded square size of the LDS-resident matrix
+  constexpr int S = SQ + 16;       // row stride (floats)
   extern __shared__ float sm[];
   const ProbParams& pp = a.pp;
-  const int D = pp.D, M = pp.M, S = a.S, Mpad = a.Mpad;
-  float* Ws = sm;                           // [Mpad * S + 16]
-  float* xs = Ws + (size_t)Mpad * S + 16;   // [S + 4]
-  float* rs = xs + S + 4;                   // [Mpad]
-  float* ys = rs + Mpad;                    // [Mpad]
-  float* fpart = ys + Mpad;                 // [8]
+  const int D = pp.D, M = pp.M;
+  float* Ws = sm;                  // [SQ][S]  W   (rows i, columns j)
+  float* WTs = Ws + SQ * S;        // [SQ][S]  W^T (rows j, columns i)
+  float* xs = WTs + SQ * S;        // [SQ]
+  float* rs = xs + SQ;             // [SQ]
+  float* ys = rs + SQ;             // [SQ]
+  float* fpart = ys + SQ;          // [8]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
-  const int c = lane & 15, q = lane >> 4;
+  const int c = lane & 15, q = lane >> 4;      // LSTM role: coordinate c, unit group q
+  const int grow = wv * kTile + (lane >> 2);   // GEMV role: matrix row (r pass) / coordinate (g pass)
+  const int gq = lane & 3;                     //            16-byte column chunk inside a 64-byte group
   const int b = blockIdx.x;
 
-  // ---- stage the problem into LDS (zero padded) -------------------------
+  // ---- stage the problem into LDS (zero padded), both orientations ---------
   const float* Wb = pp.W + (size_t)b * M * D;
-  for (int i = tid; i < Mpad * S + 16; i += blockDim.x) Ws[i] = 0.0f;
-  for (int i = tid; i < S + 4; i += blockDim.x) xs[i] = 0.0f;
-  for (int i = tid; i < Mpad; i += blockDim.x) {
-    rs[i] = 0.0f;
-    ys[i] = i < M ? pp.y[(size_t)b * M + i] : 0.0f;
-  }
+  for (int i = tid; i < 2 * SQ * S + 3 * SQ; i += blockDim.x) sm[i] = 0.0f;
   __syncthreads();
   for (int e = tid; e < M * D; e += blockDim.x) {
     const int i = e / D, j = e - i * D;
-    Ws[i * S + j] = Wb[e];
+    const float v = Wb[e];
+    Ws[i * S + j] = v;
+    WTs[j * S + i] = v;
   }
+  for (int i = tid; i < M; i += blockDim.x) ys[i] = pp.y[(size_t)b * M + i];
 
   // ---- per-lane persistent registers -------------------------------------
   NetW<PRE> w;
   load_netw<PRE>(w, a.np.wpack, lane);
-  const int j = wv * kTile + c;             // this lane's coordinate
+  const int j = wv * kTile + c;             // this lane's coordinate (LSTM role)
   const bool live = j < D;
   const size_t idx = (size_t)b * D + j;
   const int tile = b * nw + wv;
@@ -304,29 +329,39 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
   const float coef = KIND == L2O_PROB_QUADRATIC ? 1.0f : 0.5f;
   const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;
   constexpr float kTwoPi = 6.2831853071795864769f;
-  const int NJ = (D + 3) >> 2;
+  const float* wrow = Ws + grow * S + 4 * gq;
+  const float* wtrow = WTs + grow * S + 4 * gq;
+  const float* xsq = xs + 4 * gq;
+  const float* rsq = rs + 4 * gq;
+  const int perm_src = (4 * c) << 2;        // byte index of lane 4*c for ds_bpermute
+
+  // software pipeline of the matrix work: acc1 always holds bias + (h1 of the previous step)
+  // part of layer 1; it is produced at the END of the previous step (overlapping that step's
+  // layer-2 gate math), here for step 0.
+  f32x4 acc1[kNT], acc2[kNT];
+  lstm_acc_init<PRE>(w, acc1, acc2);
+  lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
 
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     if (live && q == 0) xs[j] = xsv;
-    __syncthreads();                                        // B1: xs complete
-    // ---- r = W xs - y for rows i0 + c ; this lane covers columns 4*jj + q -----
+    L2O_SYNC();                                             // B1: xs complete
+#pragma unroll
+    for (int u = 0; u < kNT; ++u) acc2[u] = w.b2[u];
+    // ---- r = W xs - y  ||  first 12 layer-2 MFMAs of the previous h2 -----------
+    float racc = 0.0f;
+    static_for<0, CH>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const float4 wv4 = *reinterpret_cast<const float4*>(wrow + 16 * m);
+      const float4 xv4 = *reinterpret_cast<const float4*>(xsq + 16 * m);
+      lstm_issue_l2_prev<PRE, (12 * m) / CH, (12 * (m + 1)) / CH>(w, s, acc2);
+      racc = dot4(wv4, xv4, racc);
+    });
+    const float r = quad_sum(racc) - ys[grow];
     float contrib = 0.0f;
-    for (int i0 = wv * kTile; i0 < Mpad; i0 += nw * kTile) {
-      const int i = i0 + c;
-      const float* wr = Ws + i * S + q;
-      float acc0 = 0.0f, acc1 = 0.0f;
-      int jj = 0;
-      for (; jj + 1 < NJ; jj += 2) {
-        acc0 = __builtin_fmaf(wr[4 * jj], xs[4 * jj + q], acc0);
-        acc1 = __builtin_fmaf(wr[4 * jj + 4], xs[4 * jj + 4 + q], acc1);
-      }
-      if (jj < NJ) acc0 = __builtin_fmaf(wr[4 * jj], xs[4 * jj + q], acc0);
-      const float r = quad_q_sum(acc0 + acc1) - ys[i];
-      if (q == 0) {
-        rs[i] = r;                       // rows >= M: W row and y are zero -> r == 0
-        contrib = __builtin_fmaf(coef * r, r, contrib);
-      }
+    if (gq == 0) {
+      rs[grow] = r;                       // rows >= M: W row and y are zero -> r == 0
+      contrib = coef * r * r;
     }
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
@@ -334,7 +369,7 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     }
     contrib = wave_sum64(contrib);
     if (lane == 0) fpart[wv] = contrib;
-    __syncthreads();                                        // B2: rs, fpart complete
+    L2O_SYNC();                                             // B2: rs, fpart complete
     if (tid == 0) {
       float f = fpart[0];
       for (int k = 1; k < nw; ++k) f += fpart[k];
@@ -342,20 +377,17 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     }
     if (t == a.T) break;
 
-    // ---- g_j = cg * sum_i W[i][j] r_i ; rows i = 32*mm + 8*q + ii ----------------
-    float g0 = 0.0f, g1 = 0.0f;
-    {
-      const float* wc = Ws + (8 * q) * S + (wv * kTile + c);
-      const float* rq = rs + 8 * q;
-      for (int mm = 0; mm < Mpad; mm += 32) {
-#pragma unroll
-        for (int ii = 0; ii < 8; ii += 2) {
-          g0 = __builtin_fmaf(wc[(mm + ii) * S], rq[mm + ii], g0);
-          g1 = __builtin_fmaf(wc[(mm + ii + 1) * S], rq[mm + ii + 1], g1);
-        }
-      }
-    }
-    float gv = quad_q_sum(g0 + g1);
+    // ---- g = W^T r for this wave's 16 coordinates  ||  the other 13 of those MFMAs ----
+    float gacc = 0.0f;
+    static_for<0, CH>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const float4 wt4 = *reinterpret_cast<const float4*>(wtrow + 16 * m);
+      const float4 rv4 = *reinterpret_cast<const float4*>(rsq + 16 * m);
+      lstm_issue_l2_prev<PRE, 12 + (13 * m) / CH, 12 + (13 * (m + 1)) / CH>(w, s, acc2);
+      gacc = dot4(wt4, rv4, gacc);
+    });
+    gacc = quad_sum(gacc);                 // lanes 4k..4k+3 hold g of coordinate 16*wv + k
+    float gv = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(gacc)));
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (KIND == L2O_PROB_RASTRIGIN) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
@@ -377,7 +409,7 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-    float d = lstm_tile_step<PRE>(w, s, in0, in1, q);
+    float d = lstm_finish<PRE, true>(w, s, acc1, acc2, in0, in1, q);
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
   }
@@ -494,32 +526,42 @@ static void pow_ff(double base, int k, float* hi, float* lo) {
   *lo = (float)(p - (double)*hi);
 }
 
-struct UnrollGeom { int S, Mpad, nw; size_t lds; };
+struct UnrollGeom { int CH, nw; size_t lds; };
 static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
   const int D = p->D, M = p->M;
   g->nw = tiles_per_problem(D);
-  if (g->nw > 8) return false;
-  g->S = ((D - 2 + 31) / 32) * 32 + 2;
-  if (g->S < D) g->S += 32;
-  g->Mpad = (M + 31) / 32 * 32;
-  g->lds = sizeof(float) * ((size_t)g->Mpad * g->S + 16 + g->S + 4 + 2 * (size_t)g->Mpad + 8);
+  if (g->nw > 8 || M > 16 * g->nw) return false;     // rows are covered by the nw waves, 16 each
+  const int need = g->nw;                            // 16-float chunks per matrix row
+  g->CH = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 8));
+  const int SQ = 16 * g->CH, S = SQ + 16;
+  g->lds = sizeof(float) * (2 * (size_t)SQ * S + 3 * (size_t)SQ + 8);
   return g->lds <= 160 * 1024;
 }
 
-template <int PRE>
-static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind, hipStream_t s) {
+template <int PRE, int KIND>
+static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s) {
   void (*fn)(UnrollArgs) = nullptr;
-  switch (kind) {
-    case L2O_PROB_QUADRATIC: fn = k_unroll<PRE, L2O_PROB_QUADRATIC>; break;
-    case L2O_PROB_LASSO: fn = k_unroll<PRE, L2O_PROB_LASSO>; break;
-    case L2O_PROB_RASTRIGIN: fn = k_unroll<PRE, L2O_PROB_RASTRIGIN>; break;
-    default: return fail(L2O_ERR_UNSUPPORTED, "no fused kernel for problem kind %d", kind);
+  switch (g.CH) {
+    case 1: fn = k_unroll<PRE, KIND, 1>; break;
+    case 2: fn = k_unroll<PRE, KIND, 2>; break;
+    case 4: fn = k_unroll<PRE, KIND, 4>; break;
+    default: fn = k_unroll<PRE, KIND, 8>; break;
   }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)g.lds));
   hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(64 * g.nw), g.lds, s, a);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
+}
+
+template <int PRE>
+static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind, hipStream_t s) {
+  switch (kind) {
+    case L2O_PROB_QUADRATIC: return launch_unroll_ch<PRE, L2O_PROB_QUADRATIC>(a, g, s);
+    case L2O_PROB_LASSO: return launch_unroll_ch<PRE, L2O_PROB_LASSO>(a, g, s);
+    case L2O_PROB_RASTRIGIN: return launch_unroll_ch<PRE, L2O_PROB_RASTRIGIN>(a, g, s);
+    default: return fail(L2O_ERR_UNSUPPORTED, "no fused kernel for problem kind %d", kind);
+  }
 }
 
 extern "C" {
@@ -706,7 +748,7 @@ int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* pr
   a.np = make_net_params(cfg, wpack);
   a.pp = make_prob_params(prob);
   a.x = x; a.st = st; a.m = m; a.v = v; a.fx_part = fx_part;
-  a.T = T; a.S = g.S; a.Mpad = g.Mpad;
+  a.T = T;
   pow_ff(cfg->beta1, step0, &a.p1_hi, &a.p1_lo);
   pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
   hipStream_t s = (hipStream_t)stream;

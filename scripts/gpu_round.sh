@@ -1,10 +1,18 @@
 #!/bin/bash
-# One GPU-box round: parity tests, smoke, bench, rocprof kernel trace.  Run via gpurun.
-set -x
-mkdir -p gpurun_out
-python -m pytest tests -q -m gpu 2>&1 | tee gpurun_out/pytest_gpu.log | tail -5
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py --steps 20 --warmup 3 2>gpurun_out/bench.err | tee gpurun_out/bench.json
+# One GPU-box round: parity tests, smoke, bench (C2 + C3 + C4 shard), rocprof kernel trace
+# and the HBM-traffic PMC passes.  Run via gpurun:  gpurun --timeout 1500 -- bash scripts/gpu_round.sh TAG
+TAG=${1:-rXX}
+R=$PWD
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+python -m pytest tests -q -m gpu 2>&1 | tee $O/pytest_gpu.log | tail -4
+grep -E "rel fx|vs C oracle" $O/pytest_gpu.log | tail -8
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --steps 20 --warmup 3 2>$O/bench.err | tee $O/bench_c2.json | cut -c1-400
+python bench.py --steps 3 --warmup 1 --problem lasso --net rnnprop --dims 512 --rows 256 --batch 256 --unroll 200 2>>$O/bench.err | tee $O/bench_c3.json | cut -c1-300
+python bench.py --steps 10 --warmup 2 --problem rastrigin --net dm --dims 100 --batch 128 --unroll 100 --no-cpu-baseline 2>>$O/bench.err | tee $O/bench_c4shard.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2>$GRAFT_REPO_ROOT/gpurun_out/prof.err
-ls -R $GRAFT_REPO_ROOT/gpurun_out/prof | head -30
+rocprofv3 --kernel-trace --stats -d $O/prof_trace -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_trace_bench.json 2>$O/prof_trace.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -o fetch -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_fetch_bench.json 2>$O/prof_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -o write -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_write_bench.json 2>$O/prof_write.err
+ls $O/prof_trace $O/prof_fetch $O/prof_write 2>&1 | head -20

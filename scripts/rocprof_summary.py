@@ -21,13 +21,13 @@ def main(db, out=None):
         lines.append("%-40s %6d %10.0f %10d %10d %6s %6s %6s %8s %8s %7s %8s" % ((r[0][:40],) + tuple(r[1:])))
     try:
         rows = list(cur.execute(
-            "select k.name, p.name, count(*), avg(e.value), sum(e.value) from rocpd_pmc_event e "
-            "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id "
-            "join rocpd_info_kernel_symbol k on d.kernel_id = k.id group by k.name, p.name"))
+            "select name, counter_name, count(*), avg(counter_value), min(counter_value), max(counter_value) "
+            "from pmc_events group by name, counter_name order by 4 desc"))
         if rows:
-            lines += ["", "## PMC counters (avg per dispatch)"]
-            for kname, pname, n, avg, tot in rows:
-                lines.append("%-48s %-24s n=%-5d avg=%.6g" % (kname[:48], pname, n, avg))
+            lines += ["", "## PMC counters per dispatch (pmc_events view; FETCH_SIZE / WRITE_SIZE are in KiB)",
+                      "%-56s %-14s %6s %14s %14s %14s" % ("kernel", "counter", "n", "avg", "min", "max")]
+            for kname, cname, n, avg, mn, mx in rows:
+                lines.append("%-56s %-14s %6d %14.3f %14.3f %14.3f" % (kname[:56], cname, n, avg, mn, mx))
     except Exception as e:  # pragma: no cover
         lines += ["", "(no PMC tables: %s)" % e]
     txt = "\n".join(lines) + "\n"

@@ -243,3 +243,68 @@ def test_fused_c2_vs_oracle_trajectory(eng):
     e = rel_err(fx, res.fx)
     print("C2 fused vs oracle: rel fx=%.3g  fx0=%.5g fxT=%.5g" % (e, res.fx[0], res.fx[-1]))
     assert e < 1e-5
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full-size configurations (checked against the multi-threaded C oracle,
+# which finishes these sizes in seconds on the GPU box's host)
+# ---------------------------------------------------------------------------
+def test_c4_rastrigin_shard_full_size(eng):
+    """Config 4: L2O-DM on Rastrigin d=100, batch 1024 sharded over 8 GPUs -> this GPU's
+    shard is 128 problems with B_global = 1024; T=100."""
+    from oracle.c_oracle import c_unroll
+    cfg = O.DM_IDENTITY
+    params = make_params(cfg, seed=15, trained_like=True)
+    B, D, T, Bg = 128, 100, 100, 1024
+    prob, x0, arrays = make_problem("rastrigin", B, D, seed=16)
+    fx_ref, x_ref, st_ref, _, _, _ = c_unroll("rastrigin", cfg, params, arrays, x0, T, B_global=Bg)
+    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T, Bg=Bg)
+    e = rel_err(fx, fx_ref)
+    print("C4 shard fused vs C oracle: rel fx=%.3g  fx0=%.5g fxT=%.5g" % (e, fx_ref[0], fx_ref[-1]))
+    assert np.all(np.isfinite(fx)) and e < 1e-5
+
+
+def _run_steps(eng, cfg, params, arrays, x0, B, D, T, step0=1, carry=None):
+    """Step-granular path (l2o_problem_fg + l2o_cwlstm_step per step)."""
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D)
+    if carry is None:
+        xd, std, md, vd = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D), eng.zeros(B, D), eng.zeros(B, D)
+    else:
+        xd, std, md, vd = carry
+    f, g = eng.zeros(B), eng.zeros(B, D)
+    fx = eng.zeros(T + 1)
+    b95 = float(np.float32(0.95))
+    for t in range(T):
+        eng.problem_fg(pd, xd, f, g)
+        eng.reduce_fx(f, 1, B, B, fx[t:t + 1])
+        eng.lstm_step(spec, wpack, g, md, vd, b95 ** (step0 + t), b95 ** (step0 + t), std, xd, B, D)
+    eng.problem_fg(pd, xd, f, None)
+    eng.reduce_fx(f, 1, B, B, fx[T:T + 1])
+    return eng.to_numpy(fx), (xd, std, md, vd)
+
+
+def test_c3_lasso_rnnprop_full_size(eng):
+    """Config 3: L2O-RNNProp on Lasso A in R^{256x512}, lambda=0.1, batch=256, T=200
+    (per-problem A: 128 MiB streamed twice per step; step-granular kernels).
+    Parity vs the C oracle on the first 20 steps; the full T=200 trajectory through the
+    continuation property (200 steps == 2 x 100 steps with carried x/state/m/v)."""
+    from oracle.c_oracle import c_unroll
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=17, trained_like=True)
+    B, D, M = 256, 512, 256
+    prob, x0, arrays = make_problem("lasso", B, D, seed=18, M=M)
+    assert not eng.unroll_supported(spec_of(cfg), device_problem(eng, arrays, B, D))
+    fx_ref, _, _, _, _, _ = c_unroll("lasso", cfg, params, arrays, x0, 20)
+    fx20, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 20)
+    e = rel_err(fx20, fx_ref)
+    print("C3 step path vs C oracle (20 steps): rel fx=%.3g fx0=%.5g fx20=%.5g" % (e, fx_ref[0], fx_ref[-1]))
+    assert e < 1e-5
+    fx200, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 200)
+    fxa, carry = _run_steps(eng, cfg, params, arrays, x0, B, D, 100)
+    fxb, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 100, step0=101, carry=carry)
+    assert np.all(np.isfinite(fx200))
+    np.testing.assert_array_equal(fx200[:101], fxa)
+    np.testing.assert_array_equal(fx200[100:], fxb)
+    np.testing.assert_allclose(fx200[:21], fx_ref, rtol=1e-5)
