@@ -196,6 +196,14 @@ def main():
                    "rnnprop": "L2O-RNNProp (fc+ELU, tanh, 0.01)"}[args.net]
         probname = {"quadratic": "Quadratic d=%d" % D, "lasso": "Lasso A in R^{%dx%d} l=0.1" % (Mrows, D),
                     "rastrigin": "Rastrigin d=%d" % D}[args.problem]
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_c2.json")
+        if os.path.exists(pmc_file) and fused:
+            pmc = json.load(open(pmc_file))
+            if pmc["workload"] == [args.problem, args.net, D, B, T]:
+                traffic = pmc["traffic_bytes"]
+                traffic_src = ("profiles/r01_pmc_c2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               "command, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)")
         out = {
             "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
             "value": value, "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
@@ -209,7 +217,8 @@ def main():
                        "parallelism": "problem-batch sharding x%d, all-reduce of T+1 floats" % world},
             "final_loss_fx_T": float(fx_host[-1]), "fx_0": float(fx_host[0]),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg,
                          "alg_bytes_per_coord_step": bpc,
                          "kernel_ms_avg": kern_ms, "kernel_ms_min": kern_ms_min,
                          "fp32_tflops": flops / (kern_ms * 1e-3) / 1e12,
