@@ -125,39 +125,50 @@ __global__ void k_linear_step(NetParams np, const float* __restrict__ g, float* 
 //   pass 1  r = W xs - y      rows over waves, columns over lanes (coalesced), wave reduce
 //   pass 2  g = W^T r         columns over threads (coalesced), rows split over thread groups
 // ---------------------------------------------------------------------------
-constexpr int kFgThreads = 256;
+constexpr int kFgThreads = 512;
+constexpr int kFgWaves = kFgThreads / 64;
 
-__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
+__device__ __forceinline__ float block_sum_fg(float v, float* red /* >= kFgWaves floats */) {
   v = wave_sum64(v);
   const int wv = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[wv] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  float s = red[0];
+#pragma unroll
+  for (int k = 1; k < kFgWaves; ++k) s += red[k];
+  return s;
 }
 
+// VEC = true: D % 4 == 0 and 16-byte aligned rows -> dwordx4 loads, 4 rows (r pass) /
+// 4 row-strided loads (g pass) in flight per lane; VEC = false: scalar fallback.
+template <bool VEC>
 __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const float* __restrict__ x,
                                                             float* __restrict__ f_part,
                                                             float* __restrict__ gout) {
   extern __shared__ float sm[];
   const int D = pp.D, M = pp.M;
-  float* xs = sm;                 // [D]   scaled x
-  float* rs = xs + D;             // [M]   residual
-  float* part = rs + M;           // [kFgThreads] partial column sums
-  float* red = part + kFgThreads; // [4]
+  float* xs = sm;                       // [D4]  scaled x (padded to a multiple of 4)
+  const int D4 = (D + 3) & ~3;
+  float* rs = xs + D4;                  // [M]   residual
+  float* part = rs + ((M + 3) & ~3);    // [4 * kFgThreads] partial column sums
+  float* red = part + 4 * kFgThreads;   // [kFgWaves]
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* xb = x + (size_t)b * D;
   const float* sb = pp.x_scale ? pp.x_scale + (size_t)b * D : nullptr;
 
   float facc = 0.0f;   // per-thread contribution to f_b
-  for (int j = tid; j < D; j += kFgThreads) {
-    const float xv = xb[j] * (sb ? sb[j] : 1.0f);
+  for (int j = tid; j < D4; j += kFgThreads) {
+    float xv = 0.0f;
+    if (j < D) {
+      xv = xb[j] * (sb ? sb[j] : 1.0f);
+      if (pp.kind == L2O_PROB_SIMPLE) facc += xv * xv;
+      if (pp.kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xv);
+      if (pp.kind == L2O_PROB_RASTRIGIN)
+        facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j] * cosf(6.2831853071795864769f * xv);
+    }
     xs[j] = xv;
-    if (pp.kind == L2O_PROB_SIMPLE) facc += xv * xv;
-    if (pp.kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xv);
-    if (pp.kind == L2O_PROB_RASTRIGIN)
-      facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j] * cosf(6.2831853071795864769f * xv);
   }
   __syncthreads();
 
@@ -165,30 +176,51 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
     const float* Wb = pp.W + (size_t)b * M * D;
     const float* yb = pp.y + (size_t)b * M;
     const float coef = pp.kind == L2O_PROB_QUADRATIC ? 1.0f : 0.5f;
-    const bool vec4 = (D & 3) == 0;
-    for (int i = wv; i < M; i += kFgThreads / 64) {
-      const float* row = Wb + (size_t)i * D;
-      float acc = 0.0f;
-      if (vec4) {
+    if (VEC) {
+      // ---- pass 1: r = W xs - y ; each wave takes 4 rows at a time -> 4 x (D/256) dwordx4 in flight
+      for (int i0 = wv * 4; i0 < M; i0 += kFgWaves * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int j = lane * 4; j < D; j += 256) {
-          const float4 wv4 = *reinterpret_cast<const float4*>(row + j);
-          acc = __builtin_fmaf(wv4.x, xs[j], acc);
-          acc = __builtin_fmaf(wv4.y, xs[j + 1], acc);
-          acc = __builtin_fmaf(wv4.z, xs[j + 2], acc);
-          acc = __builtin_fmaf(wv4.w, xs[j + 3], acc);
+          const float4 xv4 = *reinterpret_cast<const float4*>(xs + j);
+          float4 w4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k < M ? i0 + k : M - 1;       // clamp: result of a clamped row is discarded
+            w4[k] = *reinterpret_cast<const float4*>(Wb + (size_t)i * D + j);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            acc[k] = __builtin_fmaf(w4[k].x, xv4.x, acc[k]);
+            acc[k] = __builtin_fmaf(w4[k].y, xv4.y, acc[k]);
+            acc[k] = __builtin_fmaf(w4[k].z, xv4.z, acc[k]);
+            acc[k] = __builtin_fmaf(w4[k].w, xv4.w, acc[k]);
+          }
         }
-      } else {
-        for (int j = lane; j < D; j += 64) acc = __builtin_fmaf(row[j], xs[j], acc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = wave_sum64(acc[k]);
+          if (lane == 0 && i0 + k < M) {
+            const float r = a - yb[i0 + k];
+            rs[i0 + k] = r;
+            facc += coef * r * r;
+          }
+        }
       }
-      acc = wave_sum64(acc);
-      if (lane == 0) {
-        const float r = acc - yb[i];
-        rs[i] = r;
-        facc += coef * r * r;
+    } else {
+      for (int i = wv; i < M; i += kFgWaves) {
+        const float* row = Wb + (size_t)i * D;
+        float acc = 0.0f;
+        for (int j = lane; j < D; j += 64) acc = __builtin_fmaf(row[j], xs[j], acc);
+        acc = wave_sum64(acc);
+        if (lane == 0) {
+          const float r = acc - yb[i];
+          rs[i] = r;
+          facc += coef * r * r;
+        }
       }
     }
   }
-  const float fb = block_sum_256(facc, red);   // contains a __syncthreads: rs is visible after it
+  const float fb = block_sum_fg(facc, red);   // contains a __syncthreads: rs is visible after it
   if (tid == 0) f_part[b] = fb;
   if (gout == nullptr) return;
 
@@ -199,35 +231,80 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
   }
   const float* Wb = pp.W + (size_t)b * M * D;
   const float cg = pp.kind == L2O_PROB_QUADRATIC ? 2.0f : 1.0f;
-  // column chunk of CP columns handled by RP row-groups of threads
-  const int CP = D >= kFgThreads ? kFgThreads : ((D + 63) & ~63);
-  const int RP = kFgThreads / CP;
-  const int jc = tid % CP, rp = tid / CP;
-  for (int j0 = 0; j0 < D; j0 += CP) {
-    const int j = j0 + jc;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (j < D && rp < RP) {
-      int i = rp;
-      for (; i + 3 * RP < M; i += 4 * RP) {
-        a0 = __builtin_fmaf(Wb[(size_t)i * D + j], rs[i], a0);
-        a1 = __builtin_fmaf(Wb[(size_t)(i + RP) * D + j], rs[i + RP], a1);
-        a2 = __builtin_fmaf(Wb[(size_t)(i + 2 * RP) * D + j], rs[i + 2 * RP], a2);
-        a3 = __builtin_fmaf(Wb[(size_t)(i + 3 * RP) * D + j], rs[i + 3 * RP], a3);
+  auto finish = [&](int j, float s) {
+    float gj = cg * s;
+    const float xv = xs[j];
+    if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f));
+    if (pp.kind == L2O_PROB_RASTRIGIN)
+      gj += 6.2831853071795864769f * pp.alpha * pp.C[(size_t)b * D + j] * sinf(6.2831853071795864769f * xv);
+    gb[j] = gj * pp.inv_bg * (sb ? sb[j] : 1.0f);
+  };
+  if (VEC) {
+    // ---- pass 2: g = W^T r ; a thread owns 4 adjacent columns, row groups are strided over
+    // RP thread groups; 4 dwordx4 loads in flight per thread
+    const int ncol4 = D >> 2;
+    const int CP4 = ncol4 >= kFgThreads ? kFgThreads : ((ncol4 + 63) & ~63);
+    const int RP = kFgThreads / CP4;
+    const int jc = tid % CP4, rp = tid / CP4;
+    for (int j0 = 0; j0 < ncol4; j0 += CP4) {
+      const int j4 = j0 + jc;
+      float4 a = {0.f, 0.f, 0.f, 0.f};
+      if (j4 < ncol4 && rp < RP) {
+        const float* col = Wb + 4 * (size_t)j4;
+        int i = rp;
+        for (; i + 3 * RP < M; i += 4 * RP) {
+          const float4 w0 = *reinterpret_cast<const float4*>(col + (size_t)i * D);
+          const float4 w1 = *reinterpret_cast<const float4*>(col + (size_t)(i + RP) * D);
+          const float4 w2 = *reinterpret_cast<const float4*>(col + (size_t)(i + 2 * RP) * D);
+          const float4 w3 = *reinterpret_cast<const float4*>(col + (size_t)(i + 3 * RP) * D);
+          const float r0 = rs[i], r1 = rs[i + RP], r2 = rs[i + 2 * RP], r3 = rs[i + 3 * RP];
+          a.x += (w0.x * r0 + w1.x * r1) + (w2.x * r2 + w3.x * r3);
+          a.y += (w0.y * r0 + w1.y * r1) + (w2.y * r2 + w3.y * r3);
+          a.z += (w0.z * r0 + w1.z * r1) + (w2.z * r2 + w3.z * r3);
+          a.w += (w0.w * r0 + w1.w * r1) + (w2.w * r2 + w3.w * r3);
+        }
+        for (; i < M; i += RP) {
+          const float4 w0 = *reinterpret_cast<const float4*>(col + (size_t)i * D);
+          const float r0 = rs[i];
+          a.x = __builtin_fmaf(w0.x, r0, a.x); a.y = __builtin_fmaf(w0.y, r0, a.y);
+          a.z = __builtin_fmaf(w0.z, r0, a.z); a.w = __builtin_fmaf(w0.w, r0, a.w);
+        }
       }
-      for (; i < M; i += RP) a0 = __builtin_fmaf(Wb[(size_t)i * D + j], rs[i], a0);
+      __syncthreads();
+      *reinterpret_cast<float4*>(part + 4 * tid) = a;
+      __syncthreads();
+      if (rp == 0 && j4 < ncol4) {
+        float4 s4 = *reinterpret_cast<const float4*>(part + 4 * jc);
+        for (int p = 1; p < RP; ++p) {
+          const float4 t4 = *reinterpret_cast<const float4*>(part + 4 * (p * CP4 + jc));
+          s4.x += t4.x; s4.y += t4.y; s4.z += t4.z; s4.w += t4.w;
+        }
+        finish(4 * j4, s4.x); finish(4 * j4 + 1, s4.y); finish(4 * j4 + 2, s4.z); finish(4 * j4 + 3, s4.w);
+      }
     }
-    __syncthreads();
-    part[tid] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (rp == 0 && j < D) {
-      float s = part[jc];
-      for (int p = 1; p < RP; ++p) s += part[p * CP + jc];
-      float gj = cg * s;
-      const float xv = xs[j];
-      if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f));
-      if (pp.kind == L2O_PROB_RASTRIGIN)
-        gj += 6.2831853071795864769f * pp.alpha * pp.C[(size_t)b * D + j] * sinf(6.2831853071795864769f * xv);
-      gb[j] = gj * pp.inv_bg * (sb ? sb[j] : 1.0f);
+  } else {
+    const int CP = D >= kFgThreads ? kFgThreads : ((D + 63) & ~63);
+    const int RP = kFgThreads / CP;
+    const int jc = tid % CP, rp = tid / CP;
+    for (int j0 = 0; j0 < D; j0 += CP) {
+      const int j = j0 + jc;
+      float a0 = 0.f, a1 = 0.f;
+      if (j < D && rp < RP) {
+        int i = rp;
+        for (; i + RP < M; i += 2 * RP) {
+          a0 = __builtin_fmaf(Wb[(size_t)i * D + j], rs[i], a0);
+          a1 = __builtin_fmaf(Wb[(size_t)(i + RP) * D + j], rs[i + RP], a1);
+        }
+        for (; i < M; i += RP) a0 = __builtin_fmaf(Wb[(size_t)i * D + j], rs[i], a0);
+      }
+      __syncthreads();
+      part[tid] = a0 + a1;
+      __syncthreads();
+      if (rp == 0 && j < D) {
+        float s = part[jc];
+        for (int p = 1; p < RP; ++p) s += part[p * CP + jc];
+        finish(j, s);
+      }
     }
   }
 }
@@ -673,11 +750,13 @@ int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float
   if (rc) return rc;
   if (!x || !f_part) return fail(L2O_ERR_ARG, "l2o_problem_fg: NULL x / f_part");
   const ProbParams pp = make_prob_params(prob);
-  const size_t lds = sizeof(float) * ((size_t)pp.D + pp.M + kFgThreads + 4);
+  const size_t lds = sizeof(float) * ((size_t)((pp.D + 3) & ~3) + ((pp.M + 3) & ~3) + 4 * kFgThreads + kFgWaves);
   if (lds > 160 * 1024) return fail(L2O_ERR_UNSUPPORTED, "problem too large for k_problem_fg (D=%d M=%d)", pp.D, pp.M);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_problem_fg),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_problem_fg, dim3(pp.B_local), dim3(kFgThreads), lds, (hipStream_t)stream, pp, x, f_part, g);
+  const bool vec = pp.kind != L2O_PROB_SIMPLE && (pp.D & 3) == 0 && ((uintptr_t)pp.W & 15) == 0;
+  void (*fn)(ProbParams, const float*, float*, float*) = vec ? k_problem_fg<true> : k_problem_fg<false>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  hipLaunchKernelGGL(fn, dim3(pp.B_local), dim3(kFgThreads), lds, (hipStream_t)stream, pp, x, f_part, g);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
 }
