@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 1
+#define L2O_ABI_VERSION 2
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -150,12 +150,22 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack /* device */,
  * then fx_T.  x, st (and m, v) are updated in place == the harness' `update` op.
  * fx_part[t*B_local + b] receives problem b's loss term at step t (t = 0..T).
  * step0 = the harness-fed `step` (DM/util.py:59-60, 85-86); RNNProp only.
- * Returns L2O_ERR_UNSUPPORTED when (problem size, net) has no fused kernel. */
+ * Returns L2O_ERR_UNSUPPORTED when (problem size, net) has no fused kernel.
+ *
+ * workspace: caller-owned device scratch of l2o_unroll_workspace_bytes() bytes, or NULL.
+ * With a workspace, and when 2*B_local workgroups are all co-resident on the device, every
+ * problem is split over TWO workgroups (two CUs) that exchange the iterate once per step
+ * through tagged 8-byte granules in the workspace; otherwise one workgroup per problem.
+ * The first 4 bytes of the workspace are a status word the kernel raises if a partner
+ * never showed up (bounded spin, no hang): after synchronising, copy them to the host and
+ * pass them to l2o_unroll_status(). */
+size_t l2o_unroll_workspace_bytes(const l2o_net_cfg* cfg, const l2o_problem* prob, int32_t T);
 int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack /* device */,
                const l2o_problem* prob, float* x /* device [B_local,D] in-out */,
                float* st /* device, packed, in-out */, float* m, float* v,
                int32_t T, int32_t step0,
-               float* fx_part /* device [(T+1)*B_local] */, void* stream);
+               float* fx_part /* device [(T+1)*B_local] */, void* workspace, void* stream);
+int l2o_unroll_status(const void* workspace_header_host /* host copy of the first 4 bytes */);
 /* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0. */
 int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);
 

@@ -79,6 +79,8 @@ class HipEngine(object):
                                "False); there is no CPU fallback")
         self.lib = _abi.lib()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._workspace = None
+        self._last_ws = None
 
     # -- memory plumbing (torch) ------------------------------------------
     def tensor(self, a):
@@ -143,8 +145,23 @@ class HipEngine(object):
 
     def unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part):
         cc, cp = spec.to_c(), self._cprob(p)
+        nbytes = int(self.lib.l2o_unroll_workspace_bytes(C.byref(cc), C.byref(cp), int(T)))
+        ws = None
+        if nbytes:
+            ws = self._workspace
+            if ws is None or ws.numel() < nbytes:
+                ws = self._workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self._last_ws = ws
         _abi.check(self.lib.l2o_unroll(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
-                                       _ptr(v), int(T), int(step0), _ptr(fx_part), self._stream()))
+                                       _ptr(v), int(T), int(step0), _ptr(fx_part),
+                                       None if ws is None else C.c_void_p(ws.data_ptr()), self._stream()))
+
+    def check_unroll_status(self):
+        """After a host sync: raise if the split-problem kernel reported a partner timeout."""
+        ws = self._last_ws
+        if ws is not None:
+            hdr = ws[:4].cpu().numpy().tobytes()
+            _abi.check(self.lib.l2o_unroll_status(hdr))
 
     def reduce_fx(self, fx_part, T1, B_local, B_global, fx):
         _abi.check(self.lib.l2o_reduce_fx(_ptr(fx_part), int(T1), int(B_local), int(B_global), _ptr(fx),

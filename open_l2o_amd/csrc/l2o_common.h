@@ -241,29 +241,51 @@ __device__ __forceinline__ void lstm_issue_l1_prev(const NetW<PRE>& w, const Til
     acc1[t] = mfma16(w.a1[ka][t], s.h1[kk], acc1[t]);
   });
 }
-// LSTM nonlinearity of ONE unit slice (snt.LSTM: gates i, j, f, o; forget_bias 1):
-//   c' = sigmoid(f + 1) * c + sigmoid(i) * tanh(j) ;  h' = tanh(c') * sigmoid(o)
+// LSTM nonlinearity of the 5 unit slices a lane owns (snt.LSTM: gates i, j, f, o;
+// forget_bias 1):   c' = sigmoid(f + 1) * c + sigmoid(i) * tanh(j) ;  h' = tanh(c') * sigmoid(o)
 // written with e_x = 2^(-x log2e) so that sigmoid(x) = 1/(1+e_x), tanh|x| = (1-E_x)/(1+E_x),
 // E_x = e^(-2|x|) <= 1, and the two quotients of each product share ONE v_rcp_f32:
 //   sigmoid(i) tanh(j) = sgn(j) (1-E_j) / ((1+e_i)(1+E_j))
 // (5 v_exp + 3 v_rcp per unit instead of 5 + 5; no overflow: e_i = inf -> rcp(inf) = 0).
-__device__ __forceinline__ void lstm_gate_unit(const f32x4 acc, float& c, float& h) {
+// The code is STAGE-major over the 5 independent units: MFMA and VALU instructions of one
+// SIMD do not execute concurrently on gfx950 (profiles/r01_b_microbench_*), so what matters
+// for the VALU part is instruction-level parallelism -- five independent dependency chains
+// side by side hide the ~8-cycle transcendental / ~4-cycle VALU latencies in one wave.
+__device__ __forceinline__ void lstm_gates5(const f32x4 (&acc)[kNT], float (&c)[kNT], float (&h)[kNT]) {
 #ifdef L2O_ABLATE_TRANS
-  const float cn = sigmoid_p1f_(acc[2]) * c + sigmoidf_(acc[0]) * tanhf_(acc[1]);
-  c = cn;
-  h = tanhf_(cn) * sigmoidf_(acc[3]);
-  return;
-#endif
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    c[t] = sigmoid_p1f_(acc[t][2]) * c[t] + sigmoidf_(acc[t][0]) * tanhf_(acc[t][1]);
+    h[t] = tanhf_(c[t]) * sigmoidf_(acc[t][3]);
+  }
+#else
   constexpr float kL2E = 1.4426950408889634f;
-  const float e_i = fast_exp2(acc[0] * -kL2E);
-  const float E_j = fast_exp2(__builtin_fabsf(acc[1]) * (-2.0f * kL2E));
-  const float e_f = fast_exp2(__builtin_fmaf(acc[2], -kL2E, -kL2E));
-  const float e_o = fast_exp2(acc[3] * -kL2E);
-  const float ij = __builtin_copysignf((1.0f - E_j) * fast_rcp((1.0f + e_i) * (1.0f + E_j)), acc[1]);
-  const float cn = __builtin_fmaf(fast_rcp(1.0f + e_f), c, ij);
-  const float E_c = fast_exp2(__builtin_fabsf(cn) * (-2.0f * kL2E));
-  c = cn;
-  h = __builtin_copysignf((1.0f - E_c) * fast_rcp((1.0f + E_c) * (1.0f + e_o)), cn);
+  float e_i[kNT], E_j[kNT], e_f[kNT], e_o[kNT], ij[kNT], rf[kNT], cn[kNT], E_c[kNT], ro[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) e_i[t] = fast_exp2(acc[t][0] * -kL2E);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) E_j[t] = fast_exp2(__builtin_fabsf(acc[t][1]) * (-2.0f * kL2E));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) e_f[t] = fast_exp2(__builtin_fmaf(acc[t][2], -kL2E, -kL2E));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) e_o[t] = fast_exp2(acc[t][3] * -kL2E);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) ij[t] = fast_rcp((1.0f + e_i[t]) * (1.0f + E_j[t]));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) rf[t] = fast_rcp(1.0f + e_f[t]);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+    cn[t] = __builtin_fmaf(rf[t], c[t], __builtin_copysignf((1.0f - E_j[t]) * ij[t], acc[t][1]));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) E_c[t] = fast_exp2(__builtin_fabsf(cn[t]) * (-2.0f * kL2E));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) ro[t] = fast_rcp((1.0f + E_c[t]) * (1.0f + e_o[t]));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    c[t] = cn[t];
+    h[t] = __builtin_copysignf((1.0f - E_c[t]) * ro[t], cn[t]);
+  }
+#endif
 }
 
 // everything that needs this step's gradient:
@@ -272,8 +294,8 @@ __device__ __forceinline__ void lstm_gate_unit(const f32x4 acc, float& c, float&
 //   PRE = FC_ELU   : in0 = m~, in1 = g~  (RNNProp)
 // acc1 must already hold bias + the h1(t-1) part, acc2 bias + the h2(t-1) part.
 // With NEXT = true the layer-1 MFMAs of the NEXT step (fed by the h1 just produced) are
-// issued into acc1 interleaved with the layer-2 gate math, so that the matrix pipe has
-// work while the VALU does the transcendental-heavy part (acc1 is dead by then).
+// issued into acc1 (dead by then) right behind the layer-2 ones, so that the caller's next
+// step starts with them done.
 // Returns the Linear output (before tanh / scale), identical on the four q lanes.
 template <int PRE, bool NEXT>
 __device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f32x4 (&acc1)[kNT],
@@ -293,28 +315,25 @@ __device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc1[t] = mfma16(w.a1[5][t], bv, acc1[t]);
   }
-  // layer-1 gates, unit slice by unit slice; the layer-2 MFMAs of k-step kk only need h1[kk]
+  lstm_gates5(acc1, s.c1, s.h1);
 #pragma unroll
-  for (int kk = 0; kk < kNT; ++kk) {
-    lstm_gate_unit(acc1[kk], s.c1[kk], s.h1[kk]);
+  for (int kk = 0; kk < kNT; ++kk)
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc2[t] = mfma16(w.a2[kk][t], s.h1[kk], acc2[t]);
-  }
   if (NEXT) {
 #pragma unroll
     for (int t = 0; t < kNT; ++t) {
       if (PRE == L2O_PRE_FC_ELU) acc1[t] = w.b1[t];
       else acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
   }
-  float d = 0.0f;
-  static_for<0, kNT>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    lstm_gate_unit(acc2[t], s.c2[t], s.h2[t]);
-    d = __builtin_fmaf(s.h2[t], w.wl[t], d);
-    if constexpr (NEXT) lstm_issue_l1_prev<PRE, 5 * t, 5 * t + 5>(w, s, acc1);
-  });
-  d = quad_q_sum(d);
+  lstm_gates5(acc2, s.c2, s.h2);
+  float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];
+  d0 = __builtin_fmaf(s.h2[2], w.wl[2], d0);
+  d1 = __builtin_fmaf(s.h2[3], w.wl[3], d1);
+  d0 = __builtin_fmaf(s.h2[4], w.wl[4], d0);
+  const float d = quad_q_sum(d0 + d1);
   return d + w.bl;
 }
 

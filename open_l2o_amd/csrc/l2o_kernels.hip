@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "l2o_common.h"
@@ -344,16 +345,19 @@ struct UnrollArgs {
 #else
 #define L2O_SYNC() __syncthreads()
 #endif
-__device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
+// a.b accumulated into FOUR independent partial sums (x, y, z, w lanes of `acc`): the
+// chunk loop then carries 4 short dependency chains instead of one long one
+__device__ __forceinline__ void dot4(const float4 a, const float4 b, float4& acc) {
 #ifdef L2O_ABLATE_GEMV
-  return acc + a.x;
+  acc.x += a.x;
+  return;
 #endif
-  acc = __builtin_fmaf(a.x, b.x, acc);
-  acc = __builtin_fmaf(a.y, b.y, acc);
-  acc = __builtin_fmaf(a.z, b.z, acc);
-  acc = __builtin_fmaf(a.w, b.w, acc);
-  return acc;
+  acc.x = __builtin_fmaf(a.x, b.x, acc.x);
+  acc.y = __builtin_fmaf(a.y, b.y, acc.y);
+  acc.z = __builtin_fmaf(a.z, b.z, acc.z);
+  acc.w = __builtin_fmaf(a.w, b.w, acc.w);
 }
+__device__ __forceinline__ float hsum4(const float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
 template <int PRE, int KIND, int CH>
 __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
@@ -426,15 +430,15 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
 #pragma unroll
     for (int u = 0; u < kNT; ++u) acc2[u] = w.b2[u];
     // ---- r = W xs - y  ||  first 12 layer-2 MFMAs of the previous h2 -----------
-    float racc = 0.0f;
+    float4 racc = {0.f, 0.f, 0.f, 0.f};
     static_for<0, CH>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       const float4 wv4 = *reinterpret_cast<const float4*>(wrow + 16 * m);
       const float4 xv4 = *reinterpret_cast<const float4*>(xsq + 16 * m);
       lstm_issue_l2_prev<PRE, (12 * m) / CH, (12 * (m + 1)) / CH>(w, s, acc2);
-      racc = dot4(wv4, xv4, racc);
+      dot4(wv4, xv4, racc);
     });
-    const float r = quad_sum(racc) - ys[grow];
+    const float r = quad_sum(hsum4(racc)) - ys[grow];
     float contrib = 0.0f;
     if (gq == 0) {
       rs[grow] = r;                       // rows >= M: W row and y are zero -> r == 0
@@ -455,15 +459,15 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     if (t == a.T) break;
 
     // ---- g = W^T r for this wave's 16 coordinates  ||  the other 13 of those MFMAs ----
-    float gacc = 0.0f;
+    float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
     static_for<0, CH>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       const float4 wt4 = *reinterpret_cast<const float4*>(wtrow + 16 * m);
       const float4 rv4 = *reinterpret_cast<const float4*>(rsq + 16 * m);
       lstm_issue_l2_prev<PRE, 12 + (13 * m) / CH, 12 + (13 * (m + 1)) / CH>(w, s, acc2);
-      gacc = dot4(wt4, rv4, gacc);
+      dot4(wt4, rv4, gacc4);
     });
-    gacc = quad_sum(gacc);                 // lanes 4k..4k+3 hold g of coordinate 16*wv + k
+    const float gacc = quad_sum(hsum4(gacc4));                 // lanes 4k..4k+3 hold g of coordinate 16*wv + k
     float gv = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(gacc)));
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (KIND == L2O_PROB_RASTRIGIN) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
@@ -497,6 +501,8 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
   }
   store_tile_state(s, st_tile, lane);
 }
+
+#include "l2o_unroll_pair.h"
 
 // ---------------------------------------------------------------------------
 // small utility kernels
@@ -615,8 +621,66 @@ static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
   return g->lds <= 160 * 1024;
 }
 
+static int device_cu_count() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      cus = n;
+    else
+      cus = 0;
+  }
+  return cus;
+}
+
+// Split every problem over two workgroups when that still leaves all of them co-resident.
+static bool pair_eligible(const l2o_problem* p, const UnrollGeom& g) {
+  if (getenv("L2O_NO_PAIR")) return false;
+  if (g.CH < 2) return false;
+  return 2 * p->B_local <= device_cu_count();
+}
+struct PairLayout { size_t xbuf_off, xbuf_bytes, fxh_off, total; int npg; size_t lds; };
+static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) {
+  PairLayout L;
+  const int NWH = g.CH / 2, SQ = 16 * g.CH, S = SQ + 16;
+  L.npg = NWH * 16;
+  L.xbuf_off = sizeof(PairWs);
+  L.xbuf_bytes = (size_t)p->B_local * 2 * 2 * L.npg * sizeof(unsigned long long);
+  L.fxh_off = L.xbuf_off + L.xbuf_bytes;
+  L.total = L.fxh_off + sizeof(float) * (size_t)(T + 1) * 2 * p->B_local;
+  L.lds = sizeof(float) * ((size_t)SQ * S + (size_t)NWH * 16 * S + 3 * (size_t)SQ + 8);
+  return L;
+}
+
 template <int PRE, int KIND>
-static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s) {
+static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s, const l2o_problem* prob,
+                            void* workspace) {
+  if (workspace && pair_eligible(prob, g)) {
+    const PairLayout L = pair_layout(prob, g, a.T);
+    UnrollPairArgs pa;
+    pa.u = a;
+    pa.ws = reinterpret_cast<PairWs*>(workspace);
+    pa.xbuf = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + L.xbuf_off);
+    pa.fx_half = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.fxh_off);
+    void (*fn)(UnrollPairArgs) = nullptr;
+    switch (g.CH) {
+      case 2: fn = k_unroll_pair<PRE, KIND, 2>; break;
+      case 4: fn = k_unroll_pair<PRE, KIND, 4>; break;
+      default: fn = k_unroll_pair<PRE, KIND, 8>; break;
+    }
+    HIP_TRY(hipMemsetAsync(workspace, 0, L.fxh_off, s));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)L.lds));
+    // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
+    const int groups = (a.pp.B_local + 7) / 8;
+    hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
+    HIP_TRY(hipGetLastError());
+    const int n = (a.T + 1) * a.pp.B_local;
+    hipLaunchKernelGGL(k_combine_halves, dim3((n + 255) / 256), dim3(256), 0, s, pa.fx_half, a.fx_part, n);
+    HIP_TRY(hipGetLastError());
+    return L2O_OK;
+  }
   void (*fn)(UnrollArgs) = nullptr;
   switch (g.CH) {
     case 1: fn = k_unroll<PRE, KIND, 1>; break;
@@ -632,11 +696,12 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
 }
 
 template <int PRE>
-static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind, hipStream_t s) {
+static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind, hipStream_t s,
+                              const l2o_problem* prob, void* workspace) {
   switch (kind) {
-    case L2O_PROB_QUADRATIC: return launch_unroll_ch<PRE, L2O_PROB_QUADRATIC>(a, g, s);
-    case L2O_PROB_LASSO: return launch_unroll_ch<PRE, L2O_PROB_LASSO>(a, g, s);
-    case L2O_PROB_RASTRIGIN: return launch_unroll_ch<PRE, L2O_PROB_RASTRIGIN>(a, g, s);
+    case L2O_PROB_QUADRATIC: return launch_unroll_ch<PRE, L2O_PROB_QUADRATIC>(a, g, s, prob, workspace);
+    case L2O_PROB_LASSO: return launch_unroll_ch<PRE, L2O_PROB_LASSO>(a, g, s, prob, workspace);
+    case L2O_PROB_RASTRIGIN: return launch_unroll_ch<PRE, L2O_PROB_RASTRIGIN>(a, g, s, prob, workspace);
     default: return fail(L2O_ERR_UNSUPPORTED, "no fused kernel for problem kind %d", kind);
   }
 }
@@ -813,8 +878,24 @@ int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
   return unroll_geom(prob, &g) ? 1 : 0;
 }
 
+size_t l2o_unroll_workspace_bytes(const l2o_net_cfg* cfg, const l2o_problem* prob, int32_t T) {
+  if (!l2o_unroll_supported(cfg, prob) || T < 0) return 0;
+  UnrollGeom g;
+  unroll_geom(prob, &g);
+  if (g.CH < 2) return 0;
+  return pair_layout(prob, g, T).total;
+}
+
+int l2o_unroll_status(const void* workspace_header_host) {
+  if (!workspace_header_host) return L2O_OK;
+  const unsigned st = *static_cast<const unsigned*>(workspace_header_host);
+  if (st == 0) return L2O_OK;
+  return fail(L2O_ERR_HIP, "l2o_unroll: partner workgroup timed out (status %u): the two halves of a problem "
+                           "were not co-resident; rerun with L2O_NO_PAIR=1", st);
+}
+
 int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st, float* m,
-               float* v, int32_t T, int32_t step0, float* fx_part, void* stream) {
+               float* v, int32_t T, int32_t step0, float* fx_part, void* workspace, void* stream) {
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!cfg || !wpack || !x || !st || !fx_part || T < 0) return fail(L2O_ERR_ARG, "l2o_unroll: bad argument");
@@ -832,11 +913,11 @@ int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* pr
   pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
   hipStream_t s = (hipStream_t)stream;
   switch (cfg->preprocess) {
-    case L2O_PRE_IDENTITY: return launch_unroll_kind<L2O_PRE_IDENTITY>(a, g, prob->kind, s);
-    case L2O_PRE_LOGSIGN: return launch_unroll_kind<L2O_PRE_LOGSIGN>(a, g, prob->kind, s);
+    case L2O_PRE_IDENTITY: return launch_unroll_kind<L2O_PRE_IDENTITY>(a, g, prob->kind, s, prob, workspace);
+    case L2O_PRE_LOGSIGN: return launch_unroll_kind<L2O_PRE_LOGSIGN>(a, g, prob->kind, s, prob, workspace);
     default:
       if (!m || !v) return fail(L2O_ERR_ARG, "l2o_unroll: RNNProp needs m and v");
-      return launch_unroll_kind<L2O_PRE_FC_ELU>(a, g, prob->kind, s);
+      return launch_unroll_kind<L2O_PRE_FC_ELU>(a, g, prob->kind, s, prob, workspace);
   }
 }
 

@@ -401,6 +401,8 @@ class UnrollGraph(object):
             import torch.distributed as dist
             dist.all_reduce(fx)
         fx_host = eng.to_numpy(fx)
+        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
+            eng.check_unroll_status()
 
         if commit:
             for s, st in zip(slots, states):

@@ -4,7 +4,7 @@
 #   bash scripts/ablate.sh build ; gpurun -- bash scripts/ablate.sh run
 set -e
 cd "$(dirname "$0")/.."
-VARS="BASE MFMA TRANS GEMV BARRIER MFMA_TRANS"
+VARS=${VARS:-"BASE MFMA TRANS GEMV BARRIER MFMA_TRANS EXCHANGE EXCHANGE_BARRIER"}
 if [ "$1" = build ]; then
   mkdir -p build/ablate
   for v in $VARS; do
