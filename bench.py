@@ -1,23 +1,26 @@
 #!/usr/bin/env python
-"""bench.py -- unroll-steps/sec of the L2O inner unroll loop on MI355X.
+"""bench.py -- unroll-steps/sec of the L2O inner unroll loop on MI355X, through the
+product API (open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> one unroll per step).
 
-Workload (BASELINE.json configs[1]): L2O-DM (CoordinateWiseDeepLSTM, layers (20,20),
+Default workload (BASELINE.json configs[1]): L2O-DM (CoordinateWiseDeepLSTM, layers (20,20),
 identity preprocess -- what util.get_config("quadratic") builds) on Quadratic d=128,
 batch=128 per GPU, T=100 optimizer steps per unroll, fp32, synthetic data
-(W, y ~ U[0,1), x0 ~ N(0, 0.01^2), Sonnet-default random LSTM weights).
+(W, y ~ U[0,1), x0 ~ N(0, 0.01^2) as DM/problems.py:84-96; Sonnet-default random LSTM weights,
+output Linear x0.1 so that the untrained optimizer's trajectory stays finite).
 
-One "step" of this benchmark = one complete unroll: reset x/LSTM state -> T x
+One "step" of this benchmark = one complete unroll: rewind x / LSTM state -> T x
 {f(x), grad f, LSTM optimizer step, x += delta} -> f(x_T) -> per-step loss reduction
-(-> all-reduce of the T+1 partial losses over ranks when N > 1).  Inputs are resident
-in HBM when the timed region starts.
+(-> all-reduce of the T+1 partial losses over ranks when N > 1).  Inputs are resident in
+HBM when the timed region starts; nothing is copied to the host inside it.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  value = coordinate-steps per second, whole job:
     N_gpus * B_local * D * T * steps / wall_time.
-Weak scaling: every GPU holds its own 128 problems, the loss mean is over the global
-batch 128*N (DM/problems.py:99), the only collective is the all-reduce of T+1 floats.
+Weak scaling: every GPU holds its own 128 problems of a global batch 128*N, the loss mean
+is over the global batch (DM/problems.py:99), the only collective is the all-reduce of
+T+1 floats per unroll.  The oracle is imported by the cpu_baseline leg only.
 """
 import argparse
 import json
@@ -29,10 +32,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# algorithmic bytes per coordinate-step, SURVEY.md section 8(d): x r+w (8) + LSTM state
-# r+w (640) + optimizee row+column+y (8*D + 4)
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_PEAK = 157.3e12
+
+
 def alg_bytes_per_coord_step(problem, net, D, M):
     """x r+w + LSTM state r+w (+ RNNProp m, v r+w) + the optimizee's matrix
     streamed for the forward and for the gradient."""
@@ -49,44 +53,67 @@ def alg_flops_per_coord_step(problem, net, D, M):
     return lstm + 4 * (M if problem == "lasso" else D)
 
 
-HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
-FP32_PEAK = 157.3e12
-
-
-def cpu_baseline(problem, net, D, M, B, T, max_seconds=20.0):
-    """The reference path restated for the CPU, timed on this host's cores on the SAME
-    workload (whole unrolls, bounded to ~max_seconds): the plain-C + OpenMP port
-    (oracle/l2o_oracle.c, one problem per thread) is the reported baseline; the NumPy
-    oracle (multi-threaded BLAS gate matmuls, single-threaded elementwise) is timed once
-    next to it for reference."""
+def cpu_baseline(problem, net, arrays, weights, x0, T, max_seconds=20.0):
+    """The reference path restated for the CPU (oracle/, test infrastructure), timed on this
+    host's cores on the SAME inputs (whole unrolls, bounded to ~max_seconds): the plain-C +
+    OpenMP port (oracle/l2o_oracle.c, one problem per thread) is the reported baseline; the
+    NumPy oracle (multi-threaded BLAS gate matmuls) is timed once next to it for reference."""
     import oracle as O
-    from helpers import make_params, make_problem
     from oracle.c_oracle import c_unroll
-    from helpers import ORACLE_CFGS
-    cfg = ORACLE_CFGS[net]
-    params = make_params(cfg, seed=0, trained_like=True)
-    prob, x0, arrays = make_problem(problem, B, D, seed=1, M=M)
-    c_unroll(problem, cfg, params, arrays, x0, 2)                # warm-up (thread pool, page faults)
+    cfg = {"dm": O.DM_IDENTITY, "dm_logsign": O.DM_LOGSIGN, "rnnprop": O.RNNPROP}[net]
+    B, M, D = arrays["W"].shape
+    c_unroll(problem, cfg, weights, arrays, x0, 2)                # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
     n = 0
     while True:
-        fx, _, _, _, _, threads = c_unroll(problem, cfg, params, arrays, x0, T)
+        fx, _, _, _, _, threads = c_unroll(problem, cfg, weights, arrays, x0, T)
         n += 1
         if time.perf_counter() - t0 > max_seconds or n >= 20:
             break
     dt = time.perf_counter() - t0
     out = {"value": B * D * T * n / dt, "unit": "coordinate-steps/s", "cores": int(threads),
            "host_cpus": os.cpu_count(), "kind": "port",
-           "sample": "%d full unroll(s) of the same workload (C99+OpenMP port oracle/l2o_oracle.c, "
+           "sample": "%d full unroll(s) of the same workload and inputs (C99+OpenMP port oracle/l2o_oracle.c, "
                      "%s/%s B=%d D=%d T=%d), %.1f s" % (n, net, problem, B, D, T, dt), "fx_T": float(fx[-1])}
-    if B * D * T <= 2_000_000:
-        st0 = O.net_initial_state(cfg, B * D)
+    if problem == "quadratic" and B * D * T <= 2_000_000:
+        prob = O.Quadratic(arrays["W"], arrays["y"])
         t0 = time.perf_counter()
-        res = O.unroll(prob, cfg, params, x0, st0, T)
+        res = O.unroll(prob, cfg, weights, x0, O.net_initial_state(cfg, B * D), T)
         dt = time.perf_counter() - t0
         out["numpy_oracle"] = {"value": B * D * T / dt, "unit": "coordinate-steps/s",
                                "sample": "1 unroll, %.1f s" % dt, "fx_T": float(res.fx[-1])}
     return out
+
+
+def build_workload(args, Bg):
+    """Problem + optimizer through the product API."""
+    from open_l2o_amd import meta, meta_rnnprop_eval, networks, util
+    D, T = args.dims, args.unroll
+    meta.set_random_seed(1234)                     # same global problem + weights on every rank
+    opts = {"batch_size": Bg, "num_dims": D}
+    if args.problem == "lasso":
+        opts.update(l=0.1, num_rows=args.rows)
+    problem, net_config, net_assignments = util.get_config(
+        args.problem, problem_options=opts, net_name="RNNprop" if args.net == "rnnprop" else None)
+    if args.net == "dm_logsign":
+        net_config = {"cw": util.get_default_net_config(None)}
+    key = next(iter(net_config))
+    cfg = dict(net_config[key])
+    # Sonnet-default random init, output Linear x0.1 (see module docstring)
+    weights = networks.factory(cfg["net"], cfg["net_options"]).variables
+    weights = {m: {v: np.array(a) for v, a in d.items()} for m, d in weights.items()}
+    weights["linear"] = {k: (a * np.float32(0.1)).astype(np.float32) for k, a in weights["linear"].items()}
+    cfg["net_options"] = dict(cfg["net_options"], initializer=weights)
+    net_config = {key: cfg}
+    feed = {}
+    if args.net == "rnnprop":
+        optimizer = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **net_config)
+        ml, _, _, step = optimizer.meta_loss(problem, T, net_assignments=net_assignments)
+        feed = {step: 1}
+    else:
+        optimizer = meta.MetaOptimizer(**net_config)
+        ml = optimizer.meta_loss(problem, T, net_assignments=net_assignments)
+    return optimizer, ml, feed, weights
 
 
 def main():
@@ -105,9 +132,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    import oracle as O
-    from helpers import device_problem, make_params, make_problem, spec_of
-    from open_l2o_amd._engine import HipEngine
+    from open_l2o_amd import _engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -118,49 +143,22 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda:%d" % local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    eng = HipEngine("cuda:%d" % local_rank)
+    eng = _engine.HipEngine("cuda:%d" % local_rank)        # raises without GPU / built extension
+    _engine.set_default_engine(eng)
 
     D, B, T = args.dims, args.batch, args.unroll
     Bg = B * world
-    from helpers import ORACLE_CFGS
-    cfg = ORACLE_CFGS[args.net]
-    spec = spec_of(cfg)
-    # random-init Sonnet-default weights (output Linear x0.1 so that the untrained optimizer
-    # takes small steps and the trajectory stays finite); same weights on every rank
-    params = make_params(cfg, seed=0, trained_like=True)
-    prob, x0, arrays = make_problem(args.problem, B, D, seed=1 + rank, M=args.rows)   # rank's own problems
-    wpack = eng.pack_weights(spec, params)
-    pd = device_problem(eng, arrays, B, D, B_global=Bg)
-    fused = eng.unroll_supported(spec, pd)
-    x0d = eng.tensor(x0.reshape(B, D))
-    x, st = eng.empty(B, D), eng.state_alloc(B, D)
-    mm, vv = eng.zeros(B, D), eng.zeros(B, D)
-    b95 = float(np.float32(0.95))
-    fx_part, fx = eng.zeros((T + 1) * B), eng.zeros(T + 1)
-    f1, g = eng.zeros(B), eng.zeros(B, D)
+    optimizer, ml, feed, weights = build_workload(args, Bg)
+    graph = optimizer.graph
+    graph.reset()                                           # sample x0, W, y (this rank's shard) on the device
+    x0 = [v.value.clone() for v in graph.x]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
 
     def one_unroll(i=None):
-        x.copy_(x0d)                                       # reset (DM/meta.py:379-383)
-        st.zero_()
-        if args.net == "rnnprop":
-            mm.zero_()
-            vv.zero_()
-        if i is not None:
-            ev[i][0].record()
-        if fused:
-            eng.unroll(spec, wpack, pd, x, st, mm, vv, T, 1, fx_part)
-        else:
-            for t in range(T):
-                eng.problem_fg(pd, x, fx_part[t * B:(t + 1) * B], g)
-                eng.lstm_step(spec, wpack, g, mm, vv, b95 ** (1 + t), b95 ** (1 + t), st, x, B, D)
-            eng.problem_fg(pd, x, fx_part[T * B:(T + 1) * B], None)
-        if i is not None:
-            ev[i][1].record()
-        eng.reduce_fx(fx_part, T + 1, B, Bg, fx)
-        if world > 1:
-            dist.all_reduce(fx)                            # sum of per-rank partial means
+        graph.rewind(x0)                                    # x <- x0, LSTM state (m, v) <- 0
+        fx, _ = graph.launch(feed, commit=True, events=None if i is None else ev[i])
+        return fx
 
     def fence():
         torch.cuda.synchronize()
@@ -173,7 +171,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_unroll(i)
+        fx = one_unroll(i)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -181,8 +179,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fx_host = eng.to_numpy(fx)
+    eng.check_unroll_status()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     kern_ms_min = float(np.min([a.elapsed_time(b) for a, b in ev]))
+    fused = graph.last_path == "fused"
 
     if rank == 0:
         coord_steps = B * D * T                            # per GPU per unroll
@@ -196,39 +196,46 @@ def main():
                    "rnnprop": "L2O-RNNProp (fc+ELU, tanh, 0.01)"}[args.net]
         probname = {"quadratic": "Quadratic d=%d" % D, "lasso": "Lasso A in R^{%dx%d} l=0.1" % (Mrows, D),
                     "rastrigin": "Rastrigin d=%d" % D}[args.problem]
+        is_c2 = (args.problem, args.net, D, B, T) == ("quadratic", "dm", 128, 128, 100)
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_c2.json")
-        if os.path.exists(pmc_file) and fused:
+        if os.path.exists(pmc_file) and fused and is_c2 and world == 1:
             pmc = json.load(open(pmc_file))
-            if pmc["workload"] == [args.problem, args.net, D, B, T]:
-                traffic = pmc["traffic_bytes"]
-                traffic_src = ("profiles/r01_pmc_c2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                               "command, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)")
+            traffic = pmc["traffic_bytes"]
+            traffic_src = ("profiles/r01_pmc_c2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                           "command, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)")
         out = {
             "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
             "value": value, "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
-                                   % (netname, probname, B, Bg, T,
-                                      ", BASELINE.json configs[1]" if (args.problem, args.net, D, B, T) ==
-                                      ("quadratic", "dm", 128, 128, 100) else ""),
-                       "kernel": "k_unroll (fused persistent)" if fused else "k_problem_fg + k_cwlstm_step per step",
+                                   % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
+                       "kernel": ("l2o_unroll (fused persistent, 2 CUs per problem when 2*batch <= #CUs)" if fused
+                                  else "l2o_problem_fg + l2o_cwlstm_step per step"),
+                       "api": "open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> UnrollGraph.launch",
                        "parallelism": "problem-batch sharding x%d, all-reduce of T+1 floats" % world},
             "final_loss_fx_T": float(fx_host[-1]), "fx_0": float(fx_host[0]),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg,
-                         "alg_bytes_per_coord_step": bpc,
+                         "algorithmic_bytes_per_launch": alg, "alg_bytes_per_coord_step": bpc,
                          "kernel_ms_avg": kern_ms, "kernel_ms_min": kern_ms_min,
                          "fp32_tflops": flops / (kern_ms * 1e-3) / 1e12,
                          "fp32_frac_of_157.3TF": flops / (kern_ms * 1e-3) / FP32_PEAK,
-                         "note": "step-granular algorithmic bytes (SURVEY 8d); the fused kernel keeps x, LSTM "
-                                 "state and W on-chip, so real HBM traffic is far below this figure and the "
-                                 "kernel is matrix-core/VALU bound -- see DESIGN.md"},
+                         "note": "step-granular algorithmic bytes (SURVEY 8d) over the HIP-event time of the "
+                                 "unroll kernels; the fused kernel keeps x, LSTM state and W on-chip, so real HBM "
+                                 "traffic is far below this figure and the kernel is fp32-issue bound -- DESIGN.md 5"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.problem, args.net, D, args.rows, B, T)
+            names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
+                     "rastrigin": ("A", "B", "C")}[args.problem]
+            g = graph._by_name
+            arrays = {"W": g[names[0]].eval(), "y": g[names[1]].eval().reshape(B, -1)}
+            if names[2]:
+                arrays["C"] = g[names[2]].eval().reshape(B, -1)
+            arrays["l1"], arrays["alpha"] = 0.1, 10.0
+            out["cpu_baseline"] = cpu_baseline(args.problem, args.net, arrays, weights,
+                                               eng.to_numpy(x0[0]).reshape(B, D), T)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

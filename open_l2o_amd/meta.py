@@ -343,7 +343,21 @@ class UnrollGraph(object):
         return self.engine.unroll_supported(s.net.spec, descs[0])
 
     def execute(self, feed, commit):
-        """Run one unroll from the current variables.  Returns dict(loss, fx, x)."""
+        """Run one unroll from the current variables.  Returns dict(loss, fx, x) on the host."""
+        fx, xs = self.launch(feed, commit)
+        eng = self.engine
+        T = self.len_unroll
+        fx_host = eng.to_numpy(fx)                       # host sync
+        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
+            eng.check_unroll_status()
+        x_out = [eng.to_numpy(xv).reshape(self._local_shape(var)) for xv, var in zip(xs, self.x)]
+        return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
+                "x": x_out, "fx_array": fx_host}
+
+    def launch(self, feed=None, commit=True, events=None):
+        """Enqueue one unroll on the current stream WITHOUT synchronising the host; returns
+        (device tensor fx[0..T] -- already all-reduced when sharded --, list of device x_T).
+        ``events`` = (start, end) torch.cuda.Event pair recorded around the unroll kernels only."""
         self._ensure_init()
         eng = self.engine
         T = self.len_unroll
@@ -390,26 +404,41 @@ class UnrollGraph(object):
             self.last_path = "fused"
             s, d = slots[0], descs[0]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
-            eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
-                       fx_part)
+            wpack = s.net.wpack(eng)
+            if events is not None:
+                events[0].record()
+            eng.unroll(s.net.spec, wpack, d, panels[0], states[0].packed, ms[0], vs[0], T, step0, fx_part)
+            if events is not None:
+                events[1].record()
             eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
         else:
             self.last_path = "steps"
+            if events is not None:
+                events[0].record()
             self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx)
+            if events is not None:
+                events[1].record()
 
         if self.sharded:
             import torch.distributed as dist
             dist.all_reduce(fx)
-        fx_host = eng.to_numpy(fx)
-        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
-            eng.check_unroll_status()
-
         if commit:
             for s, st in zip(slots, states):
                 s.state = st
-        x_out = [eng.to_numpy(xv).reshape(self._local_shape(var)) for xv, var in zip(xs, self.x)]
-        return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
-                "x": x_out, "fx_array": fx_host}
+        return fx, xs
+
+    def rewind(self, x0):
+        """Device-side restart of the SAME problem instance: x <- x0 (list of device tensors),
+        LSTM state / moments <- 0, without re-sampling the problem data (bench.py)."""
+        self._ensure_init()
+        for v, t in zip(self.x, x0):
+            v.value.copy_(t)
+        for s in self.slots:
+            if isinstance(s.state, PackedState):
+                s.state.zero_()
+            if s.m is not None:
+                s.m.zero_()
+                s.v.zero_()
 
     def _local_shape(self, var):
         if self.sharded:
@@ -486,6 +515,11 @@ class MetaOptimizer(object):
             self._config = {k: dict(v) for k, v in _DEFAULT_CONFIG.items()}
         else:
             self._config = kwargs
+
+    @property
+    def graph(self):
+        """The UnrollGraph of the last meta_loss call (variables, placeholders, launch())."""
+        return self._graph
 
     # -- checkpoints: DM/meta.py:255-267, DM/meta_dm_train.py:257-302 ----------
     def save(self, sess=None, path=None, index=None):
