@@ -45,11 +45,15 @@ def alg_bytes_per_coord_step(problem, net, D, M):
         return base + 8 * D + 4
     if problem == "lasso":
         return base + 8 * M + 4.0 * M / D
+    if problem == "mnist":                       # minibatch [M x 784] read for forward and for gw1
+        return base + 2.0 * M * 784 * 4 / D
     return base + 8 * D + 8                      # rastrigin
 
 
 def alg_flops_per_coord_step(problem, net, D, M):
     lstm = {"dm": 9800, "dm_logsign": 9960, "rnnprop": 12920 + 15}[net]
+    if problem == "mnist":
+        return lstm + 4 * M                      # 2 x 2 x batch MACs per weight
     return lstm + 4 * (M if problem == "lasso" else D)
 
 
@@ -93,9 +97,12 @@ def build_workload(args, Bg):
     opts = {"batch_size": Bg, "num_dims": D}
     if args.problem == "lasso":
         opts.update(l=0.1, num_rows=args.rows)
+    if args.problem == "mnist":                    # not sharded: every GPU optimizes its own replica
+        from open_l2o_amd import problems
+        opts = {"batch_size": args.batch, "data": problems.synthetic_mnist(4096, seed=5)}
     problem, net_config, net_assignments = util.get_config(
         args.problem, problem_options=opts, net_name="RNNprop" if args.net == "rnnprop" else None)
-    if args.net == "dm_logsign":
+    if args.net == "dm_logsign" or (args.problem == "mnist" and args.net == "dm"):
         net_config = {"cw": util.get_default_net_config(None)}
     key = next(iter(net_config))
     cfg = dict(net_config[key])
@@ -125,7 +132,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="problems per GPU")
     ap.add_argument("--unroll", type=int, default=100, help="T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin"])
+    ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin", "mnist"])
     ap.add_argument("--rows", type=int, default=None, help="lasso rows M (default: dims)")
     ap.add_argument("--net", default="dm", choices=["dm", "dm_logsign", "rnnprop"])
     args = ap.parse_args()
@@ -147,6 +154,8 @@ def main():
     _engine.set_default_engine(eng)
 
     D, B, T = args.dims, args.batch, args.unroll
+    if args.problem == "mnist":                    # 784-20-10 MLP: 15 910 coordinates, `batch` = minibatch
+        D = 784 * 20 + 20 + 20 * 10 + 10
     Bg = B * world
     optimizer, ml, feed, weights = build_workload(args, Bg)
     graph = optimizer.graph
@@ -185,9 +194,9 @@ def main():
     fused = graph.last_path == "fused"
 
     if rank == 0:
-        coord_steps = B * D * T                            # per GPU per unroll
+        coord_steps = (1 if args.problem == "mnist" else B) * D * T     # per GPU per unroll
         value = world * coord_steps * args.steps / dt
-        Mrows = args.rows or D
+        Mrows = B if args.problem == "mnist" else (args.rows or D)
         bpc = alg_bytes_per_coord_step(args.problem, args.net, D, Mrows)
         alg = bpc * coord_steps                            # algorithmic bytes per unroll
         achieved = alg / (kern_ms * 1e-3)
@@ -195,7 +204,8 @@ def main():
         netname = {"dm": "L2O-DM CoordinateWiseDeepLSTM(20,20)", "dm_logsign": "L2O-DM (LogAndSign k=5)",
                    "rnnprop": "L2O-RNNProp (fc+ELU, tanh, 0.01)"}[args.net]
         probname = {"quadratic": "Quadratic d=%d" % D, "lasso": "Lasso A in R^{%dx%d} l=0.1" % (Mrows, D),
-                    "rastrigin": "Rastrigin d=%d" % D}[args.problem]
+                    "rastrigin": "Rastrigin d=%d" % D,
+                    "mnist": "MLP 784-20-10 (sigmoid) on synthetic MNIST-shaped data, minibatch %d" % B}[args.problem]
         is_c2 = (args.problem, args.net, D, B, T) == ("quadratic", "dm", 128, 128, 100)
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_c2.json")
@@ -226,7 +236,7 @@ def main():
                                  "unroll kernels; the fused kernel keeps x, LSTM state and W on-chip, so real HBM "
                                  "traffic is far below this figure and the kernel is fp32-issue bound -- DESIGN.md 5"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.problem != "mnist":
             names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
                      "rastrigin": ("A", "B", "C")}[args.problem]
             g = graph._by_name

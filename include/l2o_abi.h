@@ -54,6 +54,7 @@ extern "C" {
 #define L2O_PROB_LASSO 2       /* problems.lasso :103-134 and lasso_fixed :137-175                         */
 #define L2O_PROB_RASTRIGIN 3   /* problems.rastrigin :177-213                                              */
 #define L2O_PROB_SQUARE_COS 4  /* problems.square_cos :959-994                                             */
+#define L2O_PROB_MLP 5         /* problems.mnist :254-288 (own entry point: l2o_mlp_fg)                    */
 
 /* Hyper-parameters of one optimizer network: the `net_options` dict of
  * networks.factory (DM/networks.py:34-44) as used by util.get_config
@@ -130,6 +131,26 @@ int l2o_state_unpack(const float* st, float* h1, float* c1, float* h2, float* c2
 int l2o_problem_fg(const l2o_problem* prob, const float* x /* device [B_local,D] */,
                    float* f_part /* device [B_local] */, float* g /* device [B_local,D] or NULL */,
                    void* stream);
+
+/* ---- neural optimizee: problems.mnist (DM/problems.py:246-288) = mean sparse-softmax
+ * cross-entropy of snt.nets.MLP([n_hidden, n_out]) on a minibatch gathered from a resident
+ * dataset; forward + tf.gradients w.r.t. the four variables (DM/meta.py:322, 344).
+ * One hidden layer (util.get_config("mnist"): layers=(20,), DM/util.py:147-149).
+ * loss[0] = the scalar loss; gradients may all be NULL (forward only). */
+typedef struct l2o_mlp {
+  int32_t n_in;          /* 784                                                      */
+  int32_t n_hidden;      /* layers[0] (<= 32)                                        */
+  int32_t n_out;         /* 10 (<= 16)                                               */
+  int32_t batch;         /* minibatch size (<= 256)                                  */
+  int32_t activation;    /* 0 = sigmoid, 1 = relu  (DM/problems.py:260-265)          */
+  int32_t n_data;        /* rows of `images`                                         */
+  const float* images;   /* device [n_data, n_in]                                    */
+  const int32_t* labels; /* device [n_data]                                          */
+} l2o_mlp;
+int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices /* device [batch] rows of the minibatch */,
+               const float* w1 /* device [n_in,n_hidden] */, const float* b1 /* [n_hidden] */,
+               const float* w2 /* device [n_hidden,n_out] */, const float* b2 /* [n_out] */,
+               float* loss /* device [1] */, float* gw1, float* gb1, float* gw2, float* gb2, void* stream);
 
 /* ---- one optimizer step on a gradient panel: the closure `update`
  * (DM/meta.py:319-336; RNNProp DM/meta_rnnprop_train.py:371-395) for ONE variable:

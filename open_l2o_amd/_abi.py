@@ -19,12 +19,12 @@ L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
 
 NET_CW, NET_RNNPROP = 0, 1
 PRE_IDENTITY, PRE_LOGSIGN, PRE_FC_ELU = 0, 1, 2
-PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS = 0, 1, 2, 3, 4
+PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_MLP = 0, 1, 2, 3, 4, 5
 
 # every symbol include/l2o_abi.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
-    "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg",
+    "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
     "l2o_cwlstm_step", "l2o_unroll", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
@@ -47,6 +47,14 @@ class Problem(C.Structure):
         ("D", C.c_int32), ("M", C.c_int32), ("reserved", C.c_int32),
         ("l1", C.c_double), ("alpha", C.c_double),
         ("W", C.c_void_p), ("y", C.c_void_p), ("C", C.c_void_p), ("x_scale", C.c_void_p),
+    ]
+
+
+class Mlp(C.Structure):
+    """struct l2o_mlp"""
+    _fields_ = [
+        ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32), ("batch", C.c_int32),
+        ("activation", C.c_int32), ("n_data", C.c_int32), ("images", C.c_void_p), ("labels", C.c_void_p),
     ]
 
 
@@ -90,6 +98,8 @@ def lib():
     L.l2o_state_unpack.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
     L.l2o_problem_fg.restype = C.c_int
     L.l2o_problem_fg.argtypes = [C.POINTER(Problem), vp, vp, vp, vp]
+    L.l2o_mlp_fg.restype = C.c_int
+    L.l2o_mlp_fg.argtypes = [C.POINTER(Mlp)] + [vp] * 11
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
     L.l2o_unroll.restype = C.c_int

@@ -61,6 +61,18 @@ class ProblemDesc:
     x_scale: Optional[torch.Tensor] = None
 
 
+@dataclasses.dataclass
+class MlpDesc:
+    """Device-side view of problems.mnist (struct l2o_mlp)."""
+    n_in: int
+    n_hidden: int
+    n_out: int
+    batch: int
+    activation: int           # 0 sigmoid, 1 relu
+    images: torch.Tensor      # [n_data, n_in] fp32
+    labels: torch.Tensor      # [n_data] int32
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -132,6 +144,19 @@ class HipEngine(object):
     def problem_fg(self, p: ProblemDesc, x, f_part, g):
         cp = self._cprob(p)
         _abi.check(self.lib.l2o_problem_fg(C.byref(cp), _ptr(x), _ptr(f_part), _ptr(g), self._stream()))
+
+    def int_tensor(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    def mlp_fg(self, d: MlpDesc, indices, w1, b1, w2, b2, loss, grads):
+        """grads = (gw1, gb1, gw2, gb2) device tensors or None (forward only)."""
+        c = _abi.Mlp()
+        c.n_in, c.n_hidden, c.n_out, c.batch = d.n_in, d.n_hidden, d.n_out, d.batch
+        c.activation, c.n_data = d.activation, int(d.images.shape[0])
+        c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
+        g = [None] * 4 if grads is None else [_ptr(t) for t in grads]
+        _abi.check(self.lib.l2o_mlp_fg(C.byref(c), C.c_void_p(indices.data_ptr()), _ptr(w1), _ptr(b1), _ptr(w2),
+                                       _ptr(b2), _ptr(loss), *g, self._stream()))
 
     def lstm_step(self, spec: NetSpec, wpack, g, m, v, pow1, pow2, st, x, B, D):
         cc = spec.to_c()

@@ -504,6 +504,8 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_unroll_pair.h"
 
+#include "l2o_mlp.h"
+
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
@@ -822,6 +824,33 @@ int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
   hipLaunchKernelGGL(fn, dim3(pp.B_local), dim3(kFgThreads), lds, (hipStream_t)stream, pp, x, f_part, g);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, const float* b1, const float* w2,
+               const float* b2, float* loss, float* gw1, float* gb1, float* gw2, float* gb2, void* stream) {
+  if (!mlp || !indices || !w1 || !b1 || !w2 || !b2 || !loss || !mlp->images || !mlp->labels)
+    return fail(L2O_ERR_ARG, "l2o_mlp_fg: NULL argument");
+  const bool want_g = gw1 || gb1 || gw2 || gb2;
+  if (want_g && !(gw1 && gb1 && gw2 && gb2)) return fail(L2O_ERR_ARG, "l2o_mlp_fg: pass all four gradients or none");
+  if (mlp->n_hidden < 1 || mlp->n_hidden > kMlpMaxH || mlp->n_out < 1 || mlp->n_out > kMlpMaxO ||
+      mlp->batch < 1 || mlp->batch > 256 || mlp->n_in < 1)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: sizes n_in=%d hidden=%d out=%d batch=%d not implemented",
+                mlp->n_in, mlp->n_hidden, mlp->n_out, mlp->batch);
+  MlpParams p;
+  p.n_in = mlp->n_in; p.H = mlp->n_hidden; p.O = mlp->n_out; p.batch = mlp->batch; p.act = mlp->activation;
+  p.images = mlp->images; p.labels = mlp->labels; p.idx = indices;
+  p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.loss = loss;
+  p.gw1 = gw1; p.gb1 = gb1; p.gw2 = gw2; p.gb2 = gb2;
+  const int G = kMlpThreads / p.batch;
+  const size_t pa = (size_t)G * p.batch * p.H, pb = (size_t)p.batch * (p.H + p.O);
+  const size_t lds = sizeof(float) * ((size_t)p.n_in * p.H + (pa > pb ? pa : pb) + (size_t)p.batch * p.H +
+                                      (size_t)p.H * p.O + 2 * (size_t)p.batch);
+  if (lds > 160 * 1024) return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: needs %zu bytes of LDS", lds);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fg), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  hipLaunchKernelGGL(k_mlp_fg, dim3(1), dim3(kMlpThreads), lds, (hipStream_t)stream, p);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
 }

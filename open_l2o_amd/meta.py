@@ -201,6 +201,12 @@ _DEFAULT_CONFIG = {
         }}}
 
 
+def _term_vars(term):
+    """The trainable variable declarations a loss term is a function of (one for the analytic
+    problems, four for problems.mnist)."""
+    return (term.var,) if hasattr(term.var, "initializer") else tuple(term.var)
+
+
 def _world():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -272,9 +278,10 @@ class UnrollGraph(object):
         # term of each trainable variable
         self.term_of = {}
         for t in self.terms:
-            if t.var.name in self.term_of:
-                raise ValueError("variable %s appears in two loss terms" % t.var.name)
-            self.term_of[t.var.name] = t
+            for tv in _term_vars(t):
+                if tv.name in self.term_of:
+                    raise ValueError("variable %s appears in two loss terms" % tv.name)
+                self.term_of[tv.name] = t
         for v in self.x:
             if v.decl.name not in self.term_of:
                 raise ValueError("no loss term for variable %s" % v.name)
@@ -291,7 +298,7 @@ class UnrollGraph(object):
     def _panel_shape(self, var):
         """[B_local, D] view of a variable for the kernels."""
         term = self.term_of[var.decl.name]
-        if term.kind == _abi.PROB_SIMPLE:
+        if term.kind in (_abi.PROB_SIMPLE, _abi.PROB_MLP):
             return 1, int(np.prod(var.shape)) if len(var.shape) else 1
         B = var.shape[0]
         if self.sharded:
@@ -333,7 +340,7 @@ class UnrollGraph(object):
 
     # -- execution -------------------------------------------------------------
     def _fused_ok(self, descs):
-        if len(self.x) != 1 or len(self.slots) != 1 or len(self.terms) != 1:
+        if len(self.x) != 1 or len(self.slots) != 1 or len(self.terms) != 1 or descs[0] is None:
             return False
         s = self.slots[0]
         if not isinstance(s.net, networks.StandardDeepLSTM) or self.terms[0].weight != 1.0:
@@ -389,7 +396,14 @@ class UnrollGraph(object):
             ms.append(s.m if (commit or s.m is None) else s.m.clone())
             vs.append(s.v if (commit or s.v is None) else s.v.clone())
 
-        descs = [self._desc(v, sc) for v, sc in zip(self.x, scales)]
+        descs = []
+        for v, sc in zip(self.x, scales):
+            if self.term_of[v.decl.name].kind == _abi.PROB_MLP:
+                if sc is not None:
+                    raise NotImplementedError("x-scale placeholders are not implemented for problems.mnist")
+                descs.append(None)
+            else:
+                descs.append(self._desc(v, sc))
         panels = []
         for xv, var in zip(xs, self.x):
             B, D = self._panel_shape(var)
@@ -452,38 +466,70 @@ class UnrollGraph(object):
             setattr(self, "_scr_" + name, buf)
         return buf[:n]
 
+    def _mlp_desc(self, term):
+        """Device copy of the dataset of a problems.mnist term (uploaded once)."""
+        cache = self.__dict__.setdefault("_mlp_cache", {})
+        key = id(term.hyper["images"])
+        if key not in cache:
+            from ._engine import MlpDesc
+            images = np.ascontiguousarray(term.hyper["images"], np.float32).reshape(len(term.hyper["labels"]), -1)
+            w1 = term.var[0]
+            cache[key] = MlpDesc(n_in=images.shape[1], n_hidden=w1.shape[1], n_out=term.var[2].shape[1],
+                                 batch=int(term.hyper["batch_size"]),
+                                 activation=0 if term.hyper["activation"] == "sigmoid" else 1,
+                                 images=self.engine.tensor(images),
+                                 labels=self.engine.int_tensor(term.hyper["labels"]))
+        return cache[key]
+
     def _run_steps(self, T, step0, descs, panels, slots, states, ms, vs, fx):
-        """Step-granular path: per step one l2o_problem_fg per term and one
-        l2o_cwlstm_step per (net, variable)."""
+        """Step-granular path: per step one forward+gradient launch per loss term
+        (l2o_problem_fg / l2o_mlp_fg) and one l2o_cwlstm_step per (net, variable)."""
         eng = self.engine
         nvar = len(self.x)
-        f_parts = [self._scratch("f%d" % j, descs[j].B_local) for j in range(nvar)]
-        grads = [self._scratch("g%d" % j, descs[j].B_local * descs[j].D).view(descs[j].B_local, descs[j].D)
-                 for j in range(nvar)]
+        index_of = {v.decl.name: j for j, v in enumerate(self.x)}
+        grads = [self._scratch("g%d" % j, panels[j].numel()).view(panels[j].shape) for j in range(nvar)]
         tmp = self._scratch("fx1", 1)
-        weights = [self.term_of[v.decl.name].weight for v in self.x]
-        simple_single = nvar == 1 and weights[0] == 1.0
+        single = len(self.terms) == 1 and self.terms[0].weight == 1.0
         b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
+        # fresh minibatch per evaluation of a neural optimizee (DM/problems.py:282-286)
+        mlp_idx = {}
+        for k, term in enumerate(self.terms):
+            if term.kind == _abi.PROB_MLP:
+                d = self._mlp_desc(term)
+                sampler = term.hyper.get("sampler")
+                if sampler is None:
+                    idx = _rng.integers(0, d.images.shape[0], size=(T + 1, d.batch))
+                else:
+                    idx = np.asarray(sampler(T + 1, d.batch, d.images.shape[0]))
+                mlp_idx[k] = eng.int_tensor(idx.reshape(T + 1, d.batch))
 
         def forward(t, want_grad):
-            if not simple_single:
+            if not single:
                 fx[t:t + 1].zero_()
-            for j in range(nvar):
-                eng.problem_fg(descs[j], panels[j], f_parts[j], grads[j] if want_grad else None)
-                if simple_single:
-                    eng.reduce_fx(f_parts[j], 1, descs[j].B_local, descs[j].B_global, fx[t:t + 1])
+            for k, term in enumerate(self.terms):
+                out = fx[t:t + 1] if single else tmp
+                if term.kind == _abi.PROB_MLP:
+                    js = [index_of[tv.name] for tv in _term_vars(term)]
+                    eng.mlp_fg(self._mlp_desc(term), mlp_idx[k][t], *[panels[j] for j in js], out,
+                               [grads[j] for j in js] if want_grad else None)
                 else:
-                    eng.reduce_fx(f_parts[j], 1, descs[j].B_local, descs[j].B_global, tmp)
-                    fx[t:t + 1].add_(tmp, alpha=float(weights[j]))
-                    if want_grad and weights[j] != 1.0:
-                        grads[j].mul_(float(weights[j]))
+                    js = [index_of[term.var.name]]
+                    j = js[0]
+                    f_part = self._scratch("f%d" % j, descs[j].B_local)
+                    eng.problem_fg(descs[j], panels[j], f_part, grads[j] if want_grad else None)
+                    eng.reduce_fx(f_part, 1, descs[j].B_local, descs[j].B_global, out)
+                if not single:
+                    fx[t:t + 1].add_(tmp, alpha=float(term.weight))
+                    if want_grad and term.weight != 1.0:
+                        for j in js:
+                            grads[j].mul_(float(term.weight))
 
         for t in range(T):
             forward(t, True)
             k = step0 + t
             for si, s in enumerate(slots):
                 j = s.var_index
-                B, D = descs[j].B_local, descs[j].D
+                B, D = panels[j].shape
                 if isinstance(s.net, networks.StandardDeepLSTM):
                     eng.lstm_step(s.net.spec, s.net.wpack(eng), grads[j], ms[si], vs[si], b1 ** k, b2 ** k,
                                   None if states[si].packed is None else states[si].packed, panels[j], B, D)

@@ -139,11 +139,20 @@ def get_config(problem_name, path=None, mode=None, num_hidden_layer=None, net_na
         problem = problems.lasso(**with_defaults(batch_size=128, num_dims=2))
         net_config = _cw2020(path)
         net_assignments = None
-    elif problem_name in ("mnist", "mnist_relu", "mnist_deeper", "mnist_conv", "cifar_conv", "lenet", "nas",
+    elif problem_name in ("mnist", "mnist_relu"):                      # DM/util.py:144-155
+        if mode is None:
+            mode = "train" if path is None else "test"
+        problem = problems.mnist(**with_defaults(layers=(20,), mode=mode,
+                                                 activation="sigmoid" if problem_name == "mnist" else "relu"))
+        net_config = {"cw": get_default_net_config(path)}
+        net_assignments = None
+    elif problem_name in ("mnist_deeper", "mnist_conv", "cifar_conv", "lenet", "nas",
                           "vgg16", "cifar-multi", "confocal_microscopy_3d"):
         # neural-network / data-dependent optimizees of DM/util.py:144-230: the net config is
         # reproduced, the problem factory raises (out of the accelerated hot path).
-        problem = getattr(problems, {"mnist_relu": "mnist", "mnist_deeper": "mnist", "cifar_conv": "cifar10",
+        if problem_name == "mnist_deeper":
+            problems.mnist(layers=(20, 20), data=problems.synthetic_mnist(8))     # raises: one hidden layer only
+        problem = getattr(problems, {"mnist_deeper": "mnist", "cifar_conv": "cifar10",
                                      "lenet": "LeNet", "nas": "NAS", "vgg16": "vgg16_cifar10",
                                      "cifar-multi": "cifar10"}.get(problem_name, problem_name))()
         net_config = {"cw": get_default_net_config(path)}

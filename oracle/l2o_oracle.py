@@ -19,7 +19,7 @@ __all__ = [
     "clamp", "log_and_sign", "sigmoid", "elu", "lstm_cell", "linear",
     "NetConfig", "init_net_params", "net_initial_state", "net_apply",
     "Simple", "SimpleMulti", "Quadratic", "Lasso", "Rastrigin", "SquareCos",
-    "unroll", "UnrollResult", "sgd_net", "adam_net", "truncated_normal",
+    "unroll", "UnrollResult", "sgd_net", "adam_net", "truncated_normal", "MnistMLP", "unroll_multi",
     "DM_IDENTITY", "DM_LOGSIGN", "RNNPROP",
 ]
 
@@ -407,6 +407,64 @@ class SquareCos(_Problem):
         colsum = np.sum(self.wcos, axis=1)                       # d/dc_j sum_i (wcos c)_i
         g = g + colsum * dt(10) * dt(2 * 3.1415926) * np.sin(dt(2 * 3.1415926) * x)
         return g / dt(self._bg(x.shape[0]))
+
+
+class MnistMLP(_Problem):
+    """problems.mnist, DM/problems.py:246-288: snt.nets.MLP([hidden, 10]) on flattened images,
+    loss = mean sparse-softmax cross-entropy of a minibatch gathered with ``indices``.
+    Variables (Sonnet names): mlp/linear_0/w [n_in,H], mlp/linear_0/b [H], mlp/linear_1/w [H,O],
+    mlp/linear_1/b [O], all ~ N(0, 0.01^2) (_nn_initializers, :35-38)."""
+
+    def __init__(self, images, labels, activation="sigmoid"):
+        self.images = images.reshape(images.shape[0], -1)
+        self.labels = labels
+        self.activation = activation
+
+    def init_vars(self, rng, hidden=20, n_out=10, dtype=np.float32):
+        n_in = self.images.shape[1]
+        return [(rng.standard_normal(shape) * 0.01).astype(dtype)
+                for shape in ((n_in, hidden), (hidden,), (hidden, n_out), (n_out,))]
+
+    def fg(self, variables, indices, want_grad=True):
+        w1, b1, w2, b2 = variables
+        dt = w1.dtype.type
+        x = self.images[indices].astype(w1.dtype)
+        lab = self.labels[indices]
+        a = x @ w1 + b1
+        h = sigmoid(a) if self.activation == "sigmoid" else np.maximum(a, dt(0))
+        z = h @ w2 + b2
+        zmax = z.max(axis=1, keepdims=True)
+        lse = zmax[:, 0] + np.log(np.sum(np.exp(z - zmax), axis=1))
+        n = np.arange(len(indices))
+        loss = np.sum(lse - z[n, lab]) / dt(len(indices))
+        if not want_grad:
+            return loss, None
+        dz = np.exp(z - lse[:, None])
+        dz[n, lab] -= dt(1)
+        dz = dz / dt(len(indices))
+        gw2 = h.T @ dz
+        gb2 = dz.sum(axis=0)
+        dh = dz @ w2.T
+        dh = dh * h * (dt(1) - h) if self.activation == "sigmoid" else dh * (h > 0)
+        gw1 = x.T @ dh
+        gb1 = dh.sum(axis=0)
+        return loss, [gw1, gb1, gw2, gb2]
+
+
+def unroll_multi(fg, cfg, params, variables, states, T):
+    """The unroll of DM/meta.py:338-376 for an optimizee with SEVERAL variables that share one
+    coordinate-wise net (default net_assignments): ``fg(variables, t, want_grad) ->
+    (loss, [grad per variable])``; states = one net state per variable.  CW nets only."""
+    variables = [v.copy() for v in variables]
+    states = list(states)
+    fx = np.zeros((T + 1,), variables[0].dtype)
+    for t in range(T):
+        fx[t], grads = fg(variables, t, True)
+        for j, g in enumerate(grads):
+            delta, states[j] = net_apply(cfg, params, g, states[j])
+            variables[j] = variables[j] + delta
+    fx[T], _ = fg(variables, T, False)
+    return fx, variables, states
 
 
 # ----------------------------------------------------------------------------

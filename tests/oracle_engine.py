@@ -114,6 +114,20 @@ class OracleEngine(object):
                 gr = gr * s
             g.copy_(torch.from_numpy(gr.astype(np.float32)).view_as(g))
 
+    def int_tensor(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32).copy())
+
+    def mlp_fg(self, d, indices, w1, b1, w2, b2, loss, grads):
+        self.calls.append("mlp_fg")
+        prob = O.MnistMLP(d.images.numpy(), d.labels.numpy(), "sigmoid" if d.activation == 0 else "relu")
+        variables = [w1.numpy().reshape(d.n_in, d.n_hidden), b1.numpy().reshape(-1),
+                     w2.numpy().reshape(d.n_hidden, d.n_out), b2.numpy().reshape(-1)]
+        f, g = prob.fg(variables, indices.numpy(), want_grad=grads is not None)
+        loss.copy_(torch.from_numpy(np.array([f], np.float32)))
+        if grads is not None:
+            for t, a in zip(grads, g):
+                t.copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)).view_as(t))
+
     def lstm_step(self, spec, wpack, g, m, v, pow1, pow2, st, x, B, D):
         self.calls.append("lstm_step")
         cfg = _cfg_of(spec)

@@ -308,3 +308,28 @@ def test_c3_lasso_rnnprop_full_size(eng):
     np.testing.assert_array_equal(fx200[:101], fxa)
     np.testing.assert_array_equal(fx200[100:], fxb)
     np.testing.assert_allclose(fx200[:21], fx_ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize("activation,batch", [("sigmoid", 128), ("relu", 100), ("sigmoid", 7)])
+def test_mlp_fg_kernel(eng, activation, batch):
+    """l2o_mlp_fg (problems.mnist forward + gradient) against the oracle."""
+    from open_l2o_amd._engine import MlpDesc
+    rng = np.random.default_rng(80)
+    n_data, n_in, H, Oo = 500, 784, 20, 10
+    images = rng.random((n_data, n_in)).astype(np.float32)
+    labels = rng.integers(0, Oo, n_data).astype(np.int32)
+    idx = rng.integers(0, n_data, batch).astype(np.int32)
+    ref = O.MnistMLP(images, labels, activation)
+    variables = [(rng.standard_normal(s) * 0.3).astype(np.float32) for s in ((n_in, H), (H,), (H, Oo), (Oo,))]
+    f_ref, g_ref = ref.fg(variables, idx)
+    d = MlpDesc(n_in, H, Oo, batch, 0 if activation == "sigmoid" else 1, eng.tensor(images), eng.int_tensor(labels))
+    dv = [eng.tensor(v) for v in variables]
+    loss = eng.zeros(1)
+    grads = [eng.zeros(*v.shape) for v in variables]
+    eng.mlp_fg(d, eng.int_tensor(idx), *dv, loss, grads)
+    assert rel_err(eng.to_numpy(loss)[0], f_ref) < 5e-6
+    for g, gr in zip(grads, g_ref):
+        assert max_abs(eng.to_numpy(g), gr) < 5e-6 * max(1.0, float(np.abs(gr).max()))
+    loss2 = eng.zeros(1)
+    eng.mlp_fg(d, eng.int_tensor(idx), *dv, loss2, None)            # forward only
+    assert eng.to_numpy(loss2)[0] == eng.to_numpy(loss)[0]

@@ -224,8 +224,14 @@ def test_get_config_registry():
     assert [v.shape for v in util.get_config("rastrigin")[0]().variables][0] == (128, 2, 1)
     with pytest.raises(ValueError, match="is not a valid problem"):
         util.get_config("no-such-problem")
+    with pytest.raises(FileNotFoundError):
+        util.get_config("mnist")                       # no dataset offline: must be passed / pointed to
     with pytest.raises(NotImplementedError):
-        util.get_config("mnist")
+        util.get_config("mnist_conv")
+    problem, net_config, _ = util.get_config("mnist", problem_options={"data": problems.synthetic_mnist(32)})
+    assert [v.name for v in problem().variables] == ["mlp/linear_0/w", "mlp/linear_0/b", "mlp/linear_1/w",
+                                                     "mlp/linear_1/b"]
+    assert net_config["cw"]["net_options"]["preprocess_name"] == "LogAndSign"
     cfgd = util.get_default_net_config("p")
     assert cfgd["net_options"]["preprocess_options"] == {"k": 5} and cfgd["net_path"] == "p"
 
@@ -354,3 +360,45 @@ def test_network_shapes_and_zero_init(engine):
     assert np.all(engine.to_numpy(upd) == 0) and tuple(st[1].shape) == (4, 1)
     with pytest.raises(_engine._abi.L2OUnsupported):
         networks.CoordinateWiseDeepLSTM(layers=(1,)).wpack(engine)
+
+
+# ------------------------------------------------------------- problems.mnist
+@pytest.mark.parametrize("activation", ["sigmoid", "relu"])
+def test_mnist_mlp_optimizee(engine, activation):
+    """BASELINE config 5's optimizee: the 784-20-10 MLP of problems.mnist with the default
+    LogAndSign L2O-DM net shared by its four variables, a fresh minibatch per evaluation
+    (DM/problems.py:282-286); compared with the oracle's multi-variable unroll."""
+    data = problems.synthetic_mnist(300, seed=3)
+    T, batch = 6, 32
+    rng = np.random.default_rng(70)
+    idx = rng.integers(0, 300, size=(2 * (T + 1), batch))
+    calls = {"n": 0}
+
+    def sampler(n_evals, b, n_data):
+        assert (n_evals, b, n_data) == (T + 1, batch, 300)
+        out = idx[calls["n"]:calls["n"] + n_evals]
+        calls["n"] += n_evals
+        return out
+
+    cfg = O.DM_LOGSIGN
+    params = make_params(cfg, seed=71, trained_like=True)
+    meta.set_random_seed(9)
+    problem = problems.mnist(layers=(20,), activation=activation, batch_size=batch, data=data, sampler=sampler)
+    optimizer = meta.MetaOptimizer(**_net_config(cfg, params))
+    ml = optimizer.meta_loss(problem, T)
+    with Session() as sess:
+        sess.run(ml.reset)
+        v0 = [v.eval() for v in optimizer.graph.x]
+        assert [a.shape for a in v0] == [(784, 20), (20,), (20, 10), (10,)]
+        assert 0.005 < v0[0].std() < 0.02                       # _nn_initializers: N(0, 0.01)
+        loss1, fx1, x1, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
+        loss2, fx2, x2, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
+    assert optimizer.graph.last_path == "steps"
+    ref = O.MnistMLP(data["images"], data["labels"].astype(np.int32), activation)
+    states = [O.net_initial_state(cfg, a.size) for a in v0]
+    fx_a, va, sa = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[t], wg), cfg, params, v0, states, T)
+    fx_b, vb, _ = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[T + 1 + t], wg), cfg, params, va, sa, T)
+    assert rel_err(fx1, fx_a[-1]) < 1e-5 and rel_err(loss1, fx_a.sum()) < 1e-5
+    assert rel_err(fx2, fx_b[-1]) < 2e-5 and rel_err(loss2, fx_b.sum()) < 2e-5
+    for got, want in zip(x2, vb):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
