@@ -144,11 +144,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: L2O_BENCH_BACKEND=gloo L2O_BENCH_ONE_DEVICE=1 runs the N > 1 code path with all
+    # ranks on cuda:0 (a 1-GPU box cannot host two RCCL ranks); the driver never sets these
+    backend = os.environ.get("L2O_BENCH_BACKEND", "nccl")
+    if os.environ.get("L2O_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda:%d" % local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda:%d" % local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     eng = _engine.HipEngine("cuda:%d" % local_rank)        # raises without GPU / built extension
     _engine.set_default_engine(eng)
@@ -166,7 +174,8 @@ def main():
 
     def one_unroll(i=None):
         graph.rewind(x0)                                    # x <- x0, LSTM state (m, v) <- 0
-        fx, _ = graph.launch(feed, commit=True, events=None if i is None else ev[i])
+        # (the step-granular path replays its 2..6 x T small launches from a HIP graph)
+        fx, _ = graph.launch(feed, commit=True, events=None if i is None else ev[i], use_graph=True)
         return fx
 
     def fence():

@@ -147,10 +147,12 @@ typedef struct l2o_mlp {
   const float* images;   /* device [n_data, n_in]                                    */
   const int32_t* labels; /* device [n_data]                                          */
 } l2o_mlp;
+size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp);
 int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices /* device [batch] rows of the minibatch */,
                const float* w1 /* device [n_in,n_hidden] */, const float* b1 /* [n_hidden] */,
                const float* w2 /* device [n_hidden,n_out] */, const float* b2 /* [n_out] */,
-               float* loss /* device [1] */, float* gw1, float* gb1, float* gw2, float* gb2, void* stream);
+               float* loss /* device [1] */, float* gw1, float* gb1, float* gw2, float* gb2,
+               float* scratch /* device [l2o_mlp_scratch_floats] */, void* stream);
 
 /* ---- one optimizer step on a gradient panel: the closure `update`
  * (DM/meta.py:319-336; RNNProp DM/meta_rnnprop_train.py:371-395) for ONE variable:

@@ -25,6 +25,7 @@ PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_M
 SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
+    "l2o_mlp_scratch_floats",
     "l2o_cwlstm_step", "l2o_unroll", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
@@ -99,7 +100,9 @@ def lib():
     L.l2o_problem_fg.restype = C.c_int
     L.l2o_problem_fg.argtypes = [C.POINTER(Problem), vp, vp, vp, vp]
     L.l2o_mlp_fg.restype = C.c_int
-    L.l2o_mlp_fg.argtypes = [C.POINTER(Mlp)] + [vp] * 11
+    L.l2o_mlp_fg.argtypes = [C.POINTER(Mlp)] + [vp] * 12
+    L.l2o_mlp_scratch_floats.restype = C.c_size_t
+    L.l2o_mlp_scratch_floats.argtypes = [C.POINTER(Mlp)]
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
     L.l2o_unroll.restype = C.c_int

@@ -93,6 +93,7 @@ class HipEngine(object):
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self._workspace = None
         self._last_ws = None
+        self._mlp_scratch = None
 
     # -- memory plumbing (torch) ------------------------------------------
     def tensor(self, a):
@@ -155,8 +156,11 @@ class HipEngine(object):
         c.activation, c.n_data = d.activation, int(d.images.shape[0])
         c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
         g = [None] * 4 if grads is None else [_ptr(t) for t in grads]
+        n = int(self.lib.l2o_mlp_scratch_floats(C.byref(c)))
+        if self._mlp_scratch is None or self._mlp_scratch.numel() < n:
+            self._mlp_scratch = self.empty(n)
         _abi.check(self.lib.l2o_mlp_fg(C.byref(c), C.c_void_p(indices.data_ptr()), _ptr(w1), _ptr(b1), _ptr(w2),
-                                       _ptr(b2), _ptr(loss), *g, self._stream()))
+                                       _ptr(b2), _ptr(loss), *g, _ptr(self._mlp_scratch), self._stream()))
 
     def lstm_step(self, spec: NetSpec, wpack, g, m, v, pow1, pow2, st, x, B, D):
         cc = spec.to_c()

@@ -829,7 +829,8 @@ int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float
 }
 
 int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, const float* b1, const float* w2,
-               const float* b2, float* loss, float* gw1, float* gb1, float* gw2, float* gb2, void* stream) {
+               const float* b2, float* loss, float* gw1, float* gb1, float* gw2, float* gb2, float* scratch,
+               void* stream) {
   if (!mlp || !indices || !w1 || !b1 || !w2 || !b2 || !loss || !mlp->images || !mlp->labels)
     return fail(L2O_ERR_ARG, "l2o_mlp_fg: NULL argument");
   const bool want_g = gw1 || gb1 || gw2 || gb2;
@@ -838,21 +839,33 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
       mlp->batch < 1 || mlp->batch > 256 || mlp->n_in < 1)
     return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: sizes n_in=%d hidden=%d out=%d batch=%d not implemented",
                 mlp->n_in, mlp->n_hidden, mlp->n_out, mlp->batch);
+  if (!scratch) return fail(L2O_ERR_ARG, "l2o_mlp_fg: NULL scratch (l2o_mlp_scratch_floats)");
   MlpParams p;
   p.n_in = mlp->n_in; p.H = mlp->n_hidden; p.O = mlp->n_out; p.batch = mlp->batch; p.act = mlp->activation;
   p.images = mlp->images; p.labels = mlp->labels; p.idx = indices;
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.loss = loss;
   p.gw1 = gw1; p.gb1 = gb1; p.gw2 = gw2; p.gb2 = gb2;
-  const int G = kMlpThreads / p.batch;
-  const size_t pa = (size_t)G * p.batch * p.H, pb = (size_t)p.batch * (p.H + p.O);
-  const size_t lds = sizeof(float) * ((size_t)p.n_in * p.H + (pa > pb ? pa : pb) + (size_t)p.batch * p.H +
-                                      (size_t)p.H * p.O + 2 * (size_t)p.batch);
-  if (lds > 160 * 1024) return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: needs %zu bytes of LDS", lds);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fg), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds));
-  hipLaunchKernelGGL(k_mlp_fg, dim3(1), dim3(kMlpThreads), lds, (hipStream_t)stream, p);
+  p.scratch = scratch;
+  hipStream_t s = (hipStream_t)stream;
+  const int HS = p.H | 1;
+  const size_t lds_f = sizeof(float) * ((size_t)p.n_in * HS + (size_t)kMlpSPB * 32 * p.H + (size_t)kMlpSPB * p.H +
+                                        (size_t)kMlpSPB * p.O);
+  const size_t lds_b = sizeof(float) * ((size_t)p.batch * p.H + (size_t)p.batch + 4 * (size_t)kMlpKPB * p.H);
+  if (lds_f > 160 * 1024 || lds_b > 160 * 1024)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: needs %zu / %zu bytes of LDS", lds_f, lds_b);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_f));
+  hipLaunchKernelGGL(k_mlp_fwd, dim3((p.batch + kMlpSPB - 1) / kMlpSPB), dim3(256), lds_f, s, p);
+  HIP_TRY(hipGetLastError());
+  const int nkb = (p.n_in + kMlpKPB - 1) / kMlpKPB;
+  hipLaunchKernelGGL(k_mlp_bwd, dim3(nkb + 1), dim3(256), lds_b, s, p);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
+}
+
+size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp) {
+  if (!mlp || mlp->batch < 1) return 0;
+  return (size_t)mlp->batch * (2 * (size_t)mlp->n_hidden + mlp->n_out + 1);
 }
 
 int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, float* m, float* v, double pow1,

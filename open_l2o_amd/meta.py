@@ -333,6 +333,8 @@ class UnrollGraph(object):
             else:
                 s.state = s.net.initial_state_for_inputs(var.value)
         self._initialized = True
+        self.__dict__.pop("_hip_graphs", None)           # captured launch sequences hold the old pointers
+        self.__dict__.pop("_mlp_idx", None)
 
     def _ensure_init(self):
         if not self._initialized:
@@ -361,10 +363,13 @@ class UnrollGraph(object):
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
                 "x": x_out, "fx_array": fx_host}
 
-    def launch(self, feed=None, commit=True, events=None):
+    def launch(self, feed=None, commit=True, events=None, use_graph=False):
         """Enqueue one unroll on the current stream WITHOUT synchronising the host; returns
         (device tensor fx[0..T] -- already all-reduced when sharded --, list of device x_T).
-        ``events`` = (start, end) torch.cuda.Event pair recorded around the unroll kernels only."""
+        ``events`` = (start, end) torch.cuda.Event pair recorded around the unroll kernels.
+        ``use_graph`` (with commit=True, no fed x-scale): the launch sequence of the step-granular
+        path is captured once into a HIP graph per ``step0`` and replayed afterwards, which
+        removes the per-launch host cost of its 2..6 x T small kernels."""
         self._ensure_init()
         eng = self.engine
         T = self.len_unroll
@@ -414,22 +419,38 @@ class UnrollGraph(object):
             self._fx_cache[key] = eng.zeros(T + 1)
         fx = self._fx_cache[key]
 
+        if events is not None:
+            events[0].record()
         if self._fused_ok(descs):
             self.last_path = "fused"
             s, d = slots[0], descs[0]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
-            wpack = s.net.wpack(eng)
-            if events is not None:
-                events[0].record()
-            eng.unroll(s.net.spec, wpack, d, panels[0], states[0].packed, ms[0], vs[0], T, step0, fx_part)
+            eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
+                       fx_part)
             if events is not None:
                 events[1].record()
             eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
         else:
             self.last_path = "steps"
-            if events is not None:
-                events[0].record()
-            self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx)
+            self._draw_minibatches(T)                      # host RNG -> persistent device index buffers
+            graphable = (use_graph and commit and all(sc is None for sc in scales) and
+                         all(isinstance(st, PackedState) for st in states) and hasattr(torch.cuda, "CUDAGraph")
+                         and eng.device.type == "cuda")
+            if not graphable:
+                self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx)
+            else:
+                cache = self.__dict__.setdefault("_hip_graphs", {})
+                entry = cache.get(step0)
+                if entry is None:                          # 1st call: eager (allocates every scratch buffer)
+                    self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx)
+                    cache[step0] = "warm"
+                else:
+                    if entry == "warm":                    # 2nd call: capture (records, does not execute)
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx)
+                        cache[step0] = entry = g
+                    entry.replay()
             if events is not None:
                 events[1].record()
 
@@ -440,6 +461,26 @@ class UnrollGraph(object):
             for s, st in zip(slots, states):
                 s.state = st
         return fx, xs
+
+    def _draw_minibatches(self, T):
+        """A fresh uniform minibatch per evaluation of a neural optimizee (DM/problems.py:282-286):
+        indices [T+1, batch] drawn on the host, copied into a PERSISTENT device buffer (so that a
+        captured launch sequence sees the new indices)."""
+        bufs = self.__dict__.setdefault("_mlp_idx", {})
+        for k, term in enumerate(self.terms):
+            if term.kind != _abi.PROB_MLP:
+                continue
+            d = self._mlp_desc(term)
+            sampler = term.hyper.get("sampler")
+            if sampler is None:
+                idx = _rng.integers(0, d.images.shape[0], size=(T + 1, d.batch))
+            else:
+                idx = np.asarray(sampler(T + 1, d.batch, d.images.shape[0]))
+            new = self.engine.int_tensor(idx.reshape(T + 1, d.batch))
+            if k in bufs and bufs[k].shape == new.shape:
+                bufs[k].copy_(new)
+            else:
+                bufs[k] = new
 
     def rewind(self, x0):
         """Device-side restart of the SAME problem instance: x <- x0 (list of device tensors),
@@ -491,17 +532,7 @@ class UnrollGraph(object):
         tmp = self._scratch("fx1", 1)
         single = len(self.terms) == 1 and self.terms[0].weight == 1.0
         b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
-        # fresh minibatch per evaluation of a neural optimizee (DM/problems.py:282-286)
-        mlp_idx = {}
-        for k, term in enumerate(self.terms):
-            if term.kind == _abi.PROB_MLP:
-                d = self._mlp_desc(term)
-                sampler = term.hyper.get("sampler")
-                if sampler is None:
-                    idx = _rng.integers(0, d.images.shape[0], size=(T + 1, d.batch))
-                else:
-                    idx = np.asarray(sampler(T + 1, d.batch, d.images.shape[0]))
-                mlp_idx[k] = eng.int_tensor(idx.reshape(T + 1, d.batch))
+        mlp_idx = self.__dict__.get("_mlp_idx", {})
 
         def forward(t, want_grad):
             if not single:
