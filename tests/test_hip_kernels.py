@@ -333,3 +333,45 @@ def test_mlp_fg_kernel(eng, activation, batch):
     loss2 = eng.zeros(1)
     eng.mlp_fg(d, eng.int_tensor(idx), *dv, loss2, None)            # forward only
     assert eng.to_numpy(loss2)[0] == eng.to_numpy(loss)[0]
+
+
+# ---------------------------------------------------------------------------
+# edge cases: degenerate and maximum sizes, both fused variants
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,B,D,M,T", [
+    ("quadratic", 1, 1, None, 5),        # one problem, one coordinate (the reference's problems_test shape)
+    ("quadratic", 1, 16, None, 0),       # T = 0: only f(x_0)
+    ("lasso", 2, 17, 3, 4),              # ragged tile (17 = 16 + 1), far fewer rows than columns
+    ("rastrigin", 7, 100, None, 3),      # 7 tiles -> padded to 8 in the two-CU variant
+    ("quadratic", 300, 48, None, 3),     # more problems than CUs: one workgroup per problem
+    ("lasso", 5, 128, 128, 3),           # the largest fused size (8 tiles, 128 x 128 in LDS)
+])
+@pytest.mark.parametrize("pair", [True, False])
+def test_fused_edge_cases(eng, monkeypatch, kind, B, D, M, T, pair):
+    if not pair:
+        monkeypatch.setenv("L2O_NO_PAIR", "1")
+    cfg = O.DM_LOGSIGN
+    params = make_params(cfg, seed=90, trained_like=True)
+    prob, x0, arrays = make_problem(kind, B, D, seed=91, M=M)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
+    assert fx.shape == (T + 1,)
+    assert rel_err(fx, res.fx) < 1e-5
+    assert max_abs(x, res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max()))
+
+
+def test_fused_rejects_what_it_cannot_do(eng):
+    from open_l2o_amd import _abi
+    cfg = O.DM_IDENTITY
+    spec = spec_of(cfg)
+    for kind, B, D, M in (("quadratic", 2, 129, None), ("lasso", 2, 16, 40)):
+        prob, x0, arrays = make_problem(kind, B, D, seed=92, M=M)
+        pd = device_problem(eng, arrays, B, D)
+        assert not eng.unroll_supported(spec, pd)
+        with pytest.raises(_abi.L2OUnsupported):
+            eng.unroll(spec, eng.pack_weights(spec, make_params(cfg, 1)), pd, eng.tensor(x0.reshape(B, D)),
+                       eng.state_alloc(B, D), None, None, 2, 1, eng.zeros(3 * B))
+        # ... and the step-granular kernels take over
+        fx, _ = _run_steps(eng, cfg, make_params(cfg, 1, trained_like=True), arrays, x0, B, D, 3)
+        res = O.unroll(prob, cfg, make_params(cfg, 1, trained_like=True), x0, O.net_initial_state(cfg, B * D), 3)
+        assert rel_err(fx, res.fx) < 1e-5
