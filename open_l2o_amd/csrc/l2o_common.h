@@ -205,6 +205,31 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- optional phase clock (scripts/phase_profile.sh builds with -DL2O_PROFILE_PHASES; the
+// shipped library compiles this to nothing) -------------------------------------------
+struct PhaseClock {
+#ifdef L2O_PROFILE_PHASES
+  long long prev;
+  long long acc[12];
+  __device__ __forceinline__ void start() {
+    for (int i = 0; i < 12; ++i) acc[i] = 0;
+    prev = __builtin_readcyclecounter();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    const long long n = __builtin_readcyclecounter();
+    acc[i] += n - prev;
+    prev = n;
+  }
+  __device__ __forceinline__ void dump(long long* out) {
+    for (int i = 0; i < 12; ++i) out[i] = acc[i];
+  }
+#else
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void dump(long long*) {}
+#endif
+};
+
 // ---- the optimizer network, split so that the matrix work that depends only on the
 // PREVIOUS step's state can be issued early (interleaved with the optimizee GEMV) ----
 template <int I, int N, class F>
@@ -215,32 +240,32 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int PRE>
-__device__ __forceinline__ void lstm_acc_init(const NetW<PRE>& w, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
-#pragma unroll
-  for (int t = 0; t < kNT; ++t) {
-    acc2[t] = w.b2[t];
-    if (PRE == L2O_PRE_FC_ELU) acc1[t] = w.b1[t];
-    else acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-}
-// slots LO..HI-1 of the 25 layer-2 MFMAs fed by the previous h2 (slot i: k-step i/5, slice i%5)
+// slots LO..HI-1 of the 25 layer-2 MFMAs fed by the previous h2 (slot i: k-step i/5, slice i%5).
+// The first k-step takes the bias fragment as its C operand (accumulator init for free).
 template <int PRE, int LO, int HI>
 __device__ __forceinline__ void lstm_issue_l2_prev(const NetW<PRE>& w, const TileState& s, f32x4 (&acc2)[kNT]) {
   static_for<LO, HI>([&](auto ic) {
     constexpr int i = decltype(ic)::value, kk = i / kNT, t = i % kNT;
-    acc2[t] = mfma16(w.a2[5 + kk][t], s.h2[kk], acc2[t]);
+    if constexpr (kk == 0) acc2[t] = mfma16(w.a2[5][t], s.h2[0], w.b2[t]);
+    else acc2[t] = mfma16(w.a2[5 + kk][t], s.h2[kk], acc2[t]);
   });
 }
-// slots LO..HI-1 of the 25 layer-1 MFMAs fed by the previous h1
+// slots LO..HI-1 of the 25 layer-1 MFMAs fed by the previous h1; first k-step: C = bias
+// fragment (fc / RNNProp) or the inline constant 0 (DM: the bias rides in a K slot).
 template <int PRE, int LO, int HI>
 __device__ __forceinline__ void lstm_issue_l1_prev(const NetW<PRE>& w, const TileState& s, f32x4 (&acc1)[kNT]) {
   static_for<LO, HI>([&](auto ic) {
     constexpr int i = decltype(ic)::value, kk = i / kNT, t = i % kNT;
     constexpr int ka = (PRE == L2O_PRE_FC_ELU) ? 5 + kk : kk;
-    acc1[t] = mfma16(w.a1[ka][t], s.h1[kk], acc1[t]);
+    if constexpr (kk == 0) {
+      if constexpr (PRE == L2O_PRE_FC_ELU) acc1[t] = mfma16(w.a1[ka][t], s.h1[0], w.b1[t]);
+      else acc1[t] = mfma16(w.a1[ka][t], s.h1[0], f32x4{0.f, 0.f, 0.f, 0.f});
+    } else {
+      acc1[t] = mfma16(w.a1[ka][t], s.h1[kk], acc1[t]);
+    }
   });
 }
+
 // LSTM nonlinearity of the 5 unit slices a lane owns (snt.LSTM: gates i, j, f, o;
 // forget_bias 1):   c' = sigmoid(f + 1) * c + sigmoid(i) * tanh(j) ;  h' = tanh(c') * sigmoid(o)
 // written with e_x = 2^(-x log2e) so that sigmoid(x) = 1/(1+e_x), tanh|x| = (1-E_x)/(1+E_x),
@@ -299,7 +324,7 @@ __device__ __forceinline__ void lstm_gates5(const f32x4 (&acc)[kNT], float (&c)[
 // Returns the Linear output (before tanh / scale), identical on the four q lanes.
 template <int PRE, bool NEXT>
 __device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f32x4 (&acc1)[kNT],
-                                             f32x4 (&acc2)[kNT], float in0, float in1, int q) {
+                                             f32x4 (&acc2)[kNT], float in0, float in1, int q, PhaseClock& pc) {
   if (PRE == L2O_PRE_FC_ELU) {
     float fc[kNT];
 #pragma unroll
@@ -315,20 +340,17 @@ __device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc1[t] = mfma16(w.a1[5][t], bv, acc1[t]);
   }
+  pc.mark(5);
   lstm_gates5(acc1, s.c1, s.h1);
+  pc.mark(6);
 #pragma unroll
   for (int kk = 0; kk < kNT; ++kk)
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc2[t] = mfma16(w.a2[kk][t], s.h1[kk], acc2[t]);
-  if (NEXT) {
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) {
-      if (PRE == L2O_PRE_FC_ELU) acc1[t] = w.b1[t];
-      else acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
-  }
+  if (NEXT) lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
+  pc.mark(7);
   lstm_gates5(acc2, s.c2, s.h2);
+  pc.mark(8);
   float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];
   d0 = __builtin_fmaf(s.h2[2], w.wl[2], d0);
   d1 = __builtin_fmaf(s.h2[3], w.wl[3], d1);
@@ -341,10 +363,10 @@ __device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f
 template <int PRE>
 __device__ __forceinline__ float lstm_tile_step(const NetW<PRE>& w, TileState& s, float in0, float in1, int q) {
   f32x4 acc1[kNT], acc2[kNT];
-  lstm_acc_init<PRE>(w, acc1, acc2);
   lstm_issue_l2_prev<PRE, 0, 25>(w, s, acc2);
   lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
-  return lstm_finish<PRE, false>(w, s, acc1, acc2, in0, in1, q);
+  PhaseClock pc;
+  return lstm_finish<PRE, false>(w, s, acc1, acc2, in0, in1, q, pc);
 }
 
 // Gradient preprocessing -> the (in0, in1) pair fed to lstm_tile_step.

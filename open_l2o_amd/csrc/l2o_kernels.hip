@@ -420,15 +420,12 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
   // part of layer 1; it is produced at the END of the previous step (overlapping that step's
   // layer-2 gate math), here for step 0.
   f32x4 acc1[kNT], acc2[kNT];
-  lstm_acc_init<PRE>(w, acc1, acc2);
   lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
 
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     if (live && q == 0) xs[j] = xsv;
     L2O_SYNC();                                             // B1: xs complete
-#pragma unroll
-    for (int u = 0; u < kNT; ++u) acc2[u] = w.b2[u];
     // ---- r = W xs - y  ||  first 12 layer-2 MFMAs of the previous h2 -----------
     float4 racc = {0.f, 0.f, 0.f, 0.f};
     static_for<0, CH>([&](auto mc) {
@@ -490,7 +487,8 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-    float d = lstm_finish<PRE, true>(w, s, acc1, acc2, in0, in1, q);
+    PhaseClock pc;
+    float d = lstm_finish<PRE, true>(w, s, acc1, acc2, in0, in1, q, pc);
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
   }

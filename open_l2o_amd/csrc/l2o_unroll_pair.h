@@ -25,6 +25,7 @@
 struct PairWs {               // header of the caller-owned workspace
   unsigned status;            // 0 ok, 1 = partner timeout
   unsigned pad[15];
+  long long phases[16];       // phase clock dump of the -DL2O_PROFILE_PHASES build (else unused)
 };
 
 struct UnrollPairArgs {
@@ -114,8 +115,9 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   bool dead = false;                                             // partner timed out
 
   f32x4 acc1[kNT], acc2[kNT];
-  lstm_acc_init<PRE>(w, acc1, acc2);
   lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
+  PhaseClock pc;
+  pc.start();
 
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
@@ -127,8 +129,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       __hip_atomic_store(mine + par * npg + wv * kTile + c, pack_granule(live ? xsv : 0.0f, tag),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-    for (int u = 0; u < kNT; ++u) acc2[u] = w.b2[u];
+    pc.mark(0);                                                   // publish
     lstm_issue_l2_prev<PRE, 0, 12>(w, s, acc2);                   // matrix work that covers the latency
     if (q == 0) {
       const unsigned long long* src = theirs + par * npg + wv * kTile + c;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       dead = true;
 #endif
       if (!dead) {
+#pragma nounroll
         for (;;) {
           g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(g >> 32) == tag) break;
@@ -147,7 +149,9 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       }
       xs[pj] = __uint_as_float((unsigned)g);
     }
+    pc.mark(1);                                             // 12 MFMAs + partner poll
     __syncthreads();                                        // B1: xs (both halves) complete
+    pc.mark(2);
     // ---- r = W xs - y : every half computes all rows, 2 x 16 per wave  ||  13 more MFMAs
     float contrib = 0.0f;
 #pragma unroll
@@ -173,9 +177,11 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
       if (KIND == L2O_PROB_RASTRIGIN) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
     }
+    pc.mark(3);                                             // r pass + 13 MFMAs
     contrib = wave_sum64(contrib);
     if (lane == 0) fpart[wv] = contrib;
     __syncthreads();                                        // B2: rs, fpart complete
+    pc.mark(4);
     if (tid == 0) {
       float f = fpart[0];
       for (int k = 1; k < NWH; ++k) f += fpart[k];
@@ -212,10 +218,14 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-    float d = lstm_finish<PRE, true>(w, s, acc1, acc2, in0, in1, q);
+    float d = lstm_finish<PRE, true>(w, s, acc1, acc2, in0, in1, q, pc);   // marks 5 (g pass .. input MFMAs), 6, 7, 8
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
+    pc.mark(9);
   }
+#ifdef L2O_PROFILE_PHASES
+  if (blockIdx.x == 0 && tid == 0) pc.dump(pa.ws->phases);
+#endif
 
   if (live && q == 0) {
     a.x[idx] = xv;

@@ -9,7 +9,7 @@ python -m pytest tests -q -m gpu 2>&1 | tee $O/pytest_gpu.log | tail -4
 grep -E "rel fx|vs C oracle" $O/pytest_gpu.log | tail -8
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py --steps 20 --warmup 3 2>$O/bench.err | tee $O/bench_c2.json | cut -c1-400
-python bench.py --steps 3 --warmup 1 --problem lasso --net rnnprop --dims 512 --rows 256 --batch 256 --unroll 200 2>>$O/bench.err | tee $O/bench_c3.json | cut -c1-300
+python bench.py --steps 5 --warmup 3 --problem lasso --net rnnprop --dims 512 --rows 256 --batch 256 --unroll 200 2>>$O/bench.err | tee $O/bench_c3.json | cut -c1-300
 python bench.py --steps 10 --warmup 2 --problem rastrigin --net dm --dims 100 --batch 128 --unroll 100 --no-cpu-baseline 2>>$O/bench.err | tee $O/bench_c4shard.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_trace -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_trace_bench.json 2>$O/prof_trace.err

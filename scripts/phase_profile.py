@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of k_unroll_pair (needs build/lib_phases.so built with
+-DL2O_PROFILE_PHASES; run with L2O_HIP_LIB pointing at it).  Wave 0 of workgroup 0 dumps its
+s_memtime deltas into the workspace into the workspace header."""
+import os
+import sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as O
+from helpers import device_problem, make_params, make_problem, spec_of
+from open_l2o_amd._engine import HipEngine
+
+eng = HipEngine()
+cfg = O.DM_IDENTITY
+B, D, T = 128, 128, 100
+params = make_params(cfg, 0, trained_like=True)
+prob, x0, arrays = make_problem("quadratic", B, D, seed=1)
+spec = spec_of(cfg)
+wpack = eng.pack_weights(spec, params)
+pd = device_problem(eng, arrays, B, D)
+for it in range(3):
+    x, st = eng.tensor(x0), eng.state_alloc(B, D)
+    fp = eng.zeros((T + 1) * B)
+    eng.unroll(spec, wpack, pd, x, st, None, None, T, 1, fp)
+    eng.synchronize()
+ws = eng._last_ws
+# workspace header: 64 B status block, then long long phases[16]
+raw = ws[64:64 + 12 * 8].cpu().numpy().view(np.int64)
+names = ["publish", "12 MFMA + partner poll", "barrier B1", "r pass + 13 MFMA", "wave_sum + barrier B2",
+         "g pass + preprocess + 5 input MFMA", "layer-1 gates", "50 MFMA (L2 + next L1)", "layer-2 gates",
+         "linear + x update", "-", "-"]
+tot = raw.sum()
+print("k_unroll_pair phase clock (s_memtime ticks, wave 0 of workgroup 0, %d steps; 100 MHz-independent ratios)" % T)
+for n, v in zip(names, raw):
+    if n != "-":
+        print("  %-40s %10d  %5.1f%%  (%.0f per step)" % (n, v, 100.0 * v / tot, v / T))
+print("  total %d ticks" % tot)
