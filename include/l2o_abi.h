@@ -167,6 +167,40 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack /* device */,
                     float* st /* device, packed, in-out */, float* x /* device [B,D] in-out */,
                     int64_t B, int64_t D, void* stream);
 
+/* ---- meta-gradient: one step of back-propagation-through-time of the optimizer network,
+ * i.e. what tf.train.AdamOptimizer(lr).minimize(loss) differentiates in
+ * MetaOptimizer.meta_minimize (DM/meta.py:398-414) with the optimizee gradient held constant
+ * (tf.stop_gradient, DM/meta.py:328-329).  Called for t = T-1 .. 0 with
+ *   dx_next  = dL/dx_{t+1} = sum_{tau > t} g_tau   (loss = sum_t f(x_t), DM/meta.py:376)
+ *   carry_in = (dh1, dc1, dh2, dc2) from step t+1 ([4][N][H], zeros for the last step)
+ * it recomputes the step's forward from the state saved BEFORE the step (`st_prev`, packed)
+ * and writes the rows from which the host forms the weight gradients as GEMMs over
+ * (steps x coordinates):  dW1 = act1^T dz1, db1 = sum dz1, dW2 = act2^T dz2, db2 = sum dz2,
+ * dw_lin = h2^T dd, db_lin = sum dd, (RNNProp) dW_fc = feats^T du, db_fc = sum du.
+ * Gate column order of dz* is Sonnet's (i, j, f, o).  layers=(): only act1 [N,2] and dd. */
+typedef struct l2o_net_weights {      /* device pointers, Sonnet / .l2l layouts */
+  const float *w_gates1, *b_gates1, *w_gates2, *b_gates2, *w_lin, *b_lin, *w_fc, *b_fc;
+} l2o_net_weights;
+typedef struct l2o_bwd_io {
+  const float* g;          /* device [N]   gradient fed to the net at this step               */
+  const float* m;          /* device [N]   RNNProp moments AFTER this step's update (or NULL) */
+  const float* v;
+  const float* st_prev;    /* device packed LSTM state BEFORE the step (NULL for layers=())   */
+  const float* dx_next;    /* device [N]                                                      */
+  const float* carry_in;   /* device [4][N][H] (NULL for layers=())                           */
+  float* carry_out;        /* device [4][N][H]                                                */
+  float* act1;             /* device [N][P+H]  (P = 1 | 2 | H for identity | LogAndSign | fc); layers=(): [N][2] */
+  float* dz1;              /* device [N][4H]                                                  */
+  float* act2;             /* device [N][2H]                                                  */
+  float* dz2;              /* device [N][4H]                                                  */
+  float* h2;               /* device [N][H]                                                   */
+  float* dd;               /* device [N]   dL/d(output Linear)                                */
+  float* feats;            /* device [N][2]  RNNProp (m~, g~)                                 */
+  float* du;               /* device [N][H]  RNNProp d/d(fc pre-activation)                   */
+} l2o_bwd_io;
+int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io,
+                        double pow1, double pow2, int64_t B, int64_t D, void* stream);
+
 /* ---- the fused unroll: MetaOptimizer.meta_loss's tf.while_loop
  * (DM/meta.py:338-376; RNNProp DM/meta_rnnprop_eval.py time_step) as ONE persistent
  * launch: T x { fx_t = f(x_t*s); g = s*grad f; delta,state = net(g,state); x += delta }

@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats",
-    "l2o_cwlstm_step", "l2o_unroll", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_bwd_step", "l2o_unroll", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
 
@@ -57,6 +57,18 @@ class Mlp(C.Structure):
         ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32), ("batch", C.c_int32),
         ("activation", C.c_int32), ("n_data", C.c_int32), ("images", C.c_void_p), ("labels", C.c_void_p),
     ]
+
+
+class NetWeights(C.Structure):
+    """struct l2o_net_weights"""
+    _fields_ = [(n, C.c_void_p) for n in ("w_gates1", "b_gates1", "w_gates2", "b_gates2", "w_lin", "b_lin",
+                                          "w_fc", "b_fc")]
+
+
+class BwdIO(C.Structure):
+    """struct l2o_bwd_io"""
+    _fields_ = [(n, C.c_void_p) for n in ("g", "m", "v", "st_prev", "dx_next", "carry_in", "carry_out", "act1",
+                                          "dz1", "act2", "dz2", "h2", "dd", "feats", "du")]
 
 
 class L2OError(RuntimeError):
@@ -105,6 +117,9 @@ def lib():
     L.l2o_mlp_scratch_floats.argtypes = [C.POINTER(Mlp)]
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
+    L.l2o_cwlstm_bwd_step.restype = C.c_int
+    L.l2o_cwlstm_bwd_step.argtypes = [C.POINTER(NetCfg), C.POINTER(NetWeights), C.POINTER(BwdIO), dbl, dbl, i64,
+                                      i64, vp]
     L.l2o_unroll.restype = C.c_int
     L.l2o_unroll.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Problem), vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.l2o_unroll_workspace_bytes.restype = C.c_size_t

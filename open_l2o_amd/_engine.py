@@ -168,6 +168,19 @@ class HipEngine(object):
                                             float(pow1), float(pow2), _ptr(st), _ptr(x), B, D,
                                             self._stream()))
 
+    def bwd_step(self, spec: NetSpec, weights: dict, io: dict, pow1, pow2, B, D):
+        """One BPTT step (l2o_cwlstm_bwd_step).  weights / io: dicts of device tensors keyed by the
+        field names of struct l2o_net_weights / l2o_bwd_io (missing = NULL)."""
+        cc = spec.to_c()
+        w = _abi.NetWeights()
+        for k, _ in _abi.NetWeights._fields_:
+            setattr(w, k, None if weights.get(k) is None else weights[k].data_ptr())
+        b = _abi.BwdIO()
+        for k, _ in _abi.BwdIO._fields_:
+            setattr(b, k, None if io.get(k) is None else io[k].data_ptr())
+        _abi.check(self.lib.l2o_cwlstm_bwd_step(C.byref(cc), C.byref(w), C.byref(b), float(pow1), float(pow2),
+                                                B, D, self._stream()))
+
     def unroll_supported(self, spec: NetSpec, p: ProblemDesc):
         cc, cp = spec.to_c(), self._cprob(p)
         return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))

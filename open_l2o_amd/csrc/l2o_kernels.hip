@@ -504,6 +504,8 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_mlp.h"
 
+#include "l2o_bwd.h"
+
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
@@ -904,6 +906,56 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, 
       if (!m || !v) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: RNNProp needs m and v");
       hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_FC_ELU>, grid, block, 0, s, np, g, m, v, om1, om2, st, x, (int)B,
                          (int)D, tpp);
+  }
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io, double pow1,
+                        double pow2, int64_t B, int64_t D, void* stream) {
+  if (!cfg || !w || !io || B <= 0 || D <= 0 || !io->g || !io->dx_next || !io->act1 || !io->dd || !w->w_lin ||
+      !w->b_lin)
+    return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step: bad argument");
+  BwdParams p;
+  p.B = (int)B; p.D = (int)D; p.tpp = tiles_per_problem(D);
+  p.pre = cfg->preprocess; p.tanh_output = cfg->tanh_output; p.n_layers = cfg->n_layers;
+  p.scale = (float)cfg->scale;
+  p.k_inv = cfg->logsign_k != 0.0 ? (float)(1.0 / cfg->logsign_k) : 0.0f;
+  p.exp_k = (float)std::exp(cfg->logsign_k);
+  p.beta1 = (float)cfg->beta1; p.beta2 = (float)cfg->beta2;
+  p.om1 = (float)(1.0 - pow1); p.om2 = (float)(1.0 - pow2);
+  p.wg1 = w->w_gates1; p.bg1 = w->b_gates1; p.wg2 = w->w_gates2; p.bg2 = w->b_gates2;
+  p.wl = w->w_lin; p.bl = w->b_lin; p.wfc = w->w_fc; p.bfc = w->b_fc;
+  p.g = io->g; p.m = io->m; p.v = io->v; p.st_prev = io->st_prev; p.dx_next = io->dx_next;
+  p.carry_in = io->carry_in; p.carry_out = io->carry_out; p.act1 = io->act1; p.dz1 = io->dz1;
+  p.act2 = io->act2; p.dz2 = io->dz2; p.h2o = io->h2; p.dd = io->dd; p.feats = io->feats; p.du = io->du;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = (size_t)B * D;
+  if (cfg->n_layers == 0) {
+    if (cfg->kind != L2O_NET_CW || cfg->preprocess == L2O_PRE_FC_ELU)
+      return fail(L2O_ERR_UNSUPPORTED, "layers=() is implemented for CoordinateWiseDeepLSTM only");
+    const dim3 grid((unsigned)((N + 255) / 256));
+    if (cfg->preprocess == L2O_PRE_LOGSIGN) hipLaunchKernelGGL(k_linear_bwd_step<L2O_PRE_LOGSIGN>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_linear_bwd_step<L2O_PRE_IDENTITY>, grid, dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return L2O_OK;
+  }
+  if (!net_ok_for_mfma(cfg)) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_step: only layers=(20,20) / () nets");
+  if (!w->w_gates1 || !w->b_gates1 || !w->w_gates2 || !w->b_gates2 || !io->st_prev || !io->carry_in ||
+      !io->carry_out || !io->dz1 || !io->act2 || !io->dz2 || !io->h2)
+    return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step: NULL LSTM buffer");
+  const int pre = cfg->preprocess;
+  const int P = pre == L2O_PRE_FC_ELU ? kH : (pre == L2O_PRE_LOGSIGN ? 2 : 1);
+  const size_t lds = sizeof(float) * ((size_t)(P + kH) * 4 * kH + 2 * kH * 4 * kH + 2 * 4 * kH + kH + 3 * kH +
+                                      2 * kH * 64);
+  const dim3 grid((unsigned)((N + 63) / 64)), block(64);
+  switch (pre) {
+    case L2O_PRE_IDENTITY: hipLaunchKernelGGL(k_cwlstm_bwd_step<L2O_PRE_IDENTITY>, grid, block, lds, s, p); break;
+    case L2O_PRE_LOGSIGN: hipLaunchKernelGGL(k_cwlstm_bwd_step<L2O_PRE_LOGSIGN>, grid, block, lds, s, p); break;
+    default:
+      if (!io->m || !io->v || !io->feats || !io->du || !w->w_fc || !w->b_fc)
+        return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step: RNNProp needs m, v, feats, du and the fc weights");
+      hipLaunchKernelGGL(k_cwlstm_bwd_step<L2O_PRE_FC_ELU>, grid, block, lds, s, p);
   }
   HIP_TRY(hipGetLastError());
   return L2O_OK;

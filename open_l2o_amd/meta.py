@@ -363,7 +363,7 @@ class UnrollGraph(object):
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
                 "x": x_out, "fx_array": fx_host}
 
-    def launch(self, feed=None, commit=True, events=None, use_graph=False):
+    def launch(self, feed=None, commit=True, events=None, use_graph=False, record=None):
         """Enqueue one unroll on the current stream WITHOUT synchronising the host; returns
         (device tensor fx[0..T] -- already all-reduced when sharded --, list of device x_T).
         ``events`` = (start, end) torch.cuda.Event pair recorded around the unroll kernels.
@@ -421,7 +421,12 @@ class UnrollGraph(object):
 
         if events is not None:
             events[0].record()
-        if self._fused_ok(descs):
+        if record is not None:                             # meta-gradient: needs the per-step history
+            self.last_path = "steps"
+            self._draw_minibatches(T)
+            record.update(step0=step0, shapes=[tuple(pn.shape) for pn in panels])
+            self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx, record=record)
+        elif self._fused_ok(descs):
             self.last_path = "fused"
             s, d = slots[0], descs[0]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
@@ -482,6 +487,108 @@ class UnrollGraph(object):
             else:
                 bufs[k] = new
 
+    # -- meta-gradient (DM/meta.py:398-414) --------------------------------------------
+    def train_step(self, feed, commit, learning_rate):
+        """One forward unroll (step-granular kernels, history recorded), back-propagation
+        through time of loss = sum_t fx_t w.r.t. the optimizer networks' weights with the
+        optimizee gradients held constant (tf.stop_gradient, DM/meta.py:328-329), and one Adam
+        update of those weights (tf.train.AdamOptimizer(learning_rate).minimize(loss)).
+        Returns the same dict as execute()."""
+        record = {}
+        fx, xs = self.launch(feed, commit, record=record)
+        eng = self.engine
+        T = self.len_unroll
+        fx_host = eng.to_numpy(fx)
+        x_out = [eng.to_numpy(xv).reshape(self._local_shape(var)) for xv, var in zip(xs, self.x)]
+        grads = self._backward(T, record)
+        self._adam_apply(grads, learning_rate)
+        return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
+                "x": x_out, "fx_array": fx_host}
+
+    def _backward(self, T, rec):
+        eng = self.engine
+        step0 = rec["step0"]
+        b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
+        out = {}                                           # net key -> {(module, variable): device grad}
+        for si, s in enumerate(self.slots):
+            net = s.net
+            if not isinstance(net, networks.StandardDeepLSTM):
+                continue
+            j = s.var_index
+            B, D = rec["shapes"][j]
+            N = B * D
+            spec = net.spec
+            nl = len(spec.layers)
+            fc = spec.preprocess == _abi.PRE_FC_ELU
+            P = 20 if fc else (2 if spec.preprocess == _abi.PRE_LOGSIGN else 1)
+            wdev = net.device_weights(eng)
+            acc = out.setdefault(s.key, {})
+
+            def add(mod, var, val):
+                k = (mod, var)
+                acc[k] = val if k not in acc else acc[k] + val
+
+            Gacc = rec["g_final"][j].reshape(N).clone()
+            io = {"dd": eng.empty(N)}
+            if nl:
+                H = 20
+                carry_in, carry_out = eng.zeros(4, N, H), eng.empty(4, N, H)
+                io.update(act1=eng.empty(N, P + H), dz1=eng.empty(N, 4 * H), act2=eng.empty(N, 2 * H),
+                          dz2=eng.empty(N, 4 * H), h2=eng.empty(N, H))
+                if fc:
+                    io.update(feats=eng.empty(N, 2), du=eng.empty(N, H))
+            else:
+                io.update(act1=eng.empty(N, 2))
+            for t in reversed(range(T)):
+                k = step0 + t
+                io.update(g=rec["g"][t][j], dx_next=Gacc)
+                if nl:
+                    io.update(st_prev=rec["st"][t][si], carry_in=carry_in, carry_out=carry_out,
+                              m=rec["m"][t][si], v=rec["v"][t][si])
+                eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, B, D)
+                dd = io["dd"].view(N, 1)
+                if nl:
+                    add("lstm_1", "w_gates", io["act1"].t() @ io["dz1"])
+                    add("lstm_1", "b_gates", io["dz1"].sum(0))
+                    add("lstm_2", "w_gates", io["act2"].t() @ io["dz2"])
+                    add("lstm_2", "b_gates", io["dz2"].sum(0))
+                    add("linear", "w", io["h2"].t() @ dd)
+                    if fc:
+                        add("input_projection", "w", io["feats"].t() @ io["du"])
+                        add("input_projection", "b", io["du"].sum(0))
+                    carry_in, carry_out = carry_out, carry_in
+                else:
+                    add("linear", "w", io["act1"][:, :P].t() @ dd)
+                add("linear", "b", dd.sum(0))
+                Gacc = Gacc + rec["g"][t][j].reshape(N)
+        if self.sharded:
+            import torch.distributed as dist
+            for acc in out.values():
+                for k in sorted(acc):
+                    dist.all_reduce(acc[k])
+        return {key: {k: eng.to_numpy(v) for k, v in acc.items()} for key, acc in out.items()}
+
+    def _adam_apply(self, grads, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """tf.train.AdamOptimizer's update (TF 1.x `_apply_dense`): lr_t = lr sqrt(1-b2^t)/(1-b1^t);
+        m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; var <- var - lr_t m / (sqrt(v) + eps).
+        A few thousand weights: done on the host in fp32, then re-packed for the kernels."""
+        st = self.__dict__.setdefault("_adam", {"t": 0, "m": {}, "v": {}})
+        st["t"] += 1
+        t = st["t"]
+        f = np.float32
+        lr_t = f(learning_rate * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+        for key, acc in grads.items():
+            net = self.nets[key]
+            for (mod, var), g in acc.items():
+                g = np.asarray(g, np.float32).reshape(net.variables[mod][var].shape)
+                kk = (key, mod, var)
+                m = st["m"].get(kk, np.zeros_like(g))
+                v = st["v"].get(kk, np.zeros_like(g))
+                m = f(beta1) * m + f(1.0 - beta1) * g
+                v = f(beta2) * v + f(1.0 - beta2) * g * g
+                st["m"][kk], st["v"][kk] = m, v
+                net.assign(mod, var, net.variables[mod][var] - lr_t * m / (np.sqrt(v) + f(epsilon)))
+
     def rewind(self, x0):
         """Device-side restart of the SAME problem instance: x <- x0 (list of device tensors),
         LSTM state / moments <- 0, without re-sampling the problem data (bench.py)."""
@@ -522,7 +629,7 @@ class UnrollGraph(object):
                                  labels=self.engine.int_tensor(term.hyper["labels"]))
         return cache[key]
 
-    def _run_steps(self, T, step0, descs, panels, slots, states, ms, vs, fx):
+    def _run_steps(self, T, step0, descs, panels, slots, states, ms, vs, fx, record=None):
         """Step-granular path: per step one forward+gradient launch per loss term
         (l2o_problem_fg / l2o_mlp_fg) and one l2o_cwlstm_step per (net, variable)."""
         eng = self.engine
@@ -555,9 +662,15 @@ class UnrollGraph(object):
                         for j in js:
                             grads[j].mul_(float(term.weight))
 
+        if record is not None:
+            record.update(g=[], st=[], m=[], v=[])
         for t in range(T):
             forward(t, True)
             k = step0 + t
+            if record is not None:
+                record["g"].append([g.clone() for g in grads])
+                record["st"].append([None if not isinstance(st, PackedState) or st.packed is None
+                                     else st.packed.clone() for st in states])
             for si, s in enumerate(slots):
                 j = s.var_index
                 B, D = panels[j].shape
@@ -567,7 +680,12 @@ class UnrollGraph(object):
                 else:                                    # Sgd / Adam baseline nets
                     delta, states[si] = s.net(grads[j], states[si])
                     panels[j].add_(delta.view(B, D))
-        forward(T, False)
+            if record is not None:                         # RNNProp moments AFTER this step's update
+                record["m"].append([None if mm is None else mm.clone() for mm in ms])
+                record["v"].append([None if vv is None else vv.clone() for vv in vs])
+        forward(T, record is not None)                     # training also needs the gradient at x_T
+        if record is not None:
+            record["g_final"] = [g.clone() for g in grads]
 
 
 # ---------------------------------------------------------------------------
@@ -651,8 +769,10 @@ class MetaOptimizer(object):
         return self._handles(self._build_graph(make_loss, len_unroll, net_assignments, second_derivatives))
 
     def meta_minimize(self, make_loss, len_unroll, learning_rate=0.01, **kwargs):
-        """DM/meta.py:398-414 (Adam on the meta-loss through BPTT).  The meta-gradient is
-        not part of this build's hot path."""
-        raise NotImplementedError(
-            "meta_minimize needs the meta-gradient (BPTT through the unroll), which is the next scope row "
-            "(SURVEY.md 8f rank 2); this build accelerates the forward unroll (meta_loss)")
+        """Returns handles minimizing the meta-loss: namedtuple (step, update, reset, fx, x).
+        DM/meta.py:398-414: ``step`` = one Adam update of the optimizer networks on the
+        meta-loss of the unroll (truncated BPTT: x and the LSTM state are carried over by
+        ``update`` without gradient, the optimizee gradients are constants)."""
+        info = self.meta_loss(make_loss, len_unroll, **kwargs)
+        self._graph.learning_rate = learning_rate
+        return MetaStep(Fetch(self._graph, "step"), *info[1:])

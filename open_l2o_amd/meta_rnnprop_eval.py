@@ -24,4 +24,7 @@ class MetaOptimizer(_meta.MetaOptimizer):
         return self._handles(graph), graph.scale, graph.x, graph.step
 
     def meta_minimize(self, make_loss, len_unroll, learning_rate=0.01, **kwargs):
-        return super(MetaOptimizer, self).meta_minimize(make_loss, len_unroll, learning_rate, **kwargs)
+        """DM/meta_rnnprop_eval.py:468-485: (MetaStep, scale, x, seq_step)."""
+        info, scale, x, seq_step = self.meta_loss(make_loss, len_unroll, **kwargs)
+        self._graph.learning_rate = learning_rate
+        return _meta.MetaStep(_meta.Fetch(self._graph, "step"), *info[1:]), scale, x, seq_step

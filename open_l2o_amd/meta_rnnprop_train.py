@@ -27,3 +27,10 @@ class MetaOptimizer(_meta.MetaOptimizer):
         graph = self._build_graph(make_loss, len_unroll, net_assignments, second_derivatives)
         return (self._handles(graph), graph.scale, graph.x, graph.constants, graph.subsets, graph.step,
                 [], [], [], [], [])
+
+    def meta_minimize(self, make_loss, len_unroll, learning_rate=0.01, **kwargs):
+        """DM/meta_rnnprop_train.py:595-624 (mt lists empty: num_mt == 0)."""
+        out = self.meta_loss(make_loss, len_unroll, **kwargs)
+        self._graph.learning_rate = learning_rate
+        step = _meta.MetaStep(_meta.Fetch(self._graph, "step"), *out[0][1:])
+        return (step,) + tuple(out[1:6]) + ([], [], [], [], [], [])

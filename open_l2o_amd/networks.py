@@ -189,10 +189,24 @@ class StandardDeepLSTM(Network):
         return self._wpack
 
     def assign(self, module_name, variable_name, value):
-        """Overwrite one weight (used by MetaOptimizer.restore)."""
+        """Overwrite one weight (used by MetaOptimizer.restore and the Adam meta-step)."""
         cur = self.variables[module_name][variable_name]
         self.variables[module_name][variable_name] = np.asarray(value, np.float32).reshape(cur.shape).copy()
         self._wpack = None
+        self._wdev = None
+
+    def device_weights(self, engine):
+        """Device copies of the weights in their Sonnet layouts, keyed like struct
+        l2o_net_weights (the BPTT kernel reads them unpacked)."""
+        if getattr(self, "_wdev", None) is None or self._wdev_engine is not engine:
+            v = self.variables
+            names = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"),
+                     "w_gates2": ("lstm_2", "w_gates"), "b_gates2": ("lstm_2", "b_gates"),
+                     "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+                     "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+            self._wdev = {k: engine.tensor(v[m][n]) for k, (m, n) in names.items() if m in v}
+            self._wdev_engine = engine
+        return self._wdev
 
     # -- eager call: net(inputs, prev_state) -> (delta, next_state) ----------
     def _panel(self, inputs):

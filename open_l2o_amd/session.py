@@ -64,12 +64,16 @@ class Session(object):
         for graph, fs in by_graph.values():
             keys = [f.key for f in fs]
             do_reset = "reset" in keys
-            needs_unroll = any(k in ("loss", "fx", "update", "fx_array") or isinstance(k, tuple) for k in keys)
+            needs_unroll = any(k in ("loss", "fx", "update", "fx_array", "step") or isinstance(k, tuple)
+                               for k in keys)
             if do_reset:
                 graph.reset()
-            res = graph.execute(feed_dict, commit="update" in keys) if needs_unroll else {}
+            if "step" in keys:                              # the Adam meta-step (meta_minimize)
+                res = graph.train_step(feed_dict, commit="update" in keys, learning_rate=graph.learning_rate)
+            else:
+                res = graph.execute(feed_dict, commit="update" in keys) if needs_unroll else {}
             for f in fs:
-                if f.key in ("update", "reset"):
+                if f.key in ("update", "reset", "step"):
                     values[id(f)] = None
                 elif isinstance(f.key, tuple):
                     values[id(f)] = res["x"][f.key[1]]

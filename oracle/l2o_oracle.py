@@ -20,6 +20,7 @@ __all__ = [
     "NetConfig", "init_net_params", "net_initial_state", "net_apply",
     "Simple", "SimpleMulti", "Quadratic", "Lasso", "Rastrigin", "SquareCos",
     "unroll", "UnrollResult", "sgd_net", "adam_net", "truncated_normal", "MnistMLP", "unroll_multi",
+    "net_bwd_step", "tf_adam_step",
     "DM_IDENTITY", "DM_LOGSIGN", "RNNPROP",
 ]
 
@@ -522,3 +523,83 @@ def unroll(problem, cfg, params, x0, state0, T, x_scale=None,
     xs = x if s is None else x * s
     fx[T] = problem.f(xs)
     return UnrollResult(fx, x, state, m, v, np.sum(fx))
+
+
+# ----------------------------------------------------------------------------
+# meta-gradient: what tf.train.AdamOptimizer(lr).minimize(loss) differentiates in
+# MetaOptimizer.meta_minimize (DM/meta.py:398-414) with g = stop_gradient(grad f)
+# (DM/meta.py:328-329).  One BPTT step of the optimizer network, hand-derived; the tests pin
+# it against torch autograd of the restated unroll.
+# ----------------------------------------------------------------------------
+def net_bwd_step(cfg, params, inputs, state_prev, dx_next, carry_in):
+    """inputs: g (cw) or (m_tilde, g_tilde) (rnnprop), flat [N].  state_prev: the net state BEFORE
+    the step.  dx_next [N] = dL/dx_{t+1}.  carry_in = (dh1, dc1, dh2, dc2) [N,H] from step t+1.
+    Returns (carry_out, rows) with rows = dict(act1, dz1, act2, dz2, h2, dd[, feats, du]) such that
+    dW1 = act1^T dz1, db1 = sum dz1, dW2 = act2^T dz2, db2 = sum dz2, dw_lin = h2^T dd, db_lin = sum dd,
+    dW_fc = feats^T du, db_fc = sum du."""
+    dt = dx_next.dtype.type
+    rows = {}
+    if cfg.kind == "rnnprop":
+        m, g = inputs
+        feats = np.stack([m.reshape(-1), g.reshape(-1)], -1)
+        p = params["input_projection"]
+        pre = feats @ p["w"] + p["b"]
+        a = elu(pre)
+        rows["feats"] = feats
+    else:
+        gf = inputs.reshape(-1, 1)
+        a = log_and_sign(gf[..., None], **cfg.preprocess_options).reshape(gf.shape[0], -1) \
+            if cfg.preprocess_name == "LogAndSign" else gf
+    if len(cfg.layers) == 0:
+        lin = params["linear"]
+        d = a @ lin["w"] + lin["b"]
+        dd = dx_next.reshape(-1, 1) * dt(cfg.scale)
+        if cfg.tanh_output:
+            dd = dd * (dt(1) - np.tanh(d) ** 2)
+        rows.update(act1=a, dd=dd[:, 0])
+        return None, rows
+    (h1p, c1p), (h2p, c2p) = state_prev
+    H = h1p.shape[1]
+
+    def fwd(x, h, c, p):
+        z = np.concatenate([x, h], 1) @ p["w_gates"] + p["b_gates"]
+        i, j, f, o = sigmoid(z[:, :H]), np.tanh(z[:, H:2 * H]), sigmoid(z[:, 2 * H:3 * H] + dt(1)), sigmoid(z[:, 3 * H:])
+        cn = f * c + i * j
+        return i, j, f, o, cn, np.tanh(cn)
+
+    i1, j1, f1, o1, c1, tc1 = fwd(a, h1p, c1p, params["lstm_1"])
+    h1 = tc1 * o1
+    i2, j2, f2, o2, c2, tc2 = fwd(h1, h2p, c2p, params["lstm_2"])
+    h2 = tc2 * o2
+    lin = params["linear"]
+    d = h2 @ lin["w"] + lin["b"]
+    dd = dx_next.reshape(-1, 1) * dt(cfg.scale)
+    if cfg.tanh_output:
+        dd = dd * (dt(1) - np.tanh(d) ** 2)
+    dh1_in, dc1_in, dh2_in, dc2_in = carry_in
+
+    def bwd(dh, dc_in, i, j, f, o, tc, c_prev, p, n_in):
+        dc = dc_in + dh * o * (dt(1) - tc * tc)
+        dz = np.concatenate([dc * j * i * (dt(1) - i), dc * i * (dt(1) - j * j), dc * c_prev * f * (dt(1) - f),
+                             dh * tc * o * (dt(1) - o)], 1)
+        din = dz @ p["w_gates"].T
+        return dz, din[:, :n_in], din[:, n_in:], dc * f
+
+    dh2 = dd @ lin["w"].T + dh2_in
+    dz2, dh1_from2, dh2_out, dc2_out = bwd(dh2, dc2_in, i2, j2, f2, o2, tc2, c2p, params["lstm_2"], H)
+    dh1 = dh1_from2 + dh1_in
+    dz1, da, dh1_out, dc1_out = bwd(dh1, dc1_in, i1, j1, f1, o1, tc1, c1p, params["lstm_1"], a.shape[1])
+    rows.update(act1=np.concatenate([a, h1p], 1), dz1=dz1, act2=np.concatenate([h1, h2p], 1), dz2=dz2, h2=h2,
+                dd=dd[:, 0])
+    if cfg.kind == "rnnprop":
+        rows["du"] = da * np.where(pre > 0, dt(1), np.exp(np.minimum(pre, dt(0))))
+    return (dh1_out, dc1_out, dh2_out, dc2_out), rows
+
+
+def tf_adam_step(var, g, m, v, t, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer._apply_dense (TF 1.x), fp32: returns (var', m', v')."""
+    f = np.float32
+    lr_t = f(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+    m = f(beta1) * m + f(1.0 - beta1) * g
+    v = f(beta2) * v + f(1.0 - beta2) * g * g
+    return var - lr_t * m / (np.sqrt(v) + f(eps)), m, v

@@ -154,6 +154,45 @@ class OracleEngine(object):
         if len(cfg.layers):
             st.copy_(torch.from_numpy(pack_state(nstate[0][0], nstate[0][1], nstate[1][0], nstate[1][1], B, D)))
 
+    def bwd_step(self, spec, weights, io, pow1, pow2, B, D):
+        self.calls.append("bwd_step")
+        cfg = _cfg_of(spec)
+        N = B * D
+        names = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"),
+                 "w_gates2": ("lstm_2", "w_gates"), "b_gates2": ("lstm_2", "b_gates"),
+                 "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+                 "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+        params = {}
+        for k, (m, n) in names.items():
+            if weights.get(k) is not None:
+                params.setdefault(m, {})[n] = weights[k].numpy()
+        g = io["g"].numpy().reshape(N)
+        dt = np.float32
+        if cfg.kind == "rnnprop":
+            mh = io["m"].numpy().reshape(N) / (dt(1) - dt(pow1))
+            vh = io["v"].numpy().reshape(N) / (dt(1) - dt(pow2))
+            inputs = (mh / (np.sqrt(vh) + dt(1e-8)), g / (np.sqrt(vh) + dt(1e-8)))
+        else:
+            inputs = g
+        if len(cfg.layers):
+            h1, c1, h2, c2 = unpack_state(io["st_prev"].numpy(), B, D)
+            state = ((h1, c1), (h2, c2))
+            cin = io["carry_in"].numpy().reshape(4, N, 20)
+            carry = tuple(cin[i] for i in range(4))
+        else:
+            state, carry = (), None
+        cout, rows = O.net_bwd_step(cfg, params, inputs, state, io["dx_next"].numpy().reshape(N), carry)
+        if cout is not None:
+            io["carry_out"].copy_(torch.from_numpy(np.stack(cout).astype(np.float32)).view_as(io["carry_out"]))
+        for k, v in rows.items():
+            t = io[k]
+            a = np.ascontiguousarray(v, np.float32)
+            if k == "act1" and not len(cfg.layers):                 # [N,P] -> padded [N,2]
+                pad = np.zeros((N, 2), np.float32)
+                pad[:, :a.shape[1]] = a
+                a = pad
+            t.copy_(torch.from_numpy(a).view_as(t))
+
     def unroll_supported(self, spec, p):
         cc = spec.to_c()
         import ctypes as C

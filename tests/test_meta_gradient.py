@@ -1,0 +1,243 @@
+"""The meta-gradient path: MetaOptimizer.meta_minimize (DM/meta.py:398-414).
+
+ * the reference's golden test (L2O-Swarm/src/meta_test.py:50-69) run for real: Adam(0.01) on
+   the all-zero Linear net over two 5-step unrolls of f(x) = x^2 -> cost 0.7325327, x 0.8559;
+ * the hand-derived BPTT step of the oracle (oracle.net_bwd_step) against torch autograd of the
+   restated unroll with stop-gradient on the optimizee gradient (float64);
+ * the HIP kernel l2o_cwlstm_bwd_step and the whole train step against those (GPU).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from helpers import ORACLE_CFGS, make_params, make_problem, max_abs, random_state, rel_err, spec_of
+from open_l2o_amd import _engine, meta, meta_rnnprop_eval, problems
+from open_l2o_amd.session import Session
+from test_meta_api import _net_config, engine  # noqa: F401  (fixture)
+from test_oracle_kat import _torch_lstm_from_sonnet  # noqa: F401
+
+
+def train(sess, minimize_ops, num_epochs, num_unrolls):
+    """L2L training, verbatim from meta_test.py:34-44."""
+    step, update, reset, loss_last, x_last = minimize_ops
+    for _ in range(num_epochs):
+        sess.run(reset)
+        for _ in range(num_unrolls):
+            cost, final_x, unused_1, unused_2 = sess.run([loss_last, x_last, update, step])
+    return cost, final_x
+
+
+def test_results_reference_golden_through_meta_minimize(engine):
+    """meta_test.py:50-69 testResults: 'Tests reproducibility of Torch results'."""
+    problem = problems.simple()
+    optimizer = meta.MetaOptimizer(net=dict(net="CoordinateWiseDeepLSTM",
+                                            net_options={"layers": (), "initializer": "zeros"}))
+    minimize_ops = optimizer.meta_minimize(problem, 5)
+    with Session() as sess:
+        cost, final_x = train(sess, minimize_ops, 1, 2)
+    torch_cost = 0.7325327
+    torch_final_x = 0.8559
+    assert abs(float(cost) - torch_cost) < 5e-5                  # assertAlmostEqual(places=4)
+    assert abs(float(final_x[0]) - torch_final_x) < 5e-5
+    w = optimizer._nets["net"].variables["linear"]
+    # two Adam steps of ~-lr each (the cost above was produced with the weights after the FIRST)
+    np.testing.assert_allclose([w["w"][0, 0], w["b"][0]], [-0.02, -0.02], rtol=1e-2)
+
+
+# ------------------------------------------------------------------ autograd reference
+def _torch_meta_grad(cfg, params, prob_kind, prob, x0, state0, T, step0=1):
+    """dL/dtheta of loss = sum_t f(x_t) by torch autograd (float64) with g detached."""
+    tp = {k: {v: torch.tensor(np.asarray(a, np.float64), requires_grad=True) for v, a in d.items()}
+          for k, d in params.items()}
+    W, y = torch.tensor(prob.w.astype(np.float64)), torch.tensor(prob.y.astype(np.float64))
+    B, D = x0.shape
+    x = torch.tensor(x0.astype(np.float64))
+    st = [[torch.tensor(a.astype(np.float64)) for a in hc] for hc in state0]
+    m = torch.zeros_like(x)
+    v = torch.zeros_like(x)
+    H = 20
+
+    def f(xx):
+        r = torch.matmul(W, xx.unsqueeze(-1)).squeeze(-1) - y
+        return torch.mean(torch.sum(r * r, 1))
+
+    def cell(inp, h, c, p):
+        z = torch.cat([inp, h], 1) @ p["w_gates"] + p["b_gates"]
+        i, j, fg, o = torch.sigmoid(z[:, :H]), torch.tanh(z[:, H:2 * H]), torch.sigmoid(z[:, 2 * H:3 * H] + 1), \
+            torch.sigmoid(z[:, 3 * H:])
+        cn = fg * c + i * j
+        return torch.tanh(cn) * o, cn
+
+    loss = 0
+    for t in range(T):
+        xr = x.detach().clone().requires_grad_(True)
+        fx = f(xr)
+        g = torch.autograd.grad(fx, xr)[0].detach()
+        loss = loss + f(x)
+        if cfg.kind == "rnnprop":
+            k = float(step0 + t)
+            m = 0.95 * m + (1 - 0.95) * g
+            v = 0.95 * v + (1 - 0.95) * g * g
+            mh, vh = m / (1 - 0.95 ** k), v / (1 - 0.95 ** k)
+            feats = torch.stack([(mh / (vh.sqrt() + 1e-8)).reshape(-1), (g / (vh.sqrt() + 1e-8)).reshape(-1)], -1)
+            a = torch.nn.functional.elu(feats @ tp["input_projection"]["w"] + tp["input_projection"]["b"])
+        elif cfg.preprocess_name == "LogAndSign":
+            gf = g.reshape(-1, 1)
+            eps = float(np.finfo(np.float64).eps)
+            a = torch.cat([torch.clamp(torch.log(gf.abs() + eps) / 5, min=-1.0),
+                           torch.clamp(gf * float(np.exp(5)), -1.0, 1.0)], 1)
+        else:
+            a = g.reshape(-1, 1)
+        h1, c1 = cell(a, st[0][0], st[0][1], tp["lstm_1"])
+        h2, c2 = cell(h1, st[1][0], st[1][1], tp["lstm_2"])
+        st = [[h1, c1], [h2, c2]]
+        d = h2 @ tp["linear"]["w"] + tp["linear"]["b"]
+        d = (torch.tanh(d) if cfg.tanh_output else d) * cfg.scale
+        x = x + d.reshape(x.shape)
+    loss = loss + f(x)
+    loss.backward()
+    return {k: {v: t.grad.numpy() for v, t in d.items()} for k, d in tp.items()}, float(loss.detach())
+
+
+def _oracle_meta_grad(cfg, params, prob, x0, state0, T, step0=1):
+    """Forward with the oracle, backward with oracle.net_bwd_step (float64 when params are)."""
+    dt = x0.dtype.type
+    x, state = x0.copy(), state0
+    m = np.zeros_like(x0)
+    v = np.zeros_like(x0)
+    hist = []
+    for t in range(T):
+        g = prob.grad(x)
+        if cfg.kind == "rnnprop":
+            k = dt(step0 + t)
+            m = dt(0.95) * m + dt(1 - 0.95) * g
+            v = dt(0.95) * v + dt(1 - 0.95) * g * g
+            mh, vh = m / (dt(1) - np.power(dt(0.95), k)), v / (dt(1) - np.power(dt(0.95), k))
+            inputs = ((mh / (np.sqrt(vh) + dt(1e-8))).reshape(-1), (g / (np.sqrt(vh) + dt(1e-8))).reshape(-1))
+        else:
+            inputs = g.reshape(-1)
+        hist.append((inputs, state, g))
+        delta, state = O.net_apply(cfg, params, inputs if cfg.kind == "rnnprop" else g, state)
+        x = x + delta.reshape(x.shape)
+    G = prob.grad(x).reshape(-1)
+    N = x0.size
+    carry = tuple(np.zeros((N, 20), x0.dtype) for _ in range(4))
+    grads = {}
+
+    def add(mod, var, val):
+        grads.setdefault(mod, {})
+        grads[mod][var] = val if var not in grads[mod] else grads[mod][var] + val
+
+    for t in reversed(range(T)):
+        inputs, st_prev, g = hist[t]
+        carry, rows = O.net_bwd_step(cfg, params, inputs, st_prev, G, carry)
+        add("lstm_1", "w_gates", rows["act1"].T @ rows["dz1"])
+        add("lstm_1", "b_gates", rows["dz1"].sum(0))
+        add("lstm_2", "w_gates", rows["act2"].T @ rows["dz2"])
+        add("lstm_2", "b_gates", rows["dz2"].sum(0))
+        add("linear", "w", rows["h2"].T @ rows["dd"][:, None])
+        add("linear", "b", rows["dd"].sum(keepdims=True))
+        if cfg.kind == "rnnprop":
+            add("input_projection", "w", rows["feats"].T @ rows["du"])
+            add("input_projection", "b", rows["du"].sum(0))
+        G = G + g.reshape(-1)
+    return grads
+
+
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_oracle_bptt_matches_torch_autograd(name):
+    cfg = ORACLE_CFGS[name]
+    rng = np.random.default_rng(100)
+    params = {k: {v: a.astype(np.float64) for v, a in d.items()} for k, d in make_params(cfg, 101).items()}
+    B, D, T = 3, 4, 5
+    prob, x0 = O.Quadratic.sample(rng, B, D, stddev=0.5, dtype=np.float64)
+    state0 = random_state(cfg, B * D, 102)
+    state0 = tuple((h.astype(np.float64), c.astype(np.float64)) for h, c in state0)
+    want, _ = _torch_meta_grad(cfg, params, "quadratic", prob, x0, state0, T)
+    got = _oracle_meta_grad(cfg, params, prob, x0, state0, T)
+    for mod in want:
+        for var in want[mod]:
+            np.testing.assert_allclose(got[mod][var].reshape(want[mod][var].shape), want[mod][var],
+                                       rtol=1e-8, atol=1e-11, err_msg="%s/%s" % (mod, var))
+
+
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_train_step_gradient_and_adam(engine, name):
+    """One sess.run([fx, update, step]) == forward + BPTT + Adam: the weights move exactly as
+    tf.train.AdamOptimizer would move them given the autograd gradient."""
+    cfg = ORACLE_CFGS[name]
+    params = make_params(cfg, seed=103, trained_like=True)
+    B, D, T = 4, 6, 7
+    prob, x0, _ = make_problem("quadratic", B, D, seed=104)
+    problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+    key = "rp" if cfg.kind == "rnnprop" else "cw"
+    feed = {}
+    if cfg.kind == "rnnprop":
+        optimizer = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key=key))
+        ms, _, _, step_ph = optimizer.meta_minimize(problem, T, learning_rate=0.01)
+        feed = {step_ph: 1}
+    else:
+        optimizer = meta.MetaOptimizer(**_net_config(cfg, params, key=key))
+        ms = optimizer.meta_minimize(problem, T, learning_rate=0.01)
+    with Session() as sess:
+        sess.run(ms.reset)
+        cost = sess.run([ms.fx, ms.update, ms.step], feed_dict=feed)[0]
+    st0 = O.net_initial_state(cfg, B * D)
+    want, loss = _torch_meta_grad(cfg, params, "quadratic", prob, x0, st0, T)
+    res = O.unroll(prob, cfg, params, x0, st0, T)
+    assert rel_err(cost, res.fx[-1]) < 1e-5 and rel_err(res.loss, loss) < 1e-5
+    new = optimizer._nets[key].variables
+    for mod in want:
+        for var in want[mod]:
+            g = want[mod][var].astype(np.float32).reshape(params[mod][var].shape)
+            expect, _, _ = O.tf_adam_step(params[mod][var], g, np.zeros_like(g), np.zeros_like(g), 1, lr=0.01)
+            # Adam's first step is -lr * sign(g) wherever |g| >> eps: compare where the sign is unambiguous
+            mask = np.abs(g) > 1e-5 * np.abs(g).max()
+            np.testing.assert_allclose(new[mod][var][mask], expect[mask], rtol=2e-4, atol=1e-7,
+                                       err_msg="%s/%s" % (mod, var))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+@pytest.mark.parametrize("B,D", [(3, 10), (2, 37)])
+def test_bwd_step_kernel_vs_oracle(name, B, D):
+    """l2o_cwlstm_bwd_step (teacher-forced, random state / carries) == oracle.net_bwd_step."""
+    eng = _engine.HipEngine()
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=105)
+    rng = np.random.default_rng(106)
+    N = B * D
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    state = random_state(cfg, N, 107)
+    dx = rng.standard_normal(N).astype(np.float32)
+    carry = tuple((rng.standard_normal((N, 20)) * 0.3).astype(np.float32) for _ in range(4))
+    m = (rng.standard_normal((B, D)) * 0.1).astype(np.float32)
+    v = (rng.random((B, D)) * 0.1 + 0.01).astype(np.float32)
+    k = 5
+    pw = float(np.float32(0.95)) ** k
+    if cfg.kind == "rnnprop":
+        dt = np.float32
+        mh, vh = m / (dt(1) - dt(pw)), v / (dt(1) - dt(pw))
+        inputs = ((mh / (np.sqrt(vh) + dt(1e-8))).reshape(-1), (g / (np.sqrt(vh) + dt(1e-8))).reshape(-1))
+    else:
+        inputs = g.reshape(-1)
+    cout, rows = O.net_bwd_step(cfg, params, inputs, state, dx, carry)
+    P = cfg.in_dim
+    t = eng.tensor
+    io = dict(g=t(g), m=t(m), v=t(v), st_prev=eng.state_pack(*[t(a) for hc in state for a in hc], B, D),
+              dx_next=t(dx), carry_in=t(np.stack(carry)), carry_out=eng.zeros(4, N, 20),
+              act1=eng.zeros(N, P + 20), dz1=eng.zeros(N, 80), act2=eng.zeros(N, 40), dz2=eng.zeros(N, 80),
+              h2=eng.zeros(N, 20), dd=eng.zeros(N), feats=eng.zeros(N, 2), du=eng.zeros(N, 20))
+    names = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"), "w_gates2": ("lstm_2", "w_gates"),
+             "b_gates2": ("lstm_2", "b_gates"), "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+             "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+    wdev = {kk: t(params[mm][nn]) for kk, (mm, nn) in names.items() if mm in params}
+    eng.bwd_step(spec, wdev, io, pw, pw, B, D)
+    for kk, ref in rows.items():
+        got = eng.to_numpy(io[kk]).reshape(ref.shape)
+        assert max_abs(got, ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), kk
+    got = eng.to_numpy(io["carry_out"])
+    for i in range(4):
+        assert max_abs(got[i], cout[i]) < 2e-5 * max(1.0, float(np.abs(cout[i]).max()))
