@@ -241,3 +241,24 @@ def test_bwd_step_kernel_vs_oracle(name, B, D):
     got = eng.to_numpy(io["carry_out"])
     for i in range(4):
         assert max_abs(got[i], cout[i]) < 2e-5 * max(1.0, float(np.abs(cout[i]).max()))
+
+
+def test_training_harness_learns(engine, tmp_path):
+    """scripts/train_dm.py's schedule (DM/train_dm.py: epochs of truncated-BPTT segments, periodic
+    evaluation, best-model .l2l checkpoints) runs and the meta-loss goes down."""
+    import argparse
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import _train_common as TC
+    flags = argparse.Namespace(save_path=str(tmp_path), num_epochs=12, evaluation_period=4, evaluation_epochs=2,
+                               num_steps=20, unroll_length=5, learning_rate=0.01, second_derivatives=False,
+                               problem="quadratic", if_scale=True, rd_scale_bound=1.0, if_cl=False, min_num_eval=3,
+                               if_mt=False, num_mt=1, seed=11, batch_size=4, num_dims=3)
+    tr = TC.Trainer(flags, rnnprop=False)
+    w0 = {k: v.copy() for k, v in tr.optimizer._nets["cw"].variables["linear"].items()}
+    tr.run()
+    w1 = tr.optimizer._nets["cw"].variables["linear"]
+    assert not np.array_equal(w0["w"], w1["w"])                      # the meta-step moved the weights
+    saved = sorted(os.listdir(str(tmp_path)))
+    assert "cw.l2l-0" in saved and any(s.startswith("cw.l2l-") and s != "cw.l2l-0" for s in saved)
