@@ -88,7 +88,8 @@ typedef struct l2o_problem {
   double alpha;          /* rastrigin `alpha`                                             */
   const float* W;        /* device [B_local, M, D]  quadratic w / lasso w / rastrigin A   */
   const float* y;        /* device [B_local, M]     quadratic y / lasso y / rastrigin B   */
-  const float* C;        /* device [B_local, D] rastrigin C ; [B_local, D, D] square_cos wcos ; else NULL */
+  const float* C;        /* device [B_local, D]: rastrigin C ; square_cos: the COLUMN SUMS of wcos
+                            (sum_i (wcos c)_i = sum_j colsum_j c_j; alpha is fixed to 10); else NULL */
   const float* x_scale;  /* device [B_local, D] per-coordinate scale placeholder
                             (DM/meta_dm_train.py:336-338, 384) or NULL (== ones)          */
 } l2o_problem;

@@ -55,6 +55,7 @@ struct ProbParams {
   int kind, B_local, D, M;
   float inv_bg;      // 1 / B_global
   float l1, alpha;
+  float twopi;       // 2*pi (rastrigin) or 2*3.1415926 (square_cos, DM/problems.py:989)
   const float* W;
   const float* y;
   const float* C;
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
       xv = xb[j] * (sb ? sb[j] : 1.0f);
       if (pp.kind == L2O_PROB_SIMPLE) facc += xv * xv;
       if (pp.kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xv);
-      if (pp.kind == L2O_PROB_RASTRIGIN)
-        facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j] * cosf(6.2831853071795864769f * xv);
+      if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
+        facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j] * cosf(pp.twopi * xv);
     }
     xs[j] = xv;
   }
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
   if (pp.kind != L2O_PROB_SIMPLE) {
     const float* Wb = pp.W + (size_t)b * M * D;
     const float* yb = pp.y + (size_t)b * M;
-    const float coef = pp.kind == L2O_PROB_QUADRATIC ? 1.0f : 0.5f;
+    const float coef = (pp.kind == L2O_PROB_QUADRATIC || pp.kind == L2O_PROB_SQUARE_COS) ? 1.0f : 0.5f;
     if (VEC) {
       // ---- pass 1: r = W xs - y ; each wave takes 4 rows at a time -> 4 x (D/256) dwordx4 in flight
       for (int i0 = wv * 4; i0 < M; i0 += kFgWaves * 4) {
@@ -231,13 +232,13 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
     return;
   }
   const float* Wb = pp.W + (size_t)b * M * D;
-  const float cg = pp.kind == L2O_PROB_QUADRATIC ? 2.0f : 1.0f;
+  const float cg = (pp.kind == L2O_PROB_QUADRATIC || pp.kind == L2O_PROB_SQUARE_COS) ? 2.0f : 1.0f;
   auto finish = [&](int j, float s) {
     float gj = cg * s;
     const float xv = xs[j];
     if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f));
-    if (pp.kind == L2O_PROB_RASTRIGIN)
-      gj += 6.2831853071795864769f * pp.alpha * pp.C[(size_t)b * D + j] * sinf(6.2831853071795864769f * xv);
+    if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
+      gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xv);
     gb[j] = gj * pp.inv_bg * (sb ? sb[j] : 1.0f);
   };
   if (VEC) {
@@ -403,13 +404,15 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
   float xv = live ? a.x[idx] : 0.0f;
   const float sc = (live && pp.x_scale) ? pp.x_scale[idx] : 1.0f;
   float cj = 0.0f;
-  if (KIND == L2O_PROB_RASTRIGIN) cj = live ? pp.C[idx] : 0.0f;
+  constexpr bool kCos = KIND == L2O_PROB_RASTRIGIN || KIND == L2O_PROB_SQUARE_COS;
+  if (kCos) cj = live ? pp.C[idx] : 0.0f;
   float mv = 0.0f, vv = 0.0f;
   if (PRE == L2O_PRE_FC_ELU) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
-  const float coef = KIND == L2O_PROB_QUADRATIC ? 1.0f : 0.5f;
-  const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;
-  constexpr float kTwoPi = 6.2831853071795864769f;
+  constexpr bool kSq = KIND == L2O_PROB_QUADRATIC || KIND == L2O_PROB_SQUARE_COS;
+  const float coef = kSq ? 1.0f : 0.5f;
+  const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;   // x2 folded in (exact)
+  const float kTwoPi = pp.twopi;
   const float* wrow = Ws + grow * S + 4 * gq;
   const float* wtrow = WTs + grow * S + 4 * gq;
   const float* xsq = xs + 4 * gq;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     }
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
-      if (KIND == L2O_PROB_RASTRIGIN) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
+      if (kCos) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
     }
     contrib = wave_sum64(contrib);
     if (lane == 0) fpart[wv] = contrib;
@@ -466,8 +469,9 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
     });
     const float gacc = quad_sum(hsum4(gacc4));                 // lanes 4k..4k+3 hold g of coordinate 16*wv + k
     float gv = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(gacc)));
+    if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
-    if (KIND == L2O_PROB_RASTRIGIN) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
+    if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
 
     // ---- optimizer network ----------------------------------------------------
@@ -578,7 +582,8 @@ static ProbParams make_prob_params(const l2o_problem* p) {
   pp.M = p->kind == L2O_PROB_SIMPLE ? 0 : p->M;
   pp.inv_bg = 1.0f / (float)p->B_global;
   pp.l1 = (float)p->l1;
-  pp.alpha = (float)p->alpha;
+  pp.alpha = p->kind == L2O_PROB_SQUARE_COS ? 10.0f : (float)p->alpha;
+  pp.twopi = p->kind == L2O_PROB_SQUARE_COS ? (float)(2 * 3.1415926) : 6.2831853071795864769f;
   pp.W = p->W;
   pp.y = p->y;
   pp.C = p->C;
@@ -598,7 +603,9 @@ static int check_problem(const l2o_problem* p) {
       if (p->kind == L2O_PROB_QUADRATIC && p->M != p->D) return fail(L2O_ERR_ARG, "quadratic needs M == D");
       return L2O_OK;
     case L2O_PROB_RASTRIGIN:
-      if (!p->W || !p->y || !p->C || p->M != p->D) return fail(L2O_ERR_ARG, "rastrigin needs A, B, C and M == D");
+    case L2O_PROB_SQUARE_COS:
+      if (!p->W || !p->y || !p->C || p->M != p->D)
+        return fail(L2O_ERR_ARG, "rastrigin / square_cos need W, y, C and M == D");
       return L2O_OK;
     default: return fail(L2O_ERR_UNSUPPORTED, "problem kind %d has no HIP kernel", p->kind);
   }
@@ -704,6 +711,7 @@ static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind
     case L2O_PROB_QUADRATIC: return launch_unroll_ch<PRE, L2O_PROB_QUADRATIC>(a, g, s, prob, workspace);
     case L2O_PROB_LASSO: return launch_unroll_ch<PRE, L2O_PROB_LASSO>(a, g, s, prob, workspace);
     case L2O_PROB_RASTRIGIN: return launch_unroll_ch<PRE, L2O_PROB_RASTRIGIN>(a, g, s, prob, workspace);
+    case L2O_PROB_SQUARE_COS: return launch_unroll_ch<PRE, L2O_PROB_SQUARE_COS>(a, g, s, prob, workspace);
     default: return fail(L2O_ERR_UNSUPPORTED, "no fused kernel for problem kind %d", kind);
   }
 }
@@ -963,7 +971,8 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
 
 int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
   if (!cfg || !prob || !net_ok_for_mfma(cfg)) return 0;
-  if (prob->kind != L2O_PROB_QUADRATIC && prob->kind != L2O_PROB_LASSO && prob->kind != L2O_PROB_RASTRIGIN)
+  if (prob->kind != L2O_PROB_QUADRATIC && prob->kind != L2O_PROB_LASSO && prob->kind != L2O_PROB_RASTRIGIN &&
+      prob->kind != L2O_PROB_SQUARE_COS)
     return 0;
   if (prob->D <= 0 || prob->M <= 0) return 0;
   UnrollGeom g;

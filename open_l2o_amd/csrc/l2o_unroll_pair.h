@@ -97,13 +97,15 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   float xv = live ? a.x[idx] : 0.0f;
   const float sc = (live && pp.x_scale) ? pp.x_scale[idx] : 1.0f;
   float cj = 0.0f;
-  if (KIND == L2O_PROB_RASTRIGIN) cj = live ? pp.C[idx] : 0.0f;
+  constexpr bool kCos = KIND == L2O_PROB_RASTRIGIN || KIND == L2O_PROB_SQUARE_COS;
+  if (kCos) cj = live ? pp.C[idx] : 0.0f;
   float mv = 0.0f, vv = 0.0f;
   if (PRE == L2O_PRE_FC_ELU) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
-  const float coef = KIND == L2O_PROB_QUADRATIC ? 1.0f : 0.5f;
-  const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;
-  constexpr float kTwoPi = 6.2831853071795864769f;
+  constexpr bool kSq = KIND == L2O_PROB_QUADRATIC || KIND == L2O_PROB_SQUARE_COS;
+  const float coef = kSq ? 1.0f : 0.5f;
+  const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;   // x2 folded in (exact)
+  const float kTwoPi = pp.twopi;
   const float* wtrow = WTs + (wv * kTile + gr) * S + 4 * gq;
   const float* xsq = xs + 4 * gq;
   const float* rsq = rs + 4 * gq;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     }
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
-      if (KIND == L2O_PROB_RASTRIGIN) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
+      if (kCos) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
     }
     pc.mark(3);                                             // r pass + 13 MFMAs
     contrib = wave_sum64(contrib);
@@ -199,8 +201,9 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     });
     const float gacc = quad_sum(hsum4(gacc4));
     float gv = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(gacc)));
+    if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
-    if (KIND == L2O_PROB_RASTRIGIN) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
+    if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
 
     float in0, in1;

@@ -241,7 +241,7 @@ class UnrollGraph(object):
         loss = make_loss()                                            # _get_variables, :293
         self.terms = list(loss.terms)
         decls = list(loss.variables)
-        batched_kinds = (_abi.PROB_QUADRATIC, _abi.PROB_LASSO, _abi.PROB_RASTRIGIN)
+        batched_kinds = (_abi.PROB_QUADRATIC, _abi.PROB_LASSO, _abi.PROB_RASTRIGIN, _abi.PROB_SQUARE_COS)
         self.sharded = self.world > 1 and all(t.kind in batched_kinds for t in self.terms)
         B_global = decls[0].shape[0] if self.sharded else None
         if self.sharded:
@@ -314,6 +314,14 @@ class UnrollGraph(object):
         W = self._by_name[term.consts["W"].name].value
         y = self._by_name[term.consts["y"].name].value
         C = self._by_name[term.consts["C"].name].value if "C" in term.consts else None
+        if term.kind == _abi.PROB_SQUARE_COS:
+            # sum_i (wcos c)_i = sum_j colsum_j(wcos) c_j: the kernels take the column sums
+            # (a per-reset constant of the problem instance) in the C slot
+            wc = self._by_name[term.consts["wcos"].name].value
+            cache = self.__dict__.setdefault("_colsum", {})
+            if cache.get("src") is not wc:
+                cache["src"], cache["val"] = wc, wc.sum(dim=1).contiguous()
+            C = cache["val"]
         M = term.consts["W"].shape[1]
         return ProblemDesc(term.kind, B, Bg, D, M=M, l1=term.hyper.get("l1", 0.0),
                            alpha=term.hyper.get("alpha", 0.0), W=W, y=y, C=C, x_scale=x_scale)

@@ -202,6 +202,27 @@ def rastrigin(batch_size=128, num_dims=10, alpha=10, stddev=1, dtype="float32", 
     return _Build("rastrigin", build)
 
 
+def square_cos(batch_size=128, num_dims=10, stddev=0.01, dtype="float32", data=None):
+    """f = mean_b [ ||w x - y||^2 - sum_i (wcos (10 cos(2*3.1415926 x)))_i + 10 D ].  DM/problems.py:959-994."""
+
+    def build():
+        x = get_variable("x", shape=[batch_size, num_dims], dtype=dtype,
+                         initializer=_maybe_const(data, "x", [batch_size, num_dims],
+                                                  random_normal_initializer(stddev=stddev)))
+        w = get_variable("w", shape=[batch_size, num_dims, num_dims], dtype=dtype,
+                         initializer=_maybe_const(data, "w", [batch_size, num_dims, num_dims],
+                                                  random_uniform_initializer()), trainable=False)
+        y = get_variable("y", shape=[batch_size, num_dims], dtype=dtype,
+                         initializer=_maybe_const(data, "y", [batch_size, num_dims],
+                                                  random_uniform_initializer()), trainable=False)
+        wcos = get_variable("wcos", shape=[batch_size, num_dims, num_dims], dtype=dtype,
+                            initializer=_maybe_const(data, "wcos", [batch_size, num_dims, num_dims],
+                                                     random_uniform_initializer()), trainable=False)
+        return [Term(_abi.PROB_SQUARE_COS, x, {"W": w, "y": y, "wcos": wcos}, {}, 1.0)]
+
+    return _Build("square_cos", build)
+
+
 def ensemble(problems, weights=None):
     """Ensemble of problems: sum of (weighted) losses.  DM/problems.py:215-245."""
     if weights and len(weights) != len(problems):
@@ -301,4 +322,3 @@ LeNet = _not_on_hot_path("LeNet", "DM/problems.py:461")
 NAS = _not_on_hot_path("NAS", "DM/problems.py:540")
 vgg16_cifar10 = _not_on_hot_path("vgg16_cifar10", "DM/problems.py:637")
 confocal_microscopy_3d = _not_on_hot_path("confocal_microscopy_3d", "DM/problems.py:701-956")
-square_cos = _not_on_hot_path("square_cos", "DM/problems.py:959-994; SURVEY.md 8f rank 4")

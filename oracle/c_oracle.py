@@ -71,7 +71,7 @@ def c_unroll(kind, cfg, params, arrays, x0, T, state0=None, m0=None, v0=None, st
     if "input_projection" in keep:
         n.wfc, n.bfc = _p(keep["input_projection"]["w"]), _p(keep["input_projection"]["b"])
     p = CProb()
-    p.kind = {"quadratic": 1, "lasso": 2, "rastrigin": 3}[kind]
+    p.kind = {"quadratic": 1, "lasso": 2, "rastrigin": 3, "square_cos": 4}[kind]
     p.B, p.B_global, p.D, p.M = B, B if B_global is None else B_global, D, M
     p.l1, p.alpha = float(arrays.get("l1", 0.0)), float(arrays.get("alpha", 0.0))
     p.W, p.y, p.C, p.x_scale = _p(W), _p(y), _p(Cc), _p(xs)

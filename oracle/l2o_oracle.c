@@ -35,7 +35,7 @@ typedef struct {
 } c_net;
 
 typedef struct {
-  int32_t kind;         /* 1 quadratic, 2 lasso, 3 rastrigin */
+  int32_t kind;         /* 1 quadratic, 2 lasso, 3 rastrigin, 4 square_cos (C = column sums of wcos) */
   int32_t B, B_global, D, M;
   double l1, alpha;
   const float *W, *y, *C, *x_scale;
@@ -105,15 +105,16 @@ static float prob_fg(const c_prob* p, int b, const float* xs, float* r, float* g
     r[i] = acc - y[i];
     f += r[i] * r[i];
   }
-  if (p->kind != 1) f *= 0.5f;
-  const float twopi = 6.2831853071795864769f;
+  if (p->kind != 1 && p->kind != 4) f *= 0.5f;
+  const float twopi = p->kind == 4 ? (float)(2 * 3.1415926) : 6.2831853071795864769f;
+  const float alpha = p->kind == 4 ? 10.0f : (float)p->alpha;
   if (p->kind == 2)
     for (int j = 0; j < D; ++j) f += (float)p->l1 * fabsf(xs[j]);
-  if (p->kind == 3) {
+  if (p->kind == 3 || p->kind == 4) {
     const float* C = p->C + (size_t)b * D;
     float cq = 0.0f;
     for (int j = 0; j < D; ++j) cq += C[j] * cosf(twopi * xs[j]);
-    f += -(float)p->alpha * cq + (float)p->alpha * (float)D;
+    f += -alpha * cq + alpha * (float)D;
   }
   if (g) {
     for (int j = 0; j < D; ++j) g[j] = 0.0f;
@@ -124,9 +125,9 @@ static float prob_fg(const c_prob* p, int b, const float* xs, float* r, float* g
     }
     const float inv = 1.0f / (float)p->B_global;
     for (int j = 0; j < D; ++j) {
-      float gj = p->kind == 1 ? 2.0f * g[j] : g[j];
+      float gj = (p->kind == 1 || p->kind == 4) ? 2.0f * g[j] : g[j];
       if (p->kind == 2) gj += (float)p->l1 * (xs[j] > 0.0f ? 1.0f : (xs[j] < 0.0f ? -1.0f : 0.0f));
-      if (p->kind == 3) gj += twopi * (float)p->alpha * p->C[(size_t)b * D + j] * sinf(twopi * xs[j]);
+      if (p->kind == 3 || p->kind == 4) gj += twopi * alpha * p->C[(size_t)b * D + j] * sinf(twopi * xs[j]);
       g[j] = gj * inv;
     }
   }

@@ -44,6 +44,8 @@ def parse_flags(rnnprop):
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--batch_size", type=int, default=None)
     p.add_argument("--num_dims", type=int, default=None)
+    p.add_argument("--synthetic_mnist", type=int, default=0,
+                   help="problems.mnist on N synthetic MNIST-shaped examples (no dataset ships offline)")
     if rnnprop:
         p.add_argument("--beta1", type=float, default=0.95)
         p.add_argument("--beta2", type=float, default=0.95)
@@ -61,6 +63,9 @@ class Trainer(object):
         if flags.save_path and not os.path.exists(flags.save_path):
             os.mkdir(flags.save_path)
         opts = {k: v for k, v in (("batch_size", flags.batch_size), ("num_dims", flags.num_dims)) if v is not None}
+        if getattr(flags, "synthetic_mnist", 0):
+            from open_l2o_amd import problems
+            opts["data"] = problems.synthetic_mnist(flags.synthetic_mnist)
         problem, net_config, assignments = util.get_config(flags.problem, net_name="RNNprop" if rnnprop else None,
                                                            problem_options=opts)
         kw = dict(learning_rate=flags.learning_rate, net_assignments=assignments,

@@ -29,12 +29,17 @@ def main():
     flags.add_argument("--unroll_len", type=int, default=1)
     flags.add_argument("--batch_size", type=int, default=None)
     flags.add_argument("--num_dims", type=int, default=None)
+    flags.add_argument("--synthetic_mnist", type=int, default=0,
+                       help="problems.mnist on N synthetic MNIST-shaped examples (no dataset ships offline)")
     FLAGS = flags.parse_args()
 
     num_unrolls = FLAGS.num_steps // FLAGS.unroll_len
     if FLAGS.seed:
         meta.set_random_seed(FLAGS.seed)
     opts = {k: v for k, v in (("batch_size", FLAGS.batch_size), ("num_dims", FLAGS.num_dims)) if v is not None}
+    if FLAGS.synthetic_mnist:
+        from open_l2o_amd import problems
+        opts["data"] = problems.synthetic_mnist(FLAGS.synthetic_mnist)
     problem, net_config, net_assignments = util.get_config(FLAGS.problem, FLAGS.path, net_name="RNNprop",
                                                            problem_options=opts)
     if FLAGS.optimizer != "L2L":

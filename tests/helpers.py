@@ -53,6 +53,9 @@ def make_problem(kind, B, D, seed, M=None, stddev=None):
     elif kind == "rastrigin":
         p, x = O.Rastrigin.sample(rng, B, D, stddev=1 if stddev is None else stddev)
         arrays = dict(kind=_abi.PROB_RASTRIGIN, W=p.A, y=p.B[..., 0], C=p.C[..., 0], M=D, alpha=p.alpha)
+    elif kind == "square_cos":
+        p, x = O.SquareCos.sample(rng, B, D, stddev=0.01 if stddev is None else stddev)
+        arrays = dict(kind=_abi.PROB_SQUARE_COS, W=p.w, y=p.y, C=p.wcos.sum(axis=1), M=D, alpha=10.0)
     else:
         raise ValueError(kind)
     return p, x, arrays

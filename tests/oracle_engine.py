@@ -94,6 +94,13 @@ class OracleEngine(object):
             return O.Rastrigin(n(p.W).reshape(p.B_local, p.D, p.D), n(p.y).reshape(p.B_local, p.D, 1),
                                n(p.C).reshape(p.B_local, p.D, 1), p.alpha,
                                batch_global=p.B_global), (p.B_local, p.D, 1)
+        if p.kind == _abi.PROB_SQUARE_COS:
+            # the engine interface carries the column sums of wcos: any wcos with those column
+            # sums gives the same loss and gradient -> put them in its first row
+            wcos = np.zeros((p.B_local, p.D, p.D), np.float32)
+            wcos[:, 0, :] = n(p.C).reshape(p.B_local, p.D)
+            return O.SquareCos(n(p.W).reshape(p.B_local, p.D, p.D), n(p.y).reshape(p.B_local, p.D), wcos,
+                               batch_global=p.B_global), (p.B_local, p.D)
         raise _abi.L2OUnsupported(-2, "kind %d" % p.kind)
 
     def problem_fg(self, p, x, f_part, g):

@@ -77,6 +77,8 @@ def test_bad_arguments_return_error_codes(lib):
     p.B_local = p.B_global = 2
     p.M = 4
     p.kind = _abi.PROB_SQUARE_COS
+    assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
+    p.kind = _abi.PROB_MLP                            # neural optimizee: step-granular path only
     assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 0
     p.kind = _abi.PROB_QUADRATIC
     p.D = p.M = 128

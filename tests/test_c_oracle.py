@@ -9,7 +9,8 @@ from oracle.c_oracle import c_unroll
 
 
 @pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
-@pytest.mark.parametrize("kind,B,D,M", [("quadratic", 5, 12, None), ("lasso", 4, 20, 9), ("rastrigin", 3, 7, None)])
+@pytest.mark.parametrize("kind,B,D,M", [("quadratic", 5, 12, None), ("lasso", 4, 20, 9), ("rastrigin", 3, 7, None),
+                                        ("square_cos", 3, 9, None)])
 def test_c_oracle_matches_numpy_oracle(name, kind, B, D, M):
     cfg = ORACLE_CFGS[name]
     params = make_params(cfg, seed=60, trained_like=True)

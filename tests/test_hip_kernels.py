@@ -104,7 +104,8 @@ def test_linear_only_net(eng):
 @pytest.mark.parametrize("kind,B,D,M", [("quadratic", 4, 10, None), ("quadratic", 3, 128, None),
                                         ("quadratic", 2, 300, None), ("lasso", 4, 10, None),
                                         ("lasso", 3, 50, 25), ("lasso", 2, 512, 256),
-                                        ("rastrigin", 4, 2, None), ("rastrigin", 3, 100, None)])
+                                        ("rastrigin", 4, 2, None), ("rastrigin", 3, 100, None),
+                                        ("square_cos", 4, 2, None), ("square_cos", 3, 40, None)])
 def test_problem_fg(eng, kind, B, D, M):
     prob, x0, arrays = make_problem(kind, B, D, seed=4, M=M, stddev=0.5)
     Bg = 2 * B                                         # exercise the global-batch factor
@@ -148,7 +149,8 @@ def _run_fused(eng, cfg, params, arrays, x0, B, D, T, state=None, step0=1, Bg=No
 @pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
 @pytest.mark.parametrize("kind,B,D,M", [("quadratic", 4, 10, None), ("quadratic", 3, 32, None),
                                         ("lasso", 4, 10, None), ("lasso", 3, 50, 25),
-                                        ("rastrigin", 4, 2, None), ("rastrigin", 3, 20, None)])
+                                        ("rastrigin", 4, 2, None), ("rastrigin", 3, 20, None),
+                                        ("square_cos", 4, 2, None), ("square_cos", 3, 24, None)])
 def test_fused_unroll_vs_oracle(eng, name, kind, B, D, M):
     cfg = ORACLE_CFGS[name]
     params = make_params(cfg, seed=6, trained_like=True)

@@ -123,7 +123,7 @@ def test_default_assignment_needs_single_net(engine):
 
 # ------------------------------------------------------------- the harness path
 @pytest.mark.parametrize("name", ["dm", "dm_logsign"])
-@pytest.mark.parametrize("kind", ["quadratic", "lasso", "rastrigin"])
+@pytest.mark.parametrize("kind", ["quadratic", "lasso", "rastrigin", "square_cos"])
 def test_meta_loss_matches_oracle(engine, name, kind):
     """MetaLoss(loss, update, reset, fx, x) on the registry problems == oracle unroll."""
     cfg = ORACLE_CFGS[name]
@@ -134,6 +134,9 @@ def test_meta_loss_matches_oracle(engine, name, kind):
         problem = problems.quadratic(batch_size=B, num_dims=D, data={"w": prob.w, "y": prob.y, "x": x0})
     elif kind == "lasso":
         problem = problems.lasso(batch_size=B, num_dims=D, l=prob.l, data={"w": prob.w, "y": prob.y, "x": x0})
+    elif kind == "square_cos":
+        problem = problems.square_cos(batch_size=B, num_dims=D,
+                                      data={"w": prob.w, "y": prob.y, "wcos": prob.wcos, "x": x0})
     else:
         problem = problems.rastrigin(batch_size=B, num_dims=D,
                                      data={"A": prob.A, "B": prob.B, "C": prob.C, "x": x0})
@@ -212,7 +215,7 @@ def test_reset_resamples_problem(engine):
 
 
 def test_get_config_registry():
-    for name in ("simple", "simple-multi", "quadratic", "rastrigin", "lasso"):
+    for name in ("simple", "simple-multi", "quadratic", "rastrigin", "lasso", "square_cos"):
         problem, net_config, _ = util.get_config(name)
         assert callable(problem)
         loss = problem()
@@ -287,8 +290,8 @@ def test_train_fork_arities_and_scale_placeholder(engine):
     assert len(out) == 11
     with pytest.raises(NotImplementedError):
         meta_dm_train.MetaOptimizer(1, **_net_config(cfg, params))
-    with pytest.raises(NotImplementedError):
-        optimizer.meta_minimize(problem, T)
+    out = optimizer.meta_minimize(problem, T, learning_rate=0.01)    # numerics: tests/test_meta_gradient.py
+    assert len(out) == 11 and hasattr(out[0], "step")               # DM/meta_dm_train.py:529-558
 
 
 # ------------------------------------------------------------- meta_test.py:190-236
