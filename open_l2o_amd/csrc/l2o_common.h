@@ -215,10 +215,21 @@ struct PhaseClock {
     for (int i = 0; i < 12; ++i) acc[i] = 0;
     prev = __builtin_readcyclecounter();
   }
+  // a mark is a full fence in the profiling build: nothing is scheduled across it and all
+  // outstanding memory operations are drained, so that each phase pays for its own work
   __device__ __forceinline__ void mark(int i) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const long long n = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
     acc[i] += n - prev;
     prev = n;
+  }
+  // wait for the matrix pipe: touch every accumulator
+  template <class A>
+  __device__ __forceinline__ void drain(A& a) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) asm volatile("" : "+v"(a[t]));
   }
   __device__ __forceinline__ void dump(long long* out) {
     for (int i = 0; i < 12; ++i) out[i] = acc[i];
@@ -226,6 +237,8 @@ struct PhaseClock {
 #else
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void mark(int) {}
+  template <class A>
+  __device__ __forceinline__ void drain(A&) {}
   __device__ __forceinline__ void dump(long long*) {}
 #endif
 };
@@ -340,6 +353,7 @@ __device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc1[t] = mfma16(w.a1[5][t], bv, acc1[t]);
   }
+  pc.drain(acc1);
   pc.mark(5);
   lstm_gates5(acc1, s.c1, s.h1);
   pc.mark(6);
@@ -349,6 +363,8 @@ __device__ __forceinline__ float lstm_finish(const NetW<PRE>& w, TileState& s, f
     for (int t = 0; t < kNT; ++t) acc2[t] = mfma16(w.a2[kk][t], s.h1[kk], acc2[t]);
   if (NEXT) lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
   pc.mark(7);
+  pc.drain(acc2);
+  pc.mark(10);
   lstm_gates5(acc2, s.c2, s.h2);
   pc.mark(8);
   float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];

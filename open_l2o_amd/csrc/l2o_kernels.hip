@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "l2o_common.h"
+#include "l2o_lstm_bx3.h"
 
 using namespace l2o;
 
@@ -67,42 +68,134 @@ struct ProbParams {
 // One wave per 16-coordinate tile, grid-stride over tiles; weights live in VGPRs.
 // HBM traffic per coordinate: 320 B state read + 320 B write + g + x r/w.
 // ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// s_waitcnt vmcnt(n) for a run-time n from the small set the step kernel needs
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define L2O_VMCASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    L2O_VMCASE(0) L2O_VMCASE(5) L2O_VMCASE(7) L2O_VMCASE(9) L2O_VMCASE(10) L2O_VMCASE(12) L2O_VMCASE(14)
+    L2O_VMCASE(15) L2O_VMCASE(17) L2O_VMCASE(18) L2O_VMCASE(19) L2O_VMCASE(22) L2O_VMCASE(23) L2O_VMCASE(24)
+    L2O_VMCASE(28) L2O_VMCASE(29) L2O_VMCASE(33)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#undef L2O_VMCASE
+}
+
+constexpr int kStepRing = 4;       // LDS ring slots per wave
+constexpr int kStepAhead = 3;      // tiles in flight ahead of the one being computed
+
 template <int PRE>
-__global__ __launch_bounds__(256) void k_cwlstm_step(NetParams np, const float* __restrict__ g,
-                                                      float* __restrict__ mbuf, float* __restrict__ vbuf,
-                                                      float om1, float om2, float* __restrict__ st,
-                                                      float* __restrict__ x, int B, int D, int tpp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_cwlstm_step(
+    NetParams np, const float* __restrict__ g, float* __restrict__ mbuf, float* __restrict__ vbuf, float om1,
+    float om2, float* __restrict__ st, float* __restrict__ x, int B, int D, int tpp) {
+  // One wave per SIMD (the bf16x3 weights take 180-240 registers), so memory latency is
+  // hidden by DEPTH instead of occupancy: a wave walks its tiles with the next three tiles'
+  // inputs in flight as LDS-DMA (global_load_lds: packed state 5 x dwordx4 per lane, and
+  // g / x / m / v one dword each -- no staging registers), consumed after a counted
+  // s_waitcnt.  VMEM operations retire in issue order, so "at most N outstanding" with
+  // N = (later prefetches) x (loads per prefetch) + (later tiles' state stores) guarantees
+  // that this tile has landed; the masked x / m / v stores only make the wait stricter.
+  constexpr int NL = PRE == L2O_PRE_FC_ELU ? 9 : 7;              // VMEM loads per prefetched tile
+  constexpr int kSlotF4 = 5 * 64 + 64;                           // float4 per slot: state + {g,x,m,v} rows
+  __shared__ float4 sbuf[4][kStepRing][kSlotF4];
   const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: the waits below branch on it
   const int c = lane & 15, q = lane >> 4;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
   const int nwaves = gridDim.x * (blockDim.x >> 6);
   const int ntiles = B * tpp;
   if (wave >= ntiles) return;
-  NetW<PRE> w;
-  load_netw<PRE>(w, np.wpack, lane);
-  for (int tile = wave; tile < ntiles; tile += nwaves) {
+  const int ntl = (ntiles - wave + nwaves - 1) / nwaves;         // tiles of this wave
+  bx::NetWB<PRE> w;
+  bx::load_netw<PRE>(w, np.wpack, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // weights landed: the VMEM queue is empty
+  // dead lanes (j >= D in the last tile of a problem) read the problem's last coordinate:
+  // branch-free loads, masked where they are used
+  auto prefetch = [&](int k, int kslot) {
+    const int tile = wave + k * nwaves;
+    float4* slot = sbuf[wv][kslot % kStepRing];
+    const float* src = st + (size_t)tile * kStateFloatsPerTile + lane * 4;
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src + jj * 256), (lds_void*)(slot + jj * 64), 16, 0, 0);
+    const int b_ = tile / tpp, tw_ = tile - b_ * tpp;
+    const size_t idx_ = (size_t)b_ * D + min(tw_ * kTile + c, D - 1);
+    float* aux = reinterpret_cast<float*>(slot + 5 * 64);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g + idx_), (lds_void*)(aux), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(x + idx_), (lds_void*)(aux + 64), 4, 0, 0);
+    if (PRE == L2O_PRE_FC_ELU) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)(mbuf + idx_), (lds_void*)(aux + 128), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(vbuf + idx_), (lds_void*)(aux + 192), 4, 0, 0);
+    }
+  };
+  // unconditional prologue (a wave with fewer than three tiles re-fetches its last one): a
+  // static VMEM count keeps hipcc from draining the queue at the loop entry
+#pragma unroll
+  for (int k = 0; k < kStepAhead; ++k) prefetch(min(k, ntl - 1), k);
+  for (int k = 0; k < ntl; ++k) {
+    const int tile = wave + k * nwaves;
     const int b = tile / tpp, tw = tile - b * tpp;
     const int j = tw * kTile + c;
     const bool live = j < D;
     const size_t idx = (size_t)b * D + j;
+#ifndef L2O_ABLATE_STEP_LOAD
+    wait_vmcnt_le(NL * min(kStepAhead - 1, ntl - 1 - k) + 5 * min(k, kStepAhead));
+#endif
+    // the slot is read with inline-asm ds_reads: hipcc cannot tell the ring slots apart and
+    // would drain the whole VMEM queue (vmcnt(0)) before an ordinary LDS read of sbuf
+    const unsigned slot_addr =
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&sbuf[wv][k % kStepRing][0]) + lane * 16;
+    const unsigned aux_addr = slot_addr - lane * 12 + 5 * 1024;
     TileState s;
-    float* st_tile = st + (size_t)tile * kStateFloatsPerTile;
-    load_tile_state(s, st_tile, lane);
-    float gv = live ? g[idx] : 0.0f;
+    float gv, xv, m = 0.f, v = 0.f;
+    {
+      float4 v0, v1, v2, v3, v4;
+      if (PRE == L2O_PRE_FC_ELU)
+        asm volatile(
+            "ds_read_b128 %0, %9\n\tds_read_b128 %1, %9 offset:1024\n\tds_read_b128 %2, %9 offset:2048\n\t"
+            "ds_read_b128 %3, %9 offset:3072\n\tds_read_b128 %4, %9 offset:4096\n\t"
+            "ds_read_b32 %5, %10\n\tds_read_b32 %6, %10 offset:256\n\tds_read_b32 %7, %10 offset:512\n\t"
+            "ds_read_b32 %8, %10 offset:768\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(gv), "=&v"(xv), "=&v"(m), "=&v"(v)
+            : "v"(slot_addr), "v"(aux_addr)
+            : "memory");
+      else
+        asm volatile(
+            "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:1024\n\tds_read_b128 %2, %7 offset:2048\n\t"
+            "ds_read_b128 %3, %7 offset:3072\n\tds_read_b128 %4, %7 offset:4096\n\t"
+            "ds_read_b32 %5, %8\n\tds_read_b32 %6, %8 offset:256\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(gv), "=&v"(xv)
+            : "v"(slot_addr), "v"(aux_addr)
+            : "memory");
+      // slot k is in registers now; slot (k+3)%4 = (k-1)%4 is free for the next prefetch
+      const float e[20] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y,
+                           v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) { s.h1[t] = e[t]; s.c1[t] = e[5 + t]; s.h2[t] = e[10 + t]; s.c2[t] = e[15 + t]; }
+    }
+    if (!live) { gv = 0.0f; m = 0.0f; v = 0.0f; }
+#ifndef L2O_ABLATE_STEP_LOAD
+    if (k + kStepAhead < ntl) prefetch(k + kStepAhead, k + kStepAhead);
+#endif
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
-      float m = live ? mbuf[idx] : 0.0f, v = live ? vbuf[idx] : 0.0f;
       rnnprop_inputs(gv, m, v, np.beta1, np.beta2, np.omb1, np.omb2, om1, om2, in0, in1);
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       if (live && q == 0) { mbuf[idx] = m; vbuf[idx] = v; }
     } else {
       preprocess_grad<PRE>(gv, np.k_inv_ln2, np.exp_k, in0, in1);
     }
-    float d = lstm_tile_step<PRE>(w, s, in0, in1, q);
+    float d = bx::tile_step<PRE>(w, s, in0, in1, q);
     if (np.tanh_output) d = tanhf_(d);
     d *= np.scale;
-    if (live && q == 0) x[idx] += d;
-    store_tile_state(s, st_tile, lane);
+    if (live && q == 0) x[idx] = xv + d;
+#ifndef L2O_ABLATE_STEP_STORE
+    store_tile_state(s, st + (size_t)tile * kStateFloatsPerTile, lane);
+#else
+    if (d == 1234.5f) store_tile_state(s, st + (size_t)tile * kStateFloatsPerTile, lane);
+#endif
   }
 }
 
@@ -361,7 +454,10 @@ __device__ __forceinline__ void dot4(const float4 a, const float4 b, float4& acc
 __device__ __forceinline__ float hsum4(const float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
 template <int PRE, int KIND, int CH>
-__global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
+__global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
+  // CH <= 4 <=> at most 4 waves per workgroup = one wave per SIMD: the bf16x3 gate GEMM with
+  // its weights in VGPR + AGPR; CH == 8 (5..8 waves) keeps the fp32 MFMA form
+  using Core = LstmCore<PRE, (CH <= 4)>;
   constexpr int SQ = 16 * CH;      // padded square size of the LDS-resident matrix
   constexpr int S = SQ + 16;       // row stride (floats)
   extern __shared__ float sm[];
@@ -392,8 +488,8 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
   for (int i = tid; i < M; i += blockDim.x) ys[i] = pp.y[(size_t)b * M + i];
 
   // ---- per-lane persistent registers -------------------------------------
-  NetW<PRE> w;
-  load_netw<PRE>(w, a.np.wpack, lane);
+  Core core;
+  core.load(a.np.wpack, lane);
   const int j = wv * kTile + c;             // this lane's coordinate (LSTM role)
   const bool live = j < D;
   const size_t idx = (size_t)b * D + j;
@@ -423,7 +519,8 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
   // part of layer 1; it is produced at the END of the previous step (overlapping that step's
   // layer-2 gate math), here for step 0.
   f32x4 acc1[kNT], acc2[kNT];
-  lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
+  core.init(s, q);
+  core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
 
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
@@ -435,7 +532,7 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
       constexpr int m = decltype(mc)::value;
       const float4 wv4 = *reinterpret_cast<const float4*>(wrow + 16 * m);
       const float4 xv4 = *reinterpret_cast<const float4*>(xsq + 16 * m);
-      lstm_issue_l2_prev<PRE, (12 * m) / CH, (12 * (m + 1)) / CH>(w, s, acc2);
+      core.template issue_l2_prev<(Core::kHalf * m) / CH, (Core::kHalf * (m + 1)) / CH>(s, acc2);
       dot4(wv4, xv4, racc);
     });
     const float r = quad_sum(hsum4(racc)) - ys[grow];
@@ -464,7 +561,8 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
       constexpr int m = decltype(mc)::value;
       const float4 wt4 = *reinterpret_cast<const float4*>(wtrow + 16 * m);
       const float4 rv4 = *reinterpret_cast<const float4*>(rsq + 16 * m);
-      lstm_issue_l2_prev<PRE, 12 + (13 * m) / CH, 12 + (13 * (m + 1)) / CH>(w, s, acc2);
+      core.template issue_l2_prev<Core::kHalf + ((Core::kTotal - Core::kHalf) * m) / CH,
+                                  Core::kHalf + ((Core::kTotal - Core::kHalf) * (m + 1)) / CH>(s, acc2);
       dot4(wt4, rv4, gacc4);
     });
     const float gacc = quad_sum(hsum4(gacc4));                 // lanes 4k..4k+3 hold g of coordinate 16*wv + k
@@ -492,7 +590,7 @@ __global__ __launch_bounds__(512) void k_unroll(UnrollArgs a) {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
     PhaseClock pc;
-    float d = lstm_finish<PRE, true>(w, s, acc1, acc2, in0, in1, q, pc);
+    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
   }
@@ -725,7 +823,27 @@ size_t l2o_wpack_floats(const l2o_net_cfg* cfg) {
   if (!cfg) return 0;
   if (cfg->n_layers == 0) return 4;
   if (!net_ok_for_mfma(cfg)) return 0;
-  return (size_t)wp_rows(cfg->preprocess) * 64;
+  return (size_t)wp_rows(cfg->preprocess) * 64 + (size_t)bx::words(cfg->preprocess);
+}
+
+// ---- bf16x3 section of wpack (l2o_lstm_bx3.h) --------------------------------
+static inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline double bf16_value(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return (double)f;
+}
+static inline void bf16_split3(double v, uint16_t (&out)[3]) {
+  for (int s = 0; s < 3; ++s) {
+    out[s] = bf16_rne((float)v);
+    v -= bf16_value(out[s]);
+  }
 }
 
 int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, const float* wg2,
@@ -791,6 +909,47 @@ int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, c
       }
     }
     out[wp_row_bl(pre) * 64 + l] = bl[0];
+  }
+  // ---- bf16x3 fragments: gate rows pre-scaled to exp2 arguments, split from float64 ----
+  {
+    uint32_t* ow = reinterpret_cast<uint32_t*>(out);
+    std::memset(ow + bx::base(pre), 0, sizeof(uint32_t) * bx::words(pre));
+    constexpr double kL2E = 1.4426950408889634074;
+    auto gscale = [&](int r) { return r == 1 ? 2.0 * kL2E : -kL2E; };      // rows i, j, f, o
+    for (int l = 0; l < 64; ++l) {
+      const int rho = l & 15, kq = l >> 4;
+      const int q = l >> 4;
+      for (int t = 0; t < kNT; ++t) {
+        const int cA = col(t, rho), r = rho & 3;
+        for (int ch = 0; ch < bx::nchunks(pre); ++ch) {
+          uint16_t sl[8][3];
+          std::memset(sl, 0, sizeof(sl));
+          for (int i = 0; i < 5; ++i) {
+            const int u = 4 * i + kq;
+            double v;
+            if (ch == bx::kChL1H) v = wg1[(P + u) * G + cA];
+            else if (ch == bx::kChL2A) v = wg2[u * G + cA];
+            else if (ch == bx::kChL2B) v = wg2[(kH + u) * G + cA];
+            else v = wg1[u * G + cA];                              // kChL1X: the fc features
+            bf16_split3(v * gscale(r), sl[i]);
+          }
+          if (kq == 0 && (ch == bx::kChL1H || ch == bx::kChL2A)) {
+            const double bv = (double)(ch == bx::kChL1H ? bg1[cA] : bg2[cA]) + (r == 2 ? 1.0 : 0.0);   // forget_bias
+            bf16_split3(bv * gscale(r), sl[7]);
+          }
+          for (int sp = 0; sp < 3; ++sp)
+            for (int j = 0; j < 4; ++j)
+              ow[bx::frag_off(pre, ch, t, sp) + l * 4 + j] = (uint32_t)sl[2 * j][sp] | ((uint32_t)sl[2 * j + 1][sp] << 16);
+        }
+        if (!fc)
+          for (int rr = 0; rr < 4; ++rr) {
+            const int cD = col(t, 4 * q + rr);
+            out[bx::win_off(pre) + t * 256 + l * 4 + rr] = (float)((double)wg1[0 * G + cD] * gscale(rr));
+            out[bx::win_off(pre) + (kNT + t) * 256 + l * 4 + rr] =
+                P == 2 ? (float)((double)wg1[1 * G + cD] * gscale(rr)) : 0.0f;
+          }
+      }
+    }
   }
   return L2O_OK;
 }
@@ -898,7 +1057,7 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, 
   const int tpp = tiles_per_problem(D);
   const int64_t ntiles = B * tpp;
   int blocks = (int)((ntiles + 3) / 4);
-  if (blocks > 256 * 2) blocks = 256 * 2;    // 2 x 4-wave blocks per CU, grid-stride beyond
+  if (blocks > 256) blocks = 256;            // one 4-wave block per CU (one wave per SIMD), grid-stride beyond
   const dim3 grid(blocks), block(256);
   const float om1 = (float)(1.0 - pow1), om2 = (float)(1.0 - pow2);
   switch (cfg->preprocess) {

@@ -1,0 +1,342 @@
+// l2o_lstm_bx3.h -- the LSTM gate GEMM on the bf16 matrix cores, at fp32 accuracy.
+//
+// Why: on gfx950 the fp32-input MFMA (v_mfma_f32_16x16x4_f32) executes at the fp32 VECTOR
+// rate and does not overlap with VALU work of the same SIMD (profiles/r01_b_microbench_*:
+// 32 cycles each, 80 per tile-step = 35 % of the fused kernel), while bf16 MFMAs run on the
+// matrix pipe concurrently with the VALU.  Every fp32 value is therefore split into three
+// bf16 terms  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
+// 24 mantissa bits), the weights likewise on the host (from float64), and
+//      x.w  =  x1w1 + x1w2 + x1w3 + x2w1 + x2w2 + x3w1      (dropped terms < 2^-24)
+// is accumulated by six v_mfma_f32_16x16x32_bf16 per (16 gate rows x 16 coordinates x K=32)
+// block: bf16 x bf16 products are exact in fp32 and the accumulator is fp32, so the result
+// carries an fp32-level error (measured rms 1.7e-8 vs 7.7e-8 of a sequential fp32 fmaf chain).
+//
+// Layout.  Same tile decomposition as l2o_common.h: lane (c, q) owns the units u = 4t + q of
+// coordinate c; the D operand row rho = 4q + r of M-tile t is gate r of unit 4t + q.  K = 32
+// per chunk: lane group q supplies the slots k = 8q + i,
+//      i = 0..4 : unit 4i + q of the chunk's input vector,   i = 5, 6 : zero,
+//      i = 7    : the constant 1.0 on q == 0 (bias row of the chunk), zero elsewhere
+// so the B operand of a chunk is 4 VGPRs {slot 2j | slot 2j+1 << 16} per split level, built
+// from the five values the lane already owns -- no cross-lane traffic, like the fp32 form.
+// Chunks: L1H = h1(t-1) -> layer 1 (+ b_gates1), L2A = h1(t) -> layer 2 (+ b_gates2),
+//         L2B = h2(t-1) -> layer 2, L1X = the 20 ELU features of RNNProp -> layer 1.
+// The 1-2 gradient features of the DM nets are applied with 20-40 VALU FMAs instead (they
+// arrive last; a chunk of their own would put 30 MFMAs on the critical path).
+//
+// The gate weights are pre-scaled on the host so that the accumulators ARE the exp2
+// arguments: rows i, f, o by -log2(e) (f including forget_bias = 1), rows j by +2 log2(e);
+// the nonlinearity block works on unit pairs with v_pk_{add,mul,fma}_f32 (9 instead of 19
+// VALU instructions per unit; scripts/microbench/gates_variants.hip: 317 -> 215 ns).
+#pragma once
+#include "l2o_common.h"
+
+namespace l2o {
+namespace bx {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kChL1H = 0, kChL2A = 1, kChL2B = 2, kChL1X = 3;
+constexpr int kFragWords = 256;     // 64 lanes x 4 dwords
+constexpr int kProducts = 6;        // (x level, w level) pairs below
+constexpr int kChunkMfmas = kProducts * kNT;   // 30
+
+__host__ __device__ constexpr int nchunks(int pre) { return pre == L2O_PRE_FC_ELU ? 4 : 3; }
+// word offsets inside wpack (the bf16 section follows the fp32 rows of l2o_common.h)
+__host__ __device__ constexpr int base(int pre) { return wp_rows(pre) * 64; }
+__host__ __device__ constexpr int frag_off(int pre, int ch, int t, int s) {
+  return base(pre) + ((ch * kNT + t) * 3 + s) * kFragWords;
+}
+__host__ __device__ constexpr int win_off(int pre) { return base(pre) + nchunks(pre) * kNT * 3 * kFragWords; }
+// DM nets: 2 inputs x 5 tiles rows of 64 lanes x 4 floats (the lane's four gate rows)
+__host__ __device__ constexpr int words(int pre) {
+  return nchunks(pre) * kNT * 3 * kFragWords + (pre == L2O_PRE_FC_ELU ? 0 : 2 * kNT * 256);
+}
+__host__ __device__ constexpr int prod_x(int p) { return p < 3 ? 0 : (p < 5 ? 1 : 2); }
+__host__ __device__ constexpr int prod_w(int p) { return p < 3 ? p : (p < 5 ? p - 3 : 0); }
+
+// a 5-value activation vector split into the B operands of its chunk
+struct BOp {
+  u32x4 l[3];
+};
+
+__device__ __forceinline__ unsigned cvt_pk(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ f32x2 widen(unsigned p) {
+  f32x2 r;
+  r.x = __uint_as_float(p << 16);
+  r.y = __uint_as_float(p & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ f32x2 mk2(float a, float b) {
+  f32x2 r;
+  r.x = a; r.y = b;
+  return r;
+}
+
+// one = 0x3f800000 on the q == 0 lanes (slot 7 = 1.0: the bias row), 0 elsewhere
+__device__ __forceinline__ void split5(const float (&v)[kNT], unsigned one, BOp& o) {
+#ifdef L2O_ABLATE_SPLIT
+  o.l[0][0] = __float_as_uint(v[0]); o.l[0][1] = __float_as_uint(v[1]); o.l[0][2] = __float_as_uint(v[2]); o.l[0][3] = one;
+  o.l[1][0] = __float_as_uint(v[3]); o.l[1][1] = __float_as_uint(v[4]); o.l[1][2] = 0u; o.l[1][3] = 0u;
+  o.l[2] = o.l[1];
+  return;
+#endif
+  f32x2 a = mk2(v[0], v[1]), b = mk2(v[2], v[3]), c = mk2(v[4], 0.0f);
+  unsigned pa = cvt_pk(a), pb = cvt_pk(b), pc = cvt_pk(c);
+  o.l[0][0] = pa; o.l[0][1] = pb; o.l[0][2] = pc; o.l[0][3] = one;
+  a -= widen(pa); b -= widen(pb); c -= widen(pc);
+  pa = cvt_pk(a); pb = cvt_pk(b); pc = cvt_pk(c);
+  o.l[1][0] = pa; o.l[1][1] = pb; o.l[1][2] = pc; o.l[1][3] = 0u;
+  a -= widen(pa); b -= widen(pb); c -= widen(pc);
+  o.l[2][0] = cvt_pk(a); o.l[2][1] = cvt_pk(b); o.l[2][2] = cvt_pk(c); o.l[2][3] = 0u;
+}
+
+template <int PRE>
+struct NetWB {
+  static constexpr int NCH = nchunks(PRE);
+  u32x4 a[NCH][kNT][3];            // weight fragments (A operands), 3 split levels
+  f32x4 win0[kNT], win1[kNT];      // DM: pre-scaled weights of input 0 / 1 for this lane's 4 gate rows
+  float wl[kNT];                   // output Linear
+  float bl;
+  float fcw0[kNT], fcw1[kNT], fcb[kNT];   // RNNProp input projection (2 -> 20)
+};
+
+template <int PRE>
+__device__ __forceinline__ void load_netw(NetWB<PRE>& w, const float* __restrict__ wp, int lane) {
+  const unsigned* wu = reinterpret_cast<const unsigned*>(wp);
+#pragma unroll
+  for (int ch = 0; ch < NetWB<PRE>::NCH; ++ch)
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        w.a[ch][t][s] = *reinterpret_cast<const u32x4*>(wu + frag_off(PRE, ch, t, s) + lane * 4);
+  const float* p = wp + lane;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    if (PRE != L2O_PRE_FC_ELU) {
+      w.win0[t] = *reinterpret_cast<const f32x4*>(wp + win_off(PRE) + t * 256 + lane * 4);
+      if (PRE == L2O_PRE_LOGSIGN)
+        w.win1[t] = *reinterpret_cast<const f32x4*>(wp + win_off(PRE) + (kNT + t) * 256 + lane * 4);
+    }
+    w.wl[t] = p[(wp_row_wl(PRE) + t) * 64];
+    if (PRE == L2O_PRE_FC_ELU) {
+      w.fcw0[t] = p[(wp_row_fc(PRE) + t) * 64];
+      w.fcw1[t] = p[(wp_row_fc(PRE) + kNT + t) * 64];
+      w.fcb[t] = p[(wp_row_fc(PRE) + 2 * kNT + t) * 64];
+    }
+  }
+  w.bl = p[wp_row_bl(PRE) * 64];
+}
+
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef L2O_ABLATE_MFMA
+  c[0] = __builtin_fmaf(__uint_as_float(a[0]), __uint_as_float(b[0]), c[0]);
+  return c;
+#endif
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                  0, 0);
+}
+
+// MFMAs [LO, HI) of chunk CH (index n: product n / 5, M-tile n % 5 -- consecutive MFMAs hit
+// different accumulators).  ZERO: the first product starts the accumulator (C = inline 0).
+template <int PRE, int CH, int LO, int HI, bool ZERO>
+__device__ __forceinline__ void issue(const NetWB<PRE>& w, const BOp& b, f32x4 (&acc)[kNT]) {
+  static_for<LO, HI>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    constexpr int p = n / kNT, t = n % kNT;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.l[prod_x(p)], (ZERO && p == 0) ? zero : acc[t]);
+  });
+}
+
+// acc = [-log2e*i, 2log2e*j, -log2e*(f+1), -log2e*o] of the unit pair (T0, T0+1)
+template <int T0>
+__device__ __forceinline__ void gates_pair(const f32x4 (&acc)[kNT], float (&c)[kNT], float (&h)[kNT]) {
+  constexpr int T1 = T0 + 1;
+  constexpr float k2 = 2.0f * 1.4426950408889634f;
+  const f32x2 one = mk2(1.0f, 1.0f);
+  const f32x2 e_i = mk2(fast_exp2(acc[T0][0]), fast_exp2(acc[T1][0]));
+  const f32x2 E_j = mk2(fast_exp2(-__builtin_fabsf(acc[T0][1])), fast_exp2(-__builtin_fabsf(acc[T1][1])));
+  const f32x2 e_f = mk2(fast_exp2(acc[T0][2]), fast_exp2(acc[T1][2]));
+  const f32x2 e_o = mk2(fast_exp2(acc[T0][3]), fast_exp2(acc[T1][3]));
+  const f32x2 dij = (one + e_i) * (one + E_j);
+  const f32x2 df = one + e_f;
+  const f32x2 ij = mk2(fast_rcp(dij.x), fast_rcp(dij.y));
+  const f32x2 rf = mk2(fast_rcp(df.x), fast_rcp(df.y));
+  f32x2 tj = (one - E_j) * ij;                                   // sigmoid(i) * tanh|j|
+  tj = mk2(__builtin_copysignf(tj.x, acc[T0][1]), __builtin_copysignf(tj.y, acc[T1][1]));
+  const f32x2 cn = __builtin_elementwise_fma(rf, mk2(c[T0], c[T1]), tj);
+  const f32x2 ca = cn * mk2(k2, k2);
+  const f32x2 E_c = mk2(fast_exp2(-__builtin_fabsf(ca.x)), fast_exp2(-__builtin_fabsf(ca.y)));
+  const f32x2 dro = (one + E_c) * (one + e_o);
+  const f32x2 ro = mk2(fast_rcp(dro.x), fast_rcp(dro.y));
+  const f32x2 hh = (one - E_c) * ro;                             // tanh|c'| * sigmoid(o)
+  c[T0] = cn.x; c[T1] = cn.y;
+  h[T0] = __builtin_copysignf(hh.x, cn.x);
+  h[T1] = __builtin_copysignf(hh.y, cn.y);
+}
+
+// Sonnet LSTM nonlinearities (gates i, j, f, o; forget_bias folded into the weights) for the
+// lane's five units; same algebra as l2o::lstm_gates5 (5 v_exp + 3 v_rcp per unit).
+__device__ __forceinline__ void gates5(const f32x4 (&acc)[kNT], float (&c)[kNT], float (&h)[kNT]) {
+#ifdef L2O_ABLATE_TRANS
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    c[t] = (acc[t][2] * 0.25f + 0.75f) * c[t] + (acc[t][0] * 0.25f + 0.5f) * (acc[t][1] * 0.5f);
+    h[t] = (c[t] * 0.5f) * (acc[t][3] * 0.25f + 0.5f);
+  }
+  return;
+#endif
+#ifdef L2O_ABLATE_GATES
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) { c[t] = acc[t][2] + acc[t][0]; h[t] = acc[t][1] + acc[t][3]; }
+  return;
+#endif
+  gates_pair<0>(acc, c, h);
+  gates_pair<2>(acc, c, h);
+  constexpr float k2 = 2.0f * 1.4426950408889634f;
+  const float e_i = fast_exp2(acc[4][0]), E_j = fast_exp2(-__builtin_fabsf(acc[4][1]));
+  const float e_f = fast_exp2(acc[4][2]), e_o = fast_exp2(acc[4][3]);
+  const float ij = fast_rcp((1.0f + e_i) * (1.0f + E_j)), rf = fast_rcp(1.0f + e_f);
+  const float cn = __builtin_fmaf(rf, c[4], __builtin_copysignf((1.0f - E_j) * ij, acc[4][1]));
+  const float E_c = fast_exp2(-__builtin_fabsf(cn * k2));
+  const float ro = fast_rcp((1.0f + E_c) * (1.0f + e_o));
+  c[4] = cn;
+  h[4] = __builtin_copysignf((1.0f - E_c) * ro, cn);
+}
+
+// Everything that needs this step's gradient (see l2o::lstm_finish for the contract):
+// acc1 must hold chunk L1H (h1(t-1), bias), acc2 chunk L2B (h2(t-1)).  On return s holds the
+// new state, b1 / b2 the split h1(t) / h2(t) (the next step's L1H / L2B operands) and, with
+// NEXT, acc1 the next step's chunk L1H.  Returns the Linear output (before tanh / scale).
+template <int PRE, bool NEXT>
+__device__ __forceinline__ float finish(const NetWB<PRE>& w, TileState& s, BOp& b1, BOp& b2, f32x4 (&acc1)[kNT],
+                                        f32x4 (&acc2)[kNT], float in0, float in1, unsigned one, int q,
+                                        PhaseClock& pc) {
+  if (PRE == L2O_PRE_FC_ELU) {
+    float fc[kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+      fc[t] = eluf_(__builtin_fmaf(w.fcw1[t], in1, __builtin_fmaf(w.fcw0[t], in0, w.fcb[t])));
+    BOp bf;
+    split5(fc, 0u, bf);
+    issue<PRE, kChL1X, 0, kChunkMfmas, false>(w, bf, acc1);
+  } else {
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      acc1[t] += w.win0[t] * in0;
+      if (PRE == L2O_PRE_LOGSIGN) acc1[t] += w.win1[t] * in1;
+    }
+  }
+  pc.drain(acc1);
+  pc.mark(5);
+  gates5(acc1, s.c1, s.h1);
+  pc.mark(6);
+  split5(s.h1, one, b1);
+  issue<PRE, kChL2A, 0, kChunkMfmas, false>(w, b1, acc2);
+  pc.mark(7);
+  pc.drain(acc2);
+  pc.mark(10);
+  // the next step's chunk L1H rides on the matrix pipe underneath the layer-2 nonlinearities:
+  // a single wave issues in order, so the MFMAs must be interleaved with the VALU stream in
+  // program order (30 back-to-back MFMAs stall the wave for 30 x 17 cycles)
+  __builtin_amdgcn_sched_barrier(0);
+  if (NEXT) issue<PRE, kChL1H, 0, kChunkMfmas, true>(w, b1, acc1);
+  gates5(acc2, s.c2, s.h2);
+  if (NEXT) {
+#pragma unroll
+    for (int i = 0; i < kChunkMfmas; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // three VALU / transcendental
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  pc.mark(8);
+  if (NEXT) split5(s.h2, one, b2);
+  float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];
+  d0 = __builtin_fmaf(s.h2[2], w.wl[2], d0);
+  d1 = __builtin_fmaf(s.h2[3], w.wl[3], d1);
+  d0 = __builtin_fmaf(s.h2[4], w.wl[4], d0);
+  const float d = quad_q_sum(d0 + d1);
+  return d + w.bl;
+}
+
+// One optimizer-network evaluation for a 16-coordinate tile (step-granular kernel).
+template <int PRE>
+__device__ __forceinline__ float tile_step(const NetWB<PRE>& w, TileState& s, float in0, float in1, int q) {
+  const unsigned one = q == 0 ? 0x3f800000u : 0u;
+  BOp b1, b2;
+  f32x4 acc1[kNT], acc2[kNT];
+  split5(s.h2, one, b2);
+  issue<PRE, kChL2B, 0, kChunkMfmas, true>(w, b2, acc2);
+  split5(s.h1, one, b1);
+  issue<PRE, kChL1H, 0, kChunkMfmas, true>(w, b1, acc1);
+  PhaseClock pc;
+  return finish<PRE, false>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
+}
+
+}  // namespace bx
+
+// ---- one interface over the two gate-GEMM forms, for the fused unroll kernels -----------
+// BX = true : bf16x3 on the matrix pipe; ~200-260 weight registers -> kernels that run one
+//             wave per SIMD (<= 4 waves per workgroup: 512 VGPR + AGPR per lane)
+// BX = false: the fp32 MFMA form of l2o_common.h (<= 256 registers, two waves per SIMD)
+// kTotal = MFMAs of one recurrent chunk (h(t-1) part of a layer), kHalf = where the fused
+// kernels split them between their two GEMV passes.
+template <int PRE, bool BX>
+struct LstmCore;
+
+template <int PRE>
+struct LstmCore<PRE, false> {
+  static constexpr int kTotal = 25, kHalf = 12;
+  NetW<PRE> w;
+  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { load_netw<PRE>(w, wpack, lane); }
+  __device__ __forceinline__ void init(const TileState&, int) {}
+  template <int LO, int HI>
+  __device__ __forceinline__ void issue_l1_prev(const TileState& s, f32x4 (&acc1)[kNT]) {
+    lstm_issue_l1_prev<PRE, LO, HI>(w, s, acc1);
+  }
+  template <int LO, int HI>
+  __device__ __forceinline__ void issue_l2_prev(const TileState& s, f32x4 (&acc2)[kNT]) {
+    lstm_issue_l2_prev<PRE, LO, HI>(w, s, acc2);
+  }
+  template <bool NEXT>
+  __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
+                                          int q, PhaseClock& pc) {
+    return lstm_finish<PRE, NEXT>(w, s, acc1, acc2, in0, in1, q, pc);
+  }
+};
+
+template <int PRE>
+struct LstmCore<PRE, true> {
+  static constexpr int kTotal = bx::kChunkMfmas, kHalf = bx::kChunkMfmas / 2;
+  bx::NetWB<PRE> w;
+  bx::BOp b1, b2;          // split h1(t-1), h2(t-1): the recurrent chunks' B operands
+  unsigned one;
+  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE>(w, wpack, lane); }
+  __device__ __forceinline__ void init(const TileState& s, int q) {
+    one = q == 0 ? 0x3f800000u : 0u;
+    bx::split5(s.h1, one, b1);
+    bx::split5(s.h2, one, b2);
+  }
+  template <int LO, int HI>
+  __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {
+    bx::issue<PRE, bx::kChL1H, LO, HI, true>(w, b1, acc1);
+  }
+  template <int LO, int HI>
+  __device__ __forceinline__ void issue_l2_prev(const TileState&, f32x4 (&acc2)[kNT]) {
+    bx::issue<PRE, bx::kChL2B, LO, HI, true>(w, b2, acc2);
+  }
+  template <bool NEXT>
+  __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
+                                          int q, PhaseClock& pc) {
+    return bx::finish<PRE, NEXT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
+  }
+};
+
+}  // namespace l2o

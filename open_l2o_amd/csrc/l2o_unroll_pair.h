@@ -80,8 +80,13 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   for (int i = tid; i < M; i += blockDim.x) ys[i] = pp.y[(size_t)b * M + i];
 
   // ---- per-lane persistent registers -------------------------------------
-  NetW<PRE> w;
-  load_netw<PRE>(w, a.np.wpack, lane);
+#ifdef L2O_PAIR_FP32
+  using Core = LstmCore<PRE, false>;
+#else
+  using Core = LstmCore<PRE, true>;      // <= 4 waves per workgroup: bf16x3 gate GEMM, weights in VGPR + AGPR
+#endif
+  Core core;
+  core.load(a.np.wpack, lane);
   const int j = tile_in_prob * kTile + c;
   const bool live = j < D;
   const size_t idx = (size_t)b * D + j;
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   bool dead = false;                                             // partner timed out
 
   f32x4 acc1[kNT], acc2[kNT];
-  lstm_issue_l1_prev<PRE, 0, 25>(w, s, acc1);
+  core.init(s, q);
+  core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
   PhaseClock pc;
   pc.start();
 
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     pc.mark(0);                                                   // publish
-    lstm_issue_l2_prev<PRE, 0, 12>(w, s, acc2);                   // matrix work that covers the latency
+    core.template issue_l2_prev<0, Core::kHalf>(s, acc2);                   // matrix work that covers the latency
     if (q == 0) {
       const unsigned long long* src = theirs + par * npg + wv * kTile + c;
       unsigned long long g = 0;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
         const float4 xv4 = *reinterpret_cast<const float4*>(xsq + 16 * m);
         dot4(wv4, xv4, racc);
       });
-      if (p == 0) lstm_issue_l2_prev<PRE, 12, 25>(w, s, acc2);
+      if (p == 0) core.template issue_l2_prev<Core::kHalf, Core::kTotal>(s, acc2);
       const float r = quad_sum(hsum4(racc)) - ys[row];
       if (gq == 0) {
         rs[row] = r;                      // rows >= M: W row and y are zero -> r == 0
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-    float d = lstm_finish<PRE, true>(w, s, acc1, acc2, in0, in1, q, pc);   // marks 5 (g pass .. input MFMAs), 6, 7, 8
+    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);   // marks 5 (g pass .. input MFMAs), 6, 7, 8
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
     pc.mark(9);

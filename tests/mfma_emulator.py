@@ -132,3 +132,134 @@ def pack_state_numpy(h1, c1, h2, c2, B, D):
                     a, t = e // 5, e % 5
                     st[b * tpp + tw, e // 4, l, e % 4] = refs[a][b * D + j, 4 * t + q]
     return st.reshape(-1)
+
+
+# ---------------------------------------------------------------------------
+# bf16x3 form (open_l2o_amd/csrc/l2o_lstm_bx3.h): v_mfma_f32_16x16x32_bf16 with
+# A: lane l holds A[m = l&15][k = 8*(l>>4) + i], B: lane l holds B[k = 8*(l>>4) + i][n = l&15],
+# i = 0..7 packed two bf16 per dword (slot 2j in the low half of dword j).
+# ---------------------------------------------------------------------------
+CH_L1H, CH_L2A, CH_L2B, CH_L1X = 0, 1, 2, 3
+L2E = 1.4426950408889634
+
+
+def bx_nchunks(pre):
+    return 4 if pre == 2 else 3
+
+
+def bx_words(pre):
+    return bx_nchunks(pre) * KNT * 3 * 256 + (0 if pre == 2 else 2 * KNT * 256)
+
+
+def bf16_rne(x):
+    """float32 array -> nearest-even bf16, returned as float32 values."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def split3(x):
+    x = np.asarray(x, np.float32)
+    x1 = bf16_rne(x)
+    r = (x - x1).astype(np.float32)
+    x2 = bf16_rne(r)
+    r2 = (r - x2).astype(np.float32)
+    return x1, x2, bf16_rne(r2)
+
+
+def _unpack_frag(words):
+    """[64, 4] uint32 -> [64, 8] float values of the bf16 slots."""
+    out = np.zeros((64, 8), np.float64)
+    for j in range(4):
+        lo = ((words[:, j] & 0xFFFF).astype(np.uint32) << 16).view(np.float32)
+        hi = (words[:, j] & 0xFFFF0000).astype(np.uint32).view(np.float32)
+        out[:, 2 * j], out[:, 2 * j + 1] = lo, hi
+    return out
+
+
+def mfma_bf16(a_slots, b_slots, c):
+    """a_slots, b_slots: [64, 8] per-lane operand values; c: [64, 4]."""
+    lanes = np.arange(64)
+    A = np.zeros((16, 32))
+    Bm = np.zeros((32, 16))
+    for i in range(8):
+        A[lanes & 15, 8 * (lanes >> 4) + i] = a_slots[:, i]
+        Bm[8 * (lanes >> 4) + i, lanes & 15] = b_slots[:, i]
+    Dm = A @ Bm
+    out = c.astype(np.float64).copy()
+    for r in range(4):
+        out[:, r] += Dm[4 * (lanes >> 4) + r, lanes & 15]
+    return out
+
+
+def _bop(v5, with_one):
+    """the B operand slots of a 5-value vector per lane ([64,5]) for the three split levels."""
+    q = np.arange(64) >> 4
+    levels = split3(v5)
+    out = []
+    for li, lv in enumerate(levels):
+        s = np.zeros((64, 8))
+        s[:, :5] = lv
+        if li == 0 and with_one:
+            s[:, 7] = np.where(q == 0, 1.0, 0.0)
+        out.append(s)
+    return out
+
+
+PRODUCTS = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (2, 0)]     # (x level, w level)
+
+
+def gates_scaled(acc, c):
+    """acc = [-log2e*i, 2log2e*j, -log2e*(f+1), -log2e*o] -> (c', h')."""
+    cn = np.empty_like(c)
+    hn = np.empty_like(c)
+    for t in range(KNT):
+        e_i, e_f, e_o = np.exp2(acc[t][:, 0]), np.exp2(acc[t][:, 2]), np.exp2(acc[t][:, 3])
+        tj = np.tanh(acc[t][:, 1] / (2 * L2E))
+        cn[:, t] = c[:, t] / (1 + e_f) + tj / (1 + e_i)
+        hn[:, t] = np.tanh(cn[:, t]) / (1 + e_o)
+    return cn, hn
+
+
+def tile_step_bx3(wpack, pre, h1, c1, h2, c2, in0, in1):
+    """The data flow of l2o::bx::tile_step on the packed weights (float64 accumulation)."""
+    R = wp_rows(pre)
+    wp32 = np.ascontiguousarray(wpack, np.float32)
+    W = wp32.astype(np.float64).reshape(-1)[: R["total"] * 64].reshape(-1, 64)
+    U = wp32.view(np.uint32)
+    base = R["total"] * 64
+    frag = lambda ch, t, s: _unpack_frag(U[base + ((ch * KNT + t) * 3 + s) * 256:][:256].reshape(64, 4))
+    win_off = base + bx_nchunks(pre) * KNT * 3 * 256
+
+    def chunk(ch, vec, with_one, acc):
+        b = _bop(vec, with_one)
+        for (xl, wl) in PRODUCTS:
+            for t in range(KNT):
+                acc[t] = mfma_bf16(frag(ch, t, wl), b[xl], acc[t])
+        return acc
+
+    zero = lambda: [np.zeros((64, 4)) for _ in range(KNT)]
+    acc2 = chunk(CH_L2B, h2, True, zero())
+    acc1 = chunk(CH_L1H, h1, True, zero())
+    if pre == 2:
+        fc = np.stack([W[R["fc"] + KNT + t] * in1 + (W[R["fc"] + t] * in0 + W[R["fc"] + 2 * KNT + t])
+                       for t in range(KNT)], 1)
+        fc = np.where(fc > 0, fc, np.expm1(np.minimum(fc, 0)))
+        acc1 = chunk(CH_L1X, fc, False, acc1)
+    else:
+        for t in range(KNT):
+            w0 = wp32[win_off + t * 256:][:256].reshape(64, 4).astype(np.float64)
+            acc1[t] = acc1[t] + w0 * np.asarray(in0)[:, None]
+            if pre == 1:
+                w1 = wp32[win_off + (KNT + t) * 256:][:256].reshape(64, 4).astype(np.float64)
+                acc1[t] = acc1[t] + w1 * np.asarray(in1)[:, None]
+    c1n, h1n = gates_scaled(acc1, c1)
+    acc2 = chunk(CH_L2A, h1n, True, acc2)
+    c2n, h2n = gates_scaled(acc2, c2)
+    d = np.zeros(64)
+    for t in range(KNT):
+        d += h2n[:, t] * W[R["wl"] + t]
+    lanes = np.arange(64)
+    d = d + d[lanes ^ 16]
+    d = d + d[lanes ^ 32]
+    return d + W[R["bl"]], h1n, c1n, h2n, c2n
