@@ -750,13 +750,13 @@ static bool pair_eligible(const l2o_problem* p, const UnrollGeom& g) {
 struct PairLayout { size_t xbuf_off, xbuf_bytes, fxh_off, total; int npg; size_t lds; };
 static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) {
   PairLayout L;
-  const int NWH = g.CH / 2, SQ = 16 * g.CH, S = SQ + 16;
-  L.npg = NWH * 16;
+  const int SQ = 16 * g.CH;
+  L.npg = SQ;                         // granules per (half, parity): one per residual row
   L.xbuf_off = sizeof(PairWs);
   L.xbuf_bytes = (size_t)p->B_local * 2 * 2 * L.npg * sizeof(unsigned long long);
   L.fxh_off = L.xbuf_off + L.xbuf_bytes;
   L.total = L.fxh_off + sizeof(float) * (size_t)(T + 1) * 2 * p->B_local;
-  L.lds = sizeof(float) * ((size_t)SQ * S + (size_t)NWH * 16 * S + 3 * (size_t)SQ + 8);
+  L.lds = 0;                          // static LDS only (xs, rs, fpart)
   return L;
 }
 
@@ -777,8 +777,6 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
       default: fn = k_unroll_pair<PRE, KIND, 8>; break;
     }
     HIP_TRY(hipMemsetAsync(workspace, 0, L.fxh_off, s));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)L.lds));
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
     const int groups = (a.pp.B_local + 7) / 8;
     hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);

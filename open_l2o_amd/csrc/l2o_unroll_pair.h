@@ -4,8 +4,9 @@
 // Why: a batch of B <= #CU/2 problems (BASELINE config 2: B = 128 on 256 CUs) leaves half
 // the chip idle with one problem per CU, and the per-step critical path of a problem is
 // bound by its own SIMDs' fp32 issue cycles.  Splitting the coordinates (tiles) of a problem
-// over two CUs halves that path; the price is ONE exchange of the scaled iterate x*s
-// (64 floats each way for d = 128) per step between the two partner workgroups.
+// over two CUs halves that path; the price is ONE exchange per step between the two partner
+// workgroups: each half multiplies ITS columns of W with its part of the scaled iterate and
+// the halves swap the partial residuals (one granule per row, 128 each way for d = 128).
 //
 // Exchange protocol (placement independent, MI355X_MICROARCH.md "valid forms"): data-tagged
 // 8-byte granules {float x, uint tag = step + 1} written with ONE agent-scope relaxed atomic
@@ -18,8 +19,10 @@
 // timeout the kernel raises ws->status and stops waiting (results are then garbage and the
 // host reports L2O_ERR_HIP) -- a non-resident partner can never hang the GPU.
 //
-// Each half computes the FULL residual r = W xs - y redundantly (W is resident in both CUs'
-// LDS; 2 x 16 rows per wave) and the gradient / LSTM only for its own tiles.
+// The matrix never touches LDS: a half keeps its SQ x SQ/2 column block of W twice in
+// registers (row-major for the partial residual, column-major for the gradient: 2 x SQ/4
+// floats per lane), because with W in LDS the two GEMV passes were LDS-bandwidth bound
+// (1 KB per wave ds_read_b128 x 32 per wave per pass = 1024 cycles per CU).
 #pragma once
 
 struct PairWs {               // header of the caller-owned workspace
@@ -31,7 +34,7 @@ struct PairWs {               // header of the caller-owned workspace
 struct UnrollPairArgs {
   UnrollArgs u;
   PairWs* ws;
-  unsigned long long* xbuf;   // [B][2 halves][2 parities][NWH*16] granules
+  unsigned long long* xbuf;   // [B][2 halves][2 parities][SQ] granules (partial residuals)
   float* fx_half;             // [(T+1)][2*B]
 };
 
@@ -39,21 +42,39 @@ __device__ __forceinline__ unsigned long long pack_granule(float v, unsigned tag
   return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
 
+// N ds_read_b128 at p, p + 64 B, ... issued together, then one s_waitcnt lgkmcnt(0)
+template <int N>
+__device__ __forceinline__ void lds_read_f4(float4 (&v)[N], const float* p) {
+  const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8, "");
+  if constexpr (N == 1)
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(addr) : "memory");
+  if constexpr (N == 2)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(addr) : "memory");
+  if constexpr (N == 4)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                 "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(addr) : "memory");
+  if constexpr (N == 8)
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\t"
+                 "ds_read_b128 %3, %8 offset:192\n\tds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:320\n\t"
+                 "ds_read_b128 %6, %8 offset:384\n\tds_read_b128 %7, %8 offset:448\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(addr) : "memory");
+}
+
 template <int PRE, int KIND, int CH>
 __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
-  constexpr int SQ = 16 * CH;
-  constexpr int S = SQ + 16;
-  extern __shared__ float sm[];
+  constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
+  constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
+  constexpr int NC = 16 * NWH;           // columns (coordinates) owned by a half = SQ / 2
+  __shared__ float xs[NC];               // this half's scaled iterate
+  __shared__ float rs[SQ];               // the full residual
+  __shared__ float fpart[8];
   const UnrollArgs& a = pa.u;
   const ProbParams& pp = a.pp;
   const int D = pp.D, M = pp.M;
-  constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
-  float* Ws = sm;                        // [SQ][S]       W  (all rows, all columns)
-  float* WTs = Ws + SQ * S;              // [NWH*16][S]   W^T rows of this half's coordinates
-  float* xs = WTs + NWH * 16 * S;        // [SQ]
-  float* rs = xs + SQ;                   // [SQ]
-  float* ys = rs + SQ;                   // [SQ]
-  float* fpart = ys + SQ;                // [8]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   // partner workgroups are blockIdx b and b + 8 inside a group of 16 (same XCD under the
@@ -63,21 +84,45 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const int b = ((bid >> 4) << 3) | (bid & 7);          // problem index
   if (b >= pp.B_local) return;                          // padding blocks of the last group of 16 (both halves)
   const int tile_in_prob = half * NWH + wv;             // this wave's coordinate tile
-  const int gq = lane & 3, gr = lane >> 2;              // GEMV role
+  const int gq = lane & 3, gr = lane >> 2;              // GEMV role: quarter gq of row / column gr
 
-  // ---- stage the problem into LDS -----------------------------------------
+  // ---- the matrix lives in registers: no LDS bandwidth in the two GEMV passes -------------
+  //  wr[p][m] : row (2 wv + p) 16 + gr, own columns 16 m + 4 gq + {0..3}     (partial r = W xs)
+  //  wt[m]    : own column wv 16 + gr,   rows       16 m + 4 gq + {0..3}     (g = W^T r)
   const float* Wb = pp.W + (size_t)b * M * D;
-  const int lds_floats = SQ * S + NWH * 16 * S + 3 * SQ;
-  for (int i = tid; i < lds_floats; i += blockDim.x) sm[i] = 0.0f;
-  __syncthreads();
-  const int jlo = half * NWH * 16, jhi = jlo + NWH * 16;
-  for (int e = tid; e < M * D; e += blockDim.x) {
-    const int i = e / D, j = e - i * D;
-    const float v = Wb[e];
-    Ws[i * S + j] = v;
-    if (j >= jlo && j < jhi) WTs[(j - jlo) * S + i] = v;
+  const int col0 = half * NC;
+  float4 wr[2][NWH], wt[CH];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (2 * wv + p) * kTile + gr;
+#pragma unroll
+    for (int m = 0; m < NWH; ++m) {
+      float e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = col0 + 16 * m + 4 * gq + k;
+        e[k] = (row < M && col < D) ? Wb[(size_t)row * D + col] : 0.0f;
+      }
+      wr[p][m] = make_float4(e[0], e[1], e[2], e[3]);
+    }
   }
-  for (int i = tid; i < M; i += blockDim.x) ys[i] = pp.y[(size_t)b * M + i];
+  {
+    const int col = col0 + wv * kTile + gr;
+#pragma unroll
+    for (int m = 0; m < CH; ++m) {
+      float e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 16 * m + 4 * gq + k;
+        e[k] = (row < M && col < D) ? Wb[(size_t)row * D + col] : 0.0f;
+      }
+      wt[m] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+  }
+  // the residual rows this lane finishes: gq == 0 -> p = 0, gq == 1 -> p = 1 (gq 2, 3 idle)
+  const int myrow = (2 * wv + (gq & 1)) * kTile + gr;
+  const float myy = (gq < 2 && myrow < M) ? pp.y[(size_t)b * M + myrow] : 0.0f;
+  const bool row_counted = gq < 2 && (half == 0 ? (myrow < NC) : (myrow >= NC));   // every row once per pair
 
   // ---- per-lane persistent registers -------------------------------------
 #ifdef L2O_PAIR_FP32
@@ -111,14 +156,11 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const float coef = kSq ? 1.0f : 0.5f;
   const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;   // x2 folded in (exact)
   const float kTwoPi = pp.twopi;
-  const float* wtrow = WTs + (wv * kTile + gr) * S + 4 * gq;
   const float* xsq = xs + 4 * gq;
   const float* rsq = rs + 4 * gq;
   const int perm_src = (4 * c) << 2;
-  const int npg = NWH * 16;                                      // granules per (half, parity)
-  unsigned long long* mine = pa.xbuf + ((size_t)b * 2 + half) * 2 * npg;
-  const unsigned long long* theirs = pa.xbuf + ((size_t)b * 2 + (half ^ 1)) * 2 * npg;
-  const int pj = (half ^ 1) * npg + wv * kTile + c;              // partner coordinate this lane fetches
+  unsigned long long* mine = pa.xbuf + ((size_t)b * 2 + half) * 2 * SQ;
+  const unsigned long long* theirs = pa.xbuf + ((size_t)b * 2 + (half ^ 1)) * 2 * SQ;
   bool dead = false;                                             // partner timed out
 
   f32x4 acc1[kNT], acc2[kNT];
@@ -131,16 +173,32 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     const float xsv = xv * sc;
     const unsigned tag = (unsigned)t + 1u;
     const int par = t & 1;
-    // ---- publish this half's x*s (one granule per coordinate), then fetch the partner's
-    if (q == 0) {
-      xs[j] = live ? xsv : 0.0f;
-      __hip_atomic_store(mine + par * npg + wv * kTile + c, pack_granule(live ? xsv : 0.0f, tag),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
+    pc.mark(0);
+    __syncthreads();                                        // B1: this half's xs complete
+    pc.mark(2);
+    // ---- partial residual over this half's columns: rows 2 x 16 per wave, all SQ rows per half
+    float part;
+    {
+      float4 x4[NWH];
+      lds_read_f4<NWH>(x4, xsq);
+      float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < NWH; ++m) {
+        dot4(wr[0][m], x4[m], r0);
+        dot4(wr[1][m], x4[m], r1);
+      }
+      const float p0 = quad_sum(hsum4(r0)), p1 = quad_sum(hsum4(r1));
+      part = (gq & 1) ? p1 : p0;
     }
-    pc.mark(0);                                                   // publish
-    core.template issue_l2_prev<0, Core::kHalf>(s, acc2);                   // matrix work that covers the latency
-    if (q == 0) {
-      const unsigned long long* src = theirs + par * npg + wv * kTile + c;
+    // ---- exchange the partial sums (one granule per row), the previous-h2 matrix work covers the latency
+    if (gq < 2)
+      __hip_atomic_store(mine + par * SQ + myrow, pack_granule(part, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pc.mark(3);                                             // partial r + publish
+    core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
+    float contrib = 0.0f;
+    if (gq < 2) {
+      const unsigned long long* src = theirs + par * SQ + myrow;
       unsigned long long g = 0;
       int spins = 0;
 #ifdef L2O_ABLATE_EXCHANGE
@@ -155,37 +213,15 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      xs[pj] = __uint_as_float((unsigned)g);
-    }
-    pc.mark(1);                                             // 12 MFMAs + partner poll
-    __syncthreads();                                        // B1: xs (both halves) complete
-    pc.mark(2);
-    // ---- r = W xs - y : every half computes all rows, 2 x 16 per wave  ||  13 more MFMAs
-    float contrib = 0.0f;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = (2 * wv + p) * kTile + gr;            // NWH waves x 32 rows = all SQ rows
-      float4 racc = {0.f, 0.f, 0.f, 0.f};
-      const float* wrow = Ws + row * S + 4 * gq;
-      static_for<0, CH>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        const float4 wv4 = *reinterpret_cast<const float4*>(wrow + 16 * m);
-        const float4 xv4 = *reinterpret_cast<const float4*>(xsq + 16 * m);
-        dot4(wv4, xv4, racc);
-      });
-      if (p == 0) core.template issue_l2_prev<Core::kHalf, Core::kTotal>(s, acc2);
-      const float r = quad_sum(hsum4(racc)) - ys[row];
-      if (gq == 0) {
-        rs[row] = r;                      // rows >= M: W row and y are zero -> r == 0
-        const bool mine_row = half == 0 ? (row < npg) : (row >= npg);   // count every row once
-        if (mine_row) contrib = __builtin_fmaf(coef * r, r, contrib);
-      }
+      const float r = (part + __uint_as_float((unsigned)g)) - myy;   // rows >= M: W row and y are zero -> r == 0
+      rs[myrow] = r;
+      if (row_counted) contrib = coef * r * r;
     }
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
       if (kCos) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
     }
-    pc.mark(3);                                             // r pass + 13 MFMAs
+    pc.mark(1);                                             // previous-h2 MFMAs + partner poll
     contrib = wave_sum64(contrib);
     if (lane == 0) fpart[wv] = contrib;
     __syncthreads();                                        // B2: rs, fpart complete
@@ -198,13 +234,13 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     if (t == a.T) break;
 
     // ---- g = W^T r for this wave's 16 coordinates ------------------------------
+    // all CH residual reads are issued back to back (hipcc serialises them on one register
+    // quad otherwise: CH x LDS latency on the critical path), one wait, then the FMAs
+    float4 rv4[CH];
+    lds_read_f4<CH>(rv4, rsq);
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
-    static_for<0, CH>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      const float4 wt4 = *reinterpret_cast<const float4*>(wtrow + 16 * m);
-      const float4 rv4 = *reinterpret_cast<const float4*>(rsq + 16 * m);
-      dot4(wt4, rv4, gacc4);
-    });
+#pragma unroll
+    for (int m = 0; m < CH; ++m) dot4(wt[m], rv4[m], gacc4);
     const float gacc = quad_sum(hsum4(gacc4));
     float gv = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(gacc)));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);   // marks 5 (g pass .. input MFMAs), 6, 7, 8
+    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
     pc.mark(9);
