@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
           g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(g >> 32) == tag) break;
           if (++spins > (1 << 20)) { dead = true; atomicExch(&pa.ws->status, 1u); break; }
+#ifndef L2O_POLL_NOSLEEP
           __builtin_amdgcn_s_sleep(1);
+#endif
         }
       }
       const float r = (part + __uint_as_float((unsigned)g)) - myy;   // rows >= M: W row and y are zero -> r == 0
