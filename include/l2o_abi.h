@@ -168,6 +168,20 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack /* device */,
                     float* st /* device, packed, in-out */, float* x /* device [B,D] in-out */,
                     int64_t B, int64_t D, void* stream);
 
+/* The same update for several variables that share one network in ONE launch (the reference
+ * applies `net` to every variable of a subset inside the same time step, DM/meta.py:330-336;
+ * problems.mnist has four: mlp/linear_{0,1}/{w,b}).  `segs` is a HOST array of 1..8 panels. */
+typedef struct l2o_step_seg {
+  const float* g;      /* device [B,D] */
+  float* m;            /* device [B,D], RNNProp only */
+  float* v;
+  float* st;           /* device, packed, in-out */
+  float* x;            /* device [B,D] in-out */
+  int64_t B, D;
+} l2o_step_seg;
+int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_step_seg* segs,
+                          int32_t nseg, double pow1, double pow2, void* stream);
+
 /* ---- meta-gradient: one step of back-propagation-through-time of the optimizer network,
  * i.e. what tf.train.AdamOptimizer(lr).minimize(loss) differentiates in
  * MetaOptimizer.meta_minimize (DM/meta.py:398-414) with the optimizee gradient held constant

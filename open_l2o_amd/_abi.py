@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats",
-    "l2o_cwlstm_step", "l2o_cwlstm_bwd_step", "l2o_unroll", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_unroll", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
 
@@ -69,6 +69,12 @@ class BwdIO(C.Structure):
     """struct l2o_bwd_io"""
     _fields_ = [(n, C.c_void_p) for n in ("g", "m", "v", "st_prev", "dx_next", "carry_in", "carry_out", "act1",
                                           "dz1", "act2", "dz2", "h2", "dd", "feats", "du")]
+
+
+class StepSeg(C.Structure):
+    """struct l2o_step_seg"""
+    _fields_ = [("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("st", C.c_void_p), ("x", C.c_void_p),
+                ("B", C.c_int64), ("D", C.c_int64)]
 
 
 class L2OError(RuntimeError):
@@ -117,6 +123,8 @@ def lib():
     L.l2o_mlp_scratch_floats.argtypes = [C.POINTER(Mlp)]
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
+    L.l2o_cwlstm_step_multi.restype = C.c_int
+    L.l2o_cwlstm_step_multi.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(StepSeg), C.c_int32, dbl, dbl, vp]
     L.l2o_cwlstm_bwd_step.restype = C.c_int
     L.l2o_cwlstm_bwd_step.argtypes = [C.POINTER(NetCfg), C.POINTER(NetWeights), C.POINTER(BwdIO), dbl, dbl, i64,
                                       i64, vp]

@@ -168,6 +168,20 @@ class HipEngine(object):
                                             float(pow1), float(pow2), _ptr(st), _ptr(x), B, D,
                                             self._stream()))
 
+    MAX_STEP_SEGS = 8
+
+    def lstm_step_multi(self, spec: NetSpec, wpack, segs, pow1, pow2):
+        """One launch for several variables that share a network.  segs: list of
+        (g, m, v, st, x, B, D) with device tensors (m, v, st may be None)."""
+        for i in range(0, len(segs), self.MAX_STEP_SEGS):
+            chunk = segs[i:i + self.MAX_STEP_SEGS]
+            arr = (_abi.StepSeg * len(chunk))()
+            for a, (g, m, v, st, x, B, D) in zip(arr, chunk):
+                a.g, a.m, a.v, a.st, a.x, a.B, a.D = _ptr(g), _ptr(m), _ptr(v), _ptr(st), _ptr(x), B, D
+            cc = spec.to_c()
+            _abi.check(self.lib.l2o_cwlstm_step_multi(C.byref(cc), _ptr(wpack), arr, len(chunk), float(pow1),
+                                                      float(pow2), self._stream()))
+
     def bwd_step(self, spec: NetSpec, weights: dict, io: dict, pow1, pow2, B, D):
         """One BPTT step (l2o_cwlstm_bwd_step).  weights / io: dicts of device tensors keyed by the
         field names of struct l2o_net_weights / l2o_bwd_io (missing = NULL)."""

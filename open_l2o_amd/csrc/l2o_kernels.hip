@@ -86,10 +86,22 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 constexpr int kStepRing = 4;       // LDS ring slots per wave
 constexpr int kStepAhead = 3;      // tiles in flight ahead of the one being computed
 
+// up to kMaxStepSegs (variable, state) panels updated by one launch of the same network
+constexpr int kMaxStepSegs = 8;
+struct StepSegs {
+  int n;
+  int tile_end[kMaxStepSegs];     // running tile count (exclusive end) per segment
+  int tpp[kMaxStepSegs], D[kMaxStepSegs];
+  const float* g[kMaxStepSegs];
+  float* m[kMaxStepSegs];
+  float* v[kMaxStepSegs];
+  float* st[kMaxStepSegs];
+  float* x[kMaxStepSegs];
+};
+
 template <int PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_cwlstm_step(
-    NetParams np, const float* __restrict__ g, float* __restrict__ mbuf, float* __restrict__ vbuf, float om1,
-    float om2, float* __restrict__ st, float* __restrict__ x, int B, int D, int tpp) {
+    NetParams np, StepSegs sg, float om1, float om2) {
   // One wave per SIMD (the bf16x3 weights take 180-240 registers), so memory latency is
   // hidden by DEPTH instead of occupancy: a wave walks its tiles with the next three tiles'
   // inputs in flight as LDS-DMA (global_load_lds: packed state 5 x dwordx4 per lane, and
@@ -105,16 +117,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int c = lane & 15, q = lane >> 4;
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
   const int nwaves = gridDim.x * (blockDim.x >> 6);
-  const int ntiles = B * tpp;
+  const int ntiles = sg.tile_end[sg.n - 1];
   if (wave >= ntiles) return;
   const int ntl = (ntiles - wave + nwaves - 1) / nwaves;         // tiles of this wave
+  // global tile index -> segment (wave-uniform scalar work)
+  struct Loc { const float* g; float *m, *v, *st, *x; int tile, tpp, D; };
+  auto locate = [&](int tile) {
+    int sidx = 0;
+    while (sidx + 1 < sg.n && tile >= sg.tile_end[sidx]) ++sidx;
+    Loc L;
+    L.tile = tile - (sidx ? sg.tile_end[sidx - 1] : 0);
+    L.g = sg.g[sidx]; L.m = sg.m[sidx]; L.v = sg.v[sidx]; L.st = sg.st[sidx]; L.x = sg.x[sidx];
+    L.tpp = sg.tpp[sidx]; L.D = sg.D[sidx];
+    return L;
+  };
   bx::NetWB<PRE> w;
   bx::load_netw<PRE>(w, np.wpack, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // weights landed: the VMEM queue is empty
   // dead lanes (j >= D in the last tile of a problem) read the problem's last coordinate:
   // branch-free loads, masked where they are used
   auto prefetch = [&](int k, int kslot) {
-    const int tile = wave + k * nwaves;
+    const Loc L = locate(wave + k * nwaves);
+    const int tile = L.tile, tpp = L.tpp, D = L.D;
+    const float *g = L.g, *x = L.x, *mbuf = L.m, *vbuf = L.v, *st = L.st;
     float4* slot = sbuf[wv][kslot % kStepRing];
     const float* src = st + (size_t)tile * kStateFloatsPerTile + lane * 4;
 #pragma unroll
@@ -135,7 +160,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int k = 0; k < kStepAhead; ++k) prefetch(min(k, ntl - 1), k);
   for (int k = 0; k < ntl; ++k) {
-    const int tile = wave + k * nwaves;
+    const Loc L = locate(wave + k * nwaves);
+    const int tile = L.tile, tpp = L.tpp, D = L.D;
+    float *x = L.x, *mbuf = L.m, *vbuf = L.v, *st = L.st;
     const int b = tile / tpp, tw = tile - b * tpp;
     const int j = tw * kTile + c;
     const bool live = j < D;
@@ -1001,7 +1028,7 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
   const bool want_g = gw1 || gb1 || gw2 || gb2;
   if (want_g && !(gw1 && gb1 && gw2 && gb2)) return fail(L2O_ERR_ARG, "l2o_mlp_fg: pass all four gradients or none");
   if (mlp->n_hidden < 1 || mlp->n_hidden > kMlpMaxH || mlp->n_out < 1 || mlp->n_out > kMlpMaxO ||
-      mlp->batch < 1 || mlp->batch > 256 || mlp->n_in < 1)
+      mlp->batch < 1 || mlp->batch > 256 || mlp->n_in < 1 || mlp->n_in > 32 * kMlpKPT)
     return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: sizes n_in=%d hidden=%d out=%d batch=%d not implemented",
                 mlp->n_in, mlp->n_hidden, mlp->n_out, mlp->batch);
   if (!scratch) return fail(L2O_ERR_ARG, "l2o_mlp_fg: NULL scratch (l2o_mlp_scratch_floats)");
@@ -1012,18 +1039,25 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
   p.gw1 = gw1; p.gb1 = gb1; p.gw2 = gw2; p.gb2 = gb2;
   p.scratch = scratch;
   hipStream_t s = (hipStream_t)stream;
-  const int HS = p.H | 1;
-  const size_t lds_f = sizeof(float) * ((size_t)p.n_in * HS + (size_t)kMlpSPB * 32 * p.H + (size_t)kMlpSPB * p.H +
-                                        (size_t)kMlpSPB * p.O);
-  const size_t lds_b = sizeof(float) * ((size_t)p.batch * p.H + (size_t)p.batch + 4 * (size_t)kMlpKPB * p.H);
+  const int HP = p.H == 20 ? 20 : kMlpMaxH;             // padded hidden width of the kernels' hot loops
+  const int HS = HP | 1;
+  const size_t lds_f = sizeof(float) * ((size_t)p.n_in * HS + (size_t)kMlpSPB * 32 * HP + (size_t)kMlpSPB * p.H +
+                                        (size_t)kMlpSPB * p.O + (size_t)p.H * p.O + p.H + p.O);
+  size_t lds_b = sizeof(float) * ((size_t)p.batch * HP + (size_t)p.batch + 4 * (size_t)kMlpKPB * HP);
+  const size_t lds_small = sizeof(float) * (size_t)p.batch * (2 * p.H + p.O + 1);   // the small-tensor workgroup's copy of scratch
+  if (lds_small > lds_b) lds_b = lds_small;
   if (lds_f > 160 * 1024 || lds_b > 160 * 1024)
     return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: needs %zu / %zu bytes of LDS", lds_f, lds_b);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+  void (*ffwd)(MlpParams) = HP == 20 ? k_mlp_fwd<20> : k_mlp_fwd<kMlpMaxH>;
+  void (*fbwd)(MlpParams) = HP == 20 ? k_mlp_bwd<20> : k_mlp_bwd<kMlpMaxH>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ffwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_f));
-  hipLaunchKernelGGL(k_mlp_fwd, dim3((p.batch + kMlpSPB - 1) / kMlpSPB), dim3(256), lds_f, s, p);
+  hipLaunchKernelGGL(ffwd, dim3((p.batch + kMlpSPB - 1) / kMlpSPB), dim3(256), lds_f, s, p);
   HIP_TRY(hipGetLastError());
   const int nkb = (p.n_in + kMlpKPB - 1) / kMlpKPB;
-  hipLaunchKernelGGL(k_mlp_bwd, dim3(nkb + 1), dim3(256), lds_b, s, p);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fbwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_b));
+  hipLaunchKernelGGL(fbwd, dim3(nkb + 1), dim3(256), lds_b, s, p);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
 }
@@ -1033,47 +1067,63 @@ size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp) {
   return (size_t)mlp->batch * (2 * (size_t)mlp->n_hidden + mlp->n_out + 1);
 }
 
-int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, float* m, float* v, double pow1,
-                    double pow2, float* st, float* x, int64_t B, int64_t D, void* stream) {
-  if (!cfg || !wpack || !g || !x || B <= 0 || D <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: bad argument");
+int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_step_seg* segs, int32_t nseg,
+                          double pow1, double pow2, void* stream) {
+  if (!cfg || !wpack || !segs || nseg < 1) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: bad argument");
+  if (nseg > kMaxStepSegs) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_step_multi: at most %d segments", kMaxStepSegs);
+  for (int i = 0; i < nseg; ++i)
+    if (!segs[i].g || !segs[i].x || segs[i].B <= 0 || segs[i].D <= 0)
+      return fail(L2O_ERR_ARG, "l2o_cwlstm_step: bad argument (segment %d)", i);
   const NetParams np = make_net_params(cfg, wpack);
   hipStream_t s = (hipStream_t)stream;
   if (cfg->n_layers == 0) {
     if (cfg->kind != L2O_NET_CW || cfg->preprocess == L2O_PRE_FC_ELU)
       return fail(L2O_ERR_UNSUPPORTED, "layers=() is implemented for CoordinateWiseDeepLSTM only");
-    const size_t n = (size_t)B * D;
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (cfg->preprocess == L2O_PRE_LOGSIGN)
-      hipLaunchKernelGGL(k_linear_step<L2O_PRE_LOGSIGN>, grid, dim3(256), 0, s, np, g, x, n);
-    else
-      hipLaunchKernelGGL(k_linear_step<L2O_PRE_IDENTITY>, grid, dim3(256), 0, s, np, g, x, n);
+    for (int i = 0; i < nseg; ++i) {
+      const size_t n = (size_t)segs[i].B * segs[i].D;
+      const dim3 grid((unsigned)((n + 255) / 256));
+      if (cfg->preprocess == L2O_PRE_LOGSIGN)
+        hipLaunchKernelGGL(k_linear_step<L2O_PRE_LOGSIGN>, grid, dim3(256), 0, s, np, segs[i].g, segs[i].x, n);
+      else
+        hipLaunchKernelGGL(k_linear_step<L2O_PRE_IDENTITY>, grid, dim3(256), 0, s, np, segs[i].g, segs[i].x, n);
+    }
     HIP_TRY(hipGetLastError());
     return L2O_OK;
   }
   if (!net_ok_for_mfma(cfg)) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_step: only layers=(20,20) / () nets");
-  if (!st) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: NULL state");
-  const int tpp = tiles_per_problem(D);
-  const int64_t ntiles = B * tpp;
+  StepSegs sg;
+  std::memset(&sg, 0, sizeof(sg));
+  sg.n = nseg;
+  int64_t ntiles = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!segs[i].st) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: NULL state");
+    if (cfg->preprocess == L2O_PRE_FC_ELU && (!segs[i].m || !segs[i].v))
+      return fail(L2O_ERR_ARG, "l2o_cwlstm_step: RNNProp needs m and v");
+    sg.tpp[i] = tiles_per_problem(segs[i].D);
+    sg.D[i] = (int)segs[i].D;
+    ntiles += segs[i].B * sg.tpp[i];
+    if (ntiles > INT32_MAX) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_step: too many coordinates");
+    sg.tile_end[i] = (int)ntiles;
+    sg.g[i] = segs[i].g; sg.m[i] = segs[i].m; sg.v[i] = segs[i].v; sg.st[i] = segs[i].st; sg.x[i] = segs[i].x;
+  }
   int blocks = (int)((ntiles + 3) / 4);
   if (blocks > 256) blocks = 256;            // one 4-wave block per CU (one wave per SIMD), grid-stride beyond
   const dim3 grid(blocks), block(256);
   const float om1 = (float)(1.0 - pow1), om2 = (float)(1.0 - pow2);
   switch (cfg->preprocess) {
-    case L2O_PRE_IDENTITY:
-      hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_IDENTITY>, grid, block, 0, s, np, g, m, v, om1, om2, st, x, (int)B,
-                         (int)D, tpp);
-      break;
-    case L2O_PRE_LOGSIGN:
-      hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_LOGSIGN>, grid, block, 0, s, np, g, m, v, om1, om2, st, x, (int)B,
-                         (int)D, tpp);
-      break;
-    default:
-      if (!m || !v) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: RNNProp needs m and v");
-      hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_FC_ELU>, grid, block, 0, s, np, g, m, v, om1, om2, st, x, (int)B,
-                         (int)D, tpp);
+    case L2O_PRE_IDENTITY: hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_IDENTITY>, grid, block, 0, s, np, sg, om1, om2); break;
+    case L2O_PRE_LOGSIGN: hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_LOGSIGN>, grid, block, 0, s, np, sg, om1, om2); break;
+    default: hipLaunchKernelGGL(k_cwlstm_step<L2O_PRE_FC_ELU>, grid, block, 0, s, np, sg, om1, om2);
   }
   HIP_TRY(hipGetLastError());
   return L2O_OK;
+}
+
+int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, float* m, float* v, double pow1,
+                    double pow2, float* st, float* x, int64_t B, int64_t D, void* stream) {
+  l2o_step_seg seg;
+  seg.g = g; seg.m = m; seg.v = v; seg.st = st; seg.x = x; seg.B = B; seg.D = D;
+  return l2o_cwlstm_step_multi(cfg, wpack, &seg, 1, pow1, pow2, stream);
 }
 
 int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io, double pow1,

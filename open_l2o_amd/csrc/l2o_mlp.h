@@ -13,6 +13,33 @@ constexpr int kMlpMaxH = 32;
 constexpr int kMlpMaxO = 16;
 constexpr int kMlpSPB = 8;        // samples per forward workgroup
 constexpr int kMlpKPB = 64;       // gw1 rows per backward workgroup
+constexpr int kMlpKPT = 32;       // inputs per forward thread: n_in <= 32 * kMlpKPT
+constexpr int kMlpNPT = 32;       // samples per backward thread and pass
+
+// cooperative global -> LDS copy by 256 threads with 8 independent loads in flight per thread
+// (a plain one-load-per-iteration loop pays one memory latency per iteration)
+template <class T>
+__device__ __forceinline__ void coop_copy256(T* __restrict__ dst, const T* __restrict__ src, int n, int tid) {
+  for (int base = tid; base < n; base += 256 * 8) {
+    T v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = base + 256 * j;
+      v[j] = i < n ? src[i] : T(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = base + 256 * j;
+      if (i < n) dst[i] = v[j];
+    }
+  }
+}
+
+#ifdef L2O_MLP_CLOCK
+#define MLP_CK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) ck[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MLP_CK(i) ((void)0)
+#endif
 
 struct MlpParams {
   int n_in, H, O, batch, act;
@@ -25,37 +52,79 @@ struct MlpParams {
   float* scratch;                 // [batch*H] H | [batch*O] dZ | [batch*H] dH | [batch] loss_n
 };
 
+// HP = compile-time padded hidden width (H == HP, or H < HP with zero-padded LDS columns):
+// the hot loops carry no run-time guard -- with `if (u < H)` inside the unrolled loop hipcc
+// emits one branch + ds_read + wait + FMA per element (90 cycles each, measured).
+template <int HP>
 __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
   extern __shared__ float sm[];
   const int n_in = p.n_in, H = p.H, O = p.O, Bn = p.batch;
-  const int HS = H | 1;                                 // odd row stride: conflict-free w1 reads
+  constexpr int HS = HP | 1;                            // odd row stride: conflict-free w1 reads
   float* w1s = sm;                                      // [n_in][HS]
-  float* part = w1s + n_in * HS;                        // [SPB][32][H]
-  float* hs = part + kMlpSPB * 32 * H;                  // [SPB][H]
+  float* part = w1s + n_in * HS;                        // [SPB][32][HP]
+  float* hs = part + kMlpSPB * 32 * HP;                 // [SPB][H]
   float* zs = hs + kMlpSPB * H;                         // [SPB][O]
+  float* sw2 = zs + kMlpSPB * O;                        // [H][O]  (staged: the tail below is latency bound)
+  float* sb1 = sw2 + H * O;                             // [H]
+  float* sb2 = sb1 + H;                                 // [O]
+#ifdef L2O_MLP_CLOCK
+  long long ck[10];
+#endif
   const int tid = threadIdx.x;
-  for (int i = tid; i < n_in * H; i += 256) w1s[(i / H) * HS + (i % H)] = p.w1[i];
-  __syncthreads();
   const int sl = tid >> 5, l32 = tid & 31;
+  MLP_CK(0);
+  int lab = 0;                                          // label of sample blockIdx * SPB + tid (tid < SPB)
+  if (tid < kMlpSPB && (int)blockIdx.x * kMlpSPB + tid < Bn) lab = p.labels[p.idx[blockIdx.x * kMlpSPB + tid]];
+  coop_copy256(sw2, p.w2, H * O, tid);
+  coop_copy256(sb1, p.b1, H, tid);
+  coop_copy256(sb2, p.b2, O, tid);
   const int n = blockIdx.x * kMlpSPB + sl;
   const bool valid = n < Bn;
   const int row = valid ? p.idx[n] : 0;
-  {
-    const float* xrow = p.images + (size_t)row * n_in;
-    float acc[kMlpMaxH];
+  // the sample's inputs of this thread (k = l32 + 32 i) go out first, all at once: one memory
+  // latency instead of one per loop iteration, and it overlaps the staging of w1
+  const float* xrow = p.images + (size_t)row * n_in;
+  float xr[kMlpKPT];
 #pragma unroll
-    for (int u = 0; u < kMlpMaxH; ++u) acc[u] = 0.0f;
-    for (int k = l32; k < n_in; k += 32) {
-      const float xv = xrow[k];
-      const float* wr = w1s + k * HS;
+  for (int i = 0; i < kMlpKPT; ++i) {
+    const int k = l32 + 32 * i;
+    xr[i] = k < n_in ? xrow[k] : 0.0f;
+  }
+  if (HP != 20)                                         // generic width: zero the padding columns
+    for (int i = tid; i < n_in * HS; i += 256) w1s[i] = 0.0f;
+  if (HP != 20) __syncthreads();
+  const int Hc = HP == 20 ? 20 : H;                     // compile-time divisor on the common path
+  for (int base = tid; base < n_in * Hc; base += 256 * 8) {
+    float v[8];
 #pragma unroll
-      for (int u = 0; u < kMlpMaxH; ++u)
-        if (u < H) acc[u] = __builtin_fmaf(xv, wr[u], acc[u]);
+    for (int jj = 0; jj < 8; ++jj) {
+      const int i = base + 256 * jj;
+      v[jj] = i < n_in * Hc ? p.w1[i] : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < kMlpMaxH; ++u)
-      if (u < H) part[(sl * 32 + l32) * H + u] = acc[u];
+    for (int jj = 0; jj < 8; ++jj) {
+      const int i = base + 256 * jj;
+      if (i < n_in * Hc) w1s[(i / Hc) * HS + (i % Hc)] = v[jj];
+    }
   }
+  __syncthreads();
+  MLP_CK(1);
+  {
+    float acc[HP];
+#pragma unroll
+    for (int u = 0; u < HP; ++u) acc[u] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kMlpKPT; ++i) {
+      const int k = min(l32 + 32 * i, n_in - 1);        // out-of-range slots carry xr == 0
+      const float xv = xr[i];
+      const float* wr = w1s + k * HS;
+#pragma unroll
+      for (int u = 0; u < HP; ++u) acc[u] = __builtin_fmaf(xv, wr[u], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < HP; ++u) part[(sl * 32 + l32) * HP + u] = acc[u];
+  }
+  MLP_CK(2);
   __syncthreads();
   float* gH = p.scratch;
   float* gdZ = gH + Bn * H;
@@ -63,18 +132,21 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
   float* gloss = gdH + Bn * H;
   if (tid < kMlpSPB * H) {                              // hidden activation: thread = (sample, unit)
     const int s2 = tid / H, u = tid % H;
-    float a = p.b1[u];
-    for (int l = 0; l < 32; ++l) a += part[(s2 * 32 + l) * H + u];
+    float a = sb1[u];
+#pragma unroll 8
+    for (int l = 0; l < 32; ++l) a += part[(s2 * 32 + l) * HP + u];
     hs[s2 * H + u] = p.act == 0 ? 1.0f / (1.0f + expf(-a)) : fmaxf(a, 0.0f);
   }
   __syncthreads();
+  MLP_CK(3);
   if (tid < kMlpSPB * O) {                              // logits: thread = (sample, class)
     const int s2 = tid / O, o = tid % O;
-    float a = p.b2[o];
-    for (int u = 0; u < H; ++u) a = __builtin_fmaf(hs[s2 * H + u], p.w2[u * O + o], a);
+    float a = sb2[o];
+    for (int u = 0; u < H; ++u) a = __builtin_fmaf(hs[s2 * H + u], sw2[u * O + o], a);
     zs[s2 * O + o] = a;
   }
   __syncthreads();
+  MLP_CK(4);
   if (tid < kMlpSPB) {                                  // softmax cross-entropy: thread = sample
     const int n2 = blockIdx.x * kMlpSPB + tid;
     if (n2 < Bn) {
@@ -84,7 +156,6 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
       float se = 0.0f;
       for (int o = 0; o < O; ++o) se += expf(z[o] - zmax);
       const float lse = zmax + logf(se);
-      const int lab = p.labels[p.idx[n2]];
       const float inv = 1.0f / (float)Bn;
       gloss[n2] = lse - z[lab];                         // before z is overwritten by dZ
       for (int o = 0; o < O; ++o) {
@@ -95,19 +166,27 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
     }
   }
   __syncthreads();
+  MLP_CK(5);
   if (tid < kMlpSPB * H) {                              // dH and H to HBM: thread = (sample, unit)
     const int s2 = tid / H, u = tid % H;
     const int n2 = blockIdx.x * kMlpSPB + s2;
     if (n2 < Bn) {
       float a = 0.0f;
-      for (int o = 0; o < O; ++o) a = __builtin_fmaf(zs[s2 * O + o], p.w2[u * O + o], a);
+      for (int o = 0; o < O; ++o) a = __builtin_fmaf(zs[s2 * O + o], sw2[u * O + o], a);
       const float h = hs[s2 * H + u];
       gH[n2 * H + u] = h;
       gdH[n2 * H + u] = p.act == 0 ? a * h * (1.0f - h) : (h > 0.0f ? a : 0.0f);
     }
   }
+  MLP_CK(6);
+#ifdef L2O_MLP_CLOCK
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("k_mlp_fwd ticks: x+stage %lld  gemv %lld  hidden %lld  logits %lld  softmax %lld  dH %lld\n", ck[1] - ck[0],
+           ck[2] - ck[1], ck[3] - ck[2], ck[4] - ck[3], ck[5] - ck[4], ck[6] - ck[5]);
+#endif
 }
 
+template <int HP>
 __global__ __launch_bounds__(256) void k_mlp_bwd(MlpParams p) {
   extern __shared__ float sm[];
   const int n_in = p.n_in, H = p.H, O = p.O, Bn = p.batch;
@@ -118,61 +197,100 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpParams p) {
   const int tid = threadIdx.x;
   const int nkb = (n_in + kMlpKPB - 1) / kMlpKPB;
   if ((int)blockIdx.x == nkb) {                         // the small tensors + the loss
-    if (tid == 0) {
-      float s = 0.0f;
-      for (int n = 0; n < Bn; ++n) s += gloss[n];       // fixed order
-      p.loss[0] = s / (float)Bn;
+    // scratch (H | dZ | dH | loss_n, contiguous) -> LDS first; everything below reads LDS
+    const int tot = Bn * (2 * H + O + 1);
+    coop_copy256(sm, p.scratch, tot, tid);
+    __syncthreads();
+    const float* sH = sm;
+    const float* sdZ = sH + Bn * H;
+    const float* sdH = sdZ + Bn * O;
+    const float* sloss = sdH + Bn * H;
+    if (tid < 64) {                                     // fixed-order loss sum: lane strides, then the wave tree
+      float a = 0.0f;
+      for (int n = tid; n < Bn; n += 64) a += sloss[n];
+      a = l2o::wave_sum64(a);
+      if (tid == 0) p.loss[0] = a / (float)Bn;
     }
     if (p.gw1 == nullptr) return;
     for (int e = tid; e < H * O; e += 256) {
       const int u = e / O, o = e % O;
       float a = 0.0f;
-      for (int n = 0; n < Bn; ++n) a = __builtin_fmaf(gH[n * H + u], gdZ[n * O + o], a);
+      for (int n = 0; n < Bn; ++n) a = __builtin_fmaf(sH[n * H + u], sdZ[n * O + o], a);
       p.gw2[e] = a;
     }
     for (int o = tid; o < O; o += 256) {
       float a = 0.0f;
-      for (int n = 0; n < Bn; ++n) a += gdZ[n * O + o];
+      for (int n = 0; n < Bn; ++n) a += sdZ[n * O + o];
       p.gb2[o] = a;
     }
     for (int u = tid; u < H; u += 256) {
       float a = 0.0f;
-      for (int n = 0; n < Bn; ++n) a += gdH[n * H + u];
+      for (int n = 0; n < Bn; ++n) a += sdH[n * H + u];
       p.gb1[u] = a;
     }
     return;
   }
   if (p.gw1 == nullptr) return;
-  float* dhs = sm;                                      // [Bn][H]
-  int* rows = reinterpret_cast<int*>(dhs + Bn * H);     // [Bn]
-  float* part = reinterpret_cast<float*>(rows + Bn);    // [4][KPB][H]
-  for (int i = tid; i < Bn * H; i += 256) dhs[i] = gdH[i];
-  for (int i = tid; i < Bn; i += 256) rows[i] = p.idx[i];
+  float* dhs = sm;                                      // [Bn][HP]  (columns >= H zero)
+  int* rows = reinterpret_cast<int*>(dhs + Bn * HP);    // [Bn]
+  float* part = reinterpret_cast<float*>(rows + Bn);    // [4][KPB][HP]
+  if (HP != 20) {
+    for (int i = tid; i < Bn * HP; i += 256) dhs[i] = 0.0f;
+    __syncthreads();
+  }
+  {
+    const int Hc = HP == 20 ? 20 : H;
+    for (int base = tid; base < Bn * Hc; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int i = base + 256 * jj;
+        v[jj] = i < Bn * Hc ? gdH[i] : 0.0f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int i = base + 256 * jj;
+        if (i < Bn * Hc) dhs[(i / Hc) * HP + (i % Hc)] = v[jj];
+      }
+    }
+  }
+  coop_copy256(rows, p.idx, Bn, tid);
   __syncthreads();
   const int kl = tid & (kMlpKPB - 1), np = tid >> 6;    // 64 rows x 4 sample-quarters
   const int k = blockIdx.x * kMlpKPB + kl;
-  float acc[kMlpMaxH];
+  float acc[HP];
 #pragma unroll
-  for (int u = 0; u < kMlpMaxH; ++u) acc[u] = 0.0f;
-  if (k < n_in) {
-    for (int n = np; n < Bn; n += 4) {
-      const float xv = p.images[(size_t)rows[n] * n_in + k];
-      const float* dh = dhs + n * H;
+  for (int u = 0; u < HP; ++u) acc[u] = 0.0f;
+  {
+    const int kc = min(k, n_in - 1);
+    // samples n = np + 4 i: the gathered image values of a pass are all requested before the
+    // first FMA (one memory latency per pass of 32, not one per sample)
+    for (int n0 = np; n0 < Bn; n0 += 4 * kMlpNPT) {
+      float xr[kMlpNPT];
 #pragma unroll
-      for (int u = 0; u < kMlpMaxH; ++u)
-        if (u < H) acc[u] = __builtin_fmaf(xv, dh[u], acc[u]);
+      for (int i = 0; i < kMlpNPT; ++i) {
+        const int n = n0 + 4 * i;
+        xr[i] = n < Bn ? p.images[(size_t)rows[n] * n_in + kc] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < kMlpNPT; ++i) {
+        const int n = min(n0 + 4 * i, Bn - 1);            // out-of-range slots carry xr == 0
+        const float xv = xr[i];
+        const float* dh = dhs + n * HP;
+#pragma unroll
+        for (int u = 0; u < HP; ++u) acc[u] = __builtin_fmaf(xv, dh[u], acc[u]);
+      }
     }
   }
 #pragma unroll
-  for (int u = 0; u < kMlpMaxH; ++u)
-    if (u < H) part[(np * kMlpKPB + kl) * H + u] = acc[u];
+  for (int u = 0; u < HP; ++u) part[(np * kMlpKPB + kl) * HP + u] = acc[u];
   __syncthreads();
   for (int e = tid; e < kMlpKPB * H; e += 256) {
     const int kk = e / H, u = e % H;
     const int kg = blockIdx.x * kMlpKPB + kk;
     if (kg < n_in) {
-      const float s = (part[(0 * kMlpKPB + kk) * H + u] + part[(1 * kMlpKPB + kk) * H + u]) +
-                      (part[(2 * kMlpKPB + kk) * H + u] + part[(3 * kMlpKPB + kk) * H + u]);
+      const float s = (part[(0 * kMlpKPB + kk) * HP + u] + part[(1 * kMlpKPB + kk) * HP + u]) +
+                      (part[(2 * kMlpKPB + kk) * HP + u] + part[(3 * kMlpKPB + kk) * HP + u]);
       p.gw1[kg * H + u] = s;
     }
   }

@@ -648,6 +648,13 @@ class UnrollGraph(object):
         single = len(self.terms) == 1 and self.terms[0].weight == 1.0
         b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
         mlp_idx = self.__dict__.get("_mlp_idx", {})
+        # one analytic term of weight 1: the per-problem losses of all T+1 steps are kept and
+        # reduced over the batch by ONE launch at the end (like the fused path) instead of a
+        # tiny reduction kernel per step
+        defer = single and self.terms[0].kind != _abi.PROB_MLP
+        if defer:
+            jd = index_of[self.terms[0].var.name]
+            f_all = self._scratch("f_all", (T + 1) * descs[jd].B_local)
 
         def forward(t, want_grad):
             if not single:
@@ -661,6 +668,10 @@ class UnrollGraph(object):
                 else:
                     js = [index_of[term.var.name]]
                     j = js[0]
+                    if defer:
+                        Bl = descs[j].B_local
+                        eng.problem_fg(descs[j], panels[j], f_all[t * Bl:(t + 1) * Bl], grads[j] if want_grad else None)
+                        continue
                     f_part = self._scratch("f%d" % j, descs[j].B_local)
                     eng.problem_fg(descs[j], panels[j], f_part, grads[j] if want_grad else None)
                     eng.reduce_fx(f_part, 1, descs[j].B_local, descs[j].B_global, out)
@@ -679,19 +690,27 @@ class UnrollGraph(object):
                 record["g"].append([g.clone() for g in grads])
                 record["st"].append([None if not isinstance(st, PackedState) or st.packed is None
                                      else st.packed.clone() for st in states])
+            # variables that share a network are updated by ONE launch (DM/meta.py:330-336 applies
+            # `net` to every variable of its subset inside the same time step)
+            groups = {}
             for si, s in enumerate(slots):
                 j = s.var_index
                 B, D = panels[j].shape
                 if isinstance(s.net, networks.StandardDeepLSTM):
-                    eng.lstm_step(s.net.spec, s.net.wpack(eng), grads[j], ms[si], vs[si], b1 ** k, b2 ** k,
-                                  None if states[si].packed is None else states[si].packed, panels[j], B, D)
+                    groups.setdefault(id(s.net), (s.net, []))[1].append(
+                        (grads[j], ms[si], vs[si], None if states[si].packed is None else states[si].packed,
+                         panels[j], B, D))
                 else:                                    # Sgd / Adam baseline nets
                     delta, states[si] = s.net(grads[j], states[si])
                     panels[j].add_(delta.view(B, D))
+            for net, segs in groups.values():
+                eng.lstm_step_multi(net.spec, net.wpack(eng), segs, b1 ** k, b2 ** k)
             if record is not None:                         # RNNProp moments AFTER this step's update
                 record["m"].append([None if mm is None else mm.clone() for mm in ms])
                 record["v"].append([None if vv is None else vv.clone() for vv in vs])
         forward(T, record is not None)                     # training also needs the gradient at x_T
+        if defer:
+            eng.reduce_fx(f_all, T + 1, descs[jd].B_local, descs[jd].B_global, fx)
         if record is not None:
             record["g_final"] = [g.clone() for g in grads]
 

@@ -135,6 +135,10 @@ class OracleEngine(object):
             for t, a in zip(grads, g):
                 t.copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)).view_as(t))
 
+    def lstm_step_multi(self, spec, wpack, segs, pow1, pow2):
+        for (g, m, v, st, x, B, D) in segs:
+            self.lstm_step(spec, wpack, g, m, v, pow1, pow2, st, x, B, D)
+
     def lstm_step(self, spec, wpack, g, m, v, pow1, pow2, st, x, B, D):
         self.calls.append("lstm_step")
         cfg = _cfg_of(spec)

@@ -128,6 +128,39 @@ def test_problem_fg(eng, kind, B, D, M):
     assert rel_err(eng.to_numpy(fx)[0], prob.f(xin)) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["dm_logsign", "rnnprop"])
+def test_lstm_step_multi_equals_separate_steps(eng, name):
+    """l2o_cwlstm_step_multi over several (variable, state) panels == one l2o_cwlstm_step per
+    panel, bit for bit (problems.mnist shapes: 784x20, 20, 20x10, 10 plus a multi-tile row)."""
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, make_params(cfg, seed=11))
+    rng = np.random.default_rng(12)
+    shapes = [(784, 20), (1, 20), (20, 10), (1, 10), (3, 37)]
+    pw = float(np.float32(0.95)) ** 3
+
+    def fresh():
+        r = np.random.default_rng(13)
+        segs = []
+        for (B, D) in shapes:
+            g = eng.tensor((r.standard_normal((B, D)) * 0.3).astype(np.float32))
+            m = eng.tensor((r.standard_normal((B, D)) * 0.1).astype(np.float32))
+            v = eng.tensor((r.random((B, D)) * 0.1).astype(np.float32))
+            x = eng.tensor(r.standard_normal((B, D)).astype(np.float32))
+            state = random_state(cfg, B * D, seed=int(r.integers(1 << 30)))
+            st = eng.state_pack(*[eng.tensor(a) for hc in state for a in hc], B, D)
+            segs.append((g, m, v, st, x, B, D))
+        return segs
+
+    a, b = fresh(), fresh()
+    eng.lstm_step_multi(spec, wpack, a, pw, pw)
+    for (g, m, v, st, x, B, D) in b:
+        eng.lstm_step(spec, wpack, g, m, v, pw, pw, st, x, B, D)
+    for sa, sb in zip(a, b):
+        for ta, tb in zip(sa[1:5], sb[1:5]):
+            assert np.array_equal(eng.to_numpy(ta), eng.to_numpy(tb))
+
+
 def _run_fused(eng, cfg, params, arrays, x0, B, D, T, state=None, step0=1, Bg=None, x_scale=None):
     spec = spec_of(cfg)
     wpack = eng.pack_weights(spec, params)
