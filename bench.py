@@ -232,6 +232,9 @@ def main():
                                    % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
                        "kernel": ("l2o_unroll (fused persistent, 2 CUs per problem when 2*batch <= #CUs)" if fused
                                   else "l2o_problem_fg + l2o_cwlstm_step per step"),
+                       "arithmetic": "fp32 state, inputs and outputs; the LSTM gate GEMM is a 6-product 3-way bf16 "
+                                     "split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level error, "
+                                     "DESIGN.md 2); everything else fp32 VALU",
                        "api": "open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> UnrollGraph.launch",
                        "parallelism": "problem-batch sharding x%d, all-reduce of T+1 floats" % world},
             "final_loss_fx_T": float(fx_host[-1]), "fx_0": float(fx_host[0]),
@@ -243,7 +246,7 @@ def main():
                          "fp32_frac_of_157.3TF": flops / (kern_ms * 1e-3) / FP32_PEAK,
                          "note": "step-granular algorithmic bytes (SURVEY 8d) over the HIP-event time of the "
                                  "unroll kernels; the fused kernel keeps x, LSTM state and W on-chip, so real HBM "
-                                 "traffic is far below this figure and the kernel is fp32-issue bound -- DESIGN.md 5"},
+                                 "traffic is far below this figure (frac can exceed 1) and the kernel is bound by one wave's serial instruction stream -- DESIGN.md 5"},
         }
         if world == 1 and not args.no_cpu_baseline and args.problem != "mnist":
             names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
