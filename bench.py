@@ -167,7 +167,11 @@ def main():
     Bg = B * world
     optimizer, ml, feed, weights = build_workload(args, Bg)
     graph = optimizer.graph
-    graph.reset()                                           # sample x0, W, y (this rank's shard) on the device
+    t_reset = time.perf_counter()
+    graph.reset()                                           # sample x0, W, y on the host (NumPy), upload this rank's shard
+    if eng.device.type == "cuda":
+        torch.cuda.synchronize()
+    t_reset = time.perf_counter() - t_reset
     x0 = [v.value.clone() for v in graph.x]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -201,6 +205,22 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     kern_ms_min = float(np.min([a.elapsed_time(b) for a, b in ev]))
     fused = graph.last_path == "fused"
+
+    copy_gbps = None
+    if rank == 0 and eng.device.type == "cuda":
+        # achievable-copy figure of this box: device-to-device copy of 512 MiB, read + write counted
+        src = torch.empty(128 << 20, dtype=torch.float32, device=eng.device).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
 
     if rank == 0:
         coord_steps = (1 if args.problem == "mnist" else B) * D * T     # per GPU per unroll
@@ -240,6 +260,9 @@ def main():
             "final_loss_fx_T": float(fx_host[-1]), "fx_0": float(fx_host[0]),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "hbm_copy_measured_GBps": copy_gbps,
+                         "reset_ms_host_sampling_plus_h2d": t_reset * 1e3,
+                         "frac_of_measured_copy": None if not copy_gbps else achieved / 1e9 / copy_gbps,
                          "algorithmic_bytes_per_launch": alg, "alg_bytes_per_coord_step": bpc,
                          "kernel_ms_avg": kern_ms, "kernel_ms_min": kern_ms_min,
                          "fp32_tflops": flops / (kern_ms * 1e-3) / 1e12,

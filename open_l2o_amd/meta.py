@@ -513,10 +513,58 @@ class UnrollGraph(object):
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
                 "x": x_out, "fx_array": fx_host}
 
+    def _bptt(self, net, acc, B, D, T, step0, gs, sts, ms, vs, dxs):
+        """Back-propagation through T recorded steps of ONE network on one [B, D] panel:
+        gs[t] the step's input gradient, sts[t] the packed state before it, ms / vs the RNNProp
+        moments after it, dxs[t] = dL/d(delta_t).  Adds the weight gradients into ``acc``
+        ({(module, variable): device tensor})."""
+        eng = self.engine
+        b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
+        N = B * D
+        spec = net.spec
+        nl = len(spec.layers)
+        fc = spec.preprocess == _abi.PRE_FC_ELU
+        P = 20 if fc else (2 if spec.preprocess == _abi.PRE_LOGSIGN else 1)
+        wdev = net.device_weights(eng)
+
+        def add(mod, var, val):
+            k = (mod, var)
+            acc[k] = val if k not in acc else acc[k] + val
+
+        io = {"dd": eng.empty(N)}
+        if nl:
+            H = 20
+            carry_in, carry_out = eng.zeros(4, N, H), eng.empty(4, N, H)
+            io.update(act1=eng.empty(N, P + H), dz1=eng.empty(N, 4 * H), act2=eng.empty(N, 2 * H),
+                      dz2=eng.empty(N, 4 * H), h2=eng.empty(N, H))
+            if fc:
+                io.update(feats=eng.empty(N, 2), du=eng.empty(N, H))
+        else:
+            io.update(act1=eng.empty(N, 2))
+        for t in reversed(range(T)):
+            k = step0 + t
+            io.update(g=gs[t], dx_next=dxs[t])
+            if nl:
+                io.update(st_prev=sts[t], carry_in=carry_in, carry_out=carry_out, m=ms[t], v=vs[t])
+            eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, B, D)
+            dd = io["dd"].view(N, 1)
+            if nl:
+                add("lstm_1", "w_gates", io["act1"].t() @ io["dz1"])
+                add("lstm_1", "b_gates", io["dz1"].sum(0))
+                add("lstm_2", "w_gates", io["act2"].t() @ io["dz2"])
+                add("lstm_2", "b_gates", io["dz2"].sum(0))
+                add("linear", "w", io["h2"].t() @ dd)
+                if fc:
+                    add("input_projection", "w", io["feats"].t() @ io["du"])
+                    add("input_projection", "b", io["du"].sum(0))
+                carry_in, carry_out = carry_out, carry_in
+            else:
+                add("linear", "w", io["act1"][:, :P].t() @ dd)
+            add("linear", "b", dd.sum(0))
+
     def _backward(self, T, rec):
         eng = self.engine
         step0 = rec["step0"]
-        b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
         out = {}                                           # net key -> {(module, variable): device grad}
         for si, s in enumerate(self.slots):
             net = s.net
@@ -525,50 +573,14 @@ class UnrollGraph(object):
             j = s.var_index
             B, D = rec["shapes"][j]
             N = B * D
-            spec = net.spec
-            nl = len(spec.layers)
-            fc = spec.preprocess == _abi.PRE_FC_ELU
-            P = 20 if fc else (2 if spec.preprocess == _abi.PRE_LOGSIGN else 1)
-            wdev = net.device_weights(eng)
-            acc = out.setdefault(s.key, {})
-
-            def add(mod, var, val):
-                k = (mod, var)
-                acc[k] = val if k not in acc else acc[k] + val
-
+            # loss = sum_t fx_t and x_{t+1} = x_t + delta_t  =>  dL/d(delta_t) = sum_{tau > t} g_tau
+            dxs = [None] * T
             Gacc = rec["g_final"][j].reshape(N).clone()
-            io = {"dd": eng.empty(N)}
-            if nl:
-                H = 20
-                carry_in, carry_out = eng.zeros(4, N, H), eng.empty(4, N, H)
-                io.update(act1=eng.empty(N, P + H), dz1=eng.empty(N, 4 * H), act2=eng.empty(N, 2 * H),
-                          dz2=eng.empty(N, 4 * H), h2=eng.empty(N, H))
-                if fc:
-                    io.update(feats=eng.empty(N, 2), du=eng.empty(N, H))
-            else:
-                io.update(act1=eng.empty(N, 2))
             for t in reversed(range(T)):
-                k = step0 + t
-                io.update(g=rec["g"][t][j], dx_next=Gacc)
-                if nl:
-                    io.update(st_prev=rec["st"][t][si], carry_in=carry_in, carry_out=carry_out,
-                              m=rec["m"][t][si], v=rec["v"][t][si])
-                eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, B, D)
-                dd = io["dd"].view(N, 1)
-                if nl:
-                    add("lstm_1", "w_gates", io["act1"].t() @ io["dz1"])
-                    add("lstm_1", "b_gates", io["dz1"].sum(0))
-                    add("lstm_2", "w_gates", io["act2"].t() @ io["dz2"])
-                    add("lstm_2", "b_gates", io["dz2"].sum(0))
-                    add("linear", "w", io["h2"].t() @ dd)
-                    if fc:
-                        add("input_projection", "w", io["feats"].t() @ io["du"])
-                        add("input_projection", "b", io["du"].sum(0))
-                    carry_in, carry_out = carry_out, carry_in
-                else:
-                    add("linear", "w", io["act1"][:, :P].t() @ dd)
-                add("linear", "b", dd.sum(0))
+                dxs[t] = Gacc
                 Gacc = Gacc + rec["g"][t][j].reshape(N)
+            self._bptt(net, out.setdefault(s.key, {}), B, D, T, step0, [g[j] for g in rec["g"]],
+                       [st[si] for st in rec["st"]], [m[si] for m in rec["m"]], [v[si] for v in rec["v"]], dxs)
         if self.sharded:
             import torch.distributed as dist
             for acc in out.values():
@@ -576,11 +588,11 @@ class UnrollGraph(object):
                     dist.all_reduce(acc[k])
         return {key: {k: eng.to_numpy(v) for k, v in acc.items()} for key, acc in out.items()}
 
-    def _adam_apply(self, grads, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    def _adam_apply(self, grads, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, slot="_adam"):
         """tf.train.AdamOptimizer's update (TF 1.x `_apply_dense`): lr_t = lr sqrt(1-b2^t)/(1-b1^t);
         m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; var <- var - lr_t m / (sqrt(v) + eps).
         A few thousand weights: done on the host in fp32, then re-packed for the kernels."""
-        st = self.__dict__.setdefault("_adam", {"t": 0, "m": {}, "v": {}})
+        st = self.__dict__.setdefault(slot, {"t": 0, "m": {}, "v": {}})   # one tf.train.AdamOptimizer per slot
         st["t"] += 1
         t = st["t"]
         f = np.float32
@@ -596,6 +608,21 @@ class UnrollGraph(object):
                 v = f(beta2) * v + f(1.0 - beta2) * g * g
                 st["m"][kk], st["v"][kk] = m, v
                 net.assign(mod, var, net.variables[mod][var] - lr_t * m / (np.sqrt(v) + f(epsilon)))
+
+    def gradients(self, feed=None):
+        """[d f(x * scale) / d x_j] at the current variables as device tensors (panel shaped),
+        without touching any state -- what DM/data_generator.py:44-45 builds with tf.gradients."""
+        T = self.len_unroll
+        self.len_unroll = 0
+        feed = dict(feed or {})
+        if self.rnnprop:
+            feed.setdefault(self.step, 1)                   # no optimizer step is taken: any value does
+        try:
+            rec = {}
+            self.launch(feed, commit=False, record=rec)
+        finally:
+            self.len_unroll = T
+        return rec["g_final"]
 
     def rewind(self, x0):
         """Device-side restart of the SAME problem instance: x <- x0 (list of device tensors),
@@ -713,6 +740,128 @@ class UnrollGraph(object):
             eng.reduce_fx(f_all, T + 1, descs[jd].B_local, descs[jd].B_global, fx)
         if record is not None:
             record["g_final"] = [g.clone() for g in grads]
+
+
+# ---------------------------------------------------------------------------
+# Imitation ("multi-task") unrolls of the train forks
+# ---------------------------------------------------------------------------
+class MtUnroll(object):
+    """One imitation-learning unroll: the optimizer networks are fed a recorded gradient
+    sequence of an analytic optimizer (``mt_inputs``, [T, P] per subset) and regress its updates
+    (``mt_labels``):  loss_mt = sum_t 0.5 sum_s ||label_t - net(input_t, state_t)||^2 / P_total,
+    with its own LSTM state (and RNNProp moments) carried between unrolls by ``update_mt``.
+    DM/meta_dm_train.py:421-499, 515-523; DM/meta_rnnprop_train.py:437-555, 567-584.
+
+    Forward = T launches of l2o_cwlstm_step on a zeroed scratch iterate (x <- 0 + delta), the
+    Adam step back-propagates through them with l2o_cwlstm_bwd_step (dL/d(delta_t) =
+    (delta_t - label_t) / P_total).  ``Session.run`` drives it like an UnrollGraph
+    (reset / execute / train_step)."""
+
+    def __init__(self, graph, mti):
+        self.graph, self.mti = graph, mti
+        self.len_unroll = graph.len_unroll
+        self.learning_rate = 0.01
+        T = self.len_unroll
+        self.keys = list(graph.net_keys)
+        self.sizes = [int(sum(int(np.prod(graph.x[j].shape)) for j in subset)) for subset in graph.subsets]
+        self.total = int(sum(self.sizes))
+        for k in self.keys:
+            if not isinstance(graph.nets[k], networks.StandardDeepLSTM):
+                raise NotImplementedError("imitation unrolls are implemented for the LSTM optimizer networks")
+        self.labels = [Placeholder("mt%d_label_subset%d" % (mti, j), (T, P)) for j, P in enumerate(self.sizes)]
+        self.inputs = [Placeholder("mt%d_input_subset%d" % (mti, j), (T, P)) for j, P in enumerate(self.sizes)]
+        self.state = None
+
+    @property
+    def engine(self):
+        return self.graph.engine
+
+    def reset(self):
+        eng, g = self.engine, self.graph
+        self.state, self.m, self.v = [], [], []
+        for k, P in zip(self.keys, self.sizes):
+            self.state.append(PackedState.zeros(eng, 1, P, g.nets[k].spec.layers))
+            self.m.append(eng.zeros(1, P) if g.rnnprop else None)
+            self.v.append(eng.zeros(1, P) if g.rnnprop else None)
+
+    def _forward(self, feed, commit, record=None):
+        eng, g = self.engine, self.graph
+        if self.state is None:
+            self.reset()
+        T = self.len_unroll
+        feed = feed or {}
+        for ph in self.inputs + self.labels:
+            if ph not in feed:
+                raise ValueError("You must feed a value for placeholder %r" % (ph.name,))
+        step0 = 1
+        if g.rnnprop:
+            if g.step not in feed:
+                raise ValueError("You must feed a value for placeholder 'step' (DM/util.py:59-60)")
+            step0 = int(feed[g.step])
+        b1, b2 = float(np.float32(g.beta1)), float(np.float32(g.beta2))
+        states = [st if commit else st.clone() for st in self.state]
+        ms = [m if (commit or m is None) else m.clone() for m in self.m]
+        vs = [v if (commit or v is None) else v.clone() for v in self.v]
+        loss = eng.zeros(1)
+        inv = 1.0 / float(self.total)
+        if record is not None:
+            record.update(step0=step0, g=[], st=[], m=[], v=[], dx=[])
+        ins = [eng.tensor(np.asarray(feed[ph], np.float32).reshape(T, P)) for ph, P in zip(self.inputs, self.sizes)]
+        labs = [eng.tensor(np.asarray(feed[ph], np.float32).reshape(T, P)) for ph, P in zip(self.labels, self.sizes)]
+        for t in range(T):
+            k = step0 + t
+            rg, rst, rm, rv, rdx = [], [], [], [], []
+            for si, (key, P) in enumerate(zip(self.keys, self.sizes)):
+                net = g.nets[key]
+                gin = ins[si][t].view(1, P)
+                delta = eng.zeros(1, P)
+                if record is not None:
+                    rg.append(gin)
+                    rst.append(None if states[si].packed is None else states[si].packed.clone())
+                eng.lstm_step(net.spec, net.wpack(eng), gin, ms[si], vs[si], b1 ** k, b2 ** k,
+                              None if states[si].packed is None else states[si].packed, delta, 1, P)
+                diff = delta.view(P) - labs[si][t]
+                loss += (0.5 * inv) * (diff * diff).sum()
+                if record is not None:
+                    rm.append(None if ms[si] is None else ms[si].clone())
+                    rv.append(None if vs[si] is None else vs[si].clone())
+                    rdx.append(diff * inv)
+            if record is not None:
+                for lst, val in zip((record["g"], record["st"], record["m"], record["v"], record["dx"]),
+                                    (rg, rst, rm, rv, rdx)):
+                    lst.append(val)
+        return loss
+
+    def execute(self, feed, commit):
+        loss = self._forward(feed, commit)
+        return {"loss": np.float32(self.engine.to_numpy(loss)[0])}
+
+    def train_step(self, feed, commit, learning_rate):
+        """loss_mt + one step of this task's own tf.train.AdamOptimizer (DM/meta_dm_train.py:549-553)."""
+        rec = {}
+        loss = self._forward(feed, commit, record=rec)
+        g = self.graph
+        T = self.len_unroll
+        out = {}
+        for si, (key, P) in enumerate(zip(self.keys, self.sizes)):
+            g._bptt(g.nets[key], out.setdefault(key, {}), 1, P, T, rec["step0"], [r[si] for r in rec["g"]],
+                    [r[si] for r in rec["st"]], [r[si] for r in rec["m"]], [r[si] for r in rec["v"]],
+                    [r[si] for r in rec["dx"]])
+        eng = self.engine
+        grads = {key: {k: eng.to_numpy(v) for k, v in acc.items()} for key, acc in out.items()}
+        g._adam_apply(grads, learning_rate, slot="_adam_mt%d" % self.mti)
+        return {"loss": np.float32(eng.to_numpy(loss)[0])}
+
+
+def make_mt_handles(graph, num_mt):
+    """(loss_mt, steps_mt, update_mt, reset_mt, mt_labels, mt_inputs) of the train forks."""
+    if not hasattr(graph, "mt") or len(graph.mt) != num_mt:
+        graph.mt = [MtUnroll(graph, i) for i in range(num_mt)]
+    loss_mt = [Fetch(m, "loss", "loss_mt%d" % i) for i, m in enumerate(graph.mt)]
+    steps_mt = [Fetch(m, "step", "step_mt%d" % i) for i, m in enumerate(graph.mt)]
+    update_mt = [[Fetch(m, "update", "update_mt%d" % i)] for i, m in enumerate(graph.mt)]
+    reset_mt = [[Fetch(m, "reset", "reset_mt%d" % i)] for i, m in enumerate(graph.mt)]
+    return loss_mt, steps_mt, update_mt, reset_mt, [m.labels for m in graph.mt], [m.inputs for m in graph.mt]
 
 
 # ---------------------------------------------------------------------------

@@ -44,9 +44,19 @@ def run_epoch(sess, cost_op, ops, reset, num_unrolls,
             if step is not None:
                 feed_dict[step] = i * unroll_len + 1
             cost = sess.run([cost_op] + ops, feed_dict=feed_dict)[0]
-    else:
-        raise NotImplementedError("task_i != -1 feeds minibatch placeholders of the NN optimizees "
-                                  "(DM/util.py:62-74), which are outside this build's hot path")
+    else:                                               # imitation epoch, DM/util.py:62-74
+        assert data is not None
+        assert input_pl is not None
+        assert label_pl is not None
+        feed_dict = {}
+        for ri in range(num_unrolls):
+            for pl, dat in zip(label_pl, data["labels"][ri]):
+                feed_dict[pl] = dat
+            for pl, dat in zip(input_pl, data["inputs"][ri]):
+                feed_dict[pl] = dat
+            if step is not None:
+                feed_dict[step] = ri * unroll_len + 1
+            cost = sess.run([cost_op] + ops, feed_dict=feed_dict)[0]
     return timer() - start, cost
 
 

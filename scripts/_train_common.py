@@ -8,11 +8,14 @@ open_l2o_amd -- same flags, same schedule:
     best optimizer (`.l2l-{epoch}` / `.l2l-0`);
   * --if_cl: curriculum over horizons 100..3000 with save / restore of the best weights per stage
     (DM/train_dm.py:65-69, 198-226);
-  * --if_scale: random per-coordinate rescaling of the optimizee (DM/util.py:40-54).
-Imitation learning (--if_mt, DM/data_generator.py) is not implemented.
+  * --if_scale: random per-coordinate rescaling of the optimizee (DM/util.py:40-54);
+  * --if_mt: with probability mt_ratio an epoch is an imitation epoch -- the trajectory of an
+    analytic optimizer (--optimizers adam,rmsprop,nag; open_l2o_amd.data_generator) is recorded
+    on a fresh problem and the networks regress its updates (DM/train_dm.py:112-146).
 """
 import argparse
 import os
+import random
 import sys
 from timeit import default_timer as timer
 
@@ -41,6 +44,10 @@ def parse_flags(rnnprop):
     p.add_argument("--min_num_eval", type=int, default=3)
     p.add_argument("--if_mt", action="store_true")
     p.add_argument("--num_mt", type=int, default=1)
+    p.add_argument("--optimizers", default="adam", help="comma list of imitation teachers: adam, rmsprop, nag")
+    p.add_argument("--mt_ratio", type=float, default=0.3)
+    p.add_argument("--mt_ratios", default="0.3 0.3 0.3" if rnnprop else "0.0 0.1 0.3 0.3 0.3 0.3 0.3 0.3")
+    p.add_argument("--k", type=int, default=1, help="teacher steps per recorded update (mt_k)")
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--batch_size", type=int, default=None)
     p.add_argument("--num_dims", type=int, default=None)
@@ -56,8 +63,6 @@ class Trainer(object):
     def __init__(self, flags, rnnprop):
         self.f = flags
         self.rnnprop = rnnprop
-        if flags.if_mt:
-            raise NotImplementedError("--if_mt (imitation learning, DM/data_generator.py) is not implemented")
         if flags.seed:
             meta.set_random_seed(flags.seed)
         if flags.save_path and not os.path.exists(flags.save_path):
@@ -71,14 +76,25 @@ class Trainer(object):
         kw = dict(learning_rate=flags.learning_rate, net_assignments=assignments,
                   second_derivatives=flags.second_derivatives)
         self.step_ph = None
+        num_mt = getattr(flags, "num_mt", 1) if flags.if_mt else 0
         if rnnprop:
-            self.optimizer = meta_rnnprop_train.MetaOptimizer(0, flags.beta1, flags.beta2, **net_config)
+            self.optimizer = meta_rnnprop_train.MetaOptimizer(num_mt, flags.beta1, flags.beta2, **net_config)
             out = self.optimizer.meta_minimize(problem, flags.unroll_length, **kw)
             self.minimize, self.scale, self.var_x, self.step_ph = out[0], out[1], out[2], out[5]
+            mt = out[6:]
         else:
-            self.optimizer = meta_dm_train.MetaOptimizer(0, **net_config)
+            self.optimizer = meta_dm_train.MetaOptimizer(num_mt, **net_config)
             out = self.optimizer.meta_minimize(problem, flags.unroll_length, **kw)
             self.minimize, self.scale, self.var_x = out[0], out[1], out[2]
+            mt = out[5:]
+        self.loss_mt, self.steps_mt, self.update_mt, self.reset_mt, self.mt_labels, self.mt_inputs = mt
+        self.data_mt = None
+        if flags.if_mt:                                        # DM/train_dm.py:91-96
+            from open_l2o_amd.data_generator import data_loader
+            self.data_mt = data_loader(problem, self.var_x, out[3], out[4], self.scale, getattr(flags, "optimizers", "adam"),
+                                       flags.unroll_length)
+            if len(self.data_mt.optimizers) < num_mt:
+                raise ValueError("--num_mt %d needs as many --optimizers" % num_mt)
 
     def _epoch(self, sess, ops, n_unrolls, train):
         step, update, reset, cost_op, _ = self.minimize
@@ -87,6 +103,20 @@ class Trainer(object):
             extra.update(scale=self.scale, rd_scale=self.f.if_scale, rd_scale_bound=self.f.rd_scale_bound,
                          assign_func=lambda vals: [v.load(a) for v, a in zip(self.var_x, vals)], var_x=self.var_x)
         return util.run_epoch(sess, cost_op, ops, reset, n_unrolls, **extra)
+
+    def _assign(self, vals):
+        for v, a in zip(self.var_x, vals):
+            v.load(a)
+
+    def _imitation_epoch(self, sess, task_i, n_unrolls):
+        """DM/train_dm.py:134-146."""
+        f = self.f
+        data = self.data_mt.get_data(task_i, sess, n_unrolls, self._assign, f.rd_scale_bound, if_scale=f.if_scale,
+                                     mt_k=getattr(f, "k", 1))
+        extra = dict(step=self.step_ph, unroll_len=f.unroll_length) if self.rnnprop else {}
+        return util.run_epoch(sess, self.loss_mt[task_i], [self.update_mt[task_i], self.steps_mt[task_i]],
+                              self.reset_mt[task_i], n_unrolls, task_i=task_i, data=data,
+                              label_pl=self.mt_labels[task_i], input_pl=self.mt_inputs[task_i], **extra)
 
     def _evaluate(self, sess, n_unrolls):
         update = self.minimize.update
@@ -99,11 +129,23 @@ class Trainer(object):
         step, update = self.minimize.step, self.minimize.update
         best, n_eval, improved = float("inf"), 0, False
         t0 = timer()
+        mt_ratios = [float(r) for r in getattr(f, "mt_ratios", "0.3").split()]
+        mti = -1
         with MonitoredSession() as sess:
-            sess.run(self.minimize.reset)
+            for rst in [self.minimize.reset] + self.reset_mt:
+                sess.run(rst)
             for e in range(f.num_epochs):
                 n_train = stages[stage] if f.if_cl else f.num_steps // f.unroll_length
-                _, cost = self._epoch(sess, [update, step], n_train, train=True)
+                task_i = -1
+                if f.if_mt:                                    # pick a task, DM/train_dm.py:112-127
+                    mt_ratio = (mt_ratios[min(stage, len(mt_ratios) - 1)] if f.if_cl else getattr(f, "mt_ratio", 0.3))
+                    if random.random() < mt_ratio:
+                        mti = (mti + 1) % f.num_mt
+                        task_i = mti
+                if task_i == -1:
+                    _, cost = self._epoch(sess, [update, step], n_train, train=True)
+                else:
+                    _, cost = self._imitation_epoch(sess, task_i, n_train)
                 print("training_loss={}".format(cost))
                 if (e + 1) % f.evaluation_period:
                     continue

@@ -288,8 +288,8 @@ def test_train_fork_arities_and_scale_placeholder(engine):
     out = meta_rnnprop_train.MetaOptimizer(0, 0.95, 0.95, **_net_config(O.RNNPROP, make_params(O.RNNPROP, 1),
                                                                         key="rp")).meta_loss(problem, 2)
     assert len(out) == 11
-    with pytest.raises(NotImplementedError):
-        meta_dm_train.MetaOptimizer(1, **_net_config(cfg, params))
+    out = meta_dm_train.MetaOptimizer(1, **_net_config(cfg, params)).meta_loss(problem, T)
+    assert len(out) == 10 and [len(o) for o in out[5:]] == [1, 1, 1, 1, 1]   # one imitation task (tests/test_imitation.py)
     out = optimizer.meta_minimize(problem, T, learning_rate=0.01)    # numerics: tests/test_meta_gradient.py
     assert len(out) == 11 and hasattr(out[0], "step")               # DM/meta_dm_train.py:529-558
 
