@@ -204,6 +204,40 @@ def test_fused_unroll_vs_oracle(eng, name, kind, B, D, M):
         assert max_abs(m, res.m.reshape(B, D)) < 1e-6 * max(1.0, np.abs(res.m).max())
 
 
+def test_fused_unroll_random_shapes(eng):
+    """Seeded sweep over odd shapes (tile counts, ragged last tiles, M != D, batch not a multiple
+    of the 8-problem launch groups): fused kernel (pair and single-CU forms) == oracle."""
+    import os
+    rng = np.random.default_rng(2024)
+    cases = []
+    for _ in range(14):
+        kind = ["quadratic", "lasso", "rastrigin", "square_cos"][int(rng.integers(4))]
+        D = int(rng.integers(1, 129))
+        B = int(rng.integers(1, 20))
+        M = int(rng.integers(1, 16 * ((D + 15) // 16) + 1)) if kind == "lasso" else None
+        name = ["dm", "dm_logsign", "rnnprop"][int(rng.integers(3))]
+        cases.append((kind, B, D, M, name))
+    worst = 0.0
+    for kind, B, D, M, name in cases:
+        cfg = ORACLE_CFGS[name]
+        params = make_params(cfg, seed=B * 131 + D, trained_like=True)
+        prob, x0, arrays = make_problem(kind, B, D, seed=D * 7 + B, M=M)
+        T = 6
+        res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=3)
+        for no_pair in (False, True):
+            if no_pair:
+                os.environ["L2O_NO_PAIR"] = "1"
+            try:
+                fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T, step0=3)
+            finally:
+                os.environ.pop("L2O_NO_PAIR", None)
+            e = rel_err(fx, res.fx)
+            worst = max(worst, e)
+            assert e < 1e-5, (kind, B, D, M, name, no_pair, e)
+            assert max_abs(x, res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max())), (kind, B, D, M, name)
+    print("random-shape sweep: worst rel fx err %.3g over %d cases x 2 kernels" % (worst, len(cases)))
+
+
 def test_fused_unroll_continuation_and_scale(eng):
     """Two T=10 launches carrying x/state/m/v (the harness' `update`) == one T=20 launch;
     x_scale placeholder chain rule; B_global > B_local."""
