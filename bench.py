@@ -183,6 +183,7 @@ def main():
         return fx
 
     def fence():
+        graph.wait_fx()                                     # the asynchronous loss all-reduces (N > 1)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -122,10 +122,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int ntl = (ntiles - wave + nwaves - 1) / nwaves;         // tiles of this wave
   // global tile index -> segment (wave-uniform scalar work)
   struct Loc { const float* g; float *m, *v, *st, *x; int tile, tpp, D; };
+  Loc L0;                                                        // the common single-panel launch: fields read once
+  L0.tile = 0; L0.g = sg.g[0]; L0.m = sg.m[0]; L0.v = sg.v[0]; L0.st = sg.st[0]; L0.x = sg.x[0];
+  L0.tpp = sg.tpp[0]; L0.D = sg.D[0];
+  const bool single = sg.n == 1;
   auto locate = [&](int tile) {
+    Loc L = L0;
+    if (single) {
+      L.tile = tile;
+      return L;
+    }
     int sidx = 0;
     while (sidx + 1 < sg.n && tile >= sg.tile_end[sidx]) ++sidx;
-    Loc L;
     L.tile = tile - (sidx ? sg.tile_end[sidx - 1] : 0);
     L.g = sg.g[sidx]; L.m = sg.m[sidx]; L.v = sg.v[sidx]; L.st = sg.st[sidx]; L.x = sg.x[sidx];
     L.tpp = sg.tpp[sidx]; L.D = sg.D[sidx];

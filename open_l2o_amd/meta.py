@@ -364,6 +364,7 @@ class UnrollGraph(object):
         fx, xs = self.launch(feed, commit)
         eng = self.engine
         T = self.len_unroll
+        self.wait_fx()
         fx_host = eng.to_numpy(fx)                       # host sync
         if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
             eng.check_unroll_status()
@@ -422,10 +423,23 @@ class UnrollGraph(object):
             B, D = self._panel_shape(var)
             panels.append(xv.view(B, D))
 
+        # fx[0..T] of this launch.  Sharded runs all-reduce it ASYNCHRONOUSLY (the next unroll
+        # does not wait for the 404-byte collective); the buffers rotate so that a collective in
+        # flight is never overwritten, and every reader goes through wait_fx().
         key = T
-        if key not in self._fx_cache:
-            self._fx_cache[key] = eng.zeros(T + 1)
-        fx = self._fx_cache[key]
+        ring = self._fx_cache.get(key)
+        if ring is None:
+            n = 4 if self.sharded else 1
+            ring = self._fx_cache[key] = {"bufs": [eng.zeros(T + 1) for _ in range(n)], "work": [None] * n, "i": 0}
+        fused_path = record is None and self._fused_ok(descs)
+        if not fused_path:
+            ring["i"] = 0                                  # a captured launch sequence owns buffer 0
+        i = ring["i"]
+        ring["i"] = (i + 1) % len(ring["bufs"]) if fused_path else 0
+        if ring["work"][i] is not None:
+            ring["work"][i].wait()
+            ring["work"][i] = None
+        fx = ring["bufs"][i]
 
         if events is not None:
             events[0].record()
@@ -434,7 +448,7 @@ class UnrollGraph(object):
             self._draw_minibatches(T)
             record.update(step0=step0, shapes=[tuple(pn.shape) for pn in panels])
             self._run_steps(T, step0, descs, panels, slots, states, ms, vs, fx, record=record)
-        elif self._fused_ok(descs):
+        elif fused_path:
             self.last_path = "fused"
             s, d = slots[0], descs[0]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
@@ -469,11 +483,19 @@ class UnrollGraph(object):
 
         if self.sharded:
             import torch.distributed as dist
-            dist.all_reduce(fx)
+            ring["work"][i] = dist.all_reduce(fx, async_op=True)
         if commit:
             for s, st in zip(slots, states):
                 s.state = st
         return fx, xs
+
+    def wait_fx(self):
+        """Make the current stream (NCCL) / the host (gloo) wait for the loss all-reduces in flight."""
+        for ring in self._fx_cache.values():
+            for k, w in enumerate(ring["work"]):
+                if w is not None:
+                    w.wait()
+                    ring["work"][k] = None
 
     def _draw_minibatches(self, T):
         """A fresh uniform minibatch per evaluation of a neural optimizee (DM/problems.py:282-286):
@@ -506,6 +528,7 @@ class UnrollGraph(object):
         fx, xs = self.launch(feed, commit, record=record)
         eng = self.engine
         T = self.len_unroll
+        self.wait_fx()
         fx_host = eng.to_numpy(fx)
         x_out = [eng.to_numpy(xv).reshape(self._local_shape(var)) for xv, var in zip(xs, self.x)]
         grads = self._backward(T, record)
