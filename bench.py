@@ -50,6 +50,11 @@ def alg_bytes_per_coord_step(problem, net, D, M):
     return base + 8 * D + 8                      # rastrigin
 
 
+def alg_bytes_lasso_shared(net, B, D, M):
+    """SURVEY.md 8(d), shared-A variant: the matrix is streamed twice per step for the WHOLE batch."""
+    return 8 + 640 + (16 if net == "rnnprop" else 0) + 8.0 * M / B + 4.0 * M / D
+
+
 def alg_flops_per_coord_step(problem, net, D, M):
     lstm = {"dm": 9800, "dm_logsign": 9960, "rnnprop": 12920 + 15}[net]
     if problem == "mnist":
@@ -102,6 +107,13 @@ def build_workload(args, Bg):
         opts = {"batch_size": args.batch, "data": problems.synthetic_mnist(4096, seed=5)}
     problem, net_config, net_assignments = util.get_config(
         args.problem, problem_options=opts, net_name="RNNprop" if args.net == "rnnprop" else None)
+    if args.problem == "lasso" and args.shared_matrix:
+        # the shared-A variant of SURVEY.md 8(d): ONE sensing matrix [rows, dims] for every problem
+        from open_l2o_amd import problems
+        rng = np.random.default_rng(4321)
+        rows = args.rows or D
+        problem = problems.lasso_fixed(rng.random((rows, D), dtype=np.float32),
+                                       rng.random((Bg, rows, 1), dtype=np.float32), l=0.1)
     if args.net == "dm_logsign" or (args.problem == "mnist" and args.net == "dm"):
         net_config = {"cw": util.get_default_net_config(None)}
     key = next(iter(net_config))
@@ -134,6 +146,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin", "mnist"])
     ap.add_argument("--rows", type=int, default=None, help="lasso rows M (default: dims)")
+    ap.add_argument("--shared-matrix", dest="shared_matrix", action="store_true",
+                    help="lasso: ONE sensing matrix for all problems (SURVEY 8d shared-A variant)")
     ap.add_argument("--net", default="dm", choices=["dm", "dm_logsign", "rnnprop"])
     args = ap.parse_args()
 
@@ -227,13 +241,16 @@ def main():
         coord_steps = (1 if args.problem == "mnist" else B) * D * T     # per GPU per unroll
         value = world * coord_steps * args.steps / dt
         Mrows = B if args.problem == "mnist" else (args.rows or D)
-        bpc = alg_bytes_per_coord_step(args.problem, args.net, D, Mrows)
+        shared = args.problem == "lasso" and args.shared_matrix
+        bpc = (alg_bytes_lasso_shared(args.net, B, D, Mrows) if shared
+               else alg_bytes_per_coord_step(args.problem, args.net, D, Mrows))
         alg = bpc * coord_steps                            # algorithmic bytes per unroll
         achieved = alg / (kern_ms * 1e-3)
         flops = alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps
         netname = {"dm": "L2O-DM CoordinateWiseDeepLSTM(20,20)", "dm_logsign": "L2O-DM (LogAndSign k=5)",
                    "rnnprop": "L2O-RNNProp (fc+ELU, tanh, 0.01)"}[args.net]
-        probname = {"quadratic": "Quadratic d=%d" % D, "lasso": "Lasso A in R^{%dx%d} l=0.1" % (Mrows, D),
+        probname = {"quadratic": "Quadratic d=%d" % D,
+                    "lasso": "Lasso A in R^{%dx%d} l=0.1%s" % (Mrows, D, " (one A shared by the batch)" if shared else ""),
                     "rastrigin": "Rastrigin d=%d" % D,
                     "mnist": "MLP 784-20-10 (sigmoid) on synthetic MNIST-shaped data, minibatch %d" % B}[args.problem]
         is_c2 = (args.problem, args.net, D, B, T) == ("quadratic", "dm", 128, 128, 100)
@@ -272,7 +289,7 @@ def main():
                                  "unroll kernels; the fused kernel keeps x, LSTM state and W on-chip, so real HBM "
                                  "traffic is far below this figure (frac can exceed 1) and the kernel is bound by one wave's serial instruction stream -- DESIGN.md 5"},
         }
-        if world == 1 and not args.no_cpu_baseline and args.problem != "mnist":
+        if world == 1 and not args.no_cpu_baseline and args.problem != "mnist" and not shared:
             names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
                      "rastrigin": ("A", "B", "C")}[args.problem]
             g = graph._by_name

@@ -77,13 +77,15 @@ typedef struct l2o_net_cfg {
  * creates through tf.get_variable (DM/problems.py:84-96, 114-126, 149-165, 186-204),
  * sharded over GPUs by problem index.  The loss is a mean over the GLOBAL batch
  * (DM/problems.py:99, 131, 211), hence B_global. */
+#define L2O_PROB_W_SHARED 1
+
 typedef struct l2o_problem {
   int32_t kind;          /* L2O_PROB_*                                                    */
   int32_t B_local;       /* problems held by this GPU                                     */
   int32_t B_global;      /* batch size in the reduce_mean (== B_local on one GPU)         */
   int32_t D;             /* optimizee parameters per problem (num_dims)                   */
   int32_t M;             /* rows of the matrix (== D except lasso_fixed)                  */
-  int32_t reserved;
+  int32_t flags;      /* L2O_PROB_W_SHARED: W is ONE [M, D] matrix used by every problem (batch stride 0) */
   double l1;             /* lasso `l`                                                     */
   double alpha;          /* rastrigin `alpha`                                             */
   const float* W;        /* device [B_local, M, D]  quadratic w / lasso w / rastrigin A   */

@@ -45,7 +45,7 @@ class Problem(C.Structure):
     """struct l2o_problem"""
     _fields_ = [
         ("kind", C.c_int32), ("B_local", C.c_int32), ("B_global", C.c_int32),
-        ("D", C.c_int32), ("M", C.c_int32), ("reserved", C.c_int32),
+        ("D", C.c_int32), ("M", C.c_int32), ("flags", C.c_int32),
         ("l1", C.c_double), ("alpha", C.c_double),
         ("W", C.c_void_p), ("y", C.c_void_p), ("C", C.c_void_p), ("x_scale", C.c_void_p),
     ]
@@ -69,6 +69,9 @@ class BwdIO(C.Structure):
     """struct l2o_bwd_io"""
     _fields_ = [(n, C.c_void_p) for n in ("g", "m", "v", "st_prev", "dx_next", "carry_in", "carry_out", "act1",
                                           "dz1", "act2", "dz2", "h2", "dd", "feats", "du")]
+
+
+PROB_W_SHARED = 1     # l2o_problem.flags: W is one [M, D] matrix for every problem
 
 
 class StepSeg(C.Structure):

@@ -59,6 +59,7 @@ class ProblemDesc:
     y: Optional[torch.Tensor] = None
     C: Optional[torch.Tensor] = None
     x_scale: Optional[torch.Tensor] = None
+    w_shared: bool = False          # W is ONE [M, D] matrix for every problem (L2O_PROB_W_SHARED)
 
 
 @dataclasses.dataclass
@@ -139,6 +140,7 @@ class HipEngine(object):
         c = _abi.Problem()
         c.kind, c.B_local, c.B_global, c.D, c.M = p.kind, p.B_local, p.B_global, p.D, p.M
         c.l1, c.alpha = float(p.l1), float(p.alpha)
+        c.flags = _abi.PROB_W_SHARED if p.w_shared else 0
         c.W, c.y, c.C, c.x_scale = _ptr(p.W), _ptr(p.y), _ptr(p.C), _ptr(p.x_scale)
         return c
 

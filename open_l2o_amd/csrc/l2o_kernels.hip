@@ -54,6 +54,7 @@ struct NetParams {
 
 struct ProbParams {
   int kind, B_local, D, M;
+  int w_shared;      // W is one [M, D] matrix for every problem
   float inv_bg;      // 1 / B_global
   float l1, alpha;
   float twopi;       // 2*pi (rastrigin) or 2*3.1415926 (square_cos, DM/problems.py:989)
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
   __syncthreads();
 
   if (pp.kind != L2O_PROB_SIMPLE) {
-    const float* Wb = pp.W + (size_t)b * M * D;
+    const float* Wb = pp.W + (pp.w_shared ? (size_t)0 : (size_t)b * M * D);
     const float* yb = pp.y + (size_t)b * M;
     const float coef = (pp.kind == L2O_PROB_QUADRATIC || pp.kind == L2O_PROB_SQUARE_COS) ? 1.0f : 0.5f;
     if (VEC) {
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
     for (int j = tid; j < D; j += kFgThreads) gb[j] = 2.0f * xs[j] * pp.inv_bg * (sb ? sb[j] : 1.0f);
     return;
   }
-  const float* Wb = pp.W + (size_t)b * M * D;
+  const float* Wb = pp.W + (pp.w_shared ? (size_t)0 : (size_t)b * M * D);
   const float cg = (pp.kind == L2O_PROB_QUADRATIC || pp.kind == L2O_PROB_SQUARE_COS) ? 2.0f : 1.0f;
   auto finish = [&](int j, float s) {
     float gj = cg * s;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   const int b = blockIdx.x;
 
   // ---- stage the problem into LDS (zero padded), both orientations ---------
-  const float* Wb = pp.W + (size_t)b * M * D;
+  const float* Wb = pp.W + (pp.w_shared ? (size_t)0 : (size_t)b * M * D);
   for (int i = tid; i < 2 * SQ * S + 3 * SQ; i += blockDim.x) sm[i] = 0.0f;
   __syncthreads();
   for (int e = tid; e < M * D; e += blockDim.x) {
@@ -713,6 +714,7 @@ static ProbParams make_prob_params(const l2o_problem* p) {
   pp.B_local = p->B_local;
   pp.D = p->D;
   pp.M = p->kind == L2O_PROB_SIMPLE ? 0 : p->M;
+  pp.w_shared = (p->flags & L2O_PROB_W_SHARED) ? 1 : 0;
   pp.inv_bg = 1.0f / (float)p->B_global;
   pp.l1 = (float)p->l1;
   pp.alpha = p->kind == L2O_PROB_SQUARE_COS ? 10.0f : (float)p->alpha;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   // ---- the matrix lives in registers: no LDS bandwidth in the two GEMV passes -------------
   //  wr[p][m] : row (2 wv + p) 16 + gr, own columns 16 m + 4 gq + {0..3}     (partial r = W xs)
   //  wt[m]    : own column wv 16 + gr,   rows       16 m + 4 gq + {0..3}     (g = W^T r)
-  const float* Wb = pp.W + (size_t)b * M * D;
+  const float* Wb = pp.W + (pp.w_shared ? (size_t)0 : (size_t)b * M * D);
   const int col0 = half * NC;
   float4 wr[2][NWH], wt[CH];
 #pragma unroll

@@ -245,7 +245,7 @@ class UnrollGraph(object):
         self.sharded = self.world > 1 and all(t.kind in batched_kinds for t in self.terms)
         B_global = decls[0].shape[0] if self.sharded else None
         if self.sharded:
-            if any(d.shape[0] != B_global for d in decls):
+            if any(d.shape[0] != B_global for d in decls if not getattr(d, "shared", False)):
                 raise ValueError("cannot shard: variables disagree on the batch dimension")
             if B_global % self.world:
                 raise ValueError("batch_size %d is not divisible by world size %d" % (B_global, self.world))
@@ -256,7 +256,7 @@ class UnrollGraph(object):
         by_name = {}
         self.x, self.constants = [], []
         for d in decls:
-            v = Variable(d, self, self.sharded)
+            v = Variable(d, self, self.sharded and not getattr(d, "shared", False))
             by_name[d.name] = v
             (self.x if d.trainable else self.constants).append(v)
         self._by_name = by_name
@@ -324,7 +324,8 @@ class UnrollGraph(object):
             C = cache["val"]
         M = term.consts["W"].shape[1]
         return ProblemDesc(term.kind, B, Bg, D, M=M, l1=term.hyper.get("l1", 0.0),
-                           alpha=term.hyper.get("alpha", 0.0), W=W, y=y, C=C, x_scale=x_scale)
+                           alpha=term.hyper.get("alpha", 0.0), W=W, y=y, C=C, x_scale=x_scale,
+                           w_shared=bool(getattr(term.consts["W"], "shared", False)))
 
     # -- reset / init (DM/meta.py:379-383; RNNProp :559-566) -------------------
     def reset(self):

@@ -41,12 +41,19 @@ def _full_name(name):
     return "/".join(_scope + [name])
 
 
-def get_variable(name, shape, dtype="float32", initializer=None, trainable=True):
+class _SharedVarDecl(VarDecl):
+    """A constant with ONE copy for the whole batch (leading dimension 1; never batch-sharded)."""
+    __slots__ = ()
+    shared = True
+
+
+def get_variable(name, shape, dtype="float32", initializer=None, trainable=True, shared=False):
     """Declare an optimizee variable (the reference calls ``tf.get_variable`` here;
     DM/meta.py:88-155 relies on that to harvest / substitute variables)."""
     if dtype not in ("float32", np.float32):
         raise ValueError("only float32 optimizees are implemented (got %r)" % (dtype,))
-    decl = VarDecl(_full_name(name), tuple(int(s) for s in shape), initializer, bool(trainable))
+    cls = _SharedVarDecl if shared else VarDecl
+    decl = cls(_full_name(name), tuple(int(s) for s in shape), initializer, bool(trainable))
     if _decls is not None:
         _decls.append(decl)
     return decl
@@ -163,17 +170,22 @@ def lasso(batch_size=128, num_dims=10, stddev=0.01, l=0.005, dtype="float32", nu
 
 
 def lasso_fixed(data_A, data_b, stddev=0.01, l=0.005, dtype="float32"):
-    """lasso problem on given data A [B,M,N], b [B,M,1].  DM/problems.py:137-175."""
+    """lasso problem on given data A [B,M,N], b [B,M,1].  DM/problems.py:137-175.
+    A 2-D ``data_A`` [M,N] is ONE sensing matrix shared by all B problems (the
+    kernels then read it with batch stride 0 -- 512 KiB instead of 128 MiB for config 3)."""
     a = np.asarray(data_A, dtype=np.float32)
     b = np.asarray(data_b, dtype=np.float32)
-    if a.ndim != 3 or b.shape[:2] != a.shape[:2]:
-        raise ValueError("lasso_fixed expects data_A [B,M,N] and data_b [B,M,1]")
+    shared = a.ndim == 2
+    if shared:
+        a = a[None]
+    if a.ndim != 3 or b.ndim != 3 or b.shape[1] != a.shape[1] or (not shared and b.shape[0] != a.shape[0]):
+        raise ValueError("lasso_fixed expects data_A [B,M,N] (or one shared [M,N]) and data_b [B,M,1]")
 
     def build():
-        x = get_variable("x", shape=[a.shape[0], a.shape[2]], dtype=dtype,
+        x = get_variable("x", shape=[b.shape[0], a.shape[2]], dtype=dtype,
                          initializer=random_normal_initializer(stddev=stddev))
         w = get_variable("w", shape=a.shape, dtype=dtype, initializer=constant_initializer(a),
-                         trainable=False)
+                         trainable=False, shared=shared)
         y = get_variable("y", shape=b.shape, dtype=dtype, initializer=constant_initializer(b),
                          trainable=False)
         return [Term(_abi.PROB_LASSO, x, {"W": w, "y": y}, {"l1": float(l)}, 1.0)]

@@ -67,7 +67,8 @@ def device_problem(eng, arrays, B, D, B_global=None, x_scale=None):
                        W=eng.tensor(arrays["W"]) if "W" in arrays else None,
                        y=eng.tensor(arrays["y"]) if "y" in arrays else None,
                        C=eng.tensor(arrays["C"]) if "C" in arrays else None,
-                       x_scale=None if x_scale is None else eng.tensor(x_scale))
+                       x_scale=None if x_scale is None else eng.tensor(x_scale),
+                       w_shared=bool(arrays.get("w_shared", False)))
 
 
 def rel_err(a, b):

@@ -82,6 +82,10 @@ class OracleEngine(object):
     # ------------------------------------------------------------------ compute
     def _oracle_problem(self, p):
         n = lambda t: None if t is None else t.numpy()
+        if getattr(p, "w_shared", False):                   # one matrix for every problem: materialise the batch
+            import dataclasses
+            Wfull = np.broadcast_to(n(p.W).reshape(1, p.M, p.D), (p.B_local, p.M, p.D)).copy()
+            p = dataclasses.replace(p, W=torch.from_numpy(Wfull), w_shared=False)
         if p.kind == _abi.PROB_SIMPLE:
             return O.SimpleMulti(p.D), (p.D,)
         if p.kind == _abi.PROB_QUADRATIC:

@@ -204,6 +204,31 @@ def test_fused_unroll_vs_oracle(eng, name, kind, B, D, M):
         assert max_abs(m, res.m.reshape(B, D)) < 1e-6 * max(1.0, np.abs(res.m).max())
 
 
+@pytest.mark.parametrize("kind,B,D,M", [("lasso", 5, 40, 24), ("quadratic", 6, 32, None), ("lasso", 3, 300, 100)])
+def test_shared_matrix_equals_replicated(eng, kind, B, D, M):
+    """L2O_PROB_W_SHARED (one [M, D] matrix, batch stride 0) == the same matrix replicated per
+    problem, bit for bit, in l2o_problem_fg and (when the size fits) in the fused unroll."""
+    cfg = ORACLE_CFGS["rnnprop"]
+    params = make_params(cfg, seed=81, trained_like=True)
+    prob, x0, arrays = make_problem(kind, B, D, seed=82, M=M)
+    W0 = np.ascontiguousarray(arrays["W"][0])
+    rep = dict(arrays, W=np.broadcast_to(W0, arrays["W"].shape).copy())
+    sh = dict(arrays, W=W0, w_shared=True)
+    outs = []
+    for a in (rep, sh):
+        pd = device_problem(eng, a, B, D)
+        x = eng.tensor(x0.reshape(B, D))
+        f, g = eng.zeros(B), eng.zeros(B, D)
+        eng.problem_fg(pd, x, f, g)
+        res = [eng.to_numpy(f), eng.to_numpy(g)]
+        if eng.unroll_supported(spec_of(cfg), pd):
+            res += list(_run_fused(eng, cfg, params, a, x0, B, D, 6)[:2])
+        outs.append(res)
+    assert len(outs[0]) == len(outs[1])
+    for r, s_ in zip(*outs):
+        assert np.array_equal(r, s_)
+
+
 def test_fused_unroll_random_shapes(eng):
     """Seeded sweep over odd shapes (tile counts, ragged last tiles, M != D, batch not a multiple
     of the 8-problem launch groups): fused kernel (pair and single-CU forms) == oracle."""

@@ -405,3 +405,23 @@ def test_mnist_mlp_optimizee(engine, activation):
     assert rel_err(fx2, fx_b[-1]) < 2e-5 and rel_err(loss2, fx_b.sum()) < 2e-5
     for got, want in zip(x2, vb):
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+
+
+def test_lasso_fixed_shared_matrix(engine):
+    """problems.lasso_fixed with ONE [M, N] sensing matrix for the whole batch == the batched form."""
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=91, trained_like=True)
+    B, Mr, N, T = 4, 6, 10, 5
+    rng = np.random.default_rng(92)
+    A = rng.random((Mr, N)).astype(np.float32)
+    b = rng.random((B, Mr, 1)).astype(np.float32)
+    fxs = []
+    for dataA in (A, np.broadcast_to(A, (B, Mr, N)).copy()):
+        meta_rnnprop_eval.set_random_seed(5)
+        problem = problems.lasso_fixed(dataA, b, l=0.1)
+        opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+        ml, scale, x, step = opt.meta_loss(problem, T)
+        with Session() as sess:
+            sess.run(ml.reset)
+            fxs.append(sess.run([ml.loss, ml.update], feed_dict={step: 1})[0])
+    assert rel_err(fxs[0], fxs[1]) < 1e-6
