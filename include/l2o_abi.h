@@ -214,6 +214,12 @@ typedef struct l2o_bwd_io {
   float* dd;               /* device [N]   dL/d(output Linear)                                */
   float* feats;            /* device [N][2]  RNNProp (m~, g~)                                 */
   float* du;               /* device [N][H]  RNNProp d/d(fc pre-activation)                   */
+  /* Row strides in floats of the two groups of emitted rows, or 0 for the dense layouts above.
+   * With a_stride / b_stride the caller interleaves  A = [act1 | act2 | h2 | feats | 1]  and
+   * Bm = [dz1 | dz2 | dd | du]  in two row-major matrices (the pointers above are then column
+   * offsets into them) and obtains EVERY weight gradient from the single product A^T Bm. */
+  int64_t a_stride;        /* act1, act2, h2, feats */
+  int64_t b_stride;        /* dz1, dz2, dd, du      */
 } l2o_bwd_io;
 int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io,
                         double pow1, double pow2, int64_t B, int64_t D, void* stream);

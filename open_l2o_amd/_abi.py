@@ -68,7 +68,8 @@ class NetWeights(C.Structure):
 class BwdIO(C.Structure):
     """struct l2o_bwd_io"""
     _fields_ = [(n, C.c_void_p) for n in ("g", "m", "v", "st_prev", "dx_next", "carry_in", "carry_out", "act1",
-                                          "dz1", "act2", "dz2", "h2", "dd", "feats", "du")]
+                                          "dz1", "act2", "dz2", "h2", "dd", "feats", "du")] + \
+               [("a_stride", C.c_int64), ("b_stride", C.c_int64)]
 
 
 PROB_W_SHARED = 1     # l2o_problem.flags: W is one [M, D] matrix for every problem

@@ -193,7 +193,10 @@ class HipEngine(object):
             setattr(w, k, None if weights.get(k) is None else weights[k].data_ptr())
         b = _abi.BwdIO()
         for k, _ in _abi.BwdIO._fields_:
-            setattr(b, k, None if io.get(k) is None else io[k].data_ptr())
+            if k in ("a_stride", "b_stride"):
+                setattr(b, k, int(io.get(k) or 0))
+            else:
+                setattr(b, k, None if io.get(k) is None else io[k].data_ptr())
         _abi.check(self.lib.l2o_cwlstm_bwd_step(C.byref(cc), C.byref(w), C.byref(b), float(pow1), float(pow2),
                                                 B, D, self._stream()))
 

@@ -119,6 +119,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
   const int nwaves = gridDim.x * (blockDim.x >> 6);
   const int ntiles = sg.tile_end[sg.n - 1];
+  // ---- the bf16x3 weight fragments (46 / 61 KB) reach the four waves through LDS: one DMA copy per
+  // workgroup instead of four L2 reads; the staging area is the (not yet used) prefetch ring
+  bx::NetWB<PRE> w;
+  {
+    constexpr int kFrags = bx::nchunks(PRE) * kNT * 3;             // 1 KB each = one wave-wide dwordx4
+    static_assert(kFrags * 1024 <= (int)sizeof(sbuf), "staging area");
+    float4* stage = &sbuf[0][0][0];
+    const float* src = np.wpack + bx::base(PRE) + lane * 4;
+#pragma unroll
+    for (int f = 0; f < (kFrags + 3) / 4; ++f) {
+      const int fr = 4 * f + wv;
+      if (fr < kFrags)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src + fr * bx::kFragWords), (lds_void*)(stage + fr * 64), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < bx::NetWB<PRE>::NCH; ++ch)
+#pragma unroll
+      for (int t = 0; t < kNT; ++t)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const float4 v4 = stage[((ch * kNT + t) * 3 + s3) * 64 + lane];
+          w.a[ch][t][s3] = __builtin_bit_cast(bx::u32x4, v4);
+        }
+    __syncthreads();                                               // everyone holds its copy: the ring may be used
+  }
   if (wave >= ntiles) return;
   const int ntl = (ntiles - wave + nwaves - 1) / nwaves;         // tiles of this wave
   // global tile index -> segment (wave-uniform scalar work)
@@ -140,8 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     L.tpp = sg.tpp[sidx]; L.D = sg.D[sidx];
     return L;
   };
-  bx::NetWB<PRE> w;
-  bx::load_netw<PRE>(w, np.wpack, lane);
+  bx::load_netw<PRE, false>(w, np.wpack, lane);                  // the small fp32 weights
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // weights landed: the VMEM queue is empty
   // dead lanes (j >= D in the last tile of a problem) read the problem's last coordinate:
   // branch-free loads, masked where they are used
@@ -1154,6 +1180,14 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
   p.g = io->g; p.m = io->m; p.v = io->v; p.st_prev = io->st_prev; p.dx_next = io->dx_next;
   p.carry_in = io->carry_in; p.carry_out = io->carry_out; p.act1 = io->act1; p.dz1 = io->dz1;
   p.act2 = io->act2; p.dz2 = io->dz2; p.h2o = io->h2; p.dd = io->dd; p.feats = io->feats; p.du = io->du;
+  {
+    const int pre_ = cfg->preprocess;
+    const long P_ = cfg->n_layers == 0 ? 2 : (pre_ == L2O_PRE_FC_ELU ? kH : (pre_ == L2O_PRE_LOGSIGN ? 2 : 1));
+    const long K1_ = cfg->n_layers == 0 ? 2 : P_ + kH;
+    const long as = (long)io->a_stride, bs = (long)io->b_stride;
+    p.s_act1 = as ? as : K1_; p.s_act2 = as ? as : 2 * kH; p.s_h2 = as ? as : kH; p.s_feats = as ? as : 2;
+    p.s_dz1 = bs ? bs : 4 * kH; p.s_dz2 = bs ? bs : 4 * kH; p.s_dd = bs ? bs : 1; p.s_du = bs ? bs : kH;
+  }
   hipStream_t s = (hipStream_t)stream;
   const size_t N = (size_t)B * D;
   if (cfg->n_layers == 0) {
@@ -1170,9 +1204,7 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
       !io->carry_out || !io->dz1 || !io->act2 || !io->dz2 || !io->h2)
     return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step: NULL LSTM buffer");
   const int pre = cfg->preprocess;
-  const int P = pre == L2O_PRE_FC_ELU ? kH : (pre == L2O_PRE_LOGSIGN ? 2 : 1);
-  const size_t lds = sizeof(float) * ((size_t)(P + kH) * 4 * kH + 2 * kH * 4 * kH + 2 * 4 * kH + kH + 3 * kH +
-                                      2 * kH * 64);
+  const size_t lds = 0;                                   // static LDS only (the per-thread input column)
   const dim3 grid((unsigned)((N + 63) / 64)), block(64);
   switch (pre) {
     case L2O_PRE_IDENTITY: hipLaunchKernelGGL(k_cwlstm_bwd_step<L2O_PRE_IDENTITY>, grid, block, lds, s, p); break;

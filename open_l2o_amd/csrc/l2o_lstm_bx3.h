@@ -105,16 +105,20 @@ struct NetWB {
   float fcw0[kNT], fcw1[kNT], fcb[kNT];   // RNNProp input projection (2 -> 20)
 };
 
-template <int PRE>
+// FRAGS = false: the caller fills w.a itself (k_cwlstm_step stages the fragments through LDS once
+// per workgroup instead of 4 x 61 KB of L2 reads)
+template <int PRE, bool FRAGS = true>
 __device__ __forceinline__ void load_netw(NetWB<PRE>& w, const float* __restrict__ wp, int lane) {
   const unsigned* wu = reinterpret_cast<const unsigned*>(wp);
+  if (FRAGS) {
 #pragma unroll
-  for (int ch = 0; ch < NetWB<PRE>::NCH; ++ch)
+    for (int ch = 0; ch < NetWB<PRE>::NCH; ++ch)
 #pragma unroll
-    for (int t = 0; t < kNT; ++t)
+      for (int t = 0; t < kNT; ++t)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-        w.a[ch][t][s] = *reinterpret_cast<const u32x4*>(wu + frag_off(PRE, ch, t, s) + lane * 4);
+        for (int s = 0; s < 3; ++s)
+          w.a[ch][t][s] = *reinterpret_cast<const u32x4*>(wu + frag_off(PRE, ch, t, s) + lane * 4);
+  }
   const float* p = wp + lane;
 #pragma unroll
   for (int t = 0; t < kNT; ++t) {

@@ -555,36 +555,48 @@ class UnrollGraph(object):
             k = (mod, var)
             acc[k] = val if k not in acc else acc[k] + val
 
-        io = {"dd": eng.empty(N)}
-        if nl:
-            H = 20
-            carry_in, carry_out = eng.zeros(4, N, H), eng.empty(4, N, H)
-            io.update(act1=eng.empty(N, P + H), dz1=eng.empty(N, 4 * H), act2=eng.empty(N, 2 * H),
-                      dz2=eng.empty(N, 4 * H), h2=eng.empty(N, H))
-            if fc:
-                io.update(feats=eng.empty(N, 2), du=eng.empty(N, H))
-        else:
-            io.update(act1=eng.empty(N, 2))
+        if not nl:                                         # Linear-only net: two tiny products per step
+            io = {"dd": eng.empty(N), "act1": eng.empty(N, 2)}
+            for t in reversed(range(T)):
+                io.update(g=gs[t], dx_next=dxs[t])
+                eng.bwd_step(spec, wdev, io, b1 ** (step0 + t), b2 ** (step0 + t), B, D)
+                dd = io["dd"].view(N, 1)
+                add("linear", "w", io["act1"][:, :P].t() @ dd)
+                add("linear", "b", dd.sum(0))
+            return
+        # The kernel emits, per step and coordinate, one row of  A = [act1 | act2 | h2 | feats | 1]
+        # and one of  Bm = [dz1 | dz2 | dd | du];  EVERY weight gradient of the unroll is a block of
+        # the single product A^T Bm over all (step, coordinate) rows.  (Three skinny rocBLAS GEMMs
+        # per step cost 320 us; one chunked batched GEMM per unroll costs a few tens.)
+        H = 20
+        K1 = P + H
+        KA = K1 + 2 * H + H + (2 if fc else 0) + 1
+        KB = 4 * H + 4 * H + 1 + (H if fc else 0)
+        A = eng.empty(T, N, KA)
+        Bm = eng.empty(T, N, KB)
+        A[:, :, KA - 1] = 1.0
+        carry_in, carry_out = eng.zeros(4, N, H), eng.empty(4, N, H)
         for t in reversed(range(T)):
             k = step0 + t
-            io.update(g=gs[t], dx_next=dxs[t])
-            if nl:
-                io.update(st_prev=sts[t], carry_in=carry_in, carry_out=carry_out, m=ms[t], v=vs[t])
+            At, Bt = A[t], Bm[t]
+            io = dict(g=gs[t], dx_next=dxs[t], st_prev=sts[t], carry_in=carry_in, carry_out=carry_out,
+                      m=ms[t], v=vs[t], a_stride=KA, b_stride=KB,
+                      act1=At[:, 0:K1], act2=At[:, K1:K1 + 2 * H], h2=At[:, K1 + 2 * H:K1 + 3 * H],
+                      dz1=Bt[:, 0:4 * H], dz2=Bt[:, 4 * H:8 * H], dd=Bt[:, 8 * H:8 * H + 1])
+            if fc:
+                io.update(feats=At[:, K1 + 3 * H:K1 + 3 * H + 2], du=Bt[:, 8 * H + 1:8 * H + 1 + H])
             eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, B, D)
-            dd = io["dd"].view(N, 1)
-            if nl:
-                add("lstm_1", "w_gates", io["act1"].t() @ io["dz1"])
-                add("lstm_1", "b_gates", io["dz1"].sum(0))
-                add("lstm_2", "w_gates", io["act2"].t() @ io["dz2"])
-                add("lstm_2", "b_gates", io["dz2"].sum(0))
-                add("linear", "w", io["h2"].t() @ dd)
-                if fc:
-                    add("input_projection", "w", io["feats"].t() @ io["du"])
-                    add("input_projection", "b", io["du"].sum(0))
-                carry_in, carry_out = carry_out, carry_in
-            else:
-                add("linear", "w", io["act1"][:, :P].t() @ dd)
-            add("linear", "b", dd.sum(0))
+            carry_in, carry_out = carry_out, carry_in
+        Gm = _chunked_atb(A.view(T * N, KA), Bm.view(T * N, KB))
+        add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
+        add("lstm_1", "b_gates", Gm[KA - 1, 0:4 * H])
+        add("lstm_2", "w_gates", Gm[K1:K1 + 2 * H, 4 * H:8 * H])
+        add("lstm_2", "b_gates", Gm[KA - 1, 4 * H:8 * H])
+        add("linear", "w", Gm[K1 + 2 * H:K1 + 3 * H, 8 * H:8 * H + 1])
+        add("linear", "b", Gm[KA - 1, 8 * H:8 * H + 1])
+        if fc:
+            add("input_projection", "w", Gm[K1 + 3 * H:K1 + 3 * H + 2, 8 * H + 1:8 * H + 1 + H])
+            add("input_projection", "b", Gm[KA - 1, 8 * H + 1:8 * H + 1 + H])
 
     def _backward(self, T, rec):
         eng = self.engine
@@ -764,6 +776,20 @@ class UnrollGraph(object):
             eng.reduce_fx(f_all, T + 1, descs[jd].B_local, descs[jd].B_global, fx)
         if record is not None:
             record["g_final"] = [g.clone() for g in grads]
+
+
+def _chunked_atb(A, B, chunk=1024):
+    """A^T B for tall-skinny A [R, ka], B [R, kb] as ONE batched GEMM over row chunks + a sum
+    (library GEMMs; rocBLAS' plain skinny-K path is ~4x slower)."""
+    R = A.shape[0]
+    n = R // chunk
+    out = None
+    if n:
+        out = torch.bmm(A[:n * chunk].view(n, chunk, -1).transpose(1, 2), B[:n * chunk].view(n, chunk, -1)).sum(0)
+    if n * chunk < R:
+        tail = A[n * chunk:].t() @ B[n * chunk:]
+        out = tail if out is None else out + tail
+    return out
 
 
 # ---------------------------------------------------------------------------
