@@ -245,6 +245,21 @@ int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack /* device */,
                float* st /* device, packed, in-out */, float* m, float* v,
                int32_t T, int32_t step0,
                float* fx_part /* device [(T+1)*B_local] */, void* workspace, void* stream);
+/* The same unroll that also RECORDS what back-propagation through time needs
+ * (MetaOptimizer.meta_minimize, DM/meta.py:398-414): for t = 0..T-1 the packed LSTM state
+ * BEFORE step t, the gradient fed to the network at step t and (RNNProp) the moments AFTER
+ * step t, plus the gradient at x_T.  hist == NULL is l2o_unroll. */
+typedef struct l2o_unroll_hist {
+  float* st;        /* device [T][l2o_state_floats(B_local, D)] */
+  float* g;         /* device [T][B_local*D]                    */
+  float* m;         /* device [T][B_local*D], RNNProp only      */
+  float* v;
+  float* g_final;   /* device [B_local*D]                       */
+} l2o_unroll_hist;
+int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device */,
+                      const l2o_problem* prob, float* x, float* st, float* m, float* v,
+                      int32_t T, int32_t step0, float* fx_part, void* workspace,
+                      const l2o_unroll_hist* hist, void* stream);
 int l2o_unroll_status(const void* workspace_header_host /* host copy of the first 4 bytes */);
 /* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0. */
 int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);

@@ -204,7 +204,9 @@ class HipEngine(object):
         cc, cp = spec.to_c(), self._cprob(p)
         return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))
 
-    def unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part):
+    def unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part, hist=None):
+        """hist: None, or dict(st=[T, state_floats], g=[T, B*D], m=, v= (RNNProp), g_final=[B*D]) of
+        device tensors that receive the per-step history the meta-gradient needs (l2o_unroll_record)."""
         cc, cp = spec.to_c(), self._cprob(p)
         nbytes = int(self.lib.l2o_unroll_workspace_bytes(C.byref(cc), C.byref(cp), int(T)))
         ws = None
@@ -213,9 +215,17 @@ class HipEngine(object):
             if ws is None or ws.numel() < nbytes:
                 ws = self._workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self._last_ws = ws
-        _abi.check(self.lib.l2o_unroll(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
-                                       _ptr(v), int(T), int(step0), _ptr(fx_part),
-                                       None if ws is None else C.c_void_p(ws.data_ptr()), self._stream()))
+        wsp = None if ws is None else C.c_void_p(ws.data_ptr())
+        if hist is None:
+            _abi.check(self.lib.l2o_unroll(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
+                                           _ptr(v), int(T), int(step0), _ptr(fx_part), wsp, self._stream()))
+        else:
+            h = _abi.UnrollHist()
+            for k, _ in _abi.UnrollHist._fields_:
+                setattr(h, k, None if hist.get(k) is None else hist[k].data_ptr())
+            _abi.check(self.lib.l2o_unroll_record(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
+                                                  _ptr(v), int(T), int(step0), _ptr(fx_part), wsp, C.byref(h),
+                                                  self._stream()))
 
     def check_unroll_status(self):
         """After a host sync: raise if the split-problem kernel reported a partner timeout."""

@@ -494,6 +494,10 @@ struct UnrollArgs {
   float* fx_part;
   int T;
   float p1_hi, p1_lo, p2_hi, p2_lo;   // beta^step0 as float-float
+  // optional per-step history for the meta-gradient (l2o_unroll_record): packed state BEFORE
+  // step t, the gradient fed to the network at step t, RNNProp moments AFTER step t, and the
+  // gradient at x_T.  All NULL for a plain unroll.
+  float *hist_st, *hist_g, *hist_m, *hist_v, *hist_gfinal;
 };
 
 #ifdef L2O_ABLATE_BARRIER
@@ -584,9 +588,12 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   core.init(s, q);
   core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
 
+  const size_t hist_n = (size_t)pp.B_local * D;
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     if (live && q == 0) xs[j] = xsv;
+    if (a.hist_st && t < a.T)
+      store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * nw + tile) * kStateFloatsPerTile, lane);
     L2O_SYNC();                                             // B1: xs complete
     // ---- r = W xs - y  ||  first 12 layer-2 MFMAs of the previous h2 -----------
     float4 racc = {0.f, 0.f, 0.f, 0.f};
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
       for (int k = 1; k < nw; ++k) f += fpart[k];
       a.fx_part[(size_t)t * pp.B_local + b] = f;
     }
-    if (t == a.T) break;
+    if (t == a.T && !a.hist_gfinal) break;
 
     // ---- g = W^T r for this wave's 16 coordinates  ||  the other 13 of those MFMAs ----
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
@@ -633,12 +640,18 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
+    if (a.hist_g && live && q == 0) {
+      if (t < a.T) a.hist_g[(size_t)t * hist_n + idx] = gv;
+      else a.hist_gfinal[idx] = gv;
+    }
+    if (t == a.T) break;                                    // (history mode: the gradient at x_T was still needed)
 
     // ---- optimizer network ----------------------------------------------------
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
       // beta^k as a float-float running product (k = step0 + t)
       rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, 1.0f - p1h, 1.0f - p2h, in0, in1);
+      if (a.hist_m && live && q == 0) { a.hist_m[(size_t)t * hist_n + idx] = mv; a.hist_v[(size_t)t * hist_n + idx] = vv; }
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       {
         float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
@@ -1246,9 +1259,18 @@ int l2o_unroll_status(const void* workspace_header_host) {
 
 int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st, float* m,
                float* v, int32_t T, int32_t step0, float* fx_part, void* workspace, void* stream) {
+  return l2o_unroll_record(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, nullptr, stream);
+}
+
+int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st,
+                      float* m, float* v, int32_t T, int32_t step0, float* fx_part, void* workspace,
+                      const l2o_unroll_hist* hist, void* stream) {
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!cfg || !wpack || !x || !st || !fx_part || T < 0) return fail(L2O_ERR_ARG, "l2o_unroll: bad argument");
+  if (hist && (!hist->st || !hist->g || !hist->g_final ||
+               (cfg->preprocess == L2O_PRE_FC_ELU && (!hist->m || !hist->v))))
+    return fail(L2O_ERR_ARG, "l2o_unroll_record: incomplete history buffers");
   if (!l2o_unroll_supported(cfg, prob))
     return fail(L2O_ERR_UNSUPPORTED, "l2o_unroll: no fused kernel for kind=%d D=%d M=%d net(kind=%d,layers=%d)",
                 prob->kind, prob->D, prob->M, cfg->kind, cfg->n_layers);
@@ -1259,6 +1281,11 @@ int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* pr
   a.pp = make_prob_params(prob);
   a.x = x; a.st = st; a.m = m; a.v = v; a.fx_part = fx_part;
   a.T = T;
+  a.hist_st = hist ? hist->st : nullptr;
+  a.hist_g = hist ? hist->g : nullptr;
+  a.hist_m = hist ? hist->m : nullptr;
+  a.hist_v = hist ? hist->v : nullptr;
+  a.hist_gfinal = hist ? hist->g_final : nullptr;
   pow_ff(cfg->beta1, step0, &a.p1_hi, &a.p1_lo);
   pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
   hipStream_t s = (hipStream_t)stream;

@@ -444,7 +444,27 @@ class UnrollGraph(object):
 
         if events is not None:
             events[0].record()
-        if record is not None:                             # meta-gradient: needs the per-step history
+        if record is not None and T > 0 and self._fused_ok(descs) and isinstance(states[0], PackedState) \
+                and states[0].packed is not None:
+            # meta-gradient on a fused-size problem: ONE launch that also records the history
+            # (state before, gradient at, moments after every step; gradient at x_T)
+            self.last_path = "fused"
+            s, d = slots[0], descs[0]
+            B, D = panels[0].shape
+            N = B * D
+            hist = {"st": eng.empty(T, states[0].packed.numel()), "g": eng.empty(T, N), "g_final": eng.empty(N)}
+            if self.rnnprop:
+                hist.update(m=eng.empty(T, N), v=eng.empty(T, N))
+            fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
+            eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
+                       fx_part, hist=hist)
+            eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
+            record.update(step0=step0, shapes=[tuple(pn.shape) for pn in panels],
+                          g=[[hist["g"][t].view(B, D)] for t in range(T)], st=[[hist["st"][t]] for t in range(T)],
+                          m=[[hist["m"][t].view(B, D) if self.rnnprop else None] for t in range(T)],
+                          v=[[hist["v"][t].view(B, D) if self.rnnprop else None] for t in range(T)],
+                          g_final=[hist["g_final"].view(B, D)])
+        elif record is not None:                           # meta-gradient: needs the per-step history
             self.last_path = "steps"
             self._draw_minibatches(T)
             record.update(step0=step0, shapes=[tuple(pn.shape) for pn in panels])

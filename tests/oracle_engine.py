@@ -215,7 +215,7 @@ class OracleEngine(object):
         cp.kind, cp.B_local, cp.B_global, cp.D, cp.M = p.kind, p.B_local, p.B_global, p.D, p.M
         return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))
 
-    def unroll(self, spec, wpack, p, x, st, m, v, T, step0, fx_part):
+    def unroll(self, spec, wpack, p, x, st, m, v, T, step0, fx_part, hist=None):
         self.calls.append("unroll")
         cfg = _cfg_of(spec)
         prob, shape = self._oracle_problem(p)
@@ -231,11 +231,22 @@ class OracleEngine(object):
         for t in range(T + 1):
             xin = xcur if s is None else xcur * s
             fparts[t] = prob.f_per_problem(xin)
+            if hist is not None:                                   # what l2o_unroll_record stores
+                gt = prob.grad(xin) if s is None else prob.grad(xin) * s
+                if t == T:
+                    hist["g_final"].copy_(torch.from_numpy(gt.reshape(-1)).view_as(hist["g_final"]))
+                else:
+                    hist["g"][t].copy_(torch.from_numpy(gt.reshape(-1)).view_as(hist["g"][t]))
+                    hist["st"][t].copy_(torch.from_numpy(pack_state(state[0][0], state[0][1], state[1][0],
+                                                                    state[1][1], B, D)).view_as(hist["st"][t]))
             if t == T:
                 break
             res = O.unroll(prob, cfg, wpack._l2l, xcur, state, 1, x_scale=s, m0=mm, v0=vv,
                            step0=step0 + t, beta1=spec.beta1, beta2=spec.beta2)
             xcur, state, mm, vv = res.x, res.state, res.m, res.v
+            if hist is not None and mm is not None and hist.get("m") is not None:
+                hist["m"][t].copy_(torch.from_numpy(mm.reshape(-1)).view_as(hist["m"][t]))
+                hist["v"][t].copy_(torch.from_numpy(vv.reshape(-1)).view_as(hist["v"][t]))
         x.copy_(torch.from_numpy(xcur.reshape(B, D)))
         st.copy_(torch.from_numpy(pack_state(state[0][0], state[0][1], state[1][0], state[1][1], B, D)))
         if mm is not None and m is not None:

@@ -262,3 +262,46 @@ def test_training_harness_learns(engine, tmp_path):
     assert not np.array_equal(w0["w"], w1["w"])                      # the meta-step moved the weights
     saved = sorted(os.listdir(str(tmp_path)))
     assert "cw.l2l-0" in saved and any(s.startswith("cw.l2l-") and s != "cw.l2l-0" for s in saved)
+
+
+@pytest.mark.parametrize("name", ["dm", "rnnprop"])
+def test_recording_fused_unroll_equals_step_path(engine, name, monkeypatch):
+    """meta_minimize on a fused-size problem takes the recording unroll (l2o_unroll_record: one
+    launch that stores the per-step history); its meta-gradient == the step-granular path's."""
+    cfg = ORACLE_CFGS[name]
+    rn = cfg.kind == "rnnprop"
+    params = make_params(cfg, seed=71, trained_like=True)
+    B, D, T = 5, 24, 6
+    prob, x0, _ = make_problem("quadratic", B, D, seed=72)
+    got = {}
+    for mode in ("fused", "steps"):
+        if mode == "steps":
+            monkeypatch.setenv("L2O_DISABLE_FUSED", "1")
+        else:
+            monkeypatch.delenv("L2O_DISABLE_FUSED", raising=False)
+        problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+        if rn:
+            opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+            out = opt.meta_minimize(problem, T, learning_rate=1e-3)
+            ms, step_ph = out[0], out[3]
+        else:
+            opt = meta.MetaOptimizer(**_net_config(cfg, params))
+            ms, step_ph = opt.meta_minimize(problem, T, learning_rate=1e-3), None
+        graph = opt.graph
+        cap = {}
+        orig = graph._adam_apply
+        graph._adam_apply = lambda grads, lr, **kw: (cap.update(grads=grads), orig(grads, lr, **kw))[1]
+        with Session() as sess:
+            sess.run(ms.reset)
+            feed = {step_ph: 3} if rn else {}
+            cost = sess.run([ms.fx, ms.update, ms.step], feed_dict=feed)[0]
+            x_after = graph.x[0].eval()
+        assert graph.last_path == mode
+        got[mode] = (cost, x_after, cap["grads"])
+    assert rel_err(got["fused"][0], got["steps"][0]) < 1e-5
+    assert max_abs(got["fused"][1], got["steps"][1]) < 1e-5
+    key = "rp" if rn else "cw"
+    for k, gref in got["steps"][2][key].items():
+        g = got["fused"][2][key][k]
+        scale = max(float(np.abs(gref).max()), 1e-12)
+        assert float(np.abs(np.asarray(g) - np.asarray(gref)).max()) / scale < 2e-4, k
