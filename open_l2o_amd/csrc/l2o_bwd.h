@@ -214,6 +214,315 @@ __global__ __launch_bounds__(64) void k_cwlstm_bwd_step(BwdParams p) {
   }
 }
 
+// The fast form for tile-aligned panels (D % 16 == 0) and the interleaved A / Bm row layout:
+// FOUR lanes per coordinate (a DPP quad): lane part p = lane & 3 owns gate type p (Sonnet column
+// block i | j | f | o) of all 20 units in both layers, so a wave covers the 16 coordinates of ONE
+// state tile and a 16 384-coordinate panel fills all 1 024 SIMDs (4 waves per workgroup share the
+// LDS copy of the weights).  The gate GEMVs read a quarter of each weight row per lane from LDS
+// (5 ds_read_b128 per 20 FMAs), the four gate types of a unit meet through quad-broadcast DPP
+// moves, the transposed products are reduced over the quad with two DPP adds.  ALL global traffic
+// is coalesced dwordx4 through per-wave LDS tiles: the packed state tile and the carries come in,
+// the 16 x KA / 16 x KB row blocks of A / Bm and the carries go out as contiguous 5-10 KB pieces
+// (the per-lane scattered form was bound by the texture addresser: ~350 VMEM instructions of
+// 16-64 cache lines each per wave).
+template <int CTRL>
+__device__ __forceinline__ float bw_quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int PRE>
+struct BwdTileGeom {
+  static constexpr int P = PRE == L2O_PRE_FC_ELU ? kH : (PRE == L2O_PRE_LOGSIGN ? 2 : 1);
+  static constexpr int K1 = P + kH, G = 4 * kH, NC = 16;
+  static constexpr int KA = K1 + 3 * kH + (PRE == L2O_PRE_FC_ELU ? 2 : 0) + 1;   // act1 | act2 | h2 | feats | 1
+  static constexpr int KB = 2 * G + 1 + (PRE == L2O_PRE_FC_ELU ? kH : 0);        // dz1 | dz2 | dd | du
+  static constexpr int kWaveFloats = 2 * kH * NC + kStateFloatsPerTile + 4 * NC * kH + NC * KA + NC * KB;
+  static constexpr int kLdsFloats = K1 * G + 2 * kH * G + 4 * kWaveFloats;
+};
+
+template <int PRE>
+__global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
+#ifdef L2O_BWD_CLOCK
+  long long ck[12]; int cki = 0;
+#define BCK() do { __syncthreads(); ck[cki++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BCK() ((void)0)
+#endif
+  using Geo = BwdTileGeom<PRE>;
+  constexpr int P = Geo::P, K1 = Geo::K1, G = Geo::G, NC = Geo::NC, KA = Geo::KA, KB = Geo::KB;
+  extern __shared__ float sm[];
+  float* W1 = sm;                 // [K1][80]
+  float* W2 = W1 + K1 * G;        // [40][80]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, part = lane & 3, cl = lane >> 2;
+  float* wbase = W2 + 2 * kH * G + wv * Geo::kWaveFloats;
+  float* xin = wbase;                         // [40][NC]  input vector of the current GEMV, k-major
+  float* stt = xin + 2 * kH * NC;             // the packed state tile (before the step)
+  float* cio = stt + kStateFloatsPerTile;     // [4][NC][20] carries in, overwritten by carries out
+  float* At = cio + 4 * NC * kH;              // [NC][KA]
+  float* Bt = At + NC * KA;                   // [NC][KB]
+  {
+    // stage both weight matrices with all loads of a thread in flight at once (a one-load-per-
+    // iteration loop pays one L2 latency per 16 bytes)
+    auto stage = [&](float* dst, const float* src, int n4) {
+      for (int base = tid; base < n4; base += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = base + 256 * q;
+          v[q] = i < n4 ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = base + 256 * q;
+          if (i < n4) reinterpret_cast<float4*>(dst)[i] = v[q];
+        }
+      }
+    };
+    stage(W1, p.wg1, K1 * G / 4);
+    stage(W2, p.wg2, 2 * kH * G / 4);
+  }
+  const l2o_cfp wl = (l2o_cfp)p.wl, wfc = (l2o_cfp)p.wfc, bfc = (l2o_cfp)p.bfc;
+  const size_t N = (size_t)p.B * p.D;                   // a multiple of 16: D % 16 == 0
+  const size_t grp = (size_t)blockIdx.x * 4 + wv;         // == the state tile index
+  const bool valid = grp * NC < N;                        // whole waves are valid or not
+  const size_t n0 = valid ? grp * NC : 0;
+  const size_t n = n0 + cl;
+  const int c = cl;
+  float* xi = xin + cl;                                   // element k at xi[k * NC]
+  // ---- coalesced loads: the state tile and the four carry blocks of these 16 coordinates ----
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.st_prev + n0 / NC * kStateFloatsPerTile);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) reinterpret_cast<float4*>(stt)[q * 64 + lane] = src[q * 64 + lane];
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+      const float4* cs = reinterpret_cast<const float4*>(p.carry_in + ((size_t)a4 * N + n0) * kH);
+      float4* cd = reinterpret_cast<float4*>(cio + a4 * NC * kH);
+      cd[lane] = cs[lane];
+      if (lane < NC * kH / 4 - 64) cd[64 + lane] = cs[64 + lane];
+    }
+  }
+  auto st_at = [&](int a, int u) {                        // (array a, unit u) of this lane's coordinate
+    const int qq = u & 3, tt = u >> 2, e = a * 5 + tt;
+    return stt[((e >> 2) * 64 + (qq * 16 + c)) * 4 + (e & 3)];
+  };
+  float* arow = At + cl * KA;
+  float* brow = Bt + cl * KB;
+  if (part == 0) arow[KA - 1] = 1.0f;
+  // this lane's activation: a * sigmoid(s x + s0) + c0  (tanh x = 2 sigmoid(2x) - 1; forget_bias = 1)
+  const float act_s = part == 1 ? 2.0f : 1.0f, act_s0 = part == 2 ? 1.0f : 0.0f;
+  const float act_a = part == 1 ? 2.0f : 1.0f, act_c0 = part == 1 ? -1.0f : 0.0f;
+
+  // z[u] = bias[part*20 + u] + sum_k in[k] W[k][part*20 + u]
+  auto gemm = [&](const float* W, const float* bias, int KK, float (&z)[kH]) {
+#pragma unroll
+    for (int u = 0; u < kH; ++u) z[u] = bias[part * kH + u];
+    const float* wp = W + part * kH;
+#pragma unroll 4
+    for (int k = 0; k < KK; ++k) {
+      const float xv = xi[k * NC];
+      const float4* wr = reinterpret_cast<const float4*>(wp + k * G);
+#pragma unroll
+      for (int u4 = 0; u4 < kH / 4; ++u4) {
+        const float4 w4 = wr[u4];
+        z[4 * u4 + 0] = __builtin_fmaf(xv, w4.x, z[4 * u4 + 0]);
+        z[4 * u4 + 1] = __builtin_fmaf(xv, w4.y, z[4 * u4 + 1]);
+        z[4 * u4 + 2] = __builtin_fmaf(xv, w4.z, z[4 * u4 + 2]);
+        z[4 * u4 + 3] = __builtin_fmaf(xv, w4.w, z[4 * u4 + 3]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kH; ++u) z[u] = __builtin_fmaf(act_a, bw_sig(__builtin_fmaf(act_s, z[u], act_s0)), act_c0);
+  };
+  // xi[k] = sum over the quad of sum_u dz[u] W[k][part*20 + u]   (every lane of the quad gets it)
+  auto gemm_t = [&](const float* W, int KK, const float (&dz)[kH]) {
+    const float* wp = W + part * kH;
+#pragma unroll 4
+    for (int k = 0; k < KK; ++k) {
+      const float4* wr = reinterpret_cast<const float4*>(wp + k * G);
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int u4 = 0; u4 < kH / 4; ++u4) {
+        const float4 w4 = wr[u4];
+        s0 = __builtin_fmaf(dz[4 * u4 + 0], w4.x, s0);
+        s1 = __builtin_fmaf(dz[4 * u4 + 1], w4.y, s1);
+        s0 = __builtin_fmaf(dz[4 * u4 + 2], w4.z, s0);
+        s1 = __builtin_fmaf(dz[4 * u4 + 3], w4.w, s1);
+      }
+      const float tot = l2o::quad_sum(s0 + s1);
+      if (part == (k & 3)) xi[k * NC] = tot;
+    }
+  };
+  // the four gates of every unit, in every lane of the quad
+  auto gather = [&](const float (&z)[kH], float (&gi)[kH], float (&gj)[kH], float (&gf)[kH], float (&go)[kH]) {
+#pragma unroll
+    for (int u = 0; u < kH; ++u) {
+      gi[u] = bw_quad_bcast<0x00>(z[u]);   // quad_perm:[0,0,0,0]
+      gj[u] = bw_quad_bcast<0x55>(z[u]);   // [1,1,1,1]
+      gf[u] = bw_quad_bcast<0xAA>(z[u]);   // [2,2,2,2]
+      go[u] = bw_quad_bcast<0xFF>(z[u]);   // [3,3,3,3]
+    }
+  };
+  BCK();
+  __syncthreads();                                          // weights staged
+  BCK();
+
+  // ---- features (every lane of the quad computes them; lane part == k & 3 owns row k) ------
+  const float gv = p.g[n];
+  float pre_fc[PRE == L2O_PRE_FC_ELU ? kH : 1];
+  float f0 = 0.0f, f1 = 0.0f;
+  if (PRE == L2O_PRE_FC_ELU) {
+    const float m_hat = p.m[n] / p.om1, v_hat = p.v[n] / p.om2;
+    const float den = sqrtf(v_hat) + 1e-8f;
+    f0 = m_hat / den;
+    f1 = gv / den;
+#pragma unroll
+    for (int u = 0; u < kH; ++u) {
+      const float zz = f0 * wfc[u] + f1 * wfc[kH + u] + bfc[u];
+      pre_fc[u] = zz;
+      if (part == (u & 3)) xi[u * NC] = zz > 0.0f ? zz : expm1f(zz);
+    }
+  } else if (PRE == L2O_PRE_LOGSIGN) {
+    if (part == 0) xi[0] = fmaxf(logf(fabsf(gv) + 1.1920928955078125e-07f) * p.k_inv, -1.0f);
+    if (part == 1) xi[NC] = fminf(fmaxf(gv * p.exp_k, -1.0f), 1.0f);
+  } else {
+    if (part == 0) xi[0] = gv;
+  }
+  float c1p[kH], c2p[kH];                                 // c1(t-1), c2(t-1)
+#pragma unroll
+  for (int u = 0; u < kH; ++u) {
+    if (part == ((P + u) & 3)) xi[(P + u) * NC] = st_at(0, u);   // h1(t-1)
+    c1p[u] = st_at(1, u);
+    c2p[u] = st_at(3, u);
+  }
+  __syncthreads();
+  for (int k = part; k < K1; k += 4) arow[k] = xi[k * NC];
+
+  BCK();
+  // ---- layer 1 forward -------------------------------------------------------------------
+  float z1[kH];
+  gemm(W1, p.bg1, K1, z1);
+  BCK();
+  float gi1[kH], gj1[kH], gf1[kH], go1[kH], tc1[kH];
+  gather(z1, gi1, gj1, gf1, go1);
+  __syncthreads();                                          // everyone is done reading the layer-1 input
+#pragma unroll
+  for (int u = 0; u < kH; ++u) {
+    const float c1 = gf1[u] * c1p[u] + gi1[u] * gj1[u];
+    tc1[u] = bw_tanh(c1);
+    if (part == (u & 3)) {
+      xi[u * NC] = tc1[u] * go1[u];                            // h1(t): layer-2 input 0..19
+      xi[(kH + u) * NC] = st_at(2, u);   // h2(t-1)
+    }
+  }
+  __syncthreads();
+  for (int k = part; k < 2 * kH; k += 4) arow[K1 + k] = xi[k * NC];
+  // ---- layer 2 forward + backward ----------------------------------------------------------
+  BCK();
+  float z2[kH];
+  gemm(W2, p.bg2, 2 * kH, z2);
+  BCK();
+  const float* cin0 = cio + (0 * NC + cl) * kH;   // this coordinate's carries dh1, dc1, dh2, dc2
+  float* const cin1 = cio + (1 * NC + cl) * kH;
+  float* const cin2 = cio + (2 * NC + cl) * kH;
+  float* const cin3 = cio + (3 * NC + cl) * kH;
+  {
+    float gi[kH], gj[kH], gf[kH], go[kH];
+    gather(z2, gi, gj, gf, go);
+    float tc2[kH];
+    float dlin = p.bl[0];
+#pragma unroll
+    for (int u = 0; u < kH; ++u) {
+      const float c2 = gf[u] * c2p[u] + gi[u] * gj[u];
+      tc2[u] = bw_tanh(c2);
+      const float h2 = tc2[u] * go[u];
+      if (part == (u & 3)) arow[K1 + 2 * kH + u] = h2;
+      dlin = __builtin_fmaf(h2, wl[u], dlin);
+    }
+    float ddv = p.dx_next[n] * p.scale;
+    if (p.tanh_output) { const float th = bw_tanh(dlin); ddv *= 1.0f - th * th; }
+    if (part == 0) brow[2 * G] = ddv;
+#pragma unroll
+    for (int u = 0; u < kH; ++u) {
+      const float dh2 = ddv * wl[u] + cin2[u];
+      const float dc2 = cin3[u] + dh2 * go[u] * (1.0f - tc2[u] * tc2[u]);
+      if (part == (u & 3)) cin3[u] = dc2 * gf[u];             // carry out (all four lanes have read it: one wave)
+      const float d_i = dc2 * gj[u] * gi[u] * (1.0f - gi[u]);
+      const float d_j = dc2 * gi[u] * (1.0f - gj[u] * gj[u]);
+      const float d_f = dc2 * c2p[u] * gf[u] * (1.0f - gf[u]);
+      const float d_o = dh2 * tc2[u] * go[u] * (1.0f - go[u]);
+      z2[u] = part == 0 ? d_i : (part == 1 ? d_j : (part == 2 ? d_f : d_o));
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kH; ++u) brow[G + part * kH + u] = z2[u];
+  __syncthreads();                                          // layer-2 input fully consumed
+  BCK();
+  gemm_t(W2, 2 * kH, z2);                                 // d[h1; h2(t-1)] = dz2 . W2^T
+  BCK();
+  __syncthreads();
+  // ---- layer 1 backward ------------------------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < kH; ++u) {
+    const float dh1 = xi[u * NC] + cin0[u];
+    if (part == (u & 3)) cin2[u] = xi[(kH + u) * NC];
+    const float dc1 = cin1[u] + dh1 * go1[u] * (1.0f - tc1[u] * tc1[u]);
+    if (part == (u & 3)) cin1[u] = dc1 * gf1[u];
+    const float d_i = dc1 * gj1[u] * gi1[u] * (1.0f - gi1[u]);
+    const float d_j = dc1 * gi1[u] * (1.0f - gj1[u] * gj1[u]);
+    const float d_f = dc1 * c1p[u] * gf1[u] * (1.0f - gf1[u]);
+    const float d_o = dh1 * tc1[u] * go1[u] * (1.0f - go1[u]);
+    z1[u] = part == 0 ? d_i : (part == 1 ? d_j : (part == 2 ? d_f : d_o));
+  }
+#pragma unroll
+  for (int u = 0; u < kH; ++u) brow[part * kH + u] = z1[u];
+  __syncthreads();
+  BCK();
+  gemm_t(W1, K1, z1);                                     // d[inputs; h1(t-1)] = dz1 . W1^T
+  BCK();
+  __syncthreads();
+  {
+    float* c0w = cio + (0 * NC + cl) * kH;
+#pragma unroll
+    for (int u = 0; u < kH; ++u)
+      if (part == (u & 3)) c0w[u] = xi[(P + u) * NC];
+    if (PRE == L2O_PRE_FC_ELU) {
+      if (part == 0) {
+        arow[K1 + 3 * kH] = f0;
+        arow[K1 + 3 * kH + 1] = f1;
+      }
+#pragma unroll
+      for (int u = 0; u < kH; ++u)
+        if (part == (u & 3)) brow[2 * G + 1 + u] = xi[u * NC] * (pre_fc[u] > 0.0f ? 1.0f : expf(pre_fc[u]));
+    }
+  }
+  __syncthreads();
+  BCK();
+  // ---- coalesced stores: the A / Bm row blocks and the carries of these 16 coordinates ---------
+  if (valid) {
+    float4* ad = reinterpret_cast<float4*>(p.act1 + n0 * KA);
+    for (int i = lane; i < NC * KA / 4; i += 64) ad[i] = reinterpret_cast<const float4*>(At)[i];
+    float4* bd = reinterpret_cast<float4*>(p.dz1 + n0 * KB);
+    for (int i = lane; i < NC * KB / 4; i += 64) bd[i] = reinterpret_cast<const float4*>(Bt)[i];
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+      float4* cd = reinterpret_cast<float4*>(p.carry_out + ((size_t)a4 * N + n0) * kH);
+      const float4* cs = reinterpret_cast<const float4*>(cio + a4 * NC * kH);
+      cd[lane] = cs[lane];
+      if (lane < NC * kH / 4 - 64) cd[64 + lane] = cs[64 + lane];
+    }
+  }
+#ifdef L2O_BWD_CLOCK
+  BCK();
+  if (tid == 0 && blockIdx.x == 0) {
+    printf("bwd_tile ticks:");
+    for (int q = 1; q < cki; ++q) printf(" %lld", ck[q] - ck[q - 1]);
+    printf("\n");
+  }
+#endif
+#undef BCK
+}
+
 // layers == (): delta = scale * (tanh)(w . feats + b): emit feats rows and dd
 template <int PRE>
 __global__ void k_linear_bwd_step(BwdParams p) {

@@ -1217,6 +1217,32 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
       !io->carry_out || !io->dz1 || !io->act2 || !io->dz2 || !io->h2)
     return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step: NULL LSTM buffer");
   const int pre = cfg->preprocess;
+  // fast path: tile-aligned panel + the interleaved A / Bm layout -> the quad / LDS-tile kernel
+  {
+    const int Pq = pre == L2O_PRE_FC_ELU ? kH : (pre == L2O_PRE_LOGSIGN ? 2 : 1);
+    const int K1q = Pq + kH;
+    const long KA = K1q + 3 * kH + (pre == L2O_PRE_FC_ELU ? 2 : 0) + 1, KB = 8 * kH + 1 + (pre == L2O_PRE_FC_ELU ? kH : 0);
+    const bool layout = io->a_stride == KA && io->b_stride == KB && io->act2 == io->act1 + K1q &&
+                        io->h2 == io->act1 + K1q + 2 * kH && io->dz2 == io->dz1 + 4 * kH && io->dd == io->dz1 + 8 * kH &&
+                        (pre != L2O_PRE_FC_ELU || (io->feats == io->act1 + K1q + 3 * kH && io->du == io->dz1 + 8 * kH + 1 &&
+                                                   io->m && io->v && w->w_fc && w->b_fc));
+    if (layout && D % kTile == 0 && ((uintptr_t)io->act1 & 15) == 0 && ((uintptr_t)io->dz1 & 15) == 0 &&
+        !getenv("L2O_BWD_GENERIC")) {
+      const dim3 grid((unsigned)((N / kTile + 3) / 4)), block(256);
+      void (*fn)(BwdParams) = nullptr;
+      size_t lds = 0;
+      switch (pre) {
+        case L2O_PRE_IDENTITY: fn = k_cwlstm_bwd_tile<L2O_PRE_IDENTITY>; lds = BwdTileGeom<L2O_PRE_IDENTITY>::kLdsFloats; break;
+        case L2O_PRE_LOGSIGN: fn = k_cwlstm_bwd_tile<L2O_PRE_LOGSIGN>; lds = BwdTileGeom<L2O_PRE_LOGSIGN>::kLdsFloats; break;
+        default: fn = k_cwlstm_bwd_tile<L2O_PRE_FC_ELU>; lds = BwdTileGeom<L2O_PRE_FC_ELU>::kLdsFloats;
+      }
+      lds *= sizeof(float);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(fn, grid, block, lds, s, p);
+      HIP_TRY(hipGetLastError());
+      return L2O_OK;
+    }
+  }
   const size_t lds = 0;                                   // static LDS only (the per-thread input column)
   const dim3 grid((unsigned)((N + 63) / 64)), block(64);
   switch (pre) {

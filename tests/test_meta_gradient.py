@@ -305,3 +305,46 @@ def test_recording_fused_unroll_equals_step_path(engine, name, monkeypatch):
         g = got["fused"][2][key][k]
         scale = max(float(np.abs(gref).max()), 1e-12)
         assert float(np.abs(np.asarray(g) - np.asarray(gref)).max()) / scale < 2e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
+    """k_cwlstm_bwd_tile (tile-aligned panels, LDS-tiled I/O, four lanes per coordinate) against
+    the generic one-thread-per-coordinate kernel (L2O_BWD_GENERIC=1): same meta-gradient."""
+    eng = _engine.HipEngine()
+    old = _engine._default_engine
+    _engine.set_default_engine(eng)
+    try:
+        cfg = ORACLE_CFGS[name]
+        rn = cfg.kind == "rnnprop"
+        params = make_params(cfg, seed=81, trained_like=True)
+        B, D, T = 3, 32, 4                                   # D % 16 == 0 -> the tile kernel
+        prob, x0, _ = make_problem("quadratic", B, D, seed=82)
+        got = {}
+        for mode in ("tile", "generic"):
+            if mode == "generic":
+                monkeypatch.setenv("L2O_BWD_GENERIC", "1")
+            else:
+                monkeypatch.delenv("L2O_BWD_GENERIC", raising=False)
+            problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+            if rn:
+                opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+                out = opt.meta_minimize(problem, T, learning_rate=1e-3)
+                ms, step_ph = out[0], out[3]
+            else:
+                opt = meta.MetaOptimizer(**_net_config(cfg, params))
+                ms, step_ph = opt.meta_minimize(problem, T, learning_rate=1e-3), None
+            graph = opt.graph
+            cap = {}
+            orig = graph._adam_apply
+            graph._adam_apply = lambda grads, lr, **kw: (cap.update(grads=grads), orig(grads, lr, **kw))[1]
+            with Session() as sess:
+                sess.run(ms.reset)
+                sess.run([ms.fx, ms.update, ms.step], feed_dict={step_ph: 2} if rn else {})
+            got[mode] = cap["grads"]["rp" if rn else "cw"]
+        for k, gref in got["generic"].items():
+            scale = max(float(np.abs(gref).max()), 1e-12)
+            assert float(np.abs(np.asarray(got["tile"][k]) - np.asarray(gref)).max()) / scale < 1e-4, k
+    finally:
+        _engine.set_default_engine(old)
