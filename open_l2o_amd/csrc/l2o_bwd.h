@@ -282,11 +282,12 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
     stage(W2, p.wg2, 2 * kH * G / 4);
   }
   const l2o_cfp wl = (l2o_cfp)p.wl, wfc = (l2o_cfp)p.wfc, bfc = (l2o_cfp)p.bfc;
-  const size_t N = (size_t)p.B * p.D;                   // a multiple of 16: D % 16 == 0
+  const size_t N = (size_t)p.B * p.D;                   // D % 16 == 0, or one flat row (B == 1) with a ragged last tile
   const size_t grp = (size_t)blockIdx.x * 4 + wv;         // == the state tile index
-  const bool valid = grp * NC < N;                        // whole waves are valid or not
+  const bool valid = grp * NC < N;
   const size_t n0 = valid ? grp * NC : 0;
-  const size_t n = n0 + cl;
+  const int nv = valid ? (int)(N - n0 < (size_t)NC ? N - n0 : (size_t)NC) : 0;   // coordinates of this tile that exist
+  const size_t n = n0 + cl < N ? n0 + cl : N - 1;         // (tail lanes recompute the last coordinate; nothing of theirs is stored)
   const int c = cl;
   float* xi = xin + cl;                                   // element k at xi[k * NC]
   // ---- coalesced loads: the state tile and the four carry blocks of these 16 coordinates ----
@@ -298,8 +299,9 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
     for (int a4 = 0; a4 < 4; ++a4) {
       const float4* cs = reinterpret_cast<const float4*>(p.carry_in + ((size_t)a4 * N + n0) * kH);
       float4* cd = reinterpret_cast<float4*>(cio + a4 * NC * kH);
-      cd[lane] = cs[lane];
-      if (lane < NC * kH / 4 - 64) cd[64 + lane] = cs[64 + lane];
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      cd[lane] = lane < nv * 5 ? cs[lane] : zero4;
+      if (lane < NC * kH / 4 - 64) cd[64 + lane] = 64 + lane < nv * 5 ? cs[64 + lane] : zero4;
     }
   }
   auto st_at = [&](int a, int u) {                        // (array a, unit u) of this lane's coordinate
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   const float act_a = part == 1 ? 2.0f : 1.0f, act_c0 = part == 1 ? -1.0f : 0.0f;
 
   // z[u] = bias[part*20 + u] + sum_k in[k] W[k][part*20 + u]
-  auto gemm = [&](const float* W, const float* bias, int KK, float (&z)[kH]) {
+  auto gemm = [&](const float* W, const float* bias, auto kk_c, float (&z)[kH]) {
+    constexpr int KK = decltype(kk_c)::value;
 #pragma unroll
     for (int u = 0; u < kH; ++u) z[u] = bias[part * kH + u];
     const float* wp = W + part * kH;
@@ -335,7 +338,8 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
     for (int u = 0; u < kH; ++u) z[u] = __builtin_fmaf(act_a, bw_sig(__builtin_fmaf(act_s, z[u], act_s0)), act_c0);
   };
   // xi[k] = sum over the quad of sum_u dz[u] W[k][part*20 + u]   (every lane of the quad gets it)
-  auto gemm_t = [&](const float* W, int KK, const float (&dz)[kH]) {
+  auto gemm_t = [&](const float* W, auto kk_c, const float (&dz)[kH]) {
+    constexpr int KK = decltype(kk_c)::value;
     const float* wp = W + part * kH;
 #pragma unroll 4
     for (int k = 0; k < KK; ++k) {
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   BCK();
   // ---- layer 1 forward -------------------------------------------------------------------
   float z1[kH];
-  gemm(W1, p.bg1, K1, z1);
+  gemm(W1, p.bg1, std::integral_constant<int, K1>{}, z1);
   BCK();
   float gi1[kH], gj1[kH], gf1[kH], go1[kH], tc1[kH];
   gather(z1, gi1, gj1, gf1, go1);
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   // ---- layer 2 forward + backward ----------------------------------------------------------
   BCK();
   float z2[kH];
-  gemm(W2, p.bg2, 2 * kH, z2);
+  gemm(W2, p.bg2, std::integral_constant<int, 2 * kH>{}, z2);
   BCK();
   const float* cin0 = cio + (0 * NC + cl) * kH;   // this coordinate's carries dh1, dc1, dh2, dc2
   float* const cin1 = cio + (1 * NC + cl) * kH;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   for (int u = 0; u < kH; ++u) brow[G + part * kH + u] = z2[u];
   __syncthreads();                                          // layer-2 input fully consumed
   BCK();
-  gemm_t(W2, 2 * kH, z2);                                 // d[h1; h2(t-1)] = dz2 . W2^T
+  gemm_t(W2, std::integral_constant<int, 2 * kH>{}, z2);                                 // d[h1; h2(t-1)] = dz2 . W2^T
   BCK();
   __syncthreads();
   // ---- layer 1 backward ------------------------------------------------------------------------
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   for (int u = 0; u < kH; ++u) brow[part * kH + u] = z1[u];
   __syncthreads();
   BCK();
-  gemm_t(W1, K1, z1);                                     // d[inputs; h1(t-1)] = dz1 . W1^T
+  gemm_t(W1, std::integral_constant<int, K1>{}, z1);                                     // d[inputs; h1(t-1)] = dz1 . W1^T
   BCK();
   __syncthreads();
   {
@@ -500,16 +504,19 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   BCK();
   // ---- coalesced stores: the A / Bm row blocks and the carries of these 16 coordinates ---------
   if (valid) {
-    float4* ad = reinterpret_cast<float4*>(p.act1 + n0 * KA);
-    for (int i = lane; i < NC * KA / 4; i += 64) ad[i] = reinterpret_cast<const float4*>(At)[i];
-    float4* bd = reinterpret_cast<float4*>(p.dz1 + n0 * KB);
-    for (int i = lane; i < NC * KB / 4; i += 64) bd[i] = reinterpret_cast<const float4*>(Bt)[i];
+    const int na = nv * KA, nb = nv * KB;                 // floats of the row blocks that exist
+    float* ag = p.act1 + n0 * KA;
+    for (int i = lane; i < na / 4; i += 64) reinterpret_cast<float4*>(ag)[i] = reinterpret_cast<const float4*>(At)[i];
+    for (int e = (na & ~3) + lane; e < na; e += 64) ag[e] = At[e];
+    float* bg = p.dz1 + n0 * KB;
+    for (int i = lane; i < nb / 4; i += 64) reinterpret_cast<float4*>(bg)[i] = reinterpret_cast<const float4*>(Bt)[i];
+    for (int e = (nb & ~3) + lane; e < nb; e += 64) bg[e] = Bt[e];
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4) {
       float4* cd = reinterpret_cast<float4*>(p.carry_out + ((size_t)a4 * N + n0) * kH);
       const float4* cs = reinterpret_cast<const float4*>(cio + a4 * NC * kH);
-      cd[lane] = cs[lane];
-      if (lane < NC * kH / 4 - 64) cd[64 + lane] = cs[64 + lane];
+      if (lane < nv * 5) cd[lane] = cs[lane];
+      if (lane < NC * kH / 4 - 64 && 64 + lane < nv * 5) cd[64 + lane] = cs[64 + lane];
     }
   }
 #ifdef L2O_BWD_CLOCK

@@ -1226,9 +1226,9 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
                         io->h2 == io->act1 + K1q + 2 * kH && io->dz2 == io->dz1 + 4 * kH && io->dd == io->dz1 + 8 * kH &&
                         (pre != L2O_PRE_FC_ELU || (io->feats == io->act1 + K1q + 3 * kH && io->du == io->dz1 + 8 * kH + 1 &&
                                                    io->m && io->v && w->w_fc && w->b_fc));
-    if (layout && D % kTile == 0 && ((uintptr_t)io->act1 & 15) == 0 && ((uintptr_t)io->dz1 & 15) == 0 &&
+    if (layout && (D % kTile == 0 || B == 1) && ((uintptr_t)io->act1 & 15) == 0 && ((uintptr_t)io->dz1 & 15) == 0 &&
         !getenv("L2O_BWD_GENERIC")) {
-      const dim3 grid((unsigned)((N / kTile + 3) / 4)), block(256);
+      const dim3 grid((unsigned)(((N + kTile - 1) / kTile + 3) / 4)), block(256);
       void (*fn)(BwdParams) = nullptr;
       size_t lds = 0;
       switch (pre) {

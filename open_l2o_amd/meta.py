@@ -592,22 +592,25 @@ class UnrollGraph(object):
         K1 = P + H
         KA = K1 + 2 * H + H + (2 if fc else 0) + 1
         KB = 4 * H + 4 * H + 1 + (H if fc else 0)
-        A = eng.empty(T, N, KA)
-        Bm = eng.empty(T, N, KB)
-        A[:, :, KA - 1] = 1.0
+        Np = (N + 15) // 16 * 16                           # rows per step padded to whole tiles: every step's
+        if Np == N:                                        # block stays 16-byte aligned (zero padding rows add nothing)
+            A, Bm = eng.empty(T, Np, KA), eng.empty(T, Np, KB)
+        else:
+            A, Bm = eng.zeros(T, Np, KA), eng.zeros(T, Np, KB)
+        A[:, :N, KA - 1] = 1.0
         carry_in, carry_out = eng.zeros(4, N, H), eng.empty(4, N, H)
         for t in reversed(range(T)):
             k = step0 + t
             At, Bt = A[t], Bm[t]
             io = dict(g=gs[t], dx_next=dxs[t], st_prev=sts[t], carry_in=carry_in, carry_out=carry_out,
                       m=ms[t], v=vs[t], a_stride=KA, b_stride=KB,
-                      act1=At[:, 0:K1], act2=At[:, K1:K1 + 2 * H], h2=At[:, K1 + 2 * H:K1 + 3 * H],
-                      dz1=Bt[:, 0:4 * H], dz2=Bt[:, 4 * H:8 * H], dd=Bt[:, 8 * H:8 * H + 1])
+                      act1=At[:N, 0:K1], act2=At[:N, K1:K1 + 2 * H], h2=At[:N, K1 + 2 * H:K1 + 3 * H],
+                      dz1=Bt[:N, 0:4 * H], dz2=Bt[:N, 4 * H:8 * H], dd=Bt[:N, 8 * H:8 * H + 1])
             if fc:
-                io.update(feats=At[:, K1 + 3 * H:K1 + 3 * H + 2], du=Bt[:, 8 * H + 1:8 * H + 1 + H])
+                io.update(feats=At[:N, K1 + 3 * H:K1 + 3 * H + 2], du=Bt[:N, 8 * H + 1:8 * H + 1 + H])
             eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, B, D)
             carry_in, carry_out = carry_out, carry_in
-        Gm = _chunked_atb(A.view(T * N, KA), Bm.view(T * N, KB))
+        Gm = _chunked_atb(A.view(T * Np, KA), Bm.view(T * Np, KB))
         add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
         add("lstm_1", "b_gates", Gm[KA - 1, 0:4 * H])
         add("lstm_2", "w_gates", Gm[K1:K1 + 2 * H, 4 * H:8 * H])
