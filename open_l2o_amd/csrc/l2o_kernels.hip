@@ -519,7 +519,7 @@ __device__ __forceinline__ void dot4(const float4 a, const float4 b, float4& acc
 }
 __device__ __forceinline__ float hsum4(const float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-template <int PRE, int KIND, int CH>
+template <int PRE, int KIND, int CH, bool HIST>
 __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   // CH <= 4 <=> at most 4 waves per workgroup = one wave per SIMD: the bf16x3 gate GEMM with
   // its weights in VGPR + AGPR; CH == 8 (5..8 waves) keeps the fp32 MFMA form
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     if (live && q == 0) xs[j] = xsv;
-    if (a.hist_st && t < a.T)
+    if (HIST && t < a.T)
       store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * nw + tile) * kStateFloatsPerTile, lane);
     L2O_SYNC();                                             // B1: xs complete
     // ---- r = W xs - y  ||  first 12 layer-2 MFMAs of the previous h2 -----------
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
       for (int k = 1; k < nw; ++k) f += fpart[k];
       a.fx_part[(size_t)t * pp.B_local + b] = f;
     }
-    if (t == a.T && !a.hist_gfinal) break;
+    if (t == a.T && !HIST) break;
 
     // ---- g = W^T r for this wave's 16 coordinates  ||  the other 13 of those MFMAs ----
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
@@ -640,18 +640,18 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
-    if (a.hist_g && live && q == 0) {
+    if (HIST && live && q == 0) {
       if (t < a.T) a.hist_g[(size_t)t * hist_n + idx] = gv;
       else a.hist_gfinal[idx] = gv;
     }
-    if (t == a.T) break;                                    // (history mode: the gradient at x_T was still needed)
+    if (HIST && t == a.T) break;                            // (history mode: the gradient at x_T was still needed)
 
     // ---- optimizer network ----------------------------------------------------
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
       // beta^k as a float-float running product (k = step0 + t)
       rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, 1.0f - p1h, 1.0f - p2h, in0, in1);
-      if (a.hist_m && live && q == 0) { a.hist_m[(size_t)t * hist_n + idx] = mv; a.hist_v[(size_t)t * hist_n + idx] = vv; }
+      if (HIST && live && q == 0) { a.hist_m[(size_t)t * hist_n + idx] = mv; a.hist_v[(size_t)t * hist_n + idx] = vv; }
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       {
         float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
@@ -839,6 +839,7 @@ static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) 
 template <int PRE, int KIND>
 static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s, const l2o_problem* prob,
                             void* workspace) {
+  const bool hist = a.hist_st != nullptr;
   if (workspace && pair_eligible(prob, g)) {
     const PairLayout L = pair_layout(prob, g, a.T);
     UnrollPairArgs pa;
@@ -848,9 +849,9 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     pa.fx_half = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.fxh_off);
     void (*fn)(UnrollPairArgs) = nullptr;
     switch (g.CH) {
-      case 2: fn = k_unroll_pair<PRE, KIND, 2>; break;
-      case 4: fn = k_unroll_pair<PRE, KIND, 4>; break;
-      default: fn = k_unroll_pair<PRE, KIND, 8>; break;
+      case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : k_unroll_pair<PRE, KIND, 2, false>; break;
+      case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
+      default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
     }
     HIP_TRY(hipMemsetAsync(workspace, 0, L.fxh_off, s));
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
@@ -864,10 +865,10 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
   }
   void (*fn)(UnrollArgs) = nullptr;
   switch (g.CH) {
-    case 1: fn = k_unroll<PRE, KIND, 1>; break;
-    case 2: fn = k_unroll<PRE, KIND, 2>; break;
-    case 4: fn = k_unroll<PRE, KIND, 4>; break;
-    default: fn = k_unroll<PRE, KIND, 8>; break;
+    case 1: fn = hist ? k_unroll<PRE, KIND, 1, true> : k_unroll<PRE, KIND, 1, false>; break;
+    case 2: fn = hist ? k_unroll<PRE, KIND, 2, true> : k_unroll<PRE, KIND, 2, false>; break;
+    case 4: fn = hist ? k_unroll<PRE, KIND, 4, true> : k_unroll<PRE, KIND, 4, false>; break;
+    default: fn = hist ? k_unroll<PRE, KIND, 8, true> : k_unroll<PRE, KIND, 8, false>; break;
   }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)g.lds));

@@ -64,7 +64,9 @@ __device__ __forceinline__ void lds_read_f4(float4 (&v)[N], const float* p) {
                  : "v"(addr) : "memory");
 }
 
-template <int PRE, int KIND, int CH>
+// HIST: also record the per-step history for the meta-gradient (l2o_unroll_record); a template
+// parameter so that the plain unroll carries none of it
+template <int PRE, int KIND, int CH, bool HIST>
 __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
   constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     const unsigned tag = (unsigned)t + 1u;
     const int par = t & 1;
     if (q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
-    if (a.hist_st && t < a.T && tile_real)
+    if (HIST && t < a.T && tile_real)
       store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * tpp + (size_t)b * tpp + tile_in_prob) *
                                           kStateFloatsPerTile, lane);
     pc.mark(0);
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       for (int k = 1; k < NWH; ++k) f += fpart[k];
       pa.fx_half[(size_t)t * 2 * pp.B_local + 2 * b + half] = f;
     }
-    if (t == a.T && !a.hist_gfinal) break;
+    if (t == a.T && !HIST) break;
 
     // ---- g = W^T r for this wave's 16 coordinates ------------------------------
     // all CH residual reads are issued back to back (hipcc serialises them on one register
@@ -253,16 +255,16 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
-    if (a.hist_g && live && q == 0) {
+    if (HIST && live && q == 0) {
       if (t < a.T) a.hist_g[(size_t)t * hist_n + idx] = gv;
       else a.hist_gfinal[idx] = gv;
     }
-    if (t == a.T) break;                                    // (history mode: the gradient at x_T was still needed)
+    if (HIST && t == a.T) break;                            // (history mode: the gradient at x_T was still needed)
 
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
       rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, 1.0f - p1h, 1.0f - p2h, in0, in1);
-      if (a.hist_m && live && q == 0) { a.hist_m[(size_t)t * hist_n + idx] = mv; a.hist_v[(size_t)t * hist_n + idx] = vv; }
+      if (HIST && live && q == 0) { a.hist_m[(size_t)t * hist_n + idx] = mv; a.hist_v[(size_t)t * hist_n + idx] = vv; }
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       {
         float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);

@@ -16,3 +16,9 @@ rocprofv3 --kernel-trace --stats -d $O/prof_trace -o trace -- python $R/bench.py
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -o fetch -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_fetch_bench.json 2>$O/prof_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -o write -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_write_bench.json 2>$O/prof_write.err
 ls $O/prof_trace $O/prof_fetch $O/prof_write 2>&1 | head -20
+cd $R
+python bench.py --steps 5 --warmup 3 --problem lasso --net rnnprop --dims 512 --rows 256 --batch 256 --unroll 200 --shared-matrix 2>>$O/bench.err | tee $O/bench_c3_shared.json | cut -c1-200
+python bench.py --steps 5 --warmup 3 --problem mnist --net rnnprop --unroll 100 --no-cpu-baseline 2>>$O/bench.err | tee $O/bench_mnist.json | cut -c1-200
+python scripts/microbench/train_step_timing.py 2>/dev/null | tail -1 | tee $O/train_step.txt
+python scripts/microbench/train_step_timing.py 128 128 100 2>/dev/null | tail -1 | tee -a $O/train_step.txt
+python scripts/microbench/train_step_timing_mnist.py 2>/dev/null | tail -1 | tee -a $O/train_step.txt
