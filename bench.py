@@ -181,6 +181,9 @@ def main():
     Bg = B * world
     optimizer, ml, feed, weights = build_workload(args, Bg)
     graph = optimizer.graph
+    graph.reset()                                           # (first call: allocator / context warm-up)
+    if eng.device.type == "cuda":
+        torch.cuda.synchronize()
     t_reset = time.perf_counter()
     graph.reset()                                           # sample x0, W, y on the host (NumPy), upload this rank's shard
     if eng.device.type == "cuda":

@@ -1078,7 +1078,7 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
   const bool want_g = gw1 || gb1 || gw2 || gb2;
   if (want_g && !(gw1 && gb1 && gw2 && gb2)) return fail(L2O_ERR_ARG, "l2o_mlp_fg: pass all four gradients or none");
   if (mlp->n_hidden < 1 || mlp->n_hidden > kMlpMaxH || mlp->n_out < 1 || mlp->n_out > kMlpMaxO ||
-      mlp->batch < 1 || mlp->batch > 256 || mlp->n_in < 1 || mlp->n_in > 32 * kMlpKPT)
+      mlp->batch < 1 || mlp->batch > 256 || mlp->n_in < 1 || mlp->n_in > kMlpTPS * kMlpKPT)
     return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: sizes n_in=%d hidden=%d out=%d batch=%d not implemented",
                 mlp->n_in, mlp->n_hidden, mlp->n_out, mlp->batch);
   if (!scratch) return fail(L2O_ERR_ARG, "l2o_mlp_fg: NULL scratch (l2o_mlp_scratch_floats)");
@@ -1091,7 +1091,7 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
   hipStream_t s = (hipStream_t)stream;
   const int HP = p.H == 20 ? 20 : kMlpMaxH;             // padded hidden width of the kernels' hot loops
   const int HS = HP | 1;
-  const size_t lds_f = sizeof(float) * ((size_t)p.n_in * HS + (size_t)kMlpSPB * 32 * HP + (size_t)kMlpSPB * p.H +
+  const size_t lds_f = sizeof(float) * ((HP == 20 ? 0 : (size_t)p.n_in * HS) + (size_t)kMlpSPB * kMlpTPS * HP + (size_t)kMlpSPB * p.H +
                                         (size_t)kMlpSPB * p.O + (size_t)p.H * p.O + p.H + p.O);
   size_t lds_b = sizeof(float) * ((size_t)p.batch * HP + (size_t)p.batch + 4 * (size_t)kMlpKPB * HP);
   const size_t lds_small = sizeof(float) * (size_t)p.batch * (2 * p.H + p.O + 1);   // the small-tensor workgroup's copy of scratch

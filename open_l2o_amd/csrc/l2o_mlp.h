@@ -3,7 +3,8 @@
 // cross-entropy on a gathered minibatch: forward + gradient in two small multi-workgroup
 // launches (8 MFLOP per evaluation: latency-, not throughput-bound; the LSTM step on its
 // 15 910 coordinates runs in k_cwlstm_step).  Included by l2o_kernels.hip.
-//   k_mlp_fwd : 8 samples per workgroup, 32 threads per sample over the 784 inputs
+//   k_mlp_fwd : 4 samples per workgroup, 64 threads per sample over the 784 inputs (w1 rows
+//               straight from L2 for the common hidden width 20)
 //               -> H, dZ = (softmax - onehot)/batch, dH, per-sample loss (scratch in HBM)
 //   k_mlp_bwd : 64 input rows of gw1 per workgroup (coalesced image rows), one extra
 //               workgroup for gw2, gb2, gb1 and the fixed-order loss sum
@@ -11,9 +12,10 @@
 
 constexpr int kMlpMaxH = 32;
 constexpr int kMlpMaxO = 16;
-constexpr int kMlpSPB = 8;        // samples per forward workgroup
+constexpr int kMlpTPS = 64;       // forward: threads per sample (k = lane + 64 i)
+constexpr int kMlpSPB = 256 / kMlpTPS;   // samples per forward workgroup
 constexpr int kMlpKPB = 64;       // gw1 rows per backward workgroup
-constexpr int kMlpKPT = 32;       // inputs per forward thread: n_in <= 32 * kMlpKPT
+constexpr int kMlpKPT = 16;       // inputs per forward thread: n_in <= kMlpTPS * kMlpKPT
 constexpr int kMlpNPT = 32;       // samples per backward thread and pass
 
 // cooperative global -> LDS copy by 256 threads with 8 independent loads in flight per thread
@@ -60,9 +62,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
   extern __shared__ float sm[];
   const int n_in = p.n_in, H = p.H, O = p.O, Bn = p.batch;
   constexpr int HS = HP | 1;                            // odd row stride: conflict-free w1 reads
-  float* w1s = sm;                                      // [n_in][HS]
-  float* part = w1s + n_in * HS;                        // [SPB][32][HP]
-  float* hs = part + kMlpSPB * 32 * HP;                 // [SPB][H]
+  float* w1s = sm;                                      // [n_in][HS]   (generic width only)
+  float* part = w1s + (HP == 20 ? 0 : n_in * HS);       // [SPB][TPS][HP]
+  float* hs = part + kMlpSPB * kMlpTPS * HP;            // [SPB][H]
   float* zs = hs + kMlpSPB * H;                         // [SPB][O]
   float* sw2 = zs + kMlpSPB * O;                        // [H][O]  (staged: the tail below is latency bound)
   float* sb1 = sw2 + H * O;                             // [H]
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
   long long ck[10];
 #endif
   const int tid = threadIdx.x;
-  const int sl = tid >> 5, l32 = tid & 31;
+  const int sl = tid / kMlpTPS, l32 = tid % kMlpTPS;
   MLP_CK(0);
   int lab = 0;                                          // label of sample blockIdx * SPB + tid (tid < SPB)
   if (tid < kMlpSPB && (int)blockIdx.x * kMlpSPB + tid < Bn) lab = p.labels[p.idx[blockIdx.x * kMlpSPB + tid]];
@@ -81,48 +83,80 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
   const int n = blockIdx.x * kMlpSPB + sl;
   const bool valid = n < Bn;
   const int row = valid ? p.idx[n] : 0;
-  // the sample's inputs of this thread (k = l32 + 32 i) go out first, all at once: one memory
+  // the sample's inputs of this thread (k = l32 + 64 i) go out first, all at once: one memory
   // latency instead of one per loop iteration, and it overlaps the staging of w1
   const float* xrow = p.images + (size_t)row * n_in;
   float xr[kMlpKPT];
 #pragma unroll
   for (int i = 0; i < kMlpKPT; ++i) {
-    const int k = l32 + 32 * i;
+    const int k = l32 + kMlpTPS * i;
     xr[i] = k < n_in ? xrow[k] : 0.0f;
   }
-  if (HP != 20)                                         // generic width: zero the padding columns
-    for (int i = tid; i < n_in * HS; i += 256) w1s[i] = 0.0f;
-  if (HP != 20) __syncthreads();
-  const int Hc = HP == 20 ? 20 : H;                     // compile-time divisor on the common path
-  for (int base = tid; base < n_in * Hc; base += 256 * 8) {
-    float v[8];
+  if constexpr (HP == 20) {
+    // the common width: w1 rows (20 floats = 5 dwordx4) straight from L2, four rows per thread in
+    // flight; no 62 KB staging pass per workgroup, no barrier before the GEMV
+    __syncthreads();                                      // (sw2, sb1, sb2 staged)
+    MLP_CK(1);
+    float acc[HP];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int i = base + 256 * jj;
-      v[jj] = i < n_in * Hc ? p.w1[i] : 0.0f;
+    for (int u = 0; u < HP; ++u) acc[u] = 0.0f;
+    const float4* w4 = reinterpret_cast<const float4*>(p.w1);
+#pragma unroll
+    for (int i0 = 0; i0 < kMlpKPT; i0 += 4) {
+      if (kMlpTPS * i0 < n_in) {                          // wave-uniform
+        float4 wv[4][5];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int k = min(l32 + kMlpTPS * (i0 + ii), n_in - 1);   // out-of-range slots carry xr == 0
+#pragma unroll
+          for (int c5 = 0; c5 < 5; ++c5) wv[ii][c5] = w4[k * 5 + c5];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const float xv = xr[i0 + ii];
+#pragma unroll
+          for (int c5 = 0; c5 < 5; ++c5) {
+            acc[4 * c5 + 0] = __builtin_fmaf(xv, wv[ii][c5].x, acc[4 * c5 + 0]);
+            acc[4 * c5 + 1] = __builtin_fmaf(xv, wv[ii][c5].y, acc[4 * c5 + 1]);
+            acc[4 * c5 + 2] = __builtin_fmaf(xv, wv[ii][c5].z, acc[4 * c5 + 2]);
+            acc[4 * c5 + 3] = __builtin_fmaf(xv, wv[ii][c5].w, acc[4 * c5 + 3]);
+          }
+        }
+      }
     }
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int i = base + 256 * jj;
-      if (i < n_in * Hc) w1s[(i / Hc) * HS + (i % Hc)] = v[jj];
+    for (int u = 0; u < HP; ++u) part[(sl * kMlpTPS + l32) * HP + u] = acc[u];
+  } else {
+    for (int i = tid; i < n_in * HS; i += 256) w1s[i] = 0.0f;   // generic width: zero the padding columns
+    __syncthreads();
+    for (int base = tid; base < n_in * H; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int i = base + 256 * jj;
+        v[jj] = i < n_in * H ? p.w1[i] : 0.0f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int i = base + 256 * jj;
+        if (i < n_in * H) w1s[(i / H) * HS + (i % H)] = v[jj];
+      }
     }
-  }
-  __syncthreads();
-  MLP_CK(1);
-  {
+    __syncthreads();
+    MLP_CK(1);
     float acc[HP];
 #pragma unroll
     for (int u = 0; u < HP; ++u) acc[u] = 0.0f;
 #pragma unroll
     for (int i = 0; i < kMlpKPT; ++i) {
-      const int k = min(l32 + 32 * i, n_in - 1);        // out-of-range slots carry xr == 0
+      const int k = min(l32 + kMlpTPS * i, n_in - 1);   // out-of-range slots carry xr == 0
       const float xv = xr[i];
       const float* wr = w1s + k * HS;
 #pragma unroll
       for (int u = 0; u < HP; ++u) acc[u] = __builtin_fmaf(xv, wr[u], acc[u]);
     }
 #pragma unroll
-    for (int u = 0; u < HP; ++u) part[(sl * 32 + l32) * HP + u] = acc[u];
+    for (int u = 0; u < HP; ++u) part[(sl * kMlpTPS + l32) * HP + u] = acc[u];
   }
   MLP_CK(2);
   __syncthreads();
@@ -134,7 +168,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpParams p) {
     const int s2 = tid / H, u = tid % H;
     float a = sb1[u];
 #pragma unroll 8
-    for (int l = 0; l < 32; ++l) a += part[(s2 * 32 + l) * HP + u];
+    for (int l = 0; l < kMlpTPS; ++l) a += part[(s2 * kMlpTPS + l) * HP + u];
     hs[s2 * H + u] = p.act == 0 ? 1.0f / (1.0f + expf(-a)) : fmaxf(a, 0.0f);
   }
   __syncthreads();

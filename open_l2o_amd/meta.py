@@ -100,9 +100,9 @@ class Variable(object):
         elif init[0] == "ones":
             arr = np.ones(shape, np.float32)
         elif init[0] == "normal":
-            arr = (_rng.standard_normal(shape) * init[2] + init[1]).astype(np.float32)
+            arr = _rng.standard_normal(shape, dtype=np.float32) * np.float32(init[2]) + np.float32(init[1])
         elif init[0] == "uniform":
-            arr = (_rng.random(shape) * (init[2] - init[1]) + init[1]).astype(np.float32)
+            arr = _rng.random(shape, dtype=np.float32) * np.float32(init[2] - init[1]) + np.float32(init[1])
         elif init[0] == "constant":
             arr = np.broadcast_to(init[1], shape).astype(np.float32)
         else:
