@@ -4,14 +4,17 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
-import oracle as O
-from open_l2o_amd._engine import HipEngine
-from tests.helpers import spec_of, make_params
+from open_l2o_amd import _abi, networks
+from open_l2o_amd._engine import HipEngine, NetSpec
 
 eng = HipEngine()
-for name, cfg in (("dm", O.DM_IDENTITY), ("rnnprop", O.RNNPROP)):
-    spec = spec_of(cfg)
-    wpack = eng.pack_weights(spec, make_params(cfg, 1, trained_like=True))
+NETS = (("dm", "CoordinateWiseDeepLSTM", {"layers": (20, 20)}, NetSpec(_abi.NET_CW, _abi.PRE_IDENTITY, (20, 20), 1.0, False)),
+        ("rnnprop", "RNNprop", {"layers": (20, 20), "preprocess_name": "fc", "preprocess_options": {"dim": 20},
+                                "scale": 0.01, "tanh_output": True},
+         NetSpec(_abi.NET_RNNPROP, _abi.PRE_FC_ELU, (20, 20), 0.01, True)))
+for name, cls, opts, spec in NETS:
+    net = networks.factory(cls, opts)
+    wpack = eng.pack_weights(spec, {m: {v: np.array(a) for v, a in d.items()} for m, d in net.variables.items()})
     for B, D in ((1, 16), (64, 16), (256, 64), (256, 128), (256, 256), (256, 512), (1024, 512)):
         g = eng.tensor((np.random.default_rng(0).standard_normal((B, D)) * 0.1).astype(np.float32))
         m, v, x = eng.zeros(B, D), eng.zeros(B, D), eng.zeros(B, D)

@@ -7,19 +7,20 @@ import sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle as O
-from helpers import device_problem, make_params, make_problem, spec_of
-from open_l2o_amd._engine import HipEngine
+from open_l2o_amd import _abi, networks
+from open_l2o_amd._engine import HipEngine, NetSpec, ProblemDesc
 
 eng = HipEngine()
-cfg = O.DM_IDENTITY
 B, D, T = 128, 128, 100
-params = make_params(cfg, 0, trained_like=True)
-prob, x0, arrays = make_problem("quadratic", B, D, seed=1)
-spec = spec_of(cfg)
+rng = np.random.default_rng(1)
+net = networks.factory("CoordinateWiseDeepLSTM", {"layers": (20, 20)})        # Sonnet-default random weights
+params = {m: {v: np.array(a) for v, a in d.items()} for m, d in net.variables.items()}
+params["linear"] = {k: (a * np.float32(0.1)).astype(np.float32) for k, a in params["linear"].items()}
+spec = NetSpec(_abi.NET_CW, _abi.PRE_IDENTITY, (20, 20), 1.0, False)
 wpack = eng.pack_weights(spec, params)
-pd = device_problem(eng, arrays, B, D)
+pd = ProblemDesc(kind=_abi.PROB_QUADRATIC, B_local=B, B_global=B, D=D, M=D,
+                 W=eng.tensor(rng.random((B, D, D), dtype=np.float32)), y=eng.tensor(rng.random((B, D), dtype=np.float32)))
+x0 = (rng.standard_normal((B, D)) * 0.01).astype(np.float32)
 for it in range(3):
     x, st = eng.tensor(x0), eng.state_alloc(B, D)
     fp = eng.zeros((T + 1) * B)
