@@ -283,7 +283,12 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   }
   const l2o_cfp wl = (l2o_cfp)p.wl, wfc = (l2o_cfp)p.wfc, bfc = (l2o_cfp)p.bfc;
   const size_t N = (size_t)p.B * p.D;                   // D % 16 == 0, or one flat row (B == 1) with a ragged last tile
-  const size_t grp = (size_t)blockIdx.x * 4 + wv;         // == the state tile index
+  // persistent: a workgroup walks tile groups blockIdx, blockIdx + gridDim, ... (the weights are
+  // staged once and the long straight-line body stays in the instruction cache)
+  const size_t ngrp4 = ((N + NC - 1) / NC + 3) / 4;       // groups of 4 tiles
+  for (size_t g4 = blockIdx.x; g4 < ngrp4; g4 += gridDim.x) {
+  __syncthreads();                                        // the previous group's LDS tiles are fully stored
+  const size_t grp = g4 * 4 + wv;                         // == the state tile index
   const bool valid = grp * NC < N;
   const size_t n0 = valid ? grp * NC : 0;
   const int nv = valid ? (int)(N - n0 < (size_t)NC ? N - n0 : (size_t)NC) : 0;   // coordinates of this tile that exist
@@ -321,7 +326,6 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
 #pragma unroll
     for (int u = 0; u < kH; ++u) z[u] = bias[part * kH + u];
     const float* wp = W + part * kH;
-#pragma unroll 4
     for (int k = 0; k < KK; ++k) {
       const float xv = xi[k * NC];
       const float4* wr = reinterpret_cast<const float4*>(wp + k * G);
@@ -338,10 +342,8 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
     for (int u = 0; u < kH; ++u) z[u] = __builtin_fmaf(act_a, bw_sig(__builtin_fmaf(act_s, z[u], act_s0)), act_c0);
   };
   // xi[k] = sum over the quad of sum_u dz[u] W[k][part*20 + u]   (every lane of the quad gets it)
-  auto gemm_t = [&](const float* W, auto kk_c, const float (&dz)[kH]) {
-    constexpr int KK = decltype(kk_c)::value;
+  auto gemm_t = [&](const float* W, int KK, const float (&dz)[kH]) {
     const float* wp = W + part * kH;
-#pragma unroll 4
     for (int k = 0; k < KK; ++k) {
       const float4* wr = reinterpret_cast<const float4*>(wp + k * G);
       float s0 = 0.0f, s1 = 0.0f;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   BCK();
   // ---- layer 1 forward -------------------------------------------------------------------
   float z1[kH];
-  gemm(W1, p.bg1, std::integral_constant<int, K1>{}, z1);
+  gemm(W1, p.bg1, K1, z1);
   BCK();
   float gi1[kH], gj1[kH], gf1[kH], go1[kH], tc1[kH];
   gather(z1, gi1, gj1, gf1, go1);
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   // ---- layer 2 forward + backward ----------------------------------------------------------
   BCK();
   float z2[kH];
-  gemm(W2, p.bg2, std::integral_constant<int, 2 * kH>{}, z2);
+  gemm(W2, p.bg2, 2 * kH, z2);
   BCK();
   const float* cin0 = cio + (0 * NC + cl) * kH;   // this coordinate's carries dh1, dc1, dh2, dc2
   float* const cin1 = cio + (1 * NC + cl) * kH;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   for (int u = 0; u < kH; ++u) brow[G + part * kH + u] = z2[u];
   __syncthreads();                                          // layer-2 input fully consumed
   BCK();
-  gemm_t(W2, std::integral_constant<int, 2 * kH>{}, z2);                                 // d[h1; h2(t-1)] = dz2 . W2^T
+  gemm_t(W2, 2 * kH, z2);                                 // d[h1; h2(t-1)] = dz2 . W2^T
   BCK();
   __syncthreads();
   // ---- layer 1 backward ------------------------------------------------------------------------
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   for (int u = 0; u < kH; ++u) brow[part * kH + u] = z1[u];
   __syncthreads();
   BCK();
-  gemm_t(W1, std::integral_constant<int, K1>{}, z1);                                     // d[inputs; h1(t-1)] = dz1 . W1^T
+  gemm_t(W1, K1, z1);                                     // d[inputs; h1(t-1)] = dz1 . W1^T
   BCK();
   __syncthreads();
   {
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
       if (lane < NC * kH / 4 - 64 && 64 + lane < nv * 5) cd[64 + lane] = cs[64 + lane];
     }
   }
+  }                                                       // tile groups
 #ifdef L2O_BWD_CLOCK
   BCK();
   if (tid == 0 && blockIdx.x == 0) {

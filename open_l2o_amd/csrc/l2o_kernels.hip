@@ -1229,7 +1229,11 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
                                                    io->m && io->v && w->w_fc && w->b_fc));
     if (layout && (D % kTile == 0 || B == 1) && ((uintptr_t)io->act1 & 15) == 0 && ((uintptr_t)io->dz1 & 15) == 0 &&
         !getenv("L2O_BWD_GENERIC")) {
-      const dim3 grid((unsigned)(((N + kTile - 1) / kTile + 3) / 4)), block(256);
+      size_t nblk = ((N + kTile - 1) / kTile + 3) / 4;
+      size_t cap = (size_t)device_cu_count();               // persistent: one workgroup per CU walks the tile groups
+      if (const char* e = getenv("L2O_BWD_BLOCKS")) cap = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : cap;
+      if (nblk > cap) nblk = cap;
+      const dim3 grid((unsigned)nblk), block(256);
       void (*fn)(BwdParams) = nullptr;
       size_t lds = 0;
       switch (pre) {
