@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   const float act_a = part == 1 ? 2.0f : 1.0f, act_c0 = part == 1 ? -1.0f : 0.0f;
 
   // z[u] = bias[part*20 + u] + sum_k in[k] W[k][part*20 + u]
-  auto gemm = [&](const float* W, const float* bias, auto kk_c, float (&z)[kH]) {
-    constexpr int KK = decltype(kk_c)::value;
+  // (rolled k loops on purpose: unrolling them -- fully or by 4 -- measured 10 % slower)
+  auto gemm = [&](const float* W, const float* bias, int KK, float (&z)[kH]) {
 #pragma unroll
     for (int u = 0; u < kH; ++u) z[u] = bias[part * kH + u];
     const float* wp = W + part * kH;

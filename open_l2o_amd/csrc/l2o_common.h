@@ -406,11 +406,14 @@ __device__ __forceinline__ void rnnprop_inputs(float g, float& m, float& v, floa
                                                float& m_tilde, float& g_tilde) {
   m = beta1 * m + omb1 * g;
   v = beta2 * v + omb2 * g * g;
-  const float m_hat = m / om1;
-  const float v_hat = v / om2;
-  const float den = __builtin_sqrtf(v_hat) + 1e-8f;
-  m_tilde = m_hat / den;
-  g_tilde = g / den;
+  // the two bias corrections and the common denominator through v_rcp_f32 / v_sqrt_f32 (1 ulp each)
+  // instead of four IEEE divisions and an IEEE square root (~50 VALU instructions per step): the
+  // carried moments m, v are untouched, only the network inputs move by ~1e-7 relative
+  const float m_hat = m * fast_rcp(om1);
+  const float v_hat = v * fast_rcp(om2);
+  const float inv = fast_rcp(__builtin_amdgcn_sqrtf(v_hat) + 1e-8f);
+  m_tilde = m_hat * inv;
+  g_tilde = g * inv;
 }
 
 }  // namespace l2o
