@@ -230,6 +230,18 @@ __device__ __forceinline__ float bw_quad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+// k-loop unrolling of the tile kernel's GEMVs (measured: see DESIGN.md 3)
+#ifndef L2O_BWD_UNROLL
+#define L2O_BWD_UNROLL 1
+#endif
+#if L2O_BWD_UNROLL == 1
+#define L2O_BWD_UNROLL_PRAGMA _Pragma("nounroll")
+#elif L2O_BWD_UNROLL == 0
+#define L2O_BWD_UNROLL_PRAGMA _Pragma("unroll")
+#else
+#define L2O_BWD_UNROLL_PRAGMA _Pragma("unroll 4")
+#endif
+
 template <int PRE>
 struct BwdTileGeom {
   static constexpr int P = PRE == L2O_PRE_FC_ELU ? kH : (PRE == L2O_PRE_LOGSIGN ? 2 : 1);
@@ -321,11 +333,12 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   const float act_a = part == 1 ? 2.0f : 1.0f, act_c0 = part == 1 ? -1.0f : 0.0f;
 
   // z[u] = bias[part*20 + u] + sum_k in[k] W[k][part*20 + u]
-  // (rolled k loops on purpose: unrolling them -- fully or by 4 -- measured 10 % slower)
-  auto gemm = [&](const float* W, const float* bias, int KK, float (&z)[kH]) {
+  auto gemm = [&](const float* W, const float* bias, auto kk_c, float (&z)[kH]) {
+    constexpr int KK = decltype(kk_c)::value;
 #pragma unroll
     for (int u = 0; u < kH; ++u) z[u] = bias[part * kH + u];
     const float* wp = W + part * kH;
+    L2O_BWD_UNROLL_PRAGMA
     for (int k = 0; k < KK; ++k) {
       const float xv = xi[k * NC];
       const float4* wr = reinterpret_cast<const float4*>(wp + k * G);
@@ -342,8 +355,10 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
     for (int u = 0; u < kH; ++u) z[u] = __builtin_fmaf(act_a, bw_sig(__builtin_fmaf(act_s, z[u], act_s0)), act_c0);
   };
   // xi[k] = sum over the quad of sum_u dz[u] W[k][part*20 + u]   (every lane of the quad gets it)
-  auto gemm_t = [&](const float* W, int KK, const float (&dz)[kH]) {
+  auto gemm_t = [&](const float* W, auto kk_c, const float (&dz)[kH]) {
+    constexpr int KK = decltype(kk_c)::value;
     const float* wp = W + part * kH;
+    L2O_BWD_UNROLL_PRAGMA
     for (int k = 0; k < KK; ++k) {
       const float4* wr = reinterpret_cast<const float4*>(wp + k * G);
       float s0 = 0.0f, s1 = 0.0f;
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   BCK();
   // ---- layer 1 forward -------------------------------------------------------------------
   float z1[kH];
-  gemm(W1, p.bg1, K1, z1);
+  gemm(W1, p.bg1, std::integral_constant<int, K1>{}, z1);
   BCK();
   float gi1[kH], gj1[kH], gf1[kH], go1[kH], tc1[kH];
   gather(z1, gi1, gj1, gf1, go1);
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   // ---- layer 2 forward + backward ----------------------------------------------------------
   BCK();
   float z2[kH];
-  gemm(W2, p.bg2, 2 * kH, z2);
+  gemm(W2, p.bg2, std::integral_constant<int, 2 * kH>{}, z2);
   BCK();
   const float* cin0 = cio + (0 * NC + cl) * kH;   // this coordinate's carries dh1, dc1, dh2, dc2
   float* const cin1 = cio + (1 * NC + cl) * kH;
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   for (int u = 0; u < kH; ++u) brow[G + part * kH + u] = z2[u];
   __syncthreads();                                          // layer-2 input fully consumed
   BCK();
-  gemm_t(W2, 2 * kH, z2);                                 // d[h1; h2(t-1)] = dz2 . W2^T
+  gemm_t(W2, std::integral_constant<int, 2 * kH>{}, z2);                                 // d[h1; h2(t-1)] = dz2 . W2^T
   BCK();
   __syncthreads();
   // ---- layer 1 backward ------------------------------------------------------------------------
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   for (int u = 0; u < kH; ++u) brow[part * kH + u] = z1[u];
   __syncthreads();
   BCK();
-  gemm_t(W1, K1, z1);                                     // d[inputs; h1(t-1)] = dz1 . W1^T
+  gemm_t(W1, std::integral_constant<int, K1>{}, z1);                                     // d[inputs; h1(t-1)] = dz1 . W1^T
   BCK();
   __syncthreads();
   {
