@@ -224,6 +224,24 @@ typedef struct l2o_bwd_io {
 int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io,
                         double pow1, double pow2, int64_t B, int64_t D, void* stream);
 
+/* The same step for up to 8 panels (variables) that share the network, in ONE launch
+ * (the variables of a subset, DM/meta.py:330-336; problems.mnist has four).  Panel s occupies
+ * the tiles [T_{s-1}, T_s), T_s = sum_{j<=s} ceil(B_j D_j / 16), and the rows 16 * tile of the
+ * shared matrices  A [rows][KA] = [act1 | act2 | h2 | feats | 1],  Bm [rows][KB] = [dz1 | dz2 | dd | du]
+ * (rows = 16 * T_last; the rows of a ragged last tile that do not exist are left untouched) and
+ * of the carries [4][rows][H].  Every panel needs D % 16 == 0 or B == 1. */
+typedef struct l2o_bwd_seg {
+  const float* g;          /* device [B*D] */
+  const float* m;          /* RNNProp moments AFTER the step (or NULL) */
+  const float* v;
+  const float* st_prev;    /* device packed LSTM state BEFORE the step */
+  const float* dx_next;    /* device [B*D] */
+  int64_t B, D;
+} l2o_bwd_seg;
+int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_seg* segs, int32_t nseg,
+                         const float* carry_in, float* carry_out, float* A, float* Bm,
+                         double pow1, double pow2, void* stream);
+
 /* ---- the fused unroll: MetaOptimizer.meta_loss's tf.while_loop
  * (DM/meta.py:338-376; RNNProp DM/meta_rnnprop_eval.py time_step) as ONE persistent
  * launch: T x { fx_t = f(x_t*s); g = s*grad f; delta,state = net(g,state); x += delta }

@@ -200,6 +200,23 @@ class HipEngine(object):
         _abi.check(self.lib.l2o_cwlstm_bwd_step(C.byref(cc), C.byref(w), C.byref(b), float(pow1), float(pow2),
                                                 B, D, self._stream()))
 
+    def bwd_multi(self, spec: NetSpec, weights: dict, segs, carry_in, carry_out, A, Bm, pow1, pow2):
+        """One BPTT step for several panels of one network in one launch (l2o_cwlstm_bwd_multi).
+        segs: list of dict(g=, m=, v=, st_prev=, dx_next=, B=, D=); A [rows, KA], Bm [rows, KB] and the
+        carries [4, rows, 20] are shared, rows = 16 * (total tiles)."""
+        cc = spec.to_c()
+        w = _abi.NetWeights()
+        for k, _ in _abi.NetWeights._fields_:
+            setattr(w, k, None if weights.get(k) is None else weights[k].data_ptr())
+        arr = (_abi.BwdSeg * len(segs))()
+        for a, sg in zip(arr, segs):
+            for k in ("g", "m", "v", "st_prev", "dx_next"):
+                setattr(a, k, None if sg.get(k) is None else sg[k].data_ptr())
+            a.B, a.D = int(sg["B"]), int(sg["D"])
+        _abi.check(self.lib.l2o_cwlstm_bwd_multi(C.byref(cc), C.byref(w), arr, len(segs), _ptr(carry_in),
+                                                 _ptr(carry_out), _ptr(A), _ptr(Bm), float(pow1), float(pow2),
+                                                 self._stream()))
+
     def unroll_supported(self, spec: NetSpec, p: ProblemDesc):
         cc, cp = spec.to_c(), self._cprob(p)
         return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))

@@ -21,6 +21,13 @@ struct BwdParams {
   const float *g, *m, *v, *st_prev, *dx_next, *carry_in;
   float *carry_out, *act1, *dz1, *act2, *dz2, *h2o, *dd, *feats, *du;
   long s_act1, s_dz1, s_act2, s_dz2, s_h2, s_dd, s_feats, s_du;   // row strides (floats) of the emitted rows
+  // tile kernel only: up to 8 panels that share the network in ONE launch (l2o_cwlstm_bwd_multi);
+  // panel s covers the tiles [tile_end[s-1], tile_end[s]) and the rows 16 * tile of A / Bm / the carries
+  int nseg;
+  int tile_end[8];
+  long seg_n[8];                      // coordinates of the panel
+  const float *seg_g[8], *seg_m[8], *seg_v[8], *seg_st[8], *seg_dx[8];
+  long rows_total;                    // rows of the carry arrays ([4][rows_total][20])
 };
 
 // weights are read through the CONSTANT address space: the addresses are wave-uniform, so the
@@ -265,7 +272,8 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   extern __shared__ float sm[];
   float* W1 = sm;                 // [K1][80]
   float* W2 = W1 + K1 * G;        // [40][80]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, part = lane & 3, cl = lane >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, part = lane & 3, cl = lane >> 2;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the panel lookup below stays on the scalar unit
   float* wbase = W2 + 2 * kH * G + wv * Geo::kWaveFloats;
   float* xin = wbase;                         // [40][NC]  input vector of the current GEMV, k-major
   float* stt = xin + 2 * kH * NC;             // the packed state tile (before the step)
@@ -294,27 +302,38 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
     stage(W2, p.wg2, 2 * kH * G / 4);
   }
   const l2o_cfp wl = (l2o_cfp)p.wl, wfc = (l2o_cfp)p.wfc, bfc = (l2o_cfp)p.bfc;
-  const size_t N = (size_t)p.B * p.D;                   // D % 16 == 0, or one flat row (B == 1) with a ragged last tile
   // persistent: a workgroup walks tile groups blockIdx, blockIdx + gridDim, ... (the weights are
   // staged once and the long straight-line body stays in the instruction cache)
-  const size_t ngrp4 = ((N + NC - 1) / NC + 3) / 4;       // groups of 4 tiles
+  const size_t ntiles = (size_t)p.tile_end[p.nseg - 1];
+  const size_t ngrp4 = (ntiles + 3) / 4;                  // groups of 4 tiles
+  const size_t RT = (size_t)p.rows_total;
   for (size_t g4 = blockIdx.x; g4 < ngrp4; g4 += gridDim.x) {
   __syncthreads();                                        // the previous group's LDS tiles are fully stored
-  const size_t grp = g4 * 4 + wv;                         // == the state tile index
-  const bool valid = grp * NC < N;
-  const size_t n0 = valid ? grp * NC : 0;
-  const int nv = valid ? (int)(N - n0 < (size_t)NC ? N - n0 : (size_t)NC) : 0;   // coordinates of this tile that exist
-  const size_t n = n0 + cl < N ? n0 + cl : N - 1;         // (tail lanes recompute the last coordinate; nothing of theirs is stored)
+  const size_t grp = g4 * 4 + wv;                         // global tile index == row block of A / Bm / carries
+  const bool valid = grp < ntiles;
+  // panel of this tile (wave-uniform)
+  int sg = 0;
+  while (sg + 1 < p.nseg && (int)grp >= p.tile_end[sg]) ++sg;
+  const size_t lt = valid ? grp - (sg ? p.tile_end[sg - 1] : 0) : 0;     // tile inside the panel
+  const size_t N = (size_t)p.seg_n[sg];                   // D % 16 == 0, or one flat row (B == 1) with a ragged last tile
+  const float* seg_g = p.seg_g[sg];
+  const float* seg_m = p.seg_m[sg];
+  const float* seg_v = p.seg_v[sg];
+  const float* seg_dx = p.seg_dx[sg];
+  const size_t n0 = valid ? grp * NC : 0;                 // global row
+  const size_t ln0 = lt * NC;                             // first coordinate inside the panel
+  const int nv = valid ? (int)(N - ln0 < (size_t)NC ? N - ln0 : (size_t)NC) : 0;   // coordinates of this tile that exist
+  const size_t n = ln0 + cl < N ? ln0 + cl : N - 1;       // panel coordinate (tail lanes recompute the last one; nothing of theirs is stored)
   const int c = cl;
   float* xi = xin + cl;                                   // element k at xi[k * NC]
   // ---- coalesced loads: the state tile and the four carry blocks of these 16 coordinates ----
   {
-    const float4* src = reinterpret_cast<const float4*>(p.st_prev + n0 / NC * kStateFloatsPerTile);
+    const float4* src = reinterpret_cast<const float4*>(p.seg_st[sg] + lt * kStateFloatsPerTile);
 #pragma unroll
     for (int q = 0; q < 5; ++q) reinterpret_cast<float4*>(stt)[q * 64 + lane] = src[q * 64 + lane];
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4) {
-      const float4* cs = reinterpret_cast<const float4*>(p.carry_in + ((size_t)a4 * N + n0) * kH);
+      const float4* cs = reinterpret_cast<const float4*>(p.carry_in + ((size_t)a4 * RT + n0) * kH);
       float4* cd = reinterpret_cast<float4*>(cio + a4 * NC * kH);
       const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
       cd[lane] = lane < nv * 5 ? cs[lane] : zero4;
@@ -389,11 +408,11 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
   BCK();
 
   // ---- features (every lane of the quad computes them; lane part == k & 3 owns row k) ------
-  const float gv = p.g[n];
+  const float gv = seg_g[n];
   float pre_fc[PRE == L2O_PRE_FC_ELU ? kH : 1];
   float f0 = 0.0f, f1 = 0.0f;
   if (PRE == L2O_PRE_FC_ELU) {
-    const float m_hat = p.m[n] / p.om1, v_hat = p.v[n] / p.om2;
+    const float m_hat = seg_m[n] / p.om1, v_hat = seg_v[n] / p.om2;
     const float den = sqrtf(v_hat) + 1e-8f;
     f0 = m_hat / den;
     f1 = gv / den;
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
       if (part == (u & 3)) arow[K1 + 2 * kH + u] = h2;
       dlin = __builtin_fmaf(h2, wl[u], dlin);
     }
-    float ddv = p.dx_next[n] * p.scale;
+    float ddv = seg_dx[n] * p.scale;
     if (p.tanh_output) { const float th = bw_tanh(dlin); ddv *= 1.0f - th * th; }
     if (part == 0) brow[2 * G] = ddv;
 #pragma unroll
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_tile(BwdParams p) {
     for (int e = (nb & ~3) + lane; e < nb; e += 64) bg[e] = Bt[e];
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4) {
-      float4* cd = reinterpret_cast<float4*>(p.carry_out + ((size_t)a4 * N + n0) * kH);
+      float4* cd = reinterpret_cast<float4*>(p.carry_out + ((size_t)a4 * RT + n0) * kH);
       const float4* cs = reinterpret_cast<const float4*>(cio + a4 * NC * kH);
       if (lane < nv * 5) cd[lane] = cs[lane];
       if (lane < NC * kH / 4 - 64 && 64 + lane < nv * 5) cd[64 + lane] = cs[64 + lane];

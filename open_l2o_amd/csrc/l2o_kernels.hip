@@ -1176,12 +1176,81 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, 
   return l2o_cwlstm_step_multi(cfg, wpack, &seg, 1, pow1, pow2, stream);
 }
 
+static int launch_bwd_tile(const BwdParams& p, int pre, hipStream_t s) {
+  size_t nblk = ((size_t)p.tile_end[p.nseg - 1] + 3) / 4;
+  size_t cap = (size_t)device_cu_count();               // persistent: one workgroup per CU walks the tile groups
+  if (const char* e = getenv("L2O_BWD_BLOCKS")) cap = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : cap;
+  if (nblk > cap) nblk = cap;
+  const dim3 grid((unsigned)nblk), block(256);
+  void (*fn)(BwdParams) = nullptr;
+  size_t lds = 0;
+  switch (pre) {
+    case L2O_PRE_IDENTITY: fn = k_cwlstm_bwd_tile<L2O_PRE_IDENTITY>; lds = BwdTileGeom<L2O_PRE_IDENTITY>::kLdsFloats; break;
+    case L2O_PRE_LOGSIGN: fn = k_cwlstm_bwd_tile<L2O_PRE_LOGSIGN>; lds = BwdTileGeom<L2O_PRE_LOGSIGN>::kLdsFloats; break;
+    default: fn = k_cwlstm_bwd_tile<L2O_PRE_FC_ELU>; lds = BwdTileGeom<L2O_PRE_FC_ELU>::kLdsFloats;
+  }
+  lds *= sizeof(float);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(fn, grid, block, lds, s, p);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+static void fill_bwd_net(BwdParams& p, const l2o_net_cfg* cfg, const l2o_net_weights* w, double pow1, double pow2) {
+  p.pre = cfg->preprocess; p.tanh_output = cfg->tanh_output; p.n_layers = cfg->n_layers;
+  p.scale = (float)cfg->scale;
+  p.k_inv = cfg->logsign_k != 0.0 ? (float)(1.0 / cfg->logsign_k) : 0.0f;
+  p.exp_k = (float)std::exp(cfg->logsign_k);
+  p.beta1 = (float)cfg->beta1; p.beta2 = (float)cfg->beta2;
+  p.om1 = (float)(1.0 - pow1); p.om2 = (float)(1.0 - pow2);
+  p.wg1 = w->w_gates1; p.bg1 = w->b_gates1; p.wg2 = w->w_gates2; p.bg2 = w->b_gates2;
+  p.wl = w->w_lin; p.bl = w->b_lin; p.wfc = w->w_fc; p.bfc = w->b_fc;
+}
+
+int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_seg* segs, int32_t nseg,
+                         const float* carry_in, float* carry_out, float* A, float* Bm, double pow1, double pow2,
+                         void* stream) {
+  if (!cfg || !w || !segs || nseg < 1 || !carry_in || !carry_out || !A || !Bm)
+    return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_multi: bad argument");
+  if (nseg > 8) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_multi: at most 8 panels");
+  if (!net_ok_for_mfma(cfg) || cfg->n_layers == 0)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_multi: only layers=(20,20) nets");
+  if (!w->w_gates1 || !w->b_gates1 || !w->w_gates2 || !w->b_gates2 || !w->w_lin || !w->b_lin)
+    return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_multi: NULL weights");
+  const int pre = cfg->preprocess;
+  if (pre == L2O_PRE_FC_ELU && (!w->w_fc || !w->b_fc)) return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_multi: fc weights");
+  if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_multi: A / Bm must be 16-byte aligned");
+  BwdParams p;
+  std::memset(&p, 0, sizeof(p));
+  fill_bwd_net(p, cfg, w, pow1, pow2);
+  p.carry_in = carry_in; p.carry_out = carry_out; p.act1 = A; p.dz1 = Bm;
+  p.nseg = nseg;
+  long tiles = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const l2o_bwd_seg& sgm = segs[i];
+    if (!sgm.g || !sgm.st_prev || !sgm.dx_next || sgm.B <= 0 || sgm.D <= 0 ||
+        (pre == L2O_PRE_FC_ELU && (!sgm.m || !sgm.v)))
+      return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_multi: bad panel %d", i);
+    if (sgm.D % kTile != 0 && sgm.B != 1)
+      return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_multi: panel %d needs D %% 16 == 0 or B == 1", i);
+    const long n = (long)(sgm.B * sgm.D);
+    tiles += (n + kTile - 1) / kTile;
+    if (tiles > INT32_MAX / kTile) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_multi: too many coordinates");
+    p.tile_end[i] = (int)tiles;
+    p.seg_n[i] = n;
+    p.seg_g[i] = sgm.g; p.seg_m[i] = sgm.m; p.seg_v[i] = sgm.v; p.seg_st[i] = sgm.st_prev; p.seg_dx[i] = sgm.dx_next;
+  }
+  p.rows_total = tiles * kTile;
+  return launch_bwd_tile(p, pre, (hipStream_t)stream);
+}
+
 int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io, double pow1,
                         double pow2, int64_t B, int64_t D, void* stream) {
   if (!cfg || !w || !io || B <= 0 || D <= 0 || !io->g || !io->dx_next || !io->act1 || !io->dd || !w->w_lin ||
       !w->b_lin)
     return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step: bad argument");
   BwdParams p;
+  std::memset(&p, 0, sizeof(p));
   p.B = (int)B; p.D = (int)D; p.tpp = tiles_per_problem(D);
   p.pre = cfg->preprocess; p.tanh_output = cfg->tanh_output; p.n_layers = cfg->n_layers;
   p.scale = (float)cfg->scale;
@@ -1229,22 +1298,12 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
                                                    io->m && io->v && w->w_fc && w->b_fc));
     if (layout && (D % kTile == 0 || B == 1) && ((uintptr_t)io->act1 & 15) == 0 && ((uintptr_t)io->dz1 & 15) == 0 &&
         !getenv("L2O_BWD_GENERIC")) {
-      size_t nblk = ((N + kTile - 1) / kTile + 3) / 4;
-      size_t cap = (size_t)device_cu_count();               // persistent: one workgroup per CU walks the tile groups
-      if (const char* e = getenv("L2O_BWD_BLOCKS")) cap = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : cap;
-      if (nblk > cap) nblk = cap;
-      const dim3 grid((unsigned)nblk), block(256);
-      void (*fn)(BwdParams) = nullptr;
-      size_t lds = 0;
-      switch (pre) {
-        case L2O_PRE_IDENTITY: fn = k_cwlstm_bwd_tile<L2O_PRE_IDENTITY>; lds = BwdTileGeom<L2O_PRE_IDENTITY>::kLdsFloats; break;
-        case L2O_PRE_LOGSIGN: fn = k_cwlstm_bwd_tile<L2O_PRE_LOGSIGN>; lds = BwdTileGeom<L2O_PRE_LOGSIGN>::kLdsFloats; break;
-        default: fn = k_cwlstm_bwd_tile<L2O_PRE_FC_ELU>; lds = BwdTileGeom<L2O_PRE_FC_ELU>::kLdsFloats;
-      }
-      lds *= sizeof(float);
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(fn, grid, block, lds, s, p);
-      HIP_TRY(hipGetLastError());
+      p.nseg = 1;
+      p.tile_end[0] = (int)((N + kTile - 1) / kTile);
+      p.seg_n[0] = (long)N;
+      p.seg_g[0] = io->g; p.seg_m[0] = io->m; p.seg_v[0] = io->v; p.seg_st[0] = io->st_prev; p.seg_dx[0] = io->dx_next;
+      p.rows_total = (long)N;
+      return launch_bwd_tile(p, pre, s);
       return L2O_OK;
     }
   }

@@ -562,9 +562,14 @@ class UnrollGraph(object):
         gs[t] the step's input gradient, sts[t] the packed state before it, ms / vs the RNNProp
         moments after it, dxs[t] = dL/d(delta_t).  Adds the weight gradients into ``acc``
         ({(module, variable): device tensor})."""
+        self._bptt_panels(net, acc, T, step0, [dict(B=B, D=D, gs=gs, sts=sts, ms=ms, vs=vs, dxs=dxs)])
+
+    def _bptt_panels(self, net, acc, T, step0, panels):
+        """The same for several panels (variables) that share the network: ONE backward launch
+        per step for all of them (l2o_cwlstm_bwd_multi) when every panel is tile-aligned
+        (D % 16 == 0 or B == 1), else panel by panel."""
         eng = self.engine
         b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
-        N = B * D
         spec = net.spec
         nl = len(spec.layers)
         fc = spec.preprocess == _abi.PRE_FC_ELU
@@ -576,55 +581,73 @@ class UnrollGraph(object):
             acc[k] = val if k not in acc else acc[k] + val
 
         if not nl:                                         # Linear-only net: two tiny products per step
-            io = {"dd": eng.empty(N), "act1": eng.empty(N, 2)}
-            for t in reversed(range(T)):
-                io.update(g=gs[t], dx_next=dxs[t])
-                eng.bwd_step(spec, wdev, io, b1 ** (step0 + t), b2 ** (step0 + t), B, D)
-                dd = io["dd"].view(N, 1)
-                add("linear", "w", io["act1"][:, :P].t() @ dd)
-                add("linear", "b", dd.sum(0))
+            for pn in panels:
+                N = pn["B"] * pn["D"]
+                io = {"dd": eng.empty(N), "act1": eng.empty(N, 2)}
+                for t in reversed(range(T)):
+                    io.update(g=pn["gs"][t], dx_next=pn["dxs"][t])
+                    eng.bwd_step(spec, wdev, io, b1 ** (step0 + t), b2 ** (step0 + t), pn["B"], pn["D"])
+                    dd = io["dd"].view(N, 1)
+                    add("linear", "w", io["act1"][:, :P].t() @ dd)
+                    add("linear", "b", dd.sum(0))
             return
         # The kernel emits, per step and coordinate, one row of  A = [act1 | act2 | h2 | feats | 1]
         # and one of  Bm = [dz1 | dz2 | dd | du];  EVERY weight gradient of the unroll is a block of
-        # the single product A^T Bm over all (step, coordinate) rows.  (Three skinny rocBLAS GEMMs
-        # per step cost 320 us; one chunked batched GEMM per unroll costs a few tens.)
+        # the single product A^T Bm over all (step, panel, coordinate) rows.  (Three skinny rocBLAS
+        # GEMMs per step cost 320 us; one chunked batched GEMM per unroll costs a few tens.)
         H = 20
         K1 = P + H
         KA = K1 + 2 * H + H + (2 if fc else 0) + 1
         KB = 4 * H + 4 * H + 1 + (H if fc else 0)
-        Np = (N + 15) // 16 * 16                           # rows per step padded to whole tiles: every step's
-        if Np == N:                                        # block stays 16-byte aligned (zero padding rows add nothing)
-            A, Bm = eng.empty(T, Np, KA), eng.empty(T, Np, KB)
-        else:
-            A, Bm = eng.zeros(T, Np, KA), eng.zeros(T, Np, KB)
-        A[:, :N, KA - 1] = 1.0
-        carry_in, carry_out = eng.zeros(4, N, H), eng.empty(4, N, H)
-        for t in reversed(range(T)):
-            k = step0 + t
-            At, Bt = A[t], Bm[t]
-            io = dict(g=gs[t], dx_next=dxs[t], st_prev=sts[t], carry_in=carry_in, carry_out=carry_out,
-                      m=ms[t], v=vs[t], a_stride=KA, b_stride=KB,
-                      act1=At[:N, 0:K1], act2=At[:N, K1:K1 + 2 * H], h2=At[:N, K1 + 2 * H:K1 + 3 * H],
-                      dz1=Bt[:N, 0:4 * H], dz2=Bt[:N, 4 * H:8 * H], dd=Bt[:N, 8 * H:8 * H + 1])
+        multi = all(pn["D"] % 16 == 0 or pn["B"] == 1 for pn in panels) and len(panels) <= 8
+        groups = [panels] if multi else [[pn] for pn in panels]
+        for grp in groups:
+            Ns = [pn["B"] * pn["D"] for pn in grp]
+            offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in Ns])]).astype(int)   # row blocks (whole tiles)
+            R = int(offs[-1])
+            ragged = any(n % 16 for n in Ns)
+            A = (eng.zeros if ragged else eng.empty)(T, R, KA)     # zero padding rows add nothing to A^T Bm
+            Bm = (eng.zeros if ragged else eng.empty)(T, R, KB)
+            for o, n in zip(offs[:-1], Ns):
+                A[:, o:o + n, KA - 1] = 1.0
+            carry_in, carry_out = eng.zeros(4, R, H), eng.zeros(4, R, H)
+            for t in reversed(range(T)):
+                k = step0 + t
+                At, Bt = A[t], Bm[t]
+                if multi:
+                    segs = [dict(g=pn["gs"][t], m=pn["ms"][t], v=pn["vs"][t], st_prev=pn["sts"][t], dx_next=pn["dxs"][t],
+                                 B=pn["B"], D=pn["D"]) for pn in grp]
+                    eng.bwd_multi(spec, wdev, segs, carry_in, carry_out, At, Bt, b1 ** k, b2 ** k)
+                else:
+                    pn, N = grp[0], Ns[0]
+                    io = dict(g=pn["gs"][t], dx_next=pn["dxs"][t], st_prev=pn["sts"][t], carry_in=carry_in[:, :N],
+                              carry_out=carry_out[:, :N], m=pn["ms"][t], v=pn["vs"][t], a_stride=KA, b_stride=KB,
+                              act1=At[:N, 0:K1], act2=At[:N, K1:K1 + 2 * H], h2=At[:N, K1 + 2 * H:K1 + 3 * H],
+                              dz1=Bt[:N, 0:4 * H], dz2=Bt[:N, 4 * H:8 * H], dd=Bt[:N, 8 * H:8 * H + 1])
+                    if fc:
+                        io.update(feats=At[:N, K1 + 3 * H:K1 + 3 * H + 2], du=Bt[:N, 8 * H + 1:8 * H + 1 + H])
+                    if R != N:                             # the generic kernel wants dense [4][N][H] carries
+                        io["carry_in"], io["carry_out"] = carry_in[:, :N].contiguous(), eng.empty(4, N, H)
+                    eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, pn["B"], pn["D"])
+                    if R != N:
+                        carry_out[:, :N] = io["carry_out"]
+                carry_in, carry_out = carry_out, carry_in
+            Gm = _chunked_atb(A.view(T * R, KA), Bm.view(T * R, KB))
+            add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
+            add("lstm_1", "b_gates", Gm[KA - 1, 0:4 * H])
+            add("lstm_2", "w_gates", Gm[K1:K1 + 2 * H, 4 * H:8 * H])
+            add("lstm_2", "b_gates", Gm[KA - 1, 4 * H:8 * H])
+            add("linear", "w", Gm[K1 + 2 * H:K1 + 3 * H, 8 * H:8 * H + 1])
+            add("linear", "b", Gm[KA - 1, 8 * H:8 * H + 1])
             if fc:
-                io.update(feats=At[:N, K1 + 3 * H:K1 + 3 * H + 2], du=Bt[:N, 8 * H + 1:8 * H + 1 + H])
-            eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, B, D)
-            carry_in, carry_out = carry_out, carry_in
-        Gm = _chunked_atb(A.view(T * Np, KA), Bm.view(T * Np, KB))
-        add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
-        add("lstm_1", "b_gates", Gm[KA - 1, 0:4 * H])
-        add("lstm_2", "w_gates", Gm[K1:K1 + 2 * H, 4 * H:8 * H])
-        add("lstm_2", "b_gates", Gm[KA - 1, 4 * H:8 * H])
-        add("linear", "w", Gm[K1 + 2 * H:K1 + 3 * H, 8 * H:8 * H + 1])
-        add("linear", "b", Gm[KA - 1, 8 * H:8 * H + 1])
-        if fc:
-            add("input_projection", "w", Gm[K1 + 3 * H:K1 + 3 * H + 2, 8 * H + 1:8 * H + 1 + H])
-            add("input_projection", "b", Gm[KA - 1, 8 * H + 1:8 * H + 1 + H])
+                add("input_projection", "w", Gm[K1 + 3 * H:K1 + 3 * H + 2, 8 * H + 1:8 * H + 1 + H])
+                add("input_projection", "b", Gm[KA - 1, 8 * H + 1:8 * H + 1 + H])
 
     def _backward(self, T, rec):
         eng = self.engine
         step0 = rec["step0"]
         out = {}                                           # net key -> {(module, variable): device grad}
+        by_net = {}                                        # variables that share a network go through ONE launch per step
         for si, s in enumerate(self.slots):
             net = s.net
             if not isinstance(net, networks.StandardDeepLSTM):
@@ -638,8 +661,11 @@ class UnrollGraph(object):
             for t in reversed(range(T)):
                 dxs[t] = Gacc
                 Gacc = Gacc + rec["g"][t][j].reshape(N)
-            self._bptt(net, out.setdefault(s.key, {}), B, D, T, step0, [g[j] for g in rec["g"]],
-                       [st[si] for st in rec["st"]], [m[si] for m in rec["m"]], [v[si] for v in rec["v"]], dxs)
+            by_net.setdefault(s.key, (net, []))[1].append(
+                dict(B=B, D=D, gs=[g[j] for g in rec["g"]], sts=[st[si] for st in rec["st"]],
+                     ms=[m[si] for m in rec["m"]], vs=[v[si] for v in rec["v"]], dxs=dxs))
+        for key, (net, panels) in by_net.items():
+            self._bptt_panels(net, out.setdefault(key, {}), T, step0, panels)
         if self.sharded:
             import torch.distributed as dist
             for acc in out.values():

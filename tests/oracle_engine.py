@@ -208,6 +208,28 @@ class OracleEngine(object):
                 a = pad
             t.copy_(torch.from_numpy(a).view_as(t))
 
+    def bwd_multi(self, spec, weights, segs, carry_in, carry_out, A, Bm, pow1, pow2):
+        """Same contract as HipEngine.bwd_multi, through bwd_step on row-block views."""
+        fc = spec.preprocess == _abi.PRE_FC_ELU
+        P = 20 if fc else (2 if spec.preprocess == _abi.PRE_LOGSIGN else 1)
+        H, K1 = 20, P + 20
+        row = 0
+        for sg in segs:
+            B, D = sg["B"], sg["D"]
+            N = B * D
+            At, Bt = A[row:row + N], Bm[row:row + N]
+            cin = carry_in[:, row:row + N].contiguous()
+            cout = torch.empty_like(cin)
+            io = dict(g=sg["g"], m=sg.get("m"), v=sg.get("v"), st_prev=sg["st_prev"], dx_next=sg["dx_next"],
+                      carry_in=cin, carry_out=cout, act1=At[:, 0:K1], act2=At[:, K1:K1 + 2 * H],
+                      h2=At[:, K1 + 2 * H:K1 + 3 * H], dz1=Bt[:, 0:4 * H], dz2=Bt[:, 4 * H:8 * H],
+                      dd=Bt[:, 8 * H:8 * H + 1])
+            if fc:
+                io.update(feats=At[:, K1 + 3 * H:K1 + 3 * H + 2], du=Bt[:, 8 * H + 1:8 * H + 1 + H])
+            self.bwd_step(spec, weights, io, pow1, pow2, B, D)
+            carry_out[:, row:row + N] = cout
+            row += (N + 15) // 16 * 16
+
     def unroll_supported(self, spec, p):
         cc = spec.to_c()
         import ctypes as C

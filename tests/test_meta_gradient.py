@@ -348,3 +348,66 @@ def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
             assert float(np.abs(np.asarray(got["tile"][k]) - np.asarray(gref)).max()) / scale < 1e-4, k
     finally:
         _engine.set_default_engine(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_bwd_multi_equals_per_panel_bwd_step(name):
+    """l2o_cwlstm_bwd_multi (ONE launch for the panels that share a network: the five variables of the
+    mnist optimizee, DM/meta.py:231-235) == l2o_cwlstm_bwd_step called once per panel, row for row
+    of A / Bm and carry for carry.  Panels: tile-aligned (2 x 32), one flat ragged row (1 x 200),
+    one short row (1 x 10)."""
+    eng = _engine.HipEngine()
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=91, trained_like=True)
+    names = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"), "w_gates2": ("lstm_2", "w_gates"),
+             "b_gates2": ("lstm_2", "b_gates"), "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+             "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+    t = eng.tensor
+    wdev = {kk: t(params[mm][nn]) for kk, (mm, nn) in names.items() if mm in params}
+    fc = cfg.kind == "rnnprop"
+    P = cfg.in_dim
+    K1 = P + 20
+    KA = K1 + 60 + (2 if fc else 0) + 1
+    KB = 161 + (20 if fc else 0)
+    shapes = [(2, 32), (1, 200), (1, 10)]
+    rows = [(b * d + 15) // 16 * 16 for b, d in shapes]
+    R = sum(rows)
+    rng = np.random.default_rng(92)
+    cin_all = (rng.standard_normal((4, R, 20)) * 0.3).astype(np.float32)
+    segs, ref_A, ref_B, ref_c = [], [], [], []
+    row = 0
+    for i, (B, D) in enumerate(shapes):
+        N = B * D
+        g = t(rng.standard_normal((B, D)).astype(np.float32))
+        m = t((rng.standard_normal((B, D)) * 0.1).astype(np.float32))
+        v = t((rng.random((B, D)) * 0.1 + 0.01).astype(np.float32))
+        state = random_state(cfg, N, 93 + i)
+        st = eng.state_pack(*[t(a) for hc in state for a in hc], B, D)
+        dx = t(rng.standard_normal(N).astype(np.float32))
+        segs.append(dict(g=g, m=m if fc else None, v=v if fc else None, st_prev=st, dx_next=dx, B=B, D=D))
+        # reference: the single-panel entry point on its own buffers
+        A1, B1 = eng.zeros(rows[i], KA), eng.zeros(rows[i], KB)
+        co = eng.zeros(4, N, 20)
+        io = dict(g=g, m=m if fc else None, v=v if fc else None, st_prev=st, dx_next=dx,
+                  carry_in=t(np.ascontiguousarray(cin_all[:, row:row + N])), carry_out=co, a_stride=KA, b_stride=KB,
+                  act1=A1[:N, 0:K1], act2=A1[:N, K1:K1 + 40], h2=A1[:N, K1 + 40:K1 + 60],
+                  dz1=B1[:N, 0:80], dz2=B1[:N, 80:160], dd=B1[:N, 160:161])
+        if fc:
+            io.update(feats=A1[:N, K1 + 60:K1 + 62], du=B1[:N, 161:181])
+        eng.bwd_step(spec, wdev, io, 0.9, 0.8, B, D)
+        ref_A.append(eng.to_numpy(A1)[:N]); ref_B.append(eng.to_numpy(B1)[:N]); ref_c.append(eng.to_numpy(co))
+        row += rows[i]
+    A, Bm = eng.zeros(R, KA), eng.zeros(R, KB)
+    cout = eng.zeros(4, R, 20)
+    eng.bwd_multi(spec, wdev, segs, t(cin_all), cout, A, Bm, 0.9, 0.8)
+    A, Bm, cout = eng.to_numpy(A), eng.to_numpy(Bm), eng.to_numpy(cout)
+    row = 0
+    for i, (B, D) in enumerate(shapes):
+        N = B * D
+        np.testing.assert_array_equal(A[row:row + N], ref_A[i])
+        np.testing.assert_array_equal(Bm[row:row + N], ref_B[i])
+        np.testing.assert_array_equal(cout[:, row:row + N], ref_c[i])
+        assert not A[row + N:row + rows[i]].any() and not Bm[row + N:row + rows[i]].any()   # padding rows stay zero
+        row += rows[i]
