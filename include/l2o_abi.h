@@ -197,6 +197,9 @@ int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack /* device *
  * Gate column order of dz* is Sonnet's (i, j, f, o).  layers=(): only act1 [N,2] and dd. */
 typedef struct l2o_net_weights {      /* device pointers, Sonnet / .l2l layouts */
   const float *w_gates1, *b_gates1, *w_gates2, *b_gates2, *w_lin, *b_lin, *w_fc, *b_fc;
+  const float* wpack;     /* optional: device copy of l2o_wpack_host's output for the SAME weights.  With it the
+                           * tile-aligned BPTT step runs on the matrix cores (k_cwlstm_bwd_mfma); NULL keeps the
+                           * fp32 kernels.  Results agree to fp32 rounding. */
 } l2o_net_weights;
 typedef struct l2o_bwd_io {
   const float* g;          /* device [N]   gradient fed to the net at this step               */
@@ -241,6 +244,27 @@ typedef struct l2o_bwd_seg {
 int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_seg* segs, int32_t nseg,
                          const float* carry_in, float* carry_out, float* A, float* Bm,
                          double pow1, double pow2, void* stream);
+
+/* ALL T steps of the back-propagation through a recorded unroll in ONE launch (the whole of what
+ * tf.gradients walks back through the while_loop of DM/meta.py:361-368): a wave keeps its tile's
+ * (dh, dc) carries in registers from step T-1 down to step 0, so only the recorded history comes in
+ * and the rows of A / Bm go out.  Needs l2o_net_weights.wpack (matrix-core kernel) and tile-aligned
+ * panels (D % 16 == 0 or B == 1).
+ *   table     device array [T][nseg][5] of device pointers: g, m, v, st_prev, dx_next of panel s at
+ *             step t (same meaning as l2o_bwd_seg; m, v NULL for the DM nets).  dx_next may be NULL:
+ *             then dL/d(delta_t) = g_final + sum_{tau > t} g_tau, the gradient of loss = sum_t fx_t
+ *             (DM/meta.py:376) through x_{t+1} = x_t + delta_t, accumulated in a register.
+ *   A, Bm     [T][rows][KA], [T][rows][KB] (rows as in l2o_cwlstm_bwd_multi)
+ *   carry_in  [4][rows][H] gradient w.r.t. the state after step T-1, or NULL (zeros);
+ *   carry_out gradient w.r.t. the state before step 0, or NULL (not wanted)
+ *   step0     RNNProp: step t uses the bias corrections 1 - beta^(step0 + t) (DM/util.py:59-60) */
+typedef struct l2o_bwd_unroll_seg {
+  int64_t B, D;
+  const float* g_final;    /* device [B*D] gradient at x_T, or NULL when the table carries dx_next */
+} l2o_bwd_unroll_seg;
+int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
+                          int32_t nseg, const float* const* table, int32_t T, int64_t step0,
+                          const float* carry_in, float* carry_out, float* A, float* Bm, void* stream);
 
 /* ---- the fused unroll: MetaOptimizer.meta_loss's tf.while_loop
  * (DM/meta.py:338-376; RNNProp DM/meta_rnnprop_eval.py time_step) as ONE persistent

@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats",
-    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
 
@@ -62,7 +62,7 @@ class Mlp(C.Structure):
 class NetWeights(C.Structure):
     """struct l2o_net_weights"""
     _fields_ = [(n, C.c_void_p) for n in ("w_gates1", "b_gates1", "w_gates2", "b_gates2", "w_lin", "b_lin",
-                                          "w_fc", "b_fc")]
+                                          "w_fc", "b_fc", "wpack")]
 
 
 class BwdIO(C.Structure):
@@ -84,6 +84,11 @@ class StepSeg(C.Structure):
 class BwdSeg(C.Structure):
     """struct l2o_bwd_seg"""
     _fields_ = [(n, C.c_void_p) for n in ("g", "m", "v", "st_prev", "dx_next")] + [("B", C.c_int64), ("D", C.c_int64)]
+
+
+class BwdUnrollSeg(C.Structure):
+    """struct l2o_bwd_unroll_seg"""
+    _fields_ = [("B", C.c_int64), ("D", C.c_int64), ("g_final", C.c_void_p)]
 
 
 class UnrollHist(C.Structure):
@@ -145,6 +150,9 @@ def lib():
     L.l2o_cwlstm_bwd_multi.restype = C.c_int
     L.l2o_cwlstm_bwd_multi.argtypes = [C.POINTER(NetCfg), C.POINTER(NetWeights), C.POINTER(BwdSeg), C.c_int32, vp, vp,
                                        vp, vp, dbl, dbl, vp]
+    L.l2o_cwlstm_bwd_unroll.restype = C.c_int
+    L.l2o_cwlstm_bwd_unroll.argtypes = [C.POINTER(NetCfg), C.POINTER(NetWeights), C.POINTER(BwdUnrollSeg), C.c_int32, vp,
+                                        C.c_int32, i64, vp, vp, vp, vp, vp]
     L.l2o_unroll.restype = C.c_int
     L.l2o_unroll.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Problem), vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.l2o_unroll_record.restype = C.c_int

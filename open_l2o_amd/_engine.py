@@ -217,6 +217,30 @@ class HipEngine(object):
                                                  _ptr(carry_out), _ptr(A), _ptr(Bm), float(pow1), float(pow2),
                                                  self._stream()))
 
+    def bwd_unroll(self, spec: NetSpec, weights: dict, panels, T, step0, A, Bm, carry_in=None, carry_out=None):
+        """All T BPTT steps of the panels that share one network in one launch (l2o_cwlstm_bwd_unroll).
+        panels: list of dict(B=, D=, gs=[T tensors], sts=[T], ms=[T] | None, vs=, dxs=[T] | None,
+        g_final= tensor | None); A [T, rows, KA], Bm [T, rows, KB]."""
+        cc = spec.to_c()
+        w = _abi.NetWeights()
+        for k, _ in _abi.NetWeights._fields_:
+            setattr(w, k, None if weights.get(k) is None else weights[k].data_ptr())
+        ptr = lambda x: 0 if x is None else x.data_ptr()
+        rows = []
+        for t in range(T):
+            for pn in panels:
+                rows.append([ptr(pn["gs"][t]), ptr(pn["ms"][t]) if pn.get("ms") else 0, ptr(pn["vs"][t]) if pn.get("vs") else 0,
+                             ptr(pn["sts"][t]), ptr(pn["dxs"][t]) if pn.get("dxs") else 0])
+        table = torch.tensor(rows, dtype=torch.int64).to(self.device, non_blocking=False)
+        arr = (_abi.BwdUnrollSeg * len(panels))()
+        for a, pn in zip(arr, panels):
+            a.B, a.D = int(pn["B"]), int(pn["D"])
+            a.g_final = None if pn.get("g_final") is None else pn["g_final"].data_ptr()
+        _abi.check(self.lib.l2o_cwlstm_bwd_unroll(C.byref(cc), C.byref(w), arr, len(panels), C.c_void_p(table.data_ptr()), int(T),
+                                                  int(step0), _ptr(carry_in), _ptr(carry_out), _ptr(A), _ptr(Bm),
+                                                  self._stream()))
+        self._bwd_table = table                              # keep the pointer table alive until the stream has run the kernel
+
     def unroll_supported(self, spec: NetSpec, p: ProblemDesc):
         cc, cp = spec.to_c(), self._cprob(p)
         return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))

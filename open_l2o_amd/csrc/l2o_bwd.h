@@ -28,6 +28,13 @@ struct BwdParams {
   long seg_n[8];                      // coordinates of the panel
   const float *seg_g[8], *seg_m[8], *seg_v[8], *seg_st[8], *seg_dx[8];
   long rows_total;                    // rows of the carry arrays ([4][rows_total][20])
+  const float* wpack;                 // l2o_wpack_host output (device) or NULL: selects k_cwlstm_bwd_mfma (l2o_bwd_mfma.h)
+  // k_cwlstm_bwd_mfma only: T steps in one launch (l2o_cwlstm_bwd_unroll).  table[(t * nseg + s) * 5 + k] =
+  // g, m, v, st_prev, dx_next (may be NULL) of panel s at step t; A / Bm hold T blocks of rows_total rows
+  int T;
+  const float* const* table;
+  const float* seg_gfinal[8];         // dx_next == NULL: dL/d(delta_t) = g_final + sum_{tau > t} g_tau
+  double pw1_last, pw2_last;          // beta^(step0 + T - 1)
 };
 
 // weights are read through the CONSTANT address space: the addresses are wave-uniform, so the

@@ -683,6 +683,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_bwd.h"
 
+#include "l2o_bwd_mfma.h"
+
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
@@ -898,7 +900,7 @@ size_t l2o_wpack_floats(const l2o_net_cfg* cfg) {
   if (!cfg) return 0;
   if (cfg->n_layers == 0) return 4;
   if (!net_ok_for_mfma(cfg)) return 0;
-  return (size_t)wp_rows(cfg->preprocess) * 64 + (size_t)bx::words(cfg->preprocess);
+  return (size_t)wp_rows(cfg->preprocess) * 64 + (size_t)bx::words(cfg->preprocess) + (size_t)bxb::words(cfg->preprocess);
 }
 
 // ---- bf16x3 section of wpack (l2o_lstm_bx3.h) --------------------------------
@@ -1023,6 +1025,31 @@ int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, c
             out[bx::win_off(pre) + (kNT + t) * 256 + l * 4 + rr] =
                 P == 2 ? (float)((double)wg1[1 * G + cD] * gscale(rr)) : 0.0f;
           }
+      }
+    }
+  }
+  // ---- bf16x3 fragments of the transposed products of the BPTT step (l2o_bwd_mfma.h): W itself,
+  //      unscaled; M-tile rows = input rows of W, K-chunk r = gate type r (Sonnet column block) ----
+  {
+    uint32_t* ow = reinterpret_cast<uint32_t*>(out) + bxb::base(pre);
+    std::memset(ow, 0, sizeof(uint32_t) * bxb::words(pre));
+    for (int tile = 0; tile < bxb::ntiles(pre); ++tile) {
+      const bool l2 = tile < bxb::tiles2();
+      const int m = l2 ? tile : tile - bxb::tiles2();
+      const float* W = l2 ? wg2 : wg1;
+      const int first = l2 ? 0 : (fc ? 0 : -1), second = l2 ? kH : (fc ? kH : P);
+      for (int l = 0; l < 64; ++l) {
+        const int rho = l & 15, kq = l >> 4;
+        const int row = bxb::src_row(m, rho, first, second);
+        if (row < 0) continue;
+        for (int r = 0; r < 4; ++r) {
+          uint16_t sl[8][3];
+          std::memset(sl, 0, sizeof(sl));
+          for (int i = 0; i < 5; ++i) bf16_split3((double)W[row * G + r * kH + 4 * i + kq], sl[i]);
+          for (int sp = 0; sp < 3; ++sp)
+            for (int j = 0; j < 4; ++j)
+              ow[bxb::frag_rel(tile, r, sp) + l * 4 + j] = (uint32_t)sl[2 * j][sp] | ((uint32_t)sl[2 * j + 1][sp] << 16);
+        }
       }
     }
   }
@@ -1180,14 +1207,22 @@ static int launch_bwd_tile(const BwdParams& p, int pre, hipStream_t s) {
   size_t nblk = ((size_t)p.tile_end[p.nseg - 1] + 3) / 4;
   size_t cap = (size_t)device_cu_count();               // persistent: one workgroup per CU walks the tile groups
   if (const char* e = getenv("L2O_BWD_BLOCKS")) cap = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : cap;
-  if (nblk > cap) nblk = cap;
+  if (nblk > cap && p.T <= 1) nblk = cap;                  // (a T-step launch keeps one workgroup per four tiles: each lives T steps)
   const dim3 grid((unsigned)nblk), block(256);
   void (*fn)(BwdParams) = nullptr;
   size_t lds = 0;
-  switch (pre) {
-    case L2O_PRE_IDENTITY: fn = k_cwlstm_bwd_tile<L2O_PRE_IDENTITY>; lds = BwdTileGeom<L2O_PRE_IDENTITY>::kLdsFloats; break;
-    case L2O_PRE_LOGSIGN: fn = k_cwlstm_bwd_tile<L2O_PRE_LOGSIGN>; lds = BwdTileGeom<L2O_PRE_LOGSIGN>::kLdsFloats; break;
-    default: fn = k_cwlstm_bwd_tile<L2O_PRE_FC_ELU>; lds = BwdTileGeom<L2O_PRE_FC_ELU>::kLdsFloats;
+  if (p.wpack && !getenv("L2O_BWD_TILE")) {                // the matrix-core form needs the packed weights
+    switch (pre) {
+      case L2O_PRE_IDENTITY: fn = k_cwlstm_bwd_mfma<L2O_PRE_IDENTITY>; lds = BwdMfmaGeom<L2O_PRE_IDENTITY>::kLdsFloats; break;
+      case L2O_PRE_LOGSIGN: fn = k_cwlstm_bwd_mfma<L2O_PRE_LOGSIGN>; lds = BwdMfmaGeom<L2O_PRE_LOGSIGN>::kLdsFloats; break;
+      default: fn = k_cwlstm_bwd_mfma<L2O_PRE_FC_ELU>; lds = BwdMfmaGeom<L2O_PRE_FC_ELU>::kLdsFloats;
+    }
+  } else {
+    switch (pre) {
+      case L2O_PRE_IDENTITY: fn = k_cwlstm_bwd_tile<L2O_PRE_IDENTITY>; lds = BwdTileGeom<L2O_PRE_IDENTITY>::kLdsFloats; break;
+      case L2O_PRE_LOGSIGN: fn = k_cwlstm_bwd_tile<L2O_PRE_LOGSIGN>; lds = BwdTileGeom<L2O_PRE_LOGSIGN>::kLdsFloats; break;
+      default: fn = k_cwlstm_bwd_tile<L2O_PRE_FC_ELU>; lds = BwdTileGeom<L2O_PRE_FC_ELU>::kLdsFloats;
+    }
   }
   lds *= sizeof(float);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1205,6 +1240,7 @@ static void fill_bwd_net(BwdParams& p, const l2o_net_cfg* cfg, const l2o_net_wei
   p.om1 = (float)(1.0 - pow1); p.om2 = (float)(1.0 - pow2);
   p.wg1 = w->w_gates1; p.bg1 = w->b_gates1; p.wg2 = w->w_gates2; p.bg2 = w->b_gates2;
   p.wl = w->w_lin; p.bl = w->b_lin; p.wfc = w->w_fc; p.bfc = w->b_fc;
+  p.wpack = w->wpack;
 }
 
 int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_seg* segs, int32_t nseg,
@@ -1244,6 +1280,41 @@ int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const
   return launch_bwd_tile(p, pre, (hipStream_t)stream);
 }
 
+int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
+                          int32_t nseg, const float* const* table, int32_t T, int64_t step0, const float* carry_in,
+                          float* carry_out, float* A, float* Bm, void* stream) {
+  if (!cfg || !w || !segs || nseg < 1 || !table || T < 1 || step0 < 0 || !A || !Bm)
+    return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_unroll: bad argument");
+  if (nseg > 8) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll: at most 8 panels");
+  if (!net_ok_for_mfma(cfg) || cfg->n_layers == 0)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll: only layers=(20,20) nets");
+  if (!w->wpack) return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_unroll: needs l2o_net_weights.wpack");
+  if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_unroll: A / Bm must be 16-byte aligned");
+  const int pre = cfg->preprocess;
+  BwdParams p;
+  std::memset(&p, 0, sizeof(p));
+  fill_bwd_net(p, cfg, w, 0.0, 0.0);
+  p.carry_in = carry_in; p.carry_out = carry_out; p.act1 = A; p.dz1 = Bm;
+  p.nseg = nseg; p.T = T; p.table = table;
+  p.pw1_last = std::pow((double)p.beta1, (double)(step0 + T - 1));
+  p.pw2_last = std::pow((double)p.beta2, (double)(step0 + T - 1));
+  long tiles = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const l2o_bwd_unroll_seg& sgm = segs[i];
+    if (sgm.B <= 0 || sgm.D <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_unroll: bad panel %d", i);
+    if (sgm.D % kTile != 0 && sgm.B != 1)
+      return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll: panel %d needs D %% 16 == 0 or B == 1", i);
+    const long n = (long)(sgm.B * sgm.D);
+    tiles += (n + kTile - 1) / kTile;
+    if (tiles > INT32_MAX / kTile) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll: too many coordinates");
+    p.tile_end[i] = (int)tiles;
+    p.seg_n[i] = n;
+    p.seg_gfinal[i] = sgm.g_final;
+  }
+  p.rows_total = tiles * kTile;
+  return launch_bwd_tile(p, pre, (hipStream_t)stream);
+}
+
 int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io, double pow1,
                         double pow2, int64_t B, int64_t D, void* stream) {
   if (!cfg || !w || !io || B <= 0 || D <= 0 || !io->g || !io->dx_next || !io->act1 || !io->dd || !w->w_lin ||
@@ -1260,6 +1331,7 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
   p.om1 = (float)(1.0 - pow1); p.om2 = (float)(1.0 - pow2);
   p.wg1 = w->w_gates1; p.bg1 = w->b_gates1; p.wg2 = w->w_gates2; p.bg2 = w->b_gates2;
   p.wl = w->w_lin; p.bl = w->b_lin; p.wfc = w->w_fc; p.bfc = w->b_fc;
+  p.wpack = w->wpack;
   p.g = io->g; p.m = io->m; p.v = io->v; p.st_prev = io->st_prev; p.dx_next = io->dx_next;
   p.carry_in = io->carry_in; p.carry_out = io->carry_out; p.act1 = io->act1; p.dz1 = io->dz1;
   p.act2 = io->act2; p.dz2 = io->dz2; p.h2o = io->h2; p.dd = io->dd; p.feats = io->feats; p.du = io->du;

@@ -580,7 +580,18 @@ class UnrollGraph(object):
             k = (mod, var)
             acc[k] = val if k not in acc else acc[k] + val
 
+        def need_dxs():
+            for pn in panels:                               # loss = sum_t fx_t: dL/d(delta_t) = g_final + sum_{tau > t} g_tau
+                if pn.get("dxs") is None:
+                    N = pn["B"] * pn["D"]
+                    acc_g = pn["g_final"].reshape(N).clone()
+                    pn["dxs"] = [None] * T
+                    for t in reversed(range(T)):
+                        pn["dxs"][t] = acc_g
+                        acc_g = acc_g + pn["gs"][t].reshape(N)
+
         if not nl:                                         # Linear-only net: two tiny products per step
+            need_dxs()
             for pn in panels:
                 N = pn["B"] * pn["D"]
                 io = {"dd": eng.empty(N), "act1": eng.empty(N, 2)}
@@ -600,7 +611,11 @@ class UnrollGraph(object):
         KA = K1 + 2 * H + H + (2 if fc else 0) + 1
         KB = 4 * H + 4 * H + 1 + (H if fc else 0)
         multi = all(pn["D"] % 16 == 0 or pn["B"] == 1 for pn in panels) and len(panels) <= 8
+        fused = multi and wdev.get("wpack") is not None and not any(
+            os.environ.get(k) for k in ("L2O_BWD_STEPWISE", "L2O_BWD_GENERIC", "L2O_BWD_TILE"))   # A/B switches of the tests
         groups = [panels] if multi else [[pn] for pn in panels]
+        if not fused:
+            need_dxs()
         for grp in groups:
             Ns = [pn["B"] * pn["D"] for pn in grp]
             offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in Ns])]).astype(int)   # row blocks (whole tiles)
@@ -611,7 +626,9 @@ class UnrollGraph(object):
             for o, n in zip(offs[:-1], Ns):
                 A[:, o:o + n, KA - 1] = 1.0
             carry_in, carry_out = eng.zeros(4, R, H), eng.zeros(4, R, H)
-            for t in reversed(range(T)):
+            if fused:                                       # all T steps in one launch, the carries in registers
+                eng.bwd_unroll(spec, wdev, grp, T, step0, A, Bm)
+            for t in (() if fused else reversed(range(T))):
                 k = step0 + t
                 At, Bt = A[t], Bm[t]
                 if multi:
@@ -656,14 +673,11 @@ class UnrollGraph(object):
             B, D = rec["shapes"][j]
             N = B * D
             # loss = sum_t fx_t and x_{t+1} = x_t + delta_t  =>  dL/d(delta_t) = sum_{tau > t} g_tau
-            dxs = [None] * T
-            Gacc = rec["g_final"][j].reshape(N).clone()
-            for t in reversed(range(T)):
-                dxs[t] = Gacc
-                Gacc = Gacc + rec["g"][t][j].reshape(N)
+            # (accumulated inside the fused BPTT kernel, or by _bptt_panels for the step-wise kernels)
             by_net.setdefault(s.key, (net, []))[1].append(
                 dict(B=B, D=D, gs=[g[j] for g in rec["g"]], sts=[st[si] for st in rec["st"]],
-                     ms=[m[si] for m in rec["m"]], vs=[v[si] for v in rec["v"]], dxs=dxs))
+                     ms=[m[si] for m in rec["m"]], vs=[v[si] for v in rec["v"]], dxs=None,
+                     g_final=rec["g_final"][j].reshape(N)))
         for key, (net, panels) in by_net.items():
             self._bptt_panels(net, out.setdefault(key, {}), T, step0, panels)
         if self.sharded:

@@ -205,6 +205,8 @@ class StandardDeepLSTM(Network):
                      "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
                      "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
             self._wdev = {k: engine.tensor(v[m][n]) for k, (m, n) in names.items() if m in v}
+            if len(self.spec.layers):
+                self._wdev["wpack"] = self.wpack(engine)      # selects the matrix-core BPTT kernel
             self._wdev_engine = engine
         return self._wdev
 

@@ -263,3 +263,35 @@ def tile_step_bx3(wpack, pre, h1, c1, h2, c2, in0, in1):
     d = d + d[lanes ^ 16]
     d = d + d[lanes ^ 32]
     return d + W[R["bl"]], h1n, c1n, h2n, c2n
+
+
+# ---- the transposed products of the BPTT step (csrc/l2o_bwd_mfma.h) -------------------------
+def bxb_tiles1(pre):
+    return 3 if pre == 2 else 2
+
+
+def bxb_words(pre):
+    return (3 + bxb_tiles1(pre)) * 4 * 3 * 256
+
+
+def tgemm_bx3(wpack, pre, layer, dz):
+    """The data flow of l2o::bxb::tgemm on the packed weights.  dz: four [64, 5] lane arrays (gate
+    types i, j, f, o; lane (c, q) holds units 4i + q).  Returns (first, second): [64, 5] lane arrays of
+    d(first 20 input rows) and d(second 20 input rows) of the layer's W (first is None for the DM
+    layer 1, whose gradient w.r.t. the 1-2 input features is not needed)."""
+    R = wp_rows(pre)
+    U = np.ascontiguousarray(wpack, np.float32).view(np.uint32)
+    base = R["total"] * 64 + bx_words(pre)
+    tile0, nt = (0, 3) if layer == 2 else (3, bxb_tiles1(pre))
+    frag = lambda m, r, s: _unpack_frag(U[base + (((tile0 + m) * 4 + r) * 3 + s) * 256:][:256].reshape(64, 4))
+    acc = [np.zeros((64, 4)) for _ in range(nt)]
+    for r in range(4):
+        b = _bop(dz[r], False)
+        for (xl, wl) in PRODUCTS:
+            for m in range(nt):
+                acc[m] = mfma_bf16(frag(m, r, wl), b[xl], acc[m])
+    if nt == 3:
+        first = np.concatenate([acc[0], acc[2][:, 0:1]], 1)
+        second = np.concatenate([acc[1], acc[2][:, 1:2]], 1)
+        return first, second
+    return None, np.concatenate([acc[0], acc[1][:, 0:1]], 1)

@@ -230,6 +230,28 @@ class OracleEngine(object):
             carry_out[:, row:row + N] = cout
             row += (N + 15) // 16 * 16
 
+    def bwd_unroll(self, spec, weights, panels, T, step0, A, Bm, carry_in=None, carry_out=None):
+        """Same contract as HipEngine.bwd_unroll, step by step through bwd_multi."""
+        R = A.shape[1]
+        b1, b2 = float(np.float32(spec.beta1)), float(np.float32(spec.beta2))
+        cin = torch.zeros(4, R, 20) if carry_in is None else carry_in.clone()
+        cout = torch.zeros(4, R, 20)
+        acc = [None if pn.get("g_final") is None else pn["g_final"].reshape(-1).clone() for pn in panels]
+        for t in reversed(range(T)):
+            segs = []
+            for i, pn in enumerate(panels):
+                dx = pn["dxs"][t] if pn.get("dxs") else acc[i].clone()
+                segs.append(dict(g=pn["gs"][t], m=pn["ms"][t] if pn.get("ms") else None,
+                                 v=pn["vs"][t] if pn.get("vs") else None, st_prev=pn["sts"][t], dx_next=dx,
+                                 B=pn["B"], D=pn["D"]))
+                if acc[i] is not None:
+                    acc[i] = acc[i] + pn["gs"][t].reshape(-1)
+            k = step0 + t
+            self.bwd_multi(spec, weights, segs, cin, cout, A[t], Bm[t], b1 ** k, b2 ** k)
+            cin, cout = cout, cin
+        if carry_out is not None:
+            carry_out.copy_(cin)
+
     def unroll_supported(self, spec, p):
         cc = spec.to_c()
         import ctypes as C

@@ -52,7 +52,8 @@ def test_size_queries(lib):
     assert lib.l2o_state_floats(0, 5) == 0
     for name, cfg in ORACLE_CFGS.items():
         cc = spec_of(cfg).to_c()
-        assert lib.l2o_wpack_floats(C.byref(cc)) == E.wp_rows(cc.preprocess)["total"] * 64 + E.bx_words(cc.preprocess)
+        assert lib.l2o_wpack_floats(C.byref(cc)) == (E.wp_rows(cc.preprocess)["total"] * 64 + E.bx_words(cc.preprocess)
+                                                    + E.bxb_words(cc.preprocess))
 
 
 def test_unsupported_layers_are_reported(lib):
@@ -130,6 +131,34 @@ def test_packed_weights_reproduce_oracle_under_mfma_layout(lib, name):
             back = np.zeros((16, 20))
             E.lanes_to_ref(lane_arr, back, coords)
             np.testing.assert_allclose(back, ref, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_wpack_transposed_fragments_emulated(lib, name):
+    """The BPTT section of wpack (bf16x3 fragments of W itself, csrc/l2o_bwd_mfma.h), pushed through the
+    MFMA emulator with the kernel's operand construction, gives d[in | h(t-1)] = W dz of the LSTM
+    backward (the transposed gate products of tf.gradients through snt.LSTM, DM/networks.py:192-200)."""
+    from open_l2o_amd._engine import pack_weights_host
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=31)
+    wpack = pack_weights_host(lib, spec, params)
+    rng = np.random.default_rng(32)
+    lanes = np.arange(64)
+    c, q = lanes & 15, lanes >> 4
+    P = cfg.in_dim
+    for layer, W in ((2, params["lstm_2"]["w_gates"]), (1, params["lstm_1"]["w_gates"])):
+        dz = (rng.standard_normal((16, 80)) * 0.1).astype(np.float32)
+        lane_dz = [np.stack([dz[c, r * 20 + 4 * i + q] for i in range(5)], 1).astype(np.float64) for r in range(4)]
+        first, second = E.tgemm_bx3(wpack, spec.preprocess, layer, lane_dz)
+        ref = dz.astype(np.float64) @ W.astype(np.float64).T          # [16, rows of W]
+        two = layer == 2 or cfg.kind == "rnnprop"
+        sec0 = 20 if two else P
+        for i in range(5):
+            np.testing.assert_allclose(second[:, i], ref[c, sec0 + 4 * i + q], rtol=1e-6, atol=1e-7)
+            if two:
+                np.testing.assert_allclose(first[:, i], ref[c, 4 * i + q], rtol=1e-6, atol=1e-7)
+        assert (first is None) == (not two)
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -351,12 +351,15 @@ def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["tile", "mfma"])
 @pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
-def test_bwd_multi_equals_per_panel_bwd_step(name):
+def test_bwd_multi_equals_per_panel_bwd_step(name, form):
     """l2o_cwlstm_bwd_multi (ONE launch for the panels that share a network: the five variables of the
     mnist optimizee, DM/meta.py:231-235) == l2o_cwlstm_bwd_step called once per panel, row for row
     of A / Bm and carry for carry.  Panels: tile-aligned (2 x 32), one flat ragged row (1 x 200),
-    one short row (1 x 10)."""
+    one short row (1 x 10).  form == "mfma": the multi-panel launch gets the packed weights and runs
+    k_cwlstm_bwd_mfma (bf16x3 matrix-core products, csrc/l2o_bwd_mfma.h); the per-panel reference stays
+    on the fp32 tile kernel -- agreement to fp32 rounding (2e-5 of the largest entry) instead of bits."""
     eng = _engine.HipEngine()
     cfg = ORACLE_CFGS[name]
     spec = spec_of(cfg)
@@ -401,13 +404,97 @@ def test_bwd_multi_equals_per_panel_bwd_step(name):
         row += rows[i]
     A, Bm = eng.zeros(R, KA), eng.zeros(R, KB)
     cout = eng.zeros(4, R, 20)
-    eng.bwd_multi(spec, wdev, segs, t(cin_all), cout, A, Bm, 0.9, 0.8)
+    wmulti = dict(wdev, wpack=eng.pack_weights(spec, params)) if form == "mfma" else wdev
+    eng.bwd_multi(spec, wmulti, segs, t(cin_all), cout, A, Bm, 0.9, 0.8)
     A, Bm, cout = eng.to_numpy(A), eng.to_numpy(Bm), eng.to_numpy(cout)
+
+    def same(got, ref, what):
+        if form == "tile":
+            np.testing.assert_array_equal(got, ref, err_msg=what)
+        else:
+            # column-wise scale: the columns of A / Bm differ by orders of magnitude
+            tol = 2e-5 * np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30) + 1e-9
+            assert (np.abs(got - ref) <= tol).all(), (what, float(np.abs(got - ref).max()))
+
     row = 0
     for i, (B, D) in enumerate(shapes):
         N = B * D
-        np.testing.assert_array_equal(A[row:row + N], ref_A[i])
-        np.testing.assert_array_equal(Bm[row:row + N], ref_B[i])
-        np.testing.assert_array_equal(cout[:, row:row + N], ref_c[i])
+        same(A[row:row + N], ref_A[i], "A panel %d" % i)
+        same(Bm[row:row + N], ref_B[i], "Bm panel %d" % i)
+        for a in range(4):
+            same(cout[a, row:row + N], ref_c[i][a], "carry %d panel %d" % (a, i))
         assert not A[row + N:row + rows[i]].any() and not Bm[row + N:row + rows[i]].any()   # padding rows stay zero
+        row += rows[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dx_mode", ["g_final", "table"])
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_bwd_unroll_equals_stepwise_bwd_multi(name, dx_mode):
+    """l2o_cwlstm_bwd_unroll (T steps in one launch, carries in registers, dL/d(delta_t) either from the
+    pointer table or accumulated from g_final: loss = sum_t fx_t, DM/meta.py:376) == T calls of
+    l2o_cwlstm_bwd_multi on the fp32 tile kernel with the carries going through memory."""
+    eng = _engine.HipEngine()
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=95, trained_like=True)
+    names = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"), "w_gates2": ("lstm_2", "w_gates"),
+             "b_gates2": ("lstm_2", "b_gates"), "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+             "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+    t_ = eng.tensor
+    wdev = {kk: t_(params[mm][nn]) for kk, (mm, nn) in names.items() if mm in params}
+    wfused = dict(wdev, wpack=eng.pack_weights(spec, params))
+    fc = cfg.kind == "rnnprop"
+    P = cfg.in_dim
+    KA = P + 20 + 60 + (2 if fc else 0) + 1
+    KB = 161 + (20 if fc else 0)
+    T, step0 = 4, 3
+    shapes = [(2, 32), (1, 40)]
+    rows = [(b * d + 15) // 16 * 16 for b, d in shapes]
+    R = sum(rows)
+    rng = np.random.default_rng(96)
+    panels = []
+    for i, (B, D) in enumerate(shapes):
+        N = B * D
+        gs = [t_((rng.standard_normal((B, D)) * 0.5).astype(np.float32)) for _ in range(T)]
+        ms = [t_((rng.standard_normal((B, D)) * 0.1).astype(np.float32)) for _ in range(T)] if fc else [None] * T
+        vs = [t_((rng.random((B, D)) * 0.1 + 0.01).astype(np.float32)) for _ in range(T)] if fc else [None] * T
+        sts = []
+        for k in range(T):
+            state = random_state(cfg, N, 200 + 10 * i + k)
+            sts.append(eng.state_pack(*[t_(a) for hc in state for a in hc], B, D))
+        g_final = t_((rng.standard_normal(N) * 0.5).astype(np.float32))
+        dxs, acc = [None] * T, g_final.clone()
+        for k in reversed(range(T)):
+            dxs[k] = acc
+            acc = acc + gs[k].reshape(N)
+        panels.append(dict(B=B, D=D, gs=gs, ms=ms, vs=vs, sts=sts, dxs=dxs, g_final=g_final))
+    cin0 = t_((rng.standard_normal((4, R, 20)) * 0.3).astype(np.float32))
+    # reference: step by step on the fp32 tile kernel
+    A0, B0 = eng.zeros(T, R, KA), eng.zeros(T, R, KB)
+    cin, cout = cin0.clone(), eng.zeros(4, R, 20)
+    b1, b2 = float(np.float32(spec.beta1)), float(np.float32(spec.beta2))
+    for k in reversed(range(T)):
+        segs = [dict(g=pn["gs"][k], m=pn["ms"][k], v=pn["vs"][k], st_prev=pn["sts"][k], dx_next=pn["dxs"][k],
+                     B=pn["B"], D=pn["D"]) for pn in panels]
+        eng.bwd_multi(spec, wdev, segs, cin, cout, A0[k], B0[k], b1 ** (step0 + k), b2 ** (step0 + k))
+        cin, cout = cout, cin
+    ref_c = eng.to_numpy(cin)
+    A1, B1 = eng.zeros(T, R, KA), eng.zeros(T, R, KB)
+    c1 = eng.zeros(4, R, 20)
+    fused_panels = [dict(pn, dxs=None) if dx_mode == "g_final" else dict(pn, g_final=None) for pn in panels]
+    eng.bwd_unroll(spec, wfused, fused_panels, T, step0, A1, B1, carry_in=cin0, carry_out=c1)
+
+    def close(got, ref, what):
+        tol = 2e-5 * np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30) + 1e-9
+        assert (np.abs(got - ref) <= tol).all(), (what, float(np.abs(got - ref).max()))
+
+    A0, B0, A1, B1, c1 = [eng.to_numpy(x) for x in (A0, B0, A1, B1, c1)]
+    for k in range(T):
+        close(A1[k], A0[k], "A step %d" % k)
+        close(B1[k], B0[k], "Bm step %d" % k)
+    row = 0
+    for i, (B, D) in enumerate(shapes):                     # (the padding rows of a ragged last tile are not defined)
+        for a in range(4):
+            close(c1[a, row:row + B * D], ref_c[a, row:row + B * D], "carry %d panel %d" % (a, i))
         row += rows[i]
