@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 2
+#define L2O_ABI_VERSION 3
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -180,6 +180,9 @@ typedef struct l2o_step_seg {
   float* st;           /* device, packed, in-out */
   float* x;            /* device [B,D] in-out */
   int64_t B, D;
+  float* st_out;       /* NULL: in place.  Else the new state / moments are written here and st / m / v stay */
+  float* m_out;        /* as they were: a caller that records the unroll for the meta-gradient chains its     */
+  float* v_out;        /* history buffers through the steps instead of copying them (DM/meta.py:398-414)     */
 } l2o_step_seg;
 int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_step_seg* segs,
                           int32_t nseg, double pow1, double pow2, void* stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # L2O_HIP_LIB: alternative build of the SAME library (timing ablations, scripts/ablate.sh)
 LIB_PATH = os.environ.get("L2O_HIP_LIB") or os.path.join(_HERE, "libl2o_hip.so")
 
-L2O_ABI_VERSION = 2
+L2O_ABI_VERSION = 3
 L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
 
 NET_CW, NET_RNNPROP = 0, 1
@@ -78,7 +78,7 @@ PROB_W_SHARED = 1     # l2o_problem.flags: W is one [M, D] matrix for every prob
 class StepSeg(C.Structure):
     """struct l2o_step_seg"""
     _fields_ = [("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("st", C.c_void_p), ("x", C.c_void_p),
-                ("B", C.c_int64), ("D", C.c_int64)]
+                ("B", C.c_int64), ("D", C.c_int64), ("st_out", C.c_void_p), ("m_out", C.c_void_p), ("v_out", C.c_void_p)]
 
 
 class BwdSeg(C.Structure):

@@ -174,12 +174,15 @@ class HipEngine(object):
 
     def lstm_step_multi(self, spec: NetSpec, wpack, segs, pow1, pow2):
         """One launch for several variables that share a network.  segs: list of
-        (g, m, v, st, x, B, D) with device tensors (m, v, st may be None)."""
+        (g, m, v, st, x, B, D[, st_out, m_out, v_out]) with device tensors (m, v, st may be None)."""
         for i in range(0, len(segs), self.MAX_STEP_SEGS):
             chunk = segs[i:i + self.MAX_STEP_SEGS]
             arr = (_abi.StepSeg * len(chunk))()
-            for a, (g, m, v, st, x, B, D) in zip(arr, chunk):
+            for a, seg in zip(arr, chunk):
+                g, m, v, st, x, B, D = seg[:7]
                 a.g, a.m, a.v, a.st, a.x, a.B, a.D = _ptr(g), _ptr(m), _ptr(v), _ptr(st), _ptr(x), B, D
+                if len(seg) > 7:                             # (st_out, m_out, v_out): out of place, see l2o_step_seg
+                    a.st_out, a.m_out, a.v_out = _ptr(seg[7]), _ptr(seg[8]), _ptr(seg[9])
             cc = spec.to_c()
             _abi.check(self.lib.l2o_cwlstm_step_multi(C.byref(cc), _ptr(wpack), arr, len(chunk), float(pow1),
                                                       float(pow2), self._stream()))

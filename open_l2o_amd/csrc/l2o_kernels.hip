@@ -98,6 +98,9 @@ struct StepSegs {
   float* v[kMaxStepSegs];
   float* st[kMaxStepSegs];
   float* x[kMaxStepSegs];
+  float* st_out[kMaxStepSegs];    // where the new state / moments go (== st / m / v unless the caller records history)
+  float* m_out[kMaxStepSegs];
+  float* v_out[kMaxStepSegs];
 };
 
 template <int PRE>
@@ -149,9 +152,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (wave >= ntiles) return;
   const int ntl = (ntiles - wave + nwaves - 1) / nwaves;         // tiles of this wave
   // global tile index -> segment (wave-uniform scalar work)
-  struct Loc { const float* g; float *m, *v, *st, *x; int tile, tpp, D; };
+  struct Loc { const float* g; float *m, *v, *st, *x, *st_out, *m_out, *v_out; int tile, tpp, D; };
   Loc L0;                                                        // the common single-panel launch: fields read once
   L0.tile = 0; L0.g = sg.g[0]; L0.m = sg.m[0]; L0.v = sg.v[0]; L0.st = sg.st[0]; L0.x = sg.x[0];
+  L0.st_out = sg.st_out[0]; L0.m_out = sg.m_out[0]; L0.v_out = sg.v_out[0];
   L0.tpp = sg.tpp[0]; L0.D = sg.D[0];
   const bool single = sg.n == 1;
   auto locate = [&](int tile) {
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     while (sidx + 1 < sg.n && tile >= sg.tile_end[sidx]) ++sidx;
     L.tile = tile - (sidx ? sg.tile_end[sidx - 1] : 0);
     L.g = sg.g[sidx]; L.m = sg.m[sidx]; L.v = sg.v[sidx]; L.st = sg.st[sidx]; L.x = sg.x[sidx];
+    L.st_out = sg.st_out[sidx]; L.m_out = sg.m_out[sidx]; L.v_out = sg.v_out[sidx];
     L.tpp = sg.tpp[sidx]; L.D = sg.D[sidx];
     return L;
   };
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int k = 0; k < ntl; ++k) {
     const Loc L = locate(wave + k * nwaves);
     const int tile = L.tile, tpp = L.tpp, D = L.D;
-    float *x = L.x, *mbuf = L.m, *vbuf = L.v, *st = L.st;
+    float *x = L.x, *mbuf = L.m_out, *vbuf = L.v_out, *st = L.st_out;
     const int b = tile / tpp, tw = tile - b * tpp;
     const int j = tw * kTile + c;
     const bool live = j < D;
@@ -1182,6 +1187,9 @@ int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_
     if (ntiles > INT32_MAX) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_step: too many coordinates");
     sg.tile_end[i] = (int)ntiles;
     sg.g[i] = segs[i].g; sg.m[i] = segs[i].m; sg.v[i] = segs[i].v; sg.st[i] = segs[i].st; sg.x[i] = segs[i].x;
+    sg.st_out[i] = segs[i].st_out ? segs[i].st_out : segs[i].st;
+    sg.m_out[i] = segs[i].m_out ? segs[i].m_out : segs[i].m;
+    sg.v_out[i] = segs[i].v_out ? segs[i].v_out : segs[i].v;
   }
   int blocks = (int)((ntiles + 3) / 4);
   if (blocks > 256) blocks = 256;            // one 4-wave block per CU (one wave per SIMD), grid-stride beyond
@@ -1199,6 +1207,7 @@ int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_
 int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, float* m, float* v, double pow1,
                     double pow2, float* st, float* x, int64_t B, int64_t D, void* stream) {
   l2o_step_seg seg;
+  std::memset(&seg, 0, sizeof(seg));
   seg.g = g; seg.m = m; seg.v = v; seg.st = st; seg.x = x; seg.B = B; seg.D = D;
   return l2o_cwlstm_step_multi(cfg, wpack, &seg, 1, pow1, pow2, stream);
 }

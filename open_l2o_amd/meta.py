@@ -807,15 +807,33 @@ class UnrollGraph(object):
                         for j in js:
                             grads[j].mul_(float(term.weight))
 
+        chain = None
         if record is not None:
             record.update(g=[], st=[], m=[], v=[])
+            # History without copies: the gradients are written straight into their [T + 1] history
+            # buffers, and the LSTM state / RNNProp moments are CHAINED through [T + 1] buffers --
+            # step t reads slice t and writes slice t + 1 (l2o_step_seg.st_out / m_out / v_out).
+            hist_g = [eng.empty(T + 1, *panels[j].shape) for j in range(nvar)]
+            chain = {}
+            for si, s in enumerate(slots):
+                if isinstance(s.net, networks.StandardDeepLSTM) and states[si].packed is not None:
+                    hs = eng.empty(T + 1, states[si].packed.numel())
+                    hs[0].copy_(states[si].packed)
+                    hm = hv = None
+                    if ms[si] is not None:
+                        hm, hv = eng.empty(T + 1, ms[si].numel()), eng.empty(T + 1, vs[si].numel())
+                        hm[0].copy_(ms[si].reshape(-1)); hv[0].copy_(vs[si].reshape(-1))
+                    chain[si] = (hs, hm, hv)
         for t in range(T):
+            if record is not None:
+                grads[:] = [hg[t] for hg in hist_g]
             forward(t, True)
             k = step0 + t
             if record is not None:
-                record["g"].append([g.clone() for g in grads])
-                record["st"].append([None if not isinstance(st, PackedState) or st.packed is None
-                                     else st.packed.clone() for st in states])
+                record["g"].append(list(grads))
+                record["st"].append([chain[si][0][t] if si in chain else
+                                     (None if not isinstance(st, PackedState) or st.packed is None else st.packed.clone())
+                                     for si, st in enumerate(states)])
             # variables that share a network are updated by ONE launch (DM/meta.py:330-336 applies
             # `net` to every variable of its subset inside the same time step)
             groups = {}
@@ -823,22 +841,36 @@ class UnrollGraph(object):
                 j = s.var_index
                 B, D = panels[j].shape
                 if isinstance(s.net, networks.StandardDeepLSTM):
-                    groups.setdefault(id(s.net), (s.net, []))[1].append(
-                        (grads[j], ms[si], vs[si], None if states[si].packed is None else states[si].packed,
-                         panels[j], B, D))
+                    if chain is not None and si in chain:
+                        hs, hm, hv = chain[si]
+                        seg = (grads[j], None if hm is None else hm[t].view(B, D), None if hv is None else hv[t].view(B, D),
+                               hs[t], panels[j], B, D, hs[t + 1], None if hm is None else hm[t + 1].view(B, D),
+                               None if hv is None else hv[t + 1].view(B, D))
+                    else:
+                        seg = (grads[j], ms[si], vs[si], None if states[si].packed is None else states[si].packed,
+                               panels[j], B, D)
+                    groups.setdefault(id(s.net), (s.net, []))[1].append(seg)
                 else:                                    # Sgd / Adam baseline nets
                     delta, states[si] = s.net(grads[j], states[si])
                     panels[j].add_(delta.view(B, D))
             for net, segs in groups.values():
                 eng.lstm_step_multi(net.spec, net.wpack(eng), segs, b1 ** k, b2 ** k)
             if record is not None:                         # RNNProp moments AFTER this step's update
-                record["m"].append([None if mm is None else mm.clone() for mm in ms])
-                record["v"].append([None if vv is None else vv.clone() for vv in vs])
+                record["m"].append([(chain[si][1][t + 1] if si in chain else mm.clone()) if mm is not None else None
+                                    for si, mm in enumerate(ms)])
+                record["v"].append([(chain[si][2][t + 1] if si in chain else vv.clone()) if vv is not None else None
+                                    for si, vv in enumerate(vs)])
+        if record is not None:
+            grads[:] = [hg[T] for hg in hist_g]
         forward(T, record is not None)                     # training also needs the gradient at x_T
         if defer:
             eng.reduce_fx(f_all, T + 1, descs[jd].B_local, descs[jd].B_global, fx)
         if record is not None:
-            record["g_final"] = [g.clone() for g in grads]
+            record["g_final"] = list(grads)
+            for si, (hs, hm, hv) in chain.items():         # the variables take the end of the chain
+                states[si].packed.copy_(hs[T])
+                if hm is not None:
+                    ms[si].copy_(hm[T].view(ms[si].shape)); vs[si].copy_(hv[T].view(vs[si].shape))
 
 
 def _chunked_atb(A, B, chunk=1024):

@@ -140,7 +140,16 @@ class OracleEngine(object):
                 t.copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)).view_as(t))
 
     def lstm_step_multi(self, spec, wpack, segs, pow1, pow2):
-        for (g, m, v, st, x, B, D) in segs:
+        for seg in segs:
+            g, m, v, st, x, B, D = seg[:7]
+            if len(seg) > 7:                               # out of place: inputs stay, results into *_out
+                st_out, m_out, v_out = seg[7:10]
+                if st is not None:
+                    st_out.copy_(st)
+                if m is not None:
+                    m_out.copy_(m); v_out.copy_(v)
+                st, m, v = (st_out if st is not None else None), (m_out if m is not None else None), \
+                           (v_out if v is not None else None)
             self.lstm_step(spec, wpack, g, m, v, pow1, pow2, st, x, B, D)
 
     def lstm_step(self, spec, wpack, g, m, v, pow1, pow2, st, x, B, D):
