@@ -685,7 +685,17 @@ class UnrollGraph(object):
             for acc in out.values():
                 for k in sorted(acc):
                     dist.all_reduce(acc[k])
-        return {key: {k: eng.to_numpy(v) for k, v in acc.items()} for key, acc in out.items()}
+        # ONE device-to-host copy for all weight gradients (each .cpu() is a stream sync + a transfer)
+        items = [(key, k, v) for key, acc in out.items() for k, v in acc.items()]
+        if not items:
+            return {}
+        flat = eng.to_numpy(torch.cat([v.reshape(-1) for _, _, v in items]))
+        res, off = {}, 0
+        for key, k, v in items:
+            n = v.numel()
+            res.setdefault(key, {})[k] = flat[off:off + n].reshape(tuple(v.shape))
+            off += n
+        return res
 
     def _adam_apply(self, grads, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, slot="_adam"):
         """tf.train.AdamOptimizer's update (TF 1.x `_apply_dense`): lr_t = lr sqrt(1-b2^t)/(1-b1^t);

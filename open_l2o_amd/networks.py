@@ -204,7 +204,19 @@ class StandardDeepLSTM(Network):
                      "w_gates2": ("lstm_2", "w_gates"), "b_gates2": ("lstm_2", "b_gates"),
                      "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
                      "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
-            self._wdev = {k: engine.tensor(v[m][n]) for k, (m, n) in names.items() if m in v}
+            # one host-to-device copy: the tensors are 16-byte aligned views of a single buffer
+            parts, offs, off = [], {}, 0
+            for k, (m, n) in names.items():
+                if m in v:
+                    a = np.ascontiguousarray(v[m][n], np.float32)
+                    offs[k] = (off, a.shape)
+                    parts.append(a.reshape(-1))
+                    pad = (-a.size) % 4
+                    if pad:
+                        parts.append(np.zeros(pad, np.float32))
+                    off += a.size + pad
+            buf = engine.tensor(np.concatenate(parts))
+            self._wdev = {k: buf[o:o + int(np.prod(shp))].view(*shp) for k, (o, shp) in offs.items()}
             if len(self.spec.layers):
                 self._wdev["wpack"] = self.wpack(engine)      # selects the matrix-core BPTT kernel
             self._wdev_engine = engine
