@@ -883,10 +883,14 @@ class UnrollGraph(object):
                     ms[si].copy_(hm[T].view(ms[si].shape)); vs[si].copy_(hv[T].view(vs[si].shape))
 
 
-def _chunked_atb(A, B, chunk=1024):
+def _chunked_atb(A, B, chunk=None):
     """A^T B for tall-skinny A [R, ka], B [R, kb] as ONE batched GEMM over row chunks + a sum
-    (library GEMMs; rocBLAS' plain skinny-K path is ~4x slower)."""
+    (library GEMMs; rocBLAS' plain skinny-K path is ~4x slower).  Chunk size by measurement
+    (scripts/microbench/skinny_gemm_big.py: R = 0.33 M rows: 1024 -> 173 us, 4096 -> 147 us;
+    R = 1.6 M rows: 1024 -> 854 us, 8192 -> 602 us)."""
     R = A.shape[0]
+    if chunk is None:
+        chunk = 1024 if R < (1 << 16) else (4096 if R < (1 << 20) else 8192)
     n = R // chunk
     out = None
     if n:
