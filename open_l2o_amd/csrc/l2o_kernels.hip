@@ -1130,6 +1130,18 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
   if (lds_small > lds_b) lds_b = lds_small;
   if (lds_f > 160 * 1024 || lds_b > 160 * 1024)
     return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: needs %zu / %zu bytes of LDS", lds_f, lds_b);
+  if (p.H == kMlp20 && !getenv("L2O_MLP_GENERIC")) {       // the reference's width: barrier-free forward, scalar-operand backward
+    hipLaunchKernelGGL(k_mlp_fwd20, dim3(p.batch), dim3(64), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    const int nkb20 = (p.n_in + 63) / 64;
+    size_t lds20 = sizeof(float) * (size_t)kMlpBwdWaves * 64 * (kMlp20 + 1);
+    if (lds_small > lds20) lds20 = lds_small;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd20), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds20));
+    hipLaunchKernelGGL(k_mlp_bwd20, dim3(nkb20 + 1), dim3(64 * kMlpBwdWaves), lds20, s, p);
+    HIP_TRY(hipGetLastError());
+    return L2O_OK;
+  }
   void (*ffwd)(MlpParams) = HP == 20 ? k_mlp_fwd<20> : k_mlp_fwd<kMlpMaxH>;
   void (*fbwd)(MlpParams) = HP == 20 ? k_mlp_bwd<20> : k_mlp_bwd<kMlpMaxH>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ffwd), hipFuncAttributeMaxDynamicSharedMemorySize,

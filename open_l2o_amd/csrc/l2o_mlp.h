@@ -329,3 +329,231 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpParams p) {
     }
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// The reference's own MLP (problems.mnist: hidden width 20, DM/problems.py:254-288) without LDS
+// staging and without workgroup barriers -- the evaluation is 8 MFLOP, i.e. pure latency, and
+// the 4-samples-per-workgroup form above spends 16 + 10 us on 32 + 14 workgroups (five barrier
+// rounds of a few hundred cycles each after the GEMV):
+//   k_mlp_fwd20 : ONE WAVE PER SAMPLE (batch workgroups of 64 threads).  Lane l owns the inputs
+//                 k = l + 64 i; the 20 hidden pre-activations are 20 deterministic wave sums
+//                 (DPP + permlane swaps); layer 2, the softmax and dH run on lanes 0..19 with
+//                 v_readlane broadcasts.  No LDS at all.
+//   k_mlp_bwd20 : 64 rows of gw1 per workgroup of 8 waves; wave w owns the samples n = w + 8 i,
+//                 whose index and dH row are wave-uniform -> scalar loads, SGPR operands of the
+//                 FMAs; the image values are coalesced 256-byte row pieces.  One LDS round to
+//                 add the 8 partial sums in a fixed order.  The last workgroup computes gw2, gb2,
+//                 gb1 and the fixed-order loss sum as above.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMlp20 = 20;
+constexpr int kMlpBwdWaves = 16;
+typedef const __attribute__((address_space(4))) float* l2o_cfp;   // wave-uniform reads through the scalar unit
+__device__ __forceinline__ float mlp_rl(float v, int l) {         // value of lane l (wave-uniform l), in every lane
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+__global__ __launch_bounds__(64) void k_mlp_fwd20(MlpParams p) {
+  constexpr int H = kMlp20;
+  const int n_in = p.n_in, O = p.O, Bn = p.batch;
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x;
+  // Program order = issue order: everything that does NOT depend on the sample index goes out first
+  // (the rows of w1 this lane needs, 13 x 80 bytes for 784 inputs = 260 registers of a 512-register
+  // wave, and the small operands of the tail), then the index -> image row chain rides on top.
+  const float4* w4 = reinterpret_cast<const float4*>(p.w1);
+  constexpr int KI = 13;                                 // 64 * 13 = 832 >= 784 (the reference's input width)
+  const bool all = n_in <= 64 * KI;                      // (else: batches of four rows below)
+  float4 wv[KI][5];
+  if (all) {
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int k = min(lane + 64 * i, n_in - 1);        // out-of-range slots carry xr == 0
+#pragma unroll
+      for (int c5 = 0; c5 < 5; ++c5) wv[i][c5] = w4[k * 5 + c5];
+    }
+  }
+  const float b1v = lane < H ? p.b1[lane] : 0.0f;
+  const float b2v = lane < O ? p.b2[lane] : 0.0f;
+  float w2c[H];                                          // lane o < O: column o of w2
+#pragma unroll
+  for (int u = 0; u < H; ++u) w2c[u] = lane < O ? p.w2[u * O + lane] : 0.0f;
+  float w2r[kMlpMaxO];                                   // lane u < H: row u of w2
+#pragma unroll
+  for (int o = 0; o < kMlpMaxO; ++o) w2r[o] = (lane < H && o < O) ? p.w2[lane * O + o] : 0.0f;
+  const int row = p.idx[n];
+  const int lab = p.labels[row];
+  const float* xrow = p.images + (size_t)row * n_in;
+  float xr[kMlpKPT];
+#pragma unroll
+  for (int i = 0; i < kMlpKPT; ++i) {
+    const int k = lane + 64 * i;
+    xr[i] = k < n_in ? xrow[k] : 0.0f;
+  }
+  float acc[H];
+#pragma unroll
+  for (int u = 0; u < H; ++u) acc[u] = 0.0f;
+  if (all) {
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const float xv = xr[i];
+#pragma unroll
+      for (int c5 = 0; c5 < 5; ++c5) {
+        acc[4 * c5 + 0] = __builtin_fmaf(xv, wv[i][c5].x, acc[4 * c5 + 0]);
+        acc[4 * c5 + 1] = __builtin_fmaf(xv, wv[i][c5].y, acc[4 * c5 + 1]);
+        acc[4 * c5 + 2] = __builtin_fmaf(xv, wv[i][c5].z, acc[4 * c5 + 2]);
+        acc[4 * c5 + 3] = __builtin_fmaf(xv, wv[i][c5].w, acc[4 * c5 + 3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i0 = 0; i0 < kMlpKPT; i0 += 4) {
+      if (64 * i0 < n_in) {                              // wave-uniform
+        float4 wb[4][5];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int k = min(lane + 64 * (i0 + ii), n_in - 1);
+#pragma unroll
+          for (int c5 = 0; c5 < 5; ++c5) wb[ii][c5] = w4[k * 5 + c5];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const float xv = xr[i0 + ii];
+#pragma unroll
+          for (int c5 = 0; c5 < 5; ++c5) {
+            acc[4 * c5 + 0] = __builtin_fmaf(xv, wb[ii][c5].x, acc[4 * c5 + 0]);
+            acc[4 * c5 + 1] = __builtin_fmaf(xv, wb[ii][c5].y, acc[4 * c5 + 1]);
+            acc[4 * c5 + 2] = __builtin_fmaf(xv, wb[ii][c5].z, acc[4 * c5 + 2]);
+            acc[4 * c5 + 3] = __builtin_fmaf(xv, wb[ii][c5].w, acc[4 * c5 + 3]);
+          }
+        }
+      }
+    }
+  }
+  float a = 0.0f;                                        // lane u < 20 keeps pre-activation u
+#pragma unroll
+  for (int u = 0; u < H; ++u) {
+    const float t = l2o::wave_sum64(acc[u]);
+    a = lane == u ? t : a;
+  }
+  a += b1v;
+  float h = p.act == 0 ? 1.0f / (1.0f + expf(-a)) : fmaxf(a, 0.0f);
+  if (lane >= H) h = 0.0f;
+  float z = b2v;                                         // lane o < O: logit o
+#pragma unroll
+  for (int u = 0; u < H; ++u) z = __builtin_fmaf(mlp_rl(h, u), w2c[u], z);
+  float zmax = mlp_rl(z, 0);
+  for (int o = 1; o < O; ++o) zmax = fmaxf(zmax, mlp_rl(z, o));
+  const float e = lane < O ? expf(z - zmax) : 0.0f;
+  float se = 0.0f;
+  for (int o = 0; o < O; ++o) se += mlp_rl(e, o);
+  const float lse = zmax + logf(se);
+  const float zl = mlp_rl(z, lab);
+  float* gH = p.scratch;
+  float* gdZ = gH + Bn * H;
+  float* gdH = gdZ + Bn * O;
+  float* gloss = gdH + Bn * H;
+  if (lane == 0) gloss[n] = lse - zl;
+  const float d = lane < O ? (expf(z - lse) - (lane == lab ? 1.0f : 0.0f)) * (1.0f / (float)Bn) : 0.0f;
+  if (lane < O) gdZ[n * O + lane] = d;
+  float dh = 0.0f;                                       // lane u < 20: dL/dh_u
+#pragma unroll
+  for (int o = 0; o < kMlpMaxO; ++o)
+    if (o < O) dh = __builtin_fmaf(mlp_rl(d, o), w2r[o], dh);
+  if (lane < H) {
+    gH[n * H + lane] = h;
+    gdH[n * H + lane] = p.act == 0 ? dh * h * (1.0f - h) : (h > 0.0f ? dh : 0.0f);
+  }
+}
+
+__global__ __launch_bounds__(64 * kMlpBwdWaves) void k_mlp_bwd20(MlpParams p) {
+  constexpr int H = kMlp20, NW = kMlpBwdWaves, HS = H + 1;     // odd LDS row stride: conflict-free
+  constexpr int NT = 64 * NW;
+  extern __shared__ float sm[];
+  const int n_in = p.n_in, O = p.O, Bn = p.batch;
+  const float* gH = p.scratch;
+  const float* gdZ = gH + Bn * H;
+  const float* gdH = gdZ + Bn * O;
+  const int tid = threadIdx.x;
+  const int nkb = (n_in + 63) / 64;
+  if ((int)blockIdx.x == nkb) {                         // the small tensors + the loss
+    const int tot = Bn * (2 * H + O + 1);
+    for (int i = tid; i < tot; i += NT) sm[i] = p.scratch[i];
+    __syncthreads();
+    const float* sH = sm;
+    const float* sdZ = sH + Bn * H;
+    const float* sdH = sdZ + Bn * O;
+    const float* sloss = sdH + Bn * H;
+    if (tid < 64) {                                     // fixed-order loss sum: lane strides, then the wave tree
+      float a = 0.0f;
+      for (int n = tid; n < Bn; n += 64) a += sloss[n];
+      a = l2o::wave_sum64(a);
+      if (tid == 0) p.loss[0] = a / (float)Bn;
+    }
+    if (p.gw1 == nullptr) return;
+    // waves 1.. : gw2 (H*O), gb2 (O), gb1 (H): FOUR threads (a DPP quad) per output, thread part sums the
+    // samples n = part + 4 i, then the quad adds its four partial sums in a fixed order
+    const int t4 = tid - 64;
+    if (t4 < 0) return;
+    const int part = t4 & 3;
+    for (int e = t4 >> 2; e < H * O + O + H; e += (NT - 64) / 4) {     // (quad-uniform trip count)
+      float a = 0.0f;
+      if (e < H * O) {
+        const int u = e / O, o = e % O;
+        for (int n = part; n < Bn; n += 4) a = __builtin_fmaf(sH[n * H + u], sdZ[n * O + o], a);
+      } else if (e < H * O + O) {
+        const int o = e - H * O;
+        for (int n = part; n < Bn; n += 4) a += sdZ[n * O + o];
+      } else {
+        const int u = e - H * O - O;
+        for (int n = part; n < Bn; n += 4) a += sdH[n * H + u];
+      }
+      a = l2o::quad_sum(a);
+      if (part == 0) {
+        if (e < H * O) p.gw2[e] = a;
+        else if (e < H * O + O) p.gb2[e - H * O] = a;
+        else p.gb1[e - H * O - O] = a;
+      }
+    }
+    return;
+  }
+  if (p.gw1 == nullptr) return;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = blockIdx.x * 64 + lane;
+  const int kc = min(k, n_in - 1);
+  float acc[H];
+#pragma unroll
+  for (int u = 0; u < H; ++u) acc[u] = 0.0f;
+  const l2o_cfp dH = (l2o_cfp)gdH;
+  const __attribute__((address_space(4))) int* idx = (const __attribute__((address_space(4))) int*)p.idx;
+  for (int n0 = wv; n0 < Bn; n0 += NW * 8) {            // 8 samples of this wave per pass, their loads in flight together
+    float xr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + NW * i;
+      xr[i] = n < Bn ? p.images[(size_t)idx[n < Bn ? n : 0] * n_in + kc] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = min(n0 + NW * i, Bn - 1);             // out-of-range slots carry xr == 0
+      const l2o_cfp dh = dH + n * H;
+#pragma unroll
+      for (int u = 0; u < H; ++u) acc[u] = __builtin_fmaf(xr[i], dh[u], acc[u]);
+    }
+  }
+  float* part = sm;                                     // [NW][64][HS]
+#pragma unroll
+  for (int u = 0; u < H; ++u) part[(wv * 64 + lane) * HS + u] = acc[u];
+  __syncthreads();
+  for (int e = tid; e < 64 * H; e += NT) {
+    const int kk = e / H, u = e % H;
+    const int kg = blockIdx.x * 64 + kk;
+    if (kg < n_in) {
+      float s = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += part[(w * 64 + kk) * HS + u];
+      p.gw1[kg * H + u] = s;
+    }
+  }
+}
