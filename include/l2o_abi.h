@@ -257,7 +257,8 @@ int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const
  *             step t (same meaning as l2o_bwd_seg; m, v NULL for the DM nets).  dx_next may be NULL:
  *             then dL/d(delta_t) = g_final + sum_{tau > t} g_tau, the gradient of loss = sum_t fx_t
  *             (DM/meta.py:376) through x_{t+1} = x_t + delta_t, accumulated in a register.
- *   A, Bm     [T][rows][KA], [T][rows][KB] (rows as in l2o_cwlstm_bwd_multi)
+ *   A, Bm     [T][rows][KA], [T][rows][KB] (rows as in l2o_cwlstm_bwd_multi); EVERY row is written -- the rows
+ *             of a ragged last tile that do not exist as zeros, so the caller need not clear the buffers
  *   carry_in  [4][rows][H] gradient w.r.t. the state after step T-1, or NULL (zeros);
  *   carry_out gradient w.r.t. the state before step 0, or NULL (not wanted)
  *   step0     RNNProp: step t uses the bias corrections 1 - beta^(step0 + t) (DM/util.py:59-60) */

@@ -164,6 +164,49 @@ class HipEngine(object):
         _abi.check(self.lib.l2o_mlp_fg(C.byref(c), C.c_void_p(indices.data_ptr()), _ptr(w1), _ptr(b1), _ptr(w2),
                                        _ptr(b2), _ptr(loss), *g, _ptr(self._mlp_scratch), self._stream()))
 
+    # -- prepared calls: the ctypes argument objects are built ONCE for launches that repeat with the same
+    #    buffers (the T steps of a recorded unroll); per call only what changes is passed ------------------
+    def prepared_mlp_fg(self, d: MlpDesc, indices, w1, b1, w2, b2, grads):
+        """Returns call(loss_ptr): l2o_mlp_fg with everything but the address of the loss slot fixed."""
+        c = _abi.Mlp()
+        c.n_in, c.n_hidden, c.n_out, c.batch = d.n_in, d.n_hidden, d.n_out, d.batch
+        c.activation, c.n_data = d.activation, int(d.images.shape[0])
+        c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
+        g = [None] * 4 if grads is None else [_ptr(t) for t in grads]
+        n = int(self.lib.l2o_mlp_scratch_floats(C.byref(c)))
+        if self._mlp_scratch is None or self._mlp_scratch.numel() < n:
+            self._mlp_scratch = self.empty(n)
+        head = (C.byref(c), C.c_void_p(indices.data_ptr()), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2))
+        tail = tuple(g) + (_ptr(self._mlp_scratch), self._stream())
+        fn, check = self.lib.l2o_mlp_fg, _abi.check
+        keep = (c, d, indices, w1, b1, w2, b2, grads, self._mlp_scratch)
+
+        def call(loss_ptr, _keep=keep):
+            rc = fn(*head, loss_ptr, *tail)
+            if rc:
+                check(rc)
+        return call
+
+    def prepared_lstm_step_multi(self, spec: NetSpec, segs):
+        """Returns call(wpack_ptr, pow1, pow2) for at most MAX_STEP_SEGS panels."""
+        assert len(segs) <= self.MAX_STEP_SEGS
+        arr = (_abi.StepSeg * len(segs))()
+        for a, seg in zip(arr, segs):
+            g, m, v, st, x, B, D = seg[:7]
+            a.g, a.m, a.v, a.st, a.x, a.B, a.D = _ptr(g), _ptr(m), _ptr(v), _ptr(st), _ptr(x), B, D
+            if len(seg) > 7:
+                a.st_out, a.m_out, a.v_out = _ptr(seg[7]), _ptr(seg[8]), _ptr(seg[9])
+        cc = spec.to_c()
+        ccp, n, stream = C.byref(cc), len(segs), self._stream()
+        fn, check = self.lib.l2o_cwlstm_step_multi, _abi.check
+        keep = (cc, arr, segs)
+
+        def call(wpack_ptr, pow1, pow2, _keep=keep):
+            rc = fn(ccp, wpack_ptr, arr, n, pow1, pow2, stream)
+            if rc:
+                check(rc)
+        return call
+
     def lstm_step(self, spec: NetSpec, wpack, g, m, v, pow1, pow2, st, x, B, D):
         cc = spec.to_c()
         _abi.check(self.lib.l2o_cwlstm_step(C.byref(cc), _ptr(wpack), _ptr(g), _ptr(m), _ptr(v),
@@ -220,7 +263,8 @@ class HipEngine(object):
                                                  _ptr(carry_out), _ptr(A), _ptr(Bm), float(pow1), float(pow2),
                                                  self._stream()))
 
-    def bwd_unroll(self, spec: NetSpec, weights: dict, panels, T, step0, A, Bm, carry_in=None, carry_out=None):
+    def bwd_unroll(self, spec: NetSpec, weights: dict, panels, T, step0, A, Bm, carry_in=None, carry_out=None,
+                   table=None):
         """All T BPTT steps of the panels that share one network in one launch (l2o_cwlstm_bwd_unroll).
         panels: list of dict(B=, D=, gs=[T tensors], sts=[T], ms=[T] | None, vs=, dxs=[T] | None,
         g_final= tensor | None); A [T, rows, KA], Bm [T, rows, KB]."""
@@ -228,13 +272,8 @@ class HipEngine(object):
         w = _abi.NetWeights()
         for k, _ in _abi.NetWeights._fields_:
             setattr(w, k, None if weights.get(k) is None else weights[k].data_ptr())
-        ptr = lambda x: 0 if x is None else x.data_ptr()
-        rows = []
-        for t in range(T):
-            for pn in panels:
-                rows.append([ptr(pn["gs"][t]), ptr(pn["ms"][t]) if pn.get("ms") else 0, ptr(pn["vs"][t]) if pn.get("vs") else 0,
-                             ptr(pn["sts"][t]), ptr(pn["dxs"][t]) if pn.get("dxs") else 0])
-        table = torch.tensor(rows, dtype=torch.int64).to(self.device, non_blocking=False)
+        if table is None:
+            table = self.bwd_table(panels, T)
         arr = (_abi.BwdUnrollSeg * len(panels))()
         for a, pn in zip(arr, panels):
             a.B, a.D = int(pn["B"]), int(pn["D"])
@@ -243,6 +282,16 @@ class HipEngine(object):
                                                   int(step0), _ptr(carry_in), _ptr(carry_out), _ptr(A), _ptr(Bm),
                                                   self._stream()))
         self._bwd_table = table                              # keep the pointer table alive until the stream has run the kernel
+
+    def bwd_table(self, panels, T):
+        """The device pointer table [T][len(panels)][5] of l2o_cwlstm_bwd_unroll (g, m, v, st_prev, dx_next)."""
+        ptr = lambda x: 0 if x is None else x.data_ptr()
+        rows = []
+        for t in range(T):
+            for pn in panels:
+                rows.append([ptr(pn["gs"][t]), ptr(pn["ms"][t]) if pn.get("ms") else 0, ptr(pn["vs"][t]) if pn.get("vs") else 0,
+                             ptr(pn["sts"][t]), ptr(pn["dxs"][t]) if pn.get("dxs") else 0])
+        return torch.tensor(rows, dtype=torch.int64).to(self.device, non_blocking=False)
 
     def unroll_supported(self, spec: NetSpec, p: ProblemDesc):
         cc, cp = spec.to_c(), self._cprob(p)

@@ -273,28 +273,31 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     MCK();                                                  // 4: forward
     __syncthreads();                                        // the previous step's Bm block has left the staging buffer
     // ---- the A row block: [act1 = in | h1(t-1)] [act2 = h1(t) | h2(t-1)] [h2(t)] [feats] [1] ----------
+    // (the rows of a ragged last tile that do not exist are written as zeros: they add nothing to A^T Bm
+    //  and the caller need not clear A / Bm)
+    const float live = c < nv ? 1.0f : 0.0f;
     {
       float* arow = stg + c * KA;
       if (FC) {
 #pragma unroll
-        for (int t = 0; t < kNT; ++t) arow[4 * t + q] = fcv[t];
-        if (q == 0) { arow[K1 + 3 * kH] = f0; arow[K1 + 3 * kH + 1] = f1; }
+        for (int t = 0; t < kNT; ++t) arow[4 * t + q] = fcv[t] * live;
+        if (q == 0) { arow[K1 + 3 * kH] = f0 * live; arow[K1 + 3 * kH + 1] = f1 * live; }
       } else if (q == 0) {
-        arow[0] = in0;
-        if (PRE == L2O_PRE_LOGSIGN) arow[1] = in1;
+        arow[0] = in0 * live;
+        if (PRE == L2O_PRE_LOGSIGN) arow[1] = in1 * live;
       }
 #pragma unroll
       for (int t = 0; t < kNT; ++t) {
-        arow[P + 4 * t + q] = s.h1[t];
-        arow[K1 + 4 * t + q] = h1n[t];
-        arow[K1 + kH + 4 * t + q] = s.h2[t];
-        arow[K1 + 2 * kH + 4 * t + q] = h2n[t];
+        arow[P + 4 * t + q] = s.h1[t] * live;
+        arow[K1 + 4 * t + q] = h1n[t] * live;
+        arow[K1 + kH + 4 * t + q] = s.h2[t] * live;
+        arow[K1 + 2 * kH + 4 * t + q] = h2n[t] * live;
       }
-      if (q == 0) arow[KA - 1] = 1.0f;
+      if (q == 0) arow[KA - 1] = live;
     }
     __syncthreads();
     if (valid) {
-      const int na = nv * KA;
+      const int na = (p.T > 0 ? NC : nv) * KA;
       for (int i = lane; i < na / 4; i += 64) reinterpret_cast<float4*>(a_t)[i] = reinterpret_cast<const float4*>(stg)[i];
       for (int e = (na & ~3) + lane; e < na; e += 64) a_t[e] = stg[e];
     }
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     float* brow = stg + c * KB;
     float ddv = dxn * p.scale;
     if (p.tanh_output) { const float th = tanhf_(dlin); ddv *= 1.0f - th * th; }
-    if (q == 0) brow[2 * G] = ddv;
+    if (q == 0) brow[2 * G] = ddv * live;
     float dz[4][kNT], dh[kNT];
 #pragma unroll
     for (int t = 0; t < kNT; ++t) dh[t] = __builtin_fmaf(ddv, w.wl[t], cdh2[t]);
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) brow[G + r * kH + 4 * t + q] = dz[r][t];
+      for (int t = 0; t < kNT; ++t) brow[G + r * kH + 4 * t + q] = dz[r][t] * live;
     {
       f32x4 at[3];
       bxb::tgemm<3>(fr, lane, dz, at);                                   // d[h1(t) | h2(t-1)] = W2 dz2
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) brow[r * kH + 4 * t + q] = dz[r][t];
+      for (int t = 0; t < kNT; ++t) brow[r * kH + 4 * t + q] = dz[r][t] * live;
     {
       f32x4 at[NT1];
       bxb::tgemm<NT1>(fr + bxb::frag_rel(bxb::tiles2(), 0, 0), lane, dz, at);     // d[in | h1(t-1)] = W1 dz1
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
           const float dfc = t < 4 ? at[0][t] : at[NT1 - 1][0];
-          brow[2 * G + 1 + 4 * t + q] = dfc * (pre_fc[t] > 0.0f ? 1.0f : fast_exp2(pre_fc[t] * 1.4426950408889634f));
+          brow[2 * G + 1 + 4 * t + q] = live * dfc * (pre_fc[t] > 0.0f ? 1.0f : fast_exp2(pre_fc[t] * 1.4426950408889634f));
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) cdh1[t] = at[1][t];
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     MCK();                                                  // 7: layer-1 backward
     // ---- coalesced store of the Bm row block ------------------------------------------------------------
     if (valid) {
-      const int nb = nv * KB;
+      const int nb = (p.T > 0 ? NC : nv) * KB;
       for (int i = lane; i < nb / 4; i += 64) reinterpret_cast<float4*>(b_t)[i] = reinterpret_cast<const float4*>(stg)[i];
       for (int e = (nb & ~3) + lane; e < nb; e += 64) b_t[e] = stg[e];
     }

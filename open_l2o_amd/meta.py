@@ -201,6 +201,23 @@ _DEFAULT_CONFIG = {
         }}}
 
 
+class _LazyHost(object):
+    """res["x"]: the final iterates, copied device -> host when (and only when) one is fetched
+    (every .cpu() is a stream synchronisation; sess.run([fx, update, step]) does not ask for x)."""
+
+    def __init__(self, engine, tensors, shapes):
+        self._e, self._t, self._s = engine, list(tensors), list(shapes)
+
+    def __len__(self):
+        return len(self._t)
+
+    def __getitem__(self, j):
+        return self._e.to_numpy(self._t[j]).reshape(self._s[j])
+
+    def __iter__(self):
+        return (self[j] for j in range(len(self._t)))
+
+
 def _term_vars(term):
     """The trainable variable declarations a loss term is a function of (one for the analytic
     problems, four for problems.mnist)."""
@@ -551,7 +568,7 @@ class UnrollGraph(object):
         T = self.len_unroll
         self.wait_fx()
         fx_host = eng.to_numpy(fx)
-        x_out = [eng.to_numpy(xv).reshape(self._local_shape(var)) for xv, var in zip(xs, self.x)]
+        x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
         grads = self._backward(T, record)
         self._adam_apply(grads, learning_rate)
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
@@ -564,7 +581,7 @@ class UnrollGraph(object):
         ({(module, variable): device tensor})."""
         self._bptt_panels(net, acc, T, step0, [dict(B=B, D=D, gs=gs, sts=sts, ms=ms, vs=vs, dxs=dxs)])
 
-    def _bptt_panels(self, net, acc, T, step0, panels):
+    def _bptt_panels(self, net, acc, T, step0, panels, cache=None):
         """The same for several panels (variables) that share the network: ONE backward launch
         per step for all of them (l2o_cwlstm_bwd_multi) when every panel is tile-aligned
         (D % 16 == 0 or B == 1), else panel by panel."""
@@ -621,13 +638,21 @@ class UnrollGraph(object):
             offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in Ns])]).astype(int)   # row blocks (whole tiles)
             R = int(offs[-1])
             ragged = any(n % 16 for n in Ns)
-            A = (eng.zeros if ragged else eng.empty)(T, R, KA)     # zero padding rows add nothing to A^T Bm
-            Bm = (eng.zeros if ragged else eng.empty)(T, R, KB)
-            for o, n in zip(offs[:-1], Ns):
-                A[:, o:o + n, KA - 1] = 1.0
-            carry_in, carry_out = eng.zeros(4, R, H), eng.zeros(4, R, H)
-            if fused:                                       # all T steps in one launch, the carries in registers
-                eng.bwd_unroll(spec, wdev, grp, T, step0, A, Bm)
+            if fused:                                       # all T steps in one launch, the carries in registers;
+                A, Bm = eng.empty(T, R, KA), eng.empty(T, R, KB)   # the kernel writes every row (padding rows as zeros)
+                tkey = ("bwd_table", id(net), T)
+                table = None if cache is None else cache.get(tkey)
+                if table is None:
+                    table = eng.bwd_table(grp, T) if hasattr(eng, "bwd_table") else None
+                    if cache is not None:
+                        cache[tkey] = table
+                eng.bwd_unroll(spec, wdev, grp, T, step0, A, Bm, table=table)
+            else:
+                A = (eng.zeros if ragged else eng.empty)(T, R, KA)     # zero padding rows add nothing to A^T Bm
+                Bm = (eng.zeros if ragged else eng.empty)(T, R, KB)
+                for o, n in zip(offs[:-1], Ns):
+                    A[:, o:o + n, KA - 1] = 1.0
+                carry_in, carry_out = eng.zeros(4, R, H), eng.zeros(4, R, H)
             for t in (() if fused else reversed(range(T))):
                 k = step0 + t
                 At, Bt = A[t], Bm[t]
@@ -678,8 +703,8 @@ class UnrollGraph(object):
                 dict(B=B, D=D, gs=[g[j] for g in rec["g"]], sts=[st[si] for st in rec["st"]],
                      ms=[m[si] for m in rec["m"]], vs=[v[si] for v in rec["v"]], dxs=None,
                      g_final=rec["g_final"][j].reshape(N)))
-        for key, (net, panels) in by_net.items():
-            self._bptt_panels(net, out.setdefault(key, {}), T, step0, panels)
+        for key, (net, panels) in by_net.items():      # rec["plan"]: buffers of a planned unroll are reused, so is the table
+            self._bptt_panels(net, out.setdefault(key, {}), T, step0, panels, cache=rec.get("plan"))
         if self.sharded:
             import torch.distributed as dist
             for acc in out.values():
@@ -779,6 +804,8 @@ class UnrollGraph(object):
         eng = self.engine
         nvar = len(self.x)
         index_of = {v.decl.name: j for j, v in enumerate(self.x)}
+        if record is not None and self._plan_ok(slots, states, nvar):
+            return self._run_steps_planned(T, step0, panels, slots, states, ms, vs, fx, record, index_of)
         grads = [self._scratch("g%d" % j, panels[j].numel()).view(panels[j].shape) for j in range(nvar)]
         tmp = self._scratch("fx1", 1)
         single = len(self.terms) == 1 and self.terms[0].weight == 1.0
@@ -881,6 +908,94 @@ class UnrollGraph(object):
                 states[si].packed.copy_(hs[T])
                 if hm is not None:
                     ms[si].copy_(hm[T].view(ms[si].shape)); vs[si].copy_(hv[T].view(vs[si].shape))
+
+
+    # -- the recorded unroll of a neural optimizee as a PLAN: buffers and ctypes arguments built once ------
+    def _plan_ok(self, slots, states, nvar):
+        eng = self.engine
+        if os.environ.get("L2O_NO_STEP_PLAN") or not hasattr(eng, "prepared_mlp_fg"):
+            return False
+        if len(self.terms) != 1 or self.terms[0].kind != _abi.PROB_MLP or self.terms[0].weight != 1.0:
+            return False
+        if len(_term_vars(self.terms[0])) != nvar:
+            return False
+        per_net = collections.Counter()
+        for s, st in zip(slots, states):
+            if not isinstance(s.net, networks.StandardDeepLSTM) or not isinstance(st, PackedState) or st.packed is None:
+                return False
+            per_net[id(s.net)] += 1
+        return all(n <= eng.MAX_STEP_SEGS for n in per_net.values())
+
+    def _run_steps_planned(self, T, step0, panels, slots, states, ms, vs, fx, record, index_of):
+        """_run_steps(record=...) for ONE MLP loss term whose variables are all updated by LSTM nets: the
+        [T + 1] history buffers (gradients written in place, state / moments chained through them) and
+        the ctypes argument objects of the 2T + 1 launches are built once and reused by every unroll
+        with the same buffers; per step the host only passes what changes (the loss slot, the
+        bias-correction powers, the address of the re-packed weights)."""
+        eng = self.engine
+        term = self.terms[0]
+        nvar = len(self.x)
+        idxbuf = self._mlp_idx[0]
+        key = (T, idxbuf.data_ptr(), tuple(p.data_ptr() for p in panels),
+               tuple(st.packed.data_ptr() for st in states), tuple(0 if m is None else m.data_ptr() for m in ms))
+        plan = self.__dict__.get("_step_plan")
+        if plan is None or plan["key"] != key:
+            js = [index_of[tv.name] for tv in _term_vars(term)]
+            hist_g = [eng.empty(T + 1, *panels[j].shape) for j in range(nvar)]
+            chain = []
+            for si, s in enumerate(slots):
+                hs = eng.empty(T + 1, states[si].packed.numel())
+                hm = hv = None
+                if ms[si] is not None:
+                    hm, hv = eng.empty(T + 1, ms[si].numel()), eng.empty(T + 1, vs[si].numel())
+                chain.append((hs, hm, hv))
+            desc = self._mlp_desc(term)
+            mlp = [eng.prepared_mlp_fg(desc, idxbuf[t], *[panels[j] for j in js], [hist_g[j][t] for j in js])
+                   for t in range(T + 1)]
+            lstm = []
+            for t in range(T):
+                groups = {}
+                for si, s in enumerate(slots):
+                    j = s.var_index
+                    B, D = panels[j].shape
+                    hs, hm, hv = chain[si]
+                    seg = (hist_g[j][t], None if hm is None else hm[t].view(B, D), None if hv is None else hv[t].view(B, D),
+                           hs[t], panels[j], B, D, hs[t + 1], None if hm is None else hm[t + 1].view(B, D),
+                           None if hv is None else hv[t + 1].view(B, D))
+                    groups.setdefault(id(s.net), (s.net, []))[1].append(seg)
+                lstm.append([(net, eng.prepared_lstm_step_multi(net.spec, segs)) for net, segs in groups.values()])
+            plan = self.__dict__["_step_plan"] = dict(
+                key=key, chain=chain, mlp=mlp, lstm=lstm,
+                g=[[hist_g[j][t] for j in range(nvar)] for t in range(T)],
+                st=[[chain[si][0][t] for si in range(len(slots))] for t in range(T)],
+                m=[[None if chain[si][1] is None else chain[si][1][t + 1] for si in range(len(slots))] for t in range(T)],
+                v=[[None if chain[si][2] is None else chain[si][2][t + 1] for si in range(len(slots))] for t in range(T)],
+                g_final=[hist_g[j][T] for j in range(nvar)])
+        chain = plan["chain"]
+        for si, (hs, hm, hv) in enumerate(chain):
+            hs[0].copy_(states[si].packed)
+            if hm is not None:
+                hm[0].copy_(ms[si].reshape(-1)); hv[0].copy_(vs[si].reshape(-1))
+        import ctypes
+        wp = {}
+        for calls in plan["lstm"][:1]:
+            for net, _ in calls:
+                wp[id(net)] = (net.wpack(eng), ctypes.c_void_p(net.wpack(eng).data_ptr()))
+        b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
+        fxp = fx.data_ptr()
+        mlp, lstm = plan["mlp"], plan["lstm"]
+        for t in range(T):
+            mlp[t](fxp + 4 * t)
+            k = step0 + t
+            p1, p2 = b1 ** k, b2 ** k
+            for net, call in lstm[t]:
+                call(wp[id(net)][1], p1, p2)
+        mlp[T](fxp + 4 * T)                                # training also needs the gradient at x_T
+        record.update(g=plan["g"], st=plan["st"], m=plan["m"], v=plan["v"], g_final=plan["g_final"], plan=plan)
+        for si, (hs, hm, hv) in enumerate(chain):          # the variables take the end of the chain
+            states[si].packed.copy_(hs[T])
+            if hm is not None:
+                ms[si].copy_(hm[T].view(ms[si].shape)); vs[si].copy_(hv[T].view(vs[si].shape))
 
 
 def _chunked_atb(A, B, chunk=None):

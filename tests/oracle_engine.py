@@ -239,13 +239,19 @@ class OracleEngine(object):
             carry_out[:, row:row + N] = cout
             row += (N + 15) // 16 * 16
 
-    def bwd_unroll(self, spec, weights, panels, T, step0, A, Bm, carry_in=None, carry_out=None):
+    def bwd_unroll(self, spec, weights, panels, T, step0, A, Bm, carry_in=None, carry_out=None, table=None):
         """Same contract as HipEngine.bwd_unroll, step by step through bwd_multi."""
         R = A.shape[1]
         b1, b2 = float(np.float32(spec.beta1)), float(np.float32(spec.beta2))
         cin = torch.zeros(4, R, 20) if carry_in is None else carry_in.clone()
         cout = torch.zeros(4, R, 20)
         acc = [None if pn.get("g_final") is None else pn["g_final"].reshape(-1).clone() for pn in panels]
+        A.zero_(); Bm.zero_()                              # the kernel writes every row: padding rows as zeros,
+        row = 0
+        for pn in panels:                                  # the ones column on the rows that exist
+            n = pn["B"] * pn["D"]
+            A[:, row:row + n, A.shape[2] - 1] = 1.0
+            row += (n + 15) // 16 * 16
         for t in reversed(range(T)):
             segs = []
             for i, pn in enumerate(panels):
