@@ -498,3 +498,68 @@ def test_bwd_unroll_equals_stepwise_bwd_multi(name, dx_mode):
         for a in range(4):
             close(c1[a, row:row + B * D], ref_c[a, row:row + B * D], "carry %d panel %d" % (a, i))
         row += rows[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dm_logsign", "rnnprop"])
+def test_planned_mlp_unroll_equals_step_path(name, monkeypatch):
+    """The recorded unroll of problems.mnist as a plan (history buffers chained through the steps,
+    ctypes arguments prepared once, BPTT in one launch) gives the same costs and the same
+    meta-gradient as the plain step-by-step path with cloned history (L2O_NO_STEP_PLAN=1), for two
+    consecutive training steps (the second one re-uses the plan)."""
+    eng = _engine.HipEngine()
+    old = _engine._default_engine
+    _engine.set_default_engine(eng)
+    try:
+        cfg = ORACLE_CFGS[name]
+        rn = cfg.kind == "rnnprop"
+        params = make_params(cfg, seed=83, trained_like=True)
+        data = problems.synthetic_mnist(200, seed=4)
+        T, batch = 3, 16
+        idx = np.random.default_rng(5).integers(0, 200, size=(64, batch))
+
+        def sampler(n_evals, b, n_data, _state={"k": 0}):
+            k = _state["k"]
+            _state["k"] = (k + n_evals) % 32
+            return idx[k:k + n_evals, :b]
+
+        got = {}
+        for mode in ("plan", "steps"):
+            if mode == "steps":
+                monkeypatch.setenv("L2O_NO_STEP_PLAN", "1")
+            else:
+                monkeypatch.delenv("L2O_NO_STEP_PLAN", raising=False)
+            st = {"k": 0}
+            problem = problems.mnist(layers=(20,), batch_size=batch, data=data,
+                                     sampler=lambda n, b, nd, _s=st: sampler(n, b, nd, _s))
+            meta.set_random_seed(11)
+            if rn:
+                opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+                out = opt.meta_minimize(problem, T, learning_rate=1e-3)
+                ms, step_ph = out[0], out[3]
+            else:
+                opt = meta.MetaOptimizer(**_net_config(cfg, params))
+                ms, step_ph = opt.meta_minimize(problem, T, learning_rate=1e-3), None
+            graph = opt.graph
+            caps = []
+            orig = graph._adam_apply
+            graph._adam_apply = lambda grads, lr, **kw: (caps.append(grads), orig(grads, lr, **kw))[1]
+            costs = []
+            with Session() as sess:
+                sess.run(ms.reset)
+                for i in range(2):
+                    costs.append(sess.run([ms.fx, ms.update, ms.step], feed_dict={step_ph: 1 + i * T} if rn else {})[0])
+                xs = [v.eval() for v in graph.x]
+            assert ("_step_plan" in graph.__dict__) == (mode == "plan")
+            got[mode] = (costs, xs, caps)
+        for a, b in zip(got["plan"][0], got["steps"][0]):
+            assert rel_err(a, b) < 1e-6
+        for a, b in zip(got["plan"][1], got["steps"][1]):
+            assert max_abs(a, b) < 1e-6
+        key = "rp" if rn else "cw"
+        for ga, gb in zip(got["plan"][2], got["steps"][2]):
+            for k, gref in gb[key].items():
+                scale = max(float(np.abs(gref).max()), 1e-12)
+                assert float(np.abs(np.asarray(ga[key][k]) - np.asarray(gref)).max()) / scale < 1e-4, k
+    finally:
+        _engine.set_default_engine(old)
