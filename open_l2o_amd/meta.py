@@ -469,18 +469,27 @@ class UnrollGraph(object):
             s, d = slots[0], descs[0]
             B, D = panels[0].shape
             N = B * D
-            hist = {"st": eng.empty(T, states[0].packed.numel()), "g": eng.empty(T, N), "g_final": eng.empty(N)}
-            if self.rnnprop:
-                hist.update(m=eng.empty(T, N), v=eng.empty(T, N))
+            # the history buffers (and the per-step views of them, and the BPTT pointer table that
+            # _bptt_panels keeps in this dict) live as long as the unroll keeps its shape
+            key = (T, B, D, states[0].packed.numel(), bool(self.rnnprop))
+            fp = self.__dict__.get("_fused_plan")
+            if fp is None or fp["key"] != key:
+                hist = {"st": eng.empty(T, states[0].packed.numel()), "g": eng.empty(T, N), "g_final": eng.empty(N)}
+                if self.rnnprop:
+                    hist.update(m=eng.empty(T, N), v=eng.empty(T, N))
+                fp = self.__dict__["_fused_plan"] = dict(
+                    key=key, hist=hist,
+                    g=[[hist["g"][t].view(B, D)] for t in range(T)], st=[[hist["st"][t]] for t in range(T)],
+                    m=[[hist["m"][t].view(B, D) if self.rnnprop else None] for t in range(T)],
+                    v=[[hist["v"][t].view(B, D) if self.rnnprop else None] for t in range(T)],
+                    g_final=[hist["g_final"].view(B, D)])
+            hist = fp["hist"]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
             eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
                        fx_part, hist=hist)
             eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
-            record.update(step0=step0, shapes=[tuple(pn.shape) for pn in panels],
-                          g=[[hist["g"][t].view(B, D)] for t in range(T)], st=[[hist["st"][t]] for t in range(T)],
-                          m=[[hist["m"][t].view(B, D) if self.rnnprop else None] for t in range(T)],
-                          v=[[hist["v"][t].view(B, D) if self.rnnprop else None] for t in range(T)],
-                          g_final=[hist["g_final"].view(B, D)])
+            record.update(step0=step0, shapes=[tuple(pn.shape) for pn in panels], g=fp["g"], st=fp["st"],
+                          m=fp["m"], v=fp["v"], g_final=fp["g_final"], plan=fp)
         elif record is not None:                           # meta-gradient: needs the per-step history
             self.last_path = "steps"
             self._draw_minibatches(T)
@@ -566,10 +575,10 @@ class UnrollGraph(object):
         fx, xs = self.launch(feed, commit, record=record)
         eng = self.engine
         T = self.len_unroll
+        grads = self._backward(T, record)                   # (launched before the host reads anything back)
         self.wait_fx()
         fx_host = eng.to_numpy(fx)
         x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
-        grads = self._backward(T, record)
         self._adam_apply(grads, learning_rate)
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
                 "x": x_out, "fx_array": fx_host}
