@@ -22,3 +22,9 @@ python bench.py --steps 5 --warmup 3 --problem mnist --net rnnprop --unroll 100 
 python scripts/microbench/train_step_timing.py 2>/dev/null | tail -1 | tee $O/train_step.txt
 python scripts/microbench/train_step_timing.py 128 128 100 2>/dev/null | tail -1 | tee -a $O/train_step.txt
 python scripts/microbench/train_step_timing_mnist.py 2>/dev/null | tail -1 | tee -a $O/train_step.txt
+# kernel traces of the training step (forward with history + BPTT + A^T Bm) and of the MLP-optimizee unroll
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/prof_train_c2 -o t -- python $R/scripts/microbench/train_step_timing.py 128 128 100 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_train_mnist -o t -- python $R/scripts/microbench/train_step_timing_mnist.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_mnist -o t -- python $R/bench.py --steps 5 --warmup 3 --problem mnist --net rnnprop --unroll 100 --no-cpu-baseline > /dev/null 2>&1
+cd $R
