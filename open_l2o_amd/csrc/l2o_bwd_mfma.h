@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
   constexpr bool FC = PRE == L2O_PRE_FC_ELU;
   constexpr int NT1 = bxb::tiles1(PRE);
 #ifdef L2O_BWD_CLOCK
-  long long ck[12]; int cki = 0;
-#define MCK() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); ck[cki++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  long long ck[24]; int cki = 0;
+#define MCK() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); if (cki < 24) ck[cki++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define MCK() ((void)0)
 #endif
@@ -204,25 +204,40 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     }
     // steps T-1 .. 0 of this tile (l2o_cwlstm_bwd_unroll); one step with the panel table's own pointers otherwise
     double pw1 = p.pw1_last, pw2 = p.pw2_last;              // beta^(step of t) for t = T - 1
-    float dxacc = (p.table && p.seg_gfinal[sg]) ? p.seg_gfinal[sg][n] : 0.0f;   // dL/d(delta_t) = g_final + sum_{tau > t} g_tau
+    const bool acc_dx = p.table && p.seg_gfinal[sg];        // else the table (or the panel) carries dx_next
+    float dxacc = acc_dx ? p.seg_gfinal[sg][n] : 0.0f;   // dL/d(delta_t) = g_final + sum_{tau > t} g_tau
+    // The history of step ts - 1 is requested while step ts computes (a single wave per SIMD has nothing
+    // else to hide the HBM latency of its 5 KB state tile behind).
+    struct Hist { TileState s; float g, m, v, dx; };
+    auto fetch = [&](int ts, Hist& h) {
+      const float *g_t = p.seg_g[sg], *m_t = p.seg_m[sg], *v_t = p.seg_v[sg], *st_t = p.seg_st[sg], *dx_t = p.seg_dx[sg];
+      if (p.table) {
+        const float* const* row = p.table + ((size_t)ts * p.nseg + sg) * 5;
+        g_t = row[0]; m_t = row[1]; v_t = row[2]; st_t = row[3]; dx_t = row[4];
+      }
+      load_tile_state(h.s, st_t + lt * kStateFloatsPerTile, lane);
+      h.g = g_t[n];
+      h.m = FC ? m_t[n] : 0.0f;
+      h.v = FC ? v_t[n] : 0.0f;
+      h.dx = dx_t ? dx_t[n] : 0.0f;
+    };
+    Hist cur, nxt;
+    fetch(T - 1, cur);
     for (int ts = T - 1; ts >= 0; --ts) {
-    const float *g_t = p.seg_g[sg], *m_t = p.seg_m[sg], *v_t = p.seg_v[sg], *st_t = p.seg_st[sg], *dx_t = p.seg_dx[sg];
+    if (ts > 0) fetch(ts - 1, nxt);
     float om1 = p.om1, om2 = p.om2;
     if (p.table) {
-      const float* const* row = p.table + ((size_t)ts * p.nseg + sg) * 5;
-      g_t = row[0]; m_t = row[1]; v_t = row[2]; st_t = row[3]; dx_t = row[4];
       om1 = (float)(1.0 - pw1); om2 = (float)(1.0 - pw2);
       pw1 /= (double)p.beta1; pw2 /= (double)p.beta2;
     }
     float* const a_t = p.act1 + ((size_t)ts * RT + n0) * KA;
     float* const b_t = p.dz1 + ((size_t)ts * RT + n0) * KB;
-    TileState s;                                            // h1, c1, h2, c2 BEFORE the step
-    load_tile_state(s, st_t + lt * kStateFloatsPerTile, lane);
-    const float gv = g_t[n];
+    const TileState s = cur.s;                              // h1, c1, h2, c2 BEFORE the step
+    const float gv = cur.g;
     float in0 = gv, in1 = 0.0f, f0 = 0.0f, f1 = 0.0f;
     float pre_fc[kNT], fcv[kNT];
     if (FC) {
-      const float m_hat = m_t[n] / om1, v_hat = v_t[n] / om2;
+      const float m_hat = cur.m / om1, v_hat = cur.v / om2;
       const float den = sqrtf(v_hat) + 1e-8f;
       f0 = m_hat / den;
       f1 = gv / den;
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
       in0 = fmaxf(logf(fabsf(gv) + 1.1920928955078125e-07f) * p.k_inv, -1.0f);
       in1 = fminf(fmaxf(gv * p.exp_k, -1.0f), 1.0f);
     }
-    const float dxn = dx_t ? dx_t[n] : dxacc;
+    const float dxn = acc_dx ? dxacc : cur.dx;
     dxacc += gv;
     MCK();                                                  // 3: loads
     // ---- forward recompute --------------------------------------------------------------------------
@@ -357,6 +372,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
       for (int e = (nb & ~3) + lane; e < nb; e += 64) b_t[e] = stg[e];
     }
     MCK();                                                  // 8: Bm block out
+    cur = nxt;
     }                                                       // steps
     // ---- the carries into the step before the first one ----------------------------------------------------
     if (p.carry_out) {
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
 #ifdef L2O_BWD_CLOCK
   if (tid == 0 && blockIdx.x == 100) {
     printf("bwd_mfma block %d ticks:", (int)blockIdx.x);
-    for (int k = 1; k < cki && k < 12; ++k) printf(" %lld", ck[k] - ck[k - 1]);
+    for (int k = 1; k < cki && k < 24; ++k) printf(" %lld", ck[k] - ck[k - 1]);
     printf("\n");
   }
 #endif
