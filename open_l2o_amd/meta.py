@@ -402,12 +402,23 @@ class UnrollGraph(object):
         T = self.len_unroll
         feed = feed or {}
         # placeholders
+        # (persistent device buffers, re-uploaded only when a NEW array is fed: util.run_epoch feeds the same
+        #  random scaling to every unroll of an epoch, DM/util.py:40-54; stable addresses keep plans valid)
         scales = []
+        sbufs = self.__dict__.setdefault("_scale_bufs", {})
         for ph, var in zip(self.scale, self.x):
             if ph in feed:
-                arr = var._local(feed[ph])
-                B, D = self._panel_shape(var)
-                scales.append(eng.tensor(arr.reshape(B, D)))
+                src = feed[ph]
+                ent = sbufs.get(var.decl.name)
+                if ent is None or ent[0] is not src:
+                    arr = var._local(src)
+                    B, D = self._panel_shape(var)
+                    new = eng.tensor(arr.reshape(B, D))
+                    if ent is not None and ent[1].shape == new.shape:
+                        ent[1].copy_(new)
+                        new = ent[1]
+                    ent = sbufs[var.decl.name] = (src, new)
+                scales.append(ent[1])
             else:
                 scales.append(None)
         step0 = 1
@@ -431,15 +442,16 @@ class UnrollGraph(object):
         descs = []
         for v, sc in zip(self.x, scales):
             if self.term_of[v.decl.name].kind == _abi.PROB_MLP:
-                if sc is not None:
-                    raise NotImplementedError("x-scale placeholders are not implemented for problems.mnist")
-                descs.append(None)
+                descs.append(None)                          # (its x-scale is applied around l2o_mlp_fg, see _run_steps)
             else:
                 descs.append(self._desc(v, sc))
         panels = []
         for xv, var in zip(xs, self.x):
             B, D = self._panel_shape(var)
             panels.append(xv.view(B, D))
+        # the MLP optimizee is evaluated at x * scale and its gradient is scale * grad (DM/meta_dm_train.py:384)
+        self._mlp_scales = [sc if self.term_of[v.decl.name].kind == _abi.PROB_MLP else None
+                            for v, sc in zip(self.x, scales)]
 
         # fx[0..T] of this launch.  Sharded runs all-reduce it ASYNCHRONOUSLY (the next unroll
         # does not wait for the 404-byte collective); the buffers rotate so that a collective in
@@ -835,8 +847,16 @@ class UnrollGraph(object):
                 out = fx[t:t + 1] if single else tmp
                 if term.kind == _abi.PROB_MLP:
                     js = [index_of[tv.name] for tv in _term_vars(term)]
-                    eng.mlp_fg(self._mlp_desc(term), mlp_idx[k][t], *[panels[j] for j in js], out,
+                    sc = getattr(self, "_mlp_scales", None) or [None] * nvar
+                    xin = [panels[j] if sc[j] is None else
+                           torch.mul(panels[j], sc[j], out=self._scratch("xs%d" % j, panels[j].numel()).view(panels[j].shape))
+                           for j in js]
+                    eng.mlp_fg(self._mlp_desc(term), mlp_idx[k][t], *xin, out,
                                [grads[j] for j in js] if want_grad else None)
+                    if want_grad:
+                        for j in js:
+                            if sc[j] is not None:
+                                grads[j].mul_(sc[j])
                 else:
                     js = [index_of[term.var.name]]
                     j = js[0]
@@ -945,8 +965,11 @@ class UnrollGraph(object):
         term = self.terms[0]
         nvar = len(self.x)
         idxbuf = self._mlp_idx[0]
+        sc = getattr(self, "_mlp_scales", None) or [None] * nvar
+        scaled = any(x is not None for x in sc)
         key = (T, idxbuf.data_ptr(), tuple(p.data_ptr() for p in panels),
-               tuple(st.packed.data_ptr() for st in states), tuple(0 if m is None else m.data_ptr() for m in ms))
+               tuple(st.packed.data_ptr() for st in states), tuple(0 if m is None else m.data_ptr() for m in ms),
+               tuple(0 if x is None else x.data_ptr() for x in sc))
         plan = self.__dict__.get("_step_plan")
         if plan is None or plan["key"] != key:
             js = [index_of[tv.name] for tv in _term_vars(term)]
@@ -959,7 +982,14 @@ class UnrollGraph(object):
                     hm, hv = eng.empty(T + 1, ms[si].numel()), eng.empty(T + 1, vs[si].numel())
                 chain.append((hs, hm, hv))
             desc = self._mlp_desc(term)
-            mlp = [eng.prepared_mlp_fg(desc, idxbuf[t], *[panels[j] for j in js], [hist_g[j][t] for j in js])
+            # x-scale (random rescaling of the optimizee, DM/util.py:40-54): evaluate at xs = x * scale (three
+            # multi-tensor launches per step: copy, multiply, and scale the gradients afterwards)
+            ones = None
+            xs_in = [panels[j] for j in js]
+            if scaled:
+                ones = [x if x is not None else torch.ones_like(panels[j]) for j, x in enumerate(sc)]
+                xs_in = [eng.empty(*panels[j].shape) for j in js]
+            mlp = [eng.prepared_mlp_fg(desc, idxbuf[t], *xs_in, [hist_g[j][t] for j in js])
                    for t in range(T + 1)]
             lstm = []
             for t in range(T):
@@ -974,7 +1004,9 @@ class UnrollGraph(object):
                     groups.setdefault(id(s.net), (s.net, []))[1].append(seg)
                 lstm.append([(net, eng.prepared_lstm_step_multi(net.spec, segs)) for net, segs in groups.values()])
             plan = self.__dict__["_step_plan"] = dict(
-                key=key, chain=chain, mlp=mlp, lstm=lstm,
+                key=key, chain=chain, mlp=mlp, lstm=lstm, xs_in=xs_in if scaled else None,
+                x_src=[panels[j] for j in js], sc=[ones[j] for j in js] if scaled else None,
+                g_steps=[[hist_g[j][t] for j in js] for t in range(T + 1)],
                 g=[[hist_g[j][t] for j in range(nvar)] for t in range(T)],
                 st=[[chain[si][0][t] for si in range(len(slots))] for t in range(T)],
                 m=[[None if chain[si][1] is None else chain[si][1][t + 1] for si in range(len(slots))] for t in range(T)],
@@ -993,13 +1025,20 @@ class UnrollGraph(object):
         b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
         fxp = fx.data_ptr()
         mlp, lstm = plan["mlp"], plan["lstm"]
-        for t in range(T):
+        xs_in, x_src, scl, g_steps = plan["xs_in"], plan["x_src"], plan["sc"], plan["g_steps"]
+        for t in range(T + 1):                             # (training also needs the gradient at x_T)
+            if xs_in is not None:
+                torch._foreach_copy_(xs_in, x_src)
+                torch._foreach_mul_(xs_in, scl)
             mlp[t](fxp + 4 * t)
+            if xs_in is not None:
+                torch._foreach_mul_(g_steps[t], scl)
+            if t == T:
+                break
             k = step0 + t
             p1, p2 = b1 ** k, b2 ** k
             for net, call in lstm[t]:
                 call(wp[id(net)][1], p1, p2)
-        mlp[T](fxp + 4 * T)                                # training also needs the gradient at x_T
         record.update(g=plan["g"], st=plan["st"], m=plan["m"], v=plan["v"], g_final=plan["g_final"], plan=plan)
         for si, (hs, hm, hv) in enumerate(chain):          # the variables take the end of the chain
             states[si].packed.copy_(hs[T])

@@ -425,3 +425,58 @@ def test_lasso_fixed_shared_matrix(engine):
             sess.run(ml.reset)
             fxs.append(sess.run([ml.loss, ml.update], feed_dict={step: 1})[0])
     assert rel_err(fxs[0], fxs[1]) < 1e-6
+
+
+def test_mnist_mlp_optimizee_with_x_scale(engine):
+    """The random rescaling of the train forks (DM/util.py:40-54 feeds exp(U(-b, b)) per coordinate and
+    divides the variables by it; DM/meta_dm_train.py:384 evaluates the optimizee at x * scale) on the MLP
+    optimizee: f and its gradient w.r.t. x (= scale * grad f(x * scale)) against the oracle's
+    multi-variable unroll wrapped the same way, for the plain unroll and for the training step."""
+    data = problems.synthetic_mnist(200, seed=5)
+    T, batch = 4, 16
+    rng = np.random.default_rng(75)
+    idx = rng.integers(0, 200, size=(3 * (T + 1), batch))
+    calls = {"n": 0}
+
+    def sampler(n_evals, b, n_data):
+        out = idx[calls["n"]:calls["n"] + n_evals]
+        calls["n"] += n_evals
+        return out
+
+    cfg = O.DM_LOGSIGN
+    params = make_params(cfg, seed=76, trained_like=True)
+    meta.set_random_seed(10)
+    problem = problems.mnist(layers=(20,), batch_size=batch, data=data, sampler=sampler)
+    optimizer = meta_dm_train.MetaOptimizer(0, **_net_config(cfg, params))
+    out = optimizer.meta_minimize(problem, T, learning_rate=1e-3)
+    ml, scale = out[0], out[1]
+    shapes = [(784, 20), (20,), (20, 10), (10,)]
+    assert len(scale) == 4
+    scl = [np.exp(rng.uniform(-1, 1, s)).astype(np.float32) for s in shapes]
+    feed = {p: v for p, v in zip(scale, scl)}
+    with Session() as sess:
+        sess.run(ml.reset)
+        v0 = [v.eval() for v in optimizer.graph.x]
+        fx1, x1, _ = sess.run([ml.fx, ml.x, ml.update], feed_dict=feed)             # plain unroll
+        fx2, _, _ = sess.run([ml.fx, ml.update, ml.step], feed_dict=feed)           # training step (recorded unroll)
+        x2 = [v.eval() for v in optimizer.graph.x]
+    ref = O.MnistMLP(data["images"], data["labels"].astype(np.int32), "sigmoid")
+
+    def fg_scaled(off):
+        def fg(vs, t, wg):
+            res = ref.fg([v * s for v, s in zip(vs, scl)], idx[off + t], wg)
+            if not wg:
+                return res
+            f, grads = res
+            return f, [g * s for g, s in zip(grads, scl)]
+        return fg
+
+    states = [O.net_initial_state(cfg, a.size) for a in v0]
+    fx_a, va, sa = O.unroll_multi(fg_scaled(0), cfg, params, v0, states, T)
+    fx_b, vb, _ = O.unroll_multi(fg_scaled(T + 1), cfg, params, va, sa, T)
+    assert rel_err(fx1, fx_a[-1]) < 1e-5
+    assert rel_err(fx2, fx_b[-1]) < 2e-5
+    for got, want in zip(x1, va):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+    for got, want in zip(x2, vb):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
