@@ -386,9 +386,36 @@ class UnrollGraph(object):
         fx_host = eng.to_numpy(fx)                       # host sync
         if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
             eng.check_unroll_status()
-        x_out = [eng.to_numpy(xv).reshape(self._local_shape(var)) for xv, var in zip(xs, self.x)]
+        x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
                 "x": x_out, "fx_array": fx_host}
+
+    def deterministic(self):
+        """True when an unroll draws nothing at random (no minibatch sampling): then n committed unrolls
+        of L steps are exactly one unroll of n * L steps."""
+        return all(t.kind != _abi.PROB_MLP for t in self.terms)
+
+    def execute_many(self, n):
+        """n consecutive committed unrolls (what util.run_eval_epoch asks for with n sess.run calls,
+        DM/util.py:78-89: the evaluation drivers use len_unroll = 1) as ONE unroll of n * len_unroll
+        steps -- one launch of the fused kernel where it applies, no per-step host round trip.
+        x_{t+1} = x_t + delta_t and the LSTM state carry across the reference's unroll boundaries
+        unchanged (MetaLoss.update, DM/meta.py:379-383), and RNNProp's fed `step` = i * L + 1 is the
+        running step count (DM/util.py:84-87), so the k-th unroll's fx is entry (k + 1) * L of the long
+        unroll's loss array.  Returns those n values (host)."""
+        assert self.deterministic() and n >= 1
+        L = self.len_unroll
+        self.len_unroll = n * L
+        try:
+            fx, _ = self.launch({self.step: 1} if self.rnnprop else {}, commit=True)
+        finally:
+            self.len_unroll = L
+        eng = self.engine
+        self.wait_fx()
+        fx_host = eng.to_numpy(fx)
+        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
+            eng.check_unroll_status()
+        return [np.float32(fx_host[(k + 1) * L]) for k in range(n)]
 
     def launch(self, feed=None, commit=True, events=None, use_graph=False, record=None):
         """Enqueue one unroll on the current stream WITHOUT synchronising the host; returns

@@ -480,3 +480,43 @@ def test_mnist_mlp_optimizee_with_x_scale(engine):
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
     for got, want in zip(x2, vb):
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["dm", "rnnprop"])
+def test_eval_epoch_as_one_unroll_equals_the_stepwise_loop(engine, name, monkeypatch):
+    """util.run_eval_epoch (DM/util.py:78-89; evaluate_dm.py / evaluate_rnnprop.py call it with
+    len_unroll = 1 and num_steps round trips) runs a deterministic optimizee's epoch as ONE unroll:
+    same per-unroll losses and same final variables as the sess.run-per-unroll loop
+    (L2O_EVAL_STEPWISE=1)."""
+    cfg = ORACLE_CFGS[name]
+    rn = cfg.kind == "rnnprop"
+    params = make_params(cfg, seed=41, trained_like=True)
+    B, D, n = 4, 16, 12
+    prob, x0, _ = make_problem("quadratic", B, D, seed=42)
+    got = {}
+    for mode in ("one", "stepwise"):
+        if mode == "stepwise":
+            monkeypatch.setenv("L2O_EVAL_STEPWISE", "1")
+        else:
+            monkeypatch.delenv("L2O_EVAL_STEPWISE", raising=False)
+        for L in (1, 3):
+            problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+            if rn:
+                opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+                ml, _, _, step = opt.meta_loss(problem, L)
+            else:
+                opt = meta.MetaOptimizer(**_net_config(cfg, params))
+                ml, step = opt.meta_loss(problem, L), None
+            with Session() as sess:
+                sess.run(ml.reset)
+                calls = len(getattr(opt.graph.engine, "calls", []))
+                _, cost = util.run_eval_epoch(sess, ml.fx, [ml.update], n, step=step, unroll_len=L)
+                xT = opt.graph.x[0].eval()
+                if hasattr(opt.graph.engine, "calls"):     # (the oracle engine logs its entry points)
+                    new = opt.graph.engine.calls[calls:]
+                    assert (new.count("unroll") == 1) == (mode == "one"), new
+            assert len(cost) == n
+            got[mode, L] = (np.asarray(cost, np.float64), xT)
+    for L in (1, 3):
+        np.testing.assert_allclose(got["one", L][0], got["stepwise", L][0], rtol=2e-5)
+        np.testing.assert_allclose(got["one", L][1], got["stepwise", L][1], rtol=1e-4, atol=1e-6)
