@@ -176,13 +176,14 @@ class HipEngine(object):
         n = int(self.lib.l2o_mlp_scratch_floats(C.byref(c)))
         if self._mlp_scratch is None or self._mlp_scratch.numel() < n:
             self._mlp_scratch = self.empty(n)
-        head = (C.byref(c), C.c_void_p(indices.data_ptr()), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2))
+        cref, idx0 = C.byref(c), C.c_void_p(indices.data_ptr())
+        mid = (_ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2))
         tail = tuple(g) + (_ptr(self._mlp_scratch), self._stream())
         fn, check = self.lib.l2o_mlp_fg, _abi.check
         keep = (c, d, indices, w1, b1, w2, b2, grads, self._mlp_scratch)
 
-        def call(loss_ptr, _keep=keep):
-            rc = fn(*head, loss_ptr, *tail)
+        def call(loss_ptr, idx_ptr=None, _keep=keep):        # idx_ptr: another minibatch (device int32 [batch])
+            rc = fn(cref, idx0 if idx_ptr is None else idx_ptr, *mid, loss_ptr, *tail)
             if rc:
                 check(rc)
         return call

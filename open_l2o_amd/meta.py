@@ -403,7 +403,9 @@ class UnrollGraph(object):
         unchanged (MetaLoss.update, DM/meta.py:379-383), and RNNProp's fed `step` = i * L + 1 is the
         running step count (DM/util.py:84-87), so the k-th unroll's fx is entry (k + 1) * L of the long
         unroll's loss array.  Returns those n values (host)."""
-        assert self.deterministic() and n >= 1
+        assert n >= 1
+        if not self.deterministic():
+            return self._execute_many_sampled(n)
         L = self.len_unroll
         self.len_unroll = n * L
         try:
@@ -416,6 +418,81 @@ class UnrollGraph(object):
         if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
             eng.check_unroll_status()
         return [np.float32(fx_host[(k + 1) * L]) for k in range(n)]
+
+    def many_ok(self):
+        """execute_many applies: deterministic optimizee, or ONE MLP term stepped by LSTM nets on an engine
+        with prepared calls (the sampled form below)."""
+        if self.deterministic():
+            return True
+        self._ensure_init()
+        eng = self.engine
+        if not hasattr(eng, "prepared_mlp_fg") or os.environ.get("L2O_NO_STEP_PLAN") or self.sharded:
+            return False
+        states = [s.state for s in self.slots]
+        return self._plan_ok(self.slots, states, len(self.x))
+
+    def _execute_many_sampled(self, n):
+        """n committed unrolls of the minibatch-sampled MLP optimizee (evaluate_*.py --problem mnist) without a
+        host round trip per unroll.  Exactly the loop's computation and the loop's random draws: unroll k
+        draws L + 1 minibatches (DM/problems.py:282-286: one per evaluation of the loss), steps on the
+        first L and REPORTS the loss of the last one at x_L; the next unroll evaluates x_L again on a new
+        draw.  All n (L + 1) index rows are drawn up front in the same order, uploaded once, and the
+        3-launch steps go out through prepared calls; one device-to-host copy at the end."""
+        self._ensure_init()
+        eng = self.engine
+        L = self.len_unroll
+        term = self.terms[0]
+        d = self._mlp_desc(term)
+        sampler = term.hyper.get("sampler")
+        rows = []
+        for _ in range(n):                                   # the same draws, in the same order, as n x _draw_minibatches(L)
+            if sampler is None:
+                rows.append(_rng.integers(0, d.images.shape[0], size=(L + 1, d.batch)))
+            else:
+                rows.append(np.asarray(sampler(L + 1, d.batch, d.images.shape[0])).reshape(L + 1, d.batch))
+        idx = eng.int_tensor(np.stack(rows))                 # [n, L + 1, batch]
+        index_of = {v.decl.name: j for j, v in enumerate(self.x)}
+        js = [index_of[tv.name] for tv in _term_vars(term)]
+        panels = []
+        for v in self.x:
+            B, D = self._panel_shape(v)
+            panels.append(v.value.view(B, D))
+        slots = self.slots
+        key = (tuple(p.data_ptr() for p in panels), tuple(s.state.packed.data_ptr() for s in slots),
+               tuple(0 if s.m is None else s.m.data_ptr() for s in slots))
+        plan = self.__dict__.get("_eval_plan")
+        if plan is None or plan["key"] != key:
+            grads = [eng.empty(*panels[j].shape) for j in range(len(self.x))]
+            groups = {}
+            for s in slots:
+                j = s.var_index
+                B, D = panels[j].shape
+                groups.setdefault(id(s.net), (s.net, []))[1].append((grads[j], s.m, s.v, s.state.packed, panels[j], B, D))
+            plan = self.__dict__["_eval_plan"] = dict(
+                key=key, grads=grads,
+                fg=eng.prepared_mlp_fg(d, idx[0, 0], *[panels[j] for j in js], [grads[j] for j in js]),
+                f=eng.prepared_mlp_fg(d, idx[0, 0], *[panels[j] for j in js], None),
+                lstm=[(net, eng.prepared_lstm_step_multi(net.spec, segs)) for net, segs in groups.values()])
+        import ctypes
+        wp = {id(net): (net.wpack(eng), ctypes.c_void_p(net.wpack(eng).data_ptr())) for net, _ in plan["lstm"]}
+        b1, b2 = float(np.float32(self.beta1)), float(np.float32(self.beta2))
+        fxbuf = eng.empty(n * (L + 1))
+        fxp, ip, row_bytes = fxbuf.data_ptr(), idx.data_ptr(), 4 * d.batch
+        fg, f, lstm = plan["fg"], plan["f"], plan["lstm"]
+        e = 0                                                 # evaluation counter = row of idx = slot of fxbuf
+        for k in range(n):
+            for t in range(L):
+                fg(fxp + 4 * e, ip + row_bytes * e)
+                step = k * L + t + 1                          # evaluate_rnnprop feeds step = k * L + 1 (DM/util.py:84-87)
+                p1, p2 = b1 ** step, b2 ** step
+                for net, call in lstm:
+                    call(wp[id(net)][1], p1, p2)
+                e += 1
+            f(fxp + 4 * e, ip + row_bytes * e)
+            e += 1
+        self.last_path = "steps"
+        out = eng.to_numpy(fxbuf).reshape(n, L + 1)
+        return [np.float32(out[k, L]) for k in range(n)]
 
     def launch(self, feed=None, commit=True, events=None, use_graph=False, record=None):
         """Enqueue one unroll on the current stream WITHOUT synchronising the host; returns

@@ -78,7 +78,7 @@ def run_eval_epoch(sess, cost_op, ops, num_unrolls, step=None, unroll_len=None):
     _flat(ops)                                              # (MetaLoss.update is a list of ops, like the reference's)
     if (num_unrolls > 1 and not os.environ.get("L2O_EVAL_STEPWISE") and getattr(cost_op, "key", None) == "fx"
             and len(flat) == 1 and getattr(flat[0], "key", None) == "update" and getattr(flat[0], "graph", None) is graph
-            and hasattr(graph, "execute_many") and graph.deterministic()
+            and hasattr(graph, "execute_many") and graph.many_ok()
             and (step is None or unroll_len == graph.len_unroll)):
         total_cost = graph.execute_many(num_unrolls)
         return timer() - start, total_cost

@@ -520,3 +520,50 @@ def test_eval_epoch_as_one_unroll_equals_the_stepwise_loop(engine, name, monkeyp
     for L in (1, 3):
         np.testing.assert_allclose(got["one", L][0], got["stepwise", L][0], rtol=2e-5)
         np.testing.assert_allclose(got["one", L][1], got["stepwise", L][1], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["dm_logsign", "rnnprop"])
+def test_eval_epoch_of_the_sampled_mlp_optimizee(engine, name, monkeypatch):
+    """evaluate_*.py --problem mnist: util.run_eval_epoch on the minibatch-sampled MLP optimizee sends the
+    epoch's launches without a host round trip per unroll (prepared calls, all index rows drawn up front in
+    the loop's order) -- same per-unroll losses and final variables as the sess.run-per-unroll loop."""
+    cfg = ORACLE_CFGS[name]
+    rn = cfg.kind == "rnnprop"
+    params = make_params(cfg, seed=43, trained_like=True)
+    data = problems.synthetic_mnist(150, seed=6)
+    batch, n = 16, 7
+    idx = np.random.default_rng(44).integers(0, 150, size=(64, batch))
+    got = {}
+    for mode in ("one", "stepwise"):
+        if mode == "stepwise":
+            monkeypatch.setenv("L2O_EVAL_STEPWISE", "1")
+        else:
+            monkeypatch.delenv("L2O_EVAL_STEPWISE", raising=False)
+        for L in (1, 2):
+            st = {"k": 0}
+
+            def sampler(n_evals, b, n_data, _s=st):
+                out = idx[_s["k"]:_s["k"] + n_evals, :b]
+                _s["k"] += n_evals
+                return out
+
+            problem = problems.mnist(layers=(20,), batch_size=batch, data=data, sampler=sampler)
+            meta.set_random_seed(12)
+            if rn:
+                opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+                ml, _, _, step = opt.meta_loss(problem, L)
+            else:
+                opt = meta.MetaOptimizer(**_net_config(cfg, params))
+                ml, step = opt.meta_loss(problem, L), None
+            with Session() as sess:
+                sess.run(ml.reset)
+                _, cost = util.run_eval_epoch(sess, ml.fx, [ml.update], n, step=step, unroll_len=L)
+                xT = [v.eval() for v in opt.graph.x]
+            assert len(cost) == n and st["k"] == n * (L + 1)
+            if isinstance(opt.graph.engine, _engine.HipEngine):
+                assert ("_eval_plan" in opt.graph.__dict__) == (mode == "one")
+            got[mode, L] = (np.asarray(cost, np.float64), xT)
+    for L in (1, 2):
+        np.testing.assert_allclose(got["one", L][0], got["stepwise", L][0], rtol=1e-5)
+        for a, b in zip(got["one", L][1], got["stepwise", L][1]):
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
