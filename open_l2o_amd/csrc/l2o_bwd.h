@@ -40,7 +40,7 @@ struct BwdParams {
 // weights are read through the CONSTANT address space: the addresses are wave-uniform, so the
 // loads become s_load_dwordx16 and the FMAs take the weight as an SGPR operand (v_fmac v, s, v)
 // -- no LDS, no per-lane weight traffic.  (They are never written while the kernel runs.)
-// (l2o_cfp, the constant-address-space float pointer, is declared in l2o_mlp.h)
+// (l2o_cfp, the constant-address-space float pointer, is declared in l2o_common.h)
 
 __device__ __forceinline__ float bw_sig(float x) { return l2o::fast_rcp(1.0f + l2o::fast_exp2(x * -1.4426950408889634f)); }
 __device__ __forceinline__ float bw_tanh(float x) {

@@ -28,6 +28,9 @@
 
 #include "../../include/l2o_abi.h"
 
+// wave-uniform reads through the scalar unit: a float pointer in the constant address space
+typedef const __attribute__((address_space(4))) float* l2o_cfp;
+
 namespace l2o {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -472,6 +472,139 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
 }
 
 // ---------------------------------------------------------------------------
+// K2b: the same forward + gradient with the matrix read ONCE.  A wave keeps the rows it visits in
+// registers between their two uses: lane l holds the row's columns 4 (64 v + l) .. + 3 (v < NV: coalesced
+// 1 KB pieces), r_i = dot(row, xs) - y_i is a wave sum that every lane receives, and the same registers
+// then feed g += r_i * row.  Eight waves walk the rows in groups of four (4 NV dwordx4 loads in flight per
+// lane); their partial gradients are added in a fixed order through LDS.  Halves the HBM traffic of the
+// step-granular path's matrix-bound optimizees (config 3: 256 x 512 per problem, 128 MiB per batch).
+// D % 4 == 0, D <= 256 NV.
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(kFgThreads) void k_problem_fg1(ProbParams pp, const float* __restrict__ x,
+                                                             float* __restrict__ f_part,
+                                                             float* __restrict__ gout) {
+  extern __shared__ float sm[];
+  const int D = pp.D, M = pp.M;
+  float* part = sm;                     // [kFgWaves][D] partial gradients
+  float* red = part + kFgWaves * D;     // [kFgWaves]
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* xb = x + (size_t)b * D;
+  const float* sb = pp.x_scale ? pp.x_scale + (size_t)b * D : nullptr;
+  const float* Wb = pp.W + (pp.w_shared ? (size_t)0 : (size_t)b * M * D);
+  const l2o_cfp yb = (l2o_cfp)(pp.y + (size_t)b * M);
+  const bool want_g = gout != nullptr;
+  const float coef = (pp.kind == L2O_PROB_QUADRATIC || pp.kind == L2O_PROB_SQUARE_COS) ? 1.0f : 0.5f;
+
+  float4 xv[NV], sv[NV], ga[NV];
+  float facc = 0.0f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int j = 4 * (64 * v + lane);
+    const float4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+    xv[v] = zero; sv[v] = one; ga[v] = zero;
+    if (j < D) {
+      xv[v] = *reinterpret_cast<const float4*>(xb + j);
+      if (sb) sv[v] = *reinterpret_cast<const float4*>(sb + j);
+      xv[v].x *= sv[v].x; xv[v].y *= sv[v].y; xv[v].z *= sv[v].z; xv[v].w *= sv[v].w;
+      if (wv == 0) {                                        // the separable terms of f: once per problem
+        const float xe[4] = {xv[v].x, xv[v].y, xv[v].z, xv[v].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (pp.kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xe[e]);
+          if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
+            facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j + e] * cosf(pp.twopi * xe[e]);
+        }
+      }
+    }
+  }
+  // software pipeline: the next group of four rows is requested before the current one is reduced (one wave
+  // has 4 NV dwordx4 per lane in flight while it computes; without it every group pays a full memory latency)
+  auto load4 = [&](int i0, float4 (&w4)[4][NV]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k < M ? i0 + k : M - 1;             // clamped rows contribute r = 0 below
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int j = 4 * (64 * v + lane);
+        const float4 zero = {0.f, 0.f, 0.f, 0.f};
+        w4[k][v] = j < D ? *reinterpret_cast<const float4*>(Wb + (size_t)i * D + j) : zero;
+      }
+    }
+  };
+  auto use4 = [&](int i0, const float4 (&w4)[4][NV]) {
+    float acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        a = __builtin_fmaf(w4[k][v].x, xv[v].x, a);
+        a = __builtin_fmaf(w4[k][v].y, xv[v].y, a);
+        a = __builtin_fmaf(w4[k][v].z, xv[v].z, a);
+        a = __builtin_fmaf(w4[k][v].w, xv[v].w, a);
+      }
+      acc[k] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = i0 + k < M;
+      const float r = ok ? wave_sum64(acc[k]) - yb[ok ? i0 + k : 0] : 0.0f;
+      if (lane == 0) facc += coef * r * r;
+      if (want_g) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          ga[v].x = __builtin_fmaf(r, w4[k][v].x, ga[v].x);
+          ga[v].y = __builtin_fmaf(r, w4[k][v].y, ga[v].y);
+          ga[v].z = __builtin_fmaf(r, w4[k][v].z, ga[v].z);
+          ga[v].w = __builtin_fmaf(r, w4[k][v].w, ga[v].w);
+        }
+      }
+    }
+  };
+  {
+    constexpr int STEP = kFgWaves * 4;
+    float4 wa[4][NV], wb[4][NV];
+    int i0 = wv * 4;
+    if (i0 < M) load4(i0, wa);
+    for (; i0 < M; i0 += 2 * STEP) {
+      if (i0 + STEP < M) load4(i0 + STEP, wb);
+      use4(i0, wa);
+      if (i0 + STEP < M) {
+        if (i0 + 2 * STEP < M) load4(i0 + 2 * STEP, wa);
+        use4(i0 + STEP, wb);
+      }
+    }
+  }
+  if (want_g) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int j = 4 * (64 * v + lane);
+      if (j < D) *reinterpret_cast<float4*>(part + wv * D + j) = ga[v];
+    }
+  }
+  const float fb = block_sum_fg(facc, red);   // contains __syncthreads: the partial gradients are visible after it
+  if (tid == 0) f_part[b] = fb;
+  if (!want_g) return;
+  float* gb = gout + (size_t)b * D;
+  const float cg = (pp.kind == L2O_PROB_QUADRATIC || pp.kind == L2O_PROB_SQUARE_COS) ? 2.0f : 1.0f;
+  for (int j = tid; j < D; j += kFgThreads) {
+    float s = part[j];
+#pragma unroll
+    for (int w = 1; w < kFgWaves; ++w) s += part[w * D + j];
+    const float sc = sb ? sb[j] : 1.0f;
+    const float xj = xb[j] * sc;
+    float gj = cg * s;
+    if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xj > 0.f ? 1.f : (xj < 0.f ? -1.f : 0.f));
+    if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
+      gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xj);
+    gb[j] = gj * pp.inv_bg * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K3: the fused persistent unroll.  One workgroup per problem, one wave per
 // 16-coordinate tile (<= 8 waves), T steps in ONE launch.
 //   LDS  : the problem matrix TWICE -- W_b row-major and W_b^T row-major, row stride
@@ -1094,6 +1227,17 @@ int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float
   const size_t lds = sizeof(float) * ((size_t)((pp.D + 3) & ~3) + ((pp.M + 3) & ~3) + 4 * kFgThreads + kFgWaves);
   if (lds > 160 * 1024) return fail(L2O_ERR_UNSUPPORTED, "problem too large for k_problem_fg (D=%d M=%d)", pp.D, pp.M);
   const bool vec = pp.kind != L2O_PROB_SIMPLE && (pp.D & 3) == 0 && ((uintptr_t)pp.W & 15) == 0;
+  if (vec && pp.D >= 64 && pp.D <= 2048 && ((uintptr_t)x & 15) == 0 && (!pp.x_scale || ((uintptr_t)pp.x_scale & 15) == 0) &&
+      !pp.w_shared && !getenv("L2O_FG_TWO_PASS")) {         // single pass over the matrix (a shared, L2-resident
+                                                            // matrix is faster in two passes: 20 vs 28 us for config 3)
+    const size_t lds1 = sizeof(float) * ((size_t)kFgWaves * pp.D + kFgWaves);
+    void (*f1)(ProbParams, const float*, float*, float*) =
+        pp.D <= 256 ? k_problem_fg1<1> : pp.D <= 512 ? k_problem_fg1<2> : pp.D <= 1024 ? k_problem_fg1<4> : k_problem_fg1<8>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(f1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    hipLaunchKernelGGL(f1, dim3(pp.B_local), dim3(kFgThreads), lds1, (hipStream_t)stream, pp, x, f_part, g);
+    HIP_TRY(hipGetLastError());
+    return L2O_OK;
+  }
   void (*fn)(ProbParams, const float*, float*, float*) = vec ? k_problem_fg<true> : k_problem_fg<false>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));

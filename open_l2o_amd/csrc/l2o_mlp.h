@@ -348,7 +348,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpParams p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kMlp20 = 20;
 constexpr int kMlpBwdWaves = 16;
-typedef const __attribute__((address_space(4))) float* l2o_cfp;   // wave-uniform reads through the scalar unit
 __device__ __forceinline__ float mlp_rl(float v, int l) {         // value of lane l (wave-uniform l), in every lane
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }

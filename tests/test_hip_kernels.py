@@ -105,7 +105,10 @@ def test_linear_only_net(eng):
                                         ("quadratic", 2, 300, None), ("lasso", 4, 10, None),
                                         ("lasso", 3, 50, 25), ("lasso", 2, 512, 256),
                                         ("rastrigin", 4, 2, None), ("rastrigin", 3, 100, None),
-                                        ("square_cos", 4, 2, None), ("square_cos", 3, 40, None)])
+                                        ("square_cos", 4, 2, None), ("square_cos", 3, 40, None),
+                                        # the single-pass kernel k_problem_fg1<NV> (D % 4 == 0, 64 <= D <= 2048)
+                                        ("lasso", 2, 64, 37), ("rastrigin", 2, 256, None), ("square_cos", 2, 132, None),
+                                        ("lasso", 2, 1024, 70), ("quadratic", 1, 1100, None), ("lasso", 1, 2048, 33)])
 def test_problem_fg(eng, kind, B, D, M):
     prob, x0, arrays = make_problem(kind, B, D, seed=4, M=M, stddev=0.5)
     Bg = 2 * B                                         # exercise the global-batch factor
@@ -225,8 +228,14 @@ def test_shared_matrix_equals_replicated(eng, kind, B, D, M):
             res += list(_run_fused(eng, cfg, params, a, x0, B, D, 6)[:2])
         outs.append(res)
     assert len(outs[0]) == len(outs[1])
-    for r, s_ in zip(*outs):
-        assert np.array_equal(r, s_)
+    # l2o_problem_fg reads a per-problem matrix ONCE (k_problem_fg1, D % 4 == 0 and D >= 64) but an L2-resident
+    # shared one in two passes (faster there): same numbers up to the summation order; everything else bit for bit
+    one_pass = D % 4 == 0 and D >= 64
+    for k, (r, s_) in enumerate(zip(*outs)):
+        if one_pass and k < 2:
+            np.testing.assert_allclose(s_, r, rtol=2e-6, atol=2e-6 * float(np.abs(r).max()))
+        else:
+            assert np.array_equal(r, s_)
 
 
 def test_fused_unroll_random_shapes(eng):
