@@ -113,9 +113,28 @@ class HipEngine(object):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- weights -------------------------------------------------------------
-    def pack_weights(self, spec: NetSpec, params: dict):
-        """.l2l dict (Sonnet layouts) -> device wpack."""
-        return self.tensor(pack_weights_host(self.lib, spec, params))
+    def pack_weights(self, spec: NetSpec, params: dict, key=None):
+        """.l2l dict (Sonnet layouts) -> device wpack.  key: see upload()."""
+        host = pack_weights_host(self.lib, spec, params)
+        return self.tensor(host) if key is None else self.upload(key, host)
+
+    def upload(self, key, a):
+        """Host array -> a PERSISTENT device tensor per key, through a pinned staging buffer with an
+        asynchronous copy (the meta-training step re-uploads the packed weights after every Adam update:
+        a pageable torch.as_tensor(...).to(device) of ~160 KB costs ~50 us and synchronises)."""
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        ups = self.__dict__.setdefault("_uploads", {})
+        ent = ups.get(key)
+        if ent is None or ent[0].numel() != a.size:
+            ent = ups[key] = [self.empty(a.size), torch.empty(a.size, dtype=torch.float32).pin_memory(), None]
+        dev, pin, ev = ent
+        if ev is not None:
+            ev.synchronize()                                 # the previous copy out of this staging buffer is done
+        pin.numpy()[:] = a
+        dev.copy_(pin, non_blocking=True)
+        ent[2] = torch.cuda.Event()
+        ent[2].record(torch.cuda.current_stream(self.device))
+        return dev
 
     # -- state ---------------------------------------------------------------
     def state_floats(self, B, D):

@@ -856,17 +856,26 @@ class UnrollGraph(object):
         t = st["t"]
         f = np.float32
         lr_t = f(learning_rate * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
-        for key, acc in grads.items():
+        for key, acc in grads.items():                     # one flat vector per network: a handful of NumPy calls
             net = self.nets[key]
-            for (mod, var), g in acc.items():
-                g = np.asarray(g, np.float32).reshape(net.variables[mod][var].shape)
-                kk = (key, mod, var)
-                m = st["m"].get(kk, np.zeros_like(g))
-                v = st["v"].get(kk, np.zeros_like(g))
-                m = f(beta1) * m + f(1.0 - beta1) * g
-                v = f(beta2) * v + f(1.0 - beta2) * g * g
-                st["m"][kk], st["v"][kk] = m, v
-                net.assign(mod, var, net.variables[mod][var] - lr_t * m / (np.sqrt(v) + f(epsilon)))
+            names = list(acc.keys())
+            g = np.concatenate([np.asarray(acc[k], np.float32).reshape(-1) for k in names])
+            w = np.concatenate([net.variables[mod][var].reshape(-1) for mod, var in names])
+            kk = (key, tuple(names))
+            m = st["m"].get(kk)
+            if m is None:
+                m, v = np.zeros_like(g), np.zeros_like(g)
+            else:
+                v = st["v"][kk]
+            m = f(beta1) * m + f(1.0 - beta1) * g
+            v = f(beta2) * v + f(1.0 - beta2) * g * g
+            st["m"][kk], st["v"][kk] = m, v
+            w = w - lr_t * m / (np.sqrt(v) + f(epsilon))
+            off = 0
+            for mod, var in names:
+                n = net.variables[mod][var].size
+                net.assign(mod, var, w[off:off + n])
+                off += n
 
     def gradients(self, feed=None):
         """[d f(x * scale) / d x_j] at the current variables as device tensors (panel shaped),

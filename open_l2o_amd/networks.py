@@ -184,7 +184,10 @@ class StandardDeepLSTM(Network):
     def wpack(self, engine):
         """Device copy of the weights in MFMA-fragment order (cached until invalidated)."""
         if self._wpack is None or self._wpack_engine is not engine:
-            self._wpack = engine.pack_weights(self.spec, self.variables)
+            if hasattr(engine, "upload"):                 # persistent device buffer, pinned staging
+                self._wpack = engine.pack_weights(self.spec, self.variables, key=(id(self), "wpack"))
+            else:
+                self._wpack = engine.pack_weights(self.spec, self.variables)
             self._wpack_engine = engine
         return self._wpack
 
@@ -215,7 +218,8 @@ class StandardDeepLSTM(Network):
                     if pad:
                         parts.append(np.zeros(pad, np.float32))
                     off += a.size + pad
-            buf = engine.tensor(np.concatenate(parts))
+            flat = np.concatenate(parts)
+            buf = engine.upload((id(self), "wdev"), flat) if hasattr(engine, "upload") else engine.tensor(flat)
             self._wdev = {k: buf[o:o + int(np.prod(shp))].view(*shp) for k, (o, shp) in offs.items()}
             if len(self.spec.layers):
                 self._wdev["wpack"] = self.wpack(engine)      # selects the matrix-core BPTT kernel

@@ -22,4 +22,4 @@ with Session() as sess:
     torch.cuda.synchronize()
     pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(28)
+st.sort_stats("tottime").print_stats(32)
