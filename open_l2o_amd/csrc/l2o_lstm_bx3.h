@@ -314,6 +314,8 @@ struct LstmCore<PRE, false> {
                                           int q, PhaseClock& pc) {
     return lstm_finish<PRE, NEXT>(w, s, acc1, acc2, in0, in1, q, pc);
   }
+  // after finish<false>: make the recurrent operands of the NEXT step current (nothing to do here)
+  __device__ __forceinline__ void refresh(const TileState&) {}
 };
 
 template <int PRE>
@@ -341,6 +343,8 @@ struct LstmCore<PRE, true> {
                                           int q, PhaseClock& pc) {
     return bx::finish<PRE, NEXT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
   }
+  // after finish<false>: b1 already holds split h1(t) (finish builds it for chunk L2A); split h2(t) for chunk L2B
+  __device__ __forceinline__ void refresh(const TileState& s) { bx::split5(s.h2, one, b2); }
 };
 
 }  // namespace l2o

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 
   f32x4 acc1[kNT], acc2[kNT];
   core.init(s, q);
-  core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
+  // (both recurrent chunks -- L1H: h1(t-1) -> layer 1, L2B: h2(t-1) -> layer 2 -- are issued inside the step loop,
+  //  in the window where the wave waits for its partner's partial residuals)
   PhaseClock pc;
   pc.start();
 
@@ -236,16 +237,22 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
         __hip_atomic_store(mine + par * SQ + myrow, pack_granule(part, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     pc.mark(3);                                             // partial r + publish
+    // 30 MFMAs (L2B) give the partner time to publish; the first poll load goes out THEN and its L2 round trip
+    // is covered by the other 30 MFMAs (L1H) -- in program order, a single wave issues in order
     core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
+    const unsigned long long* src = theirs + par * SQ + (gq < 2 ? myrow : 0);
+    unsigned long long g = 0;
+#ifdef L2O_ABLATE_EXCHANGE
+    dead = true;
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (gq < 2 && !dead) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_sched_barrier(0);
+    core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
     float contrib = 0.0f;
     if (gq < 2) {
-      const unsigned long long* src = theirs + par * SQ + myrow;
-      unsigned long long g = 0;
       int spins = 0;
-#ifdef L2O_ABLATE_EXCHANGE
-      dead = true;
-#endif
-      if (!dead) {
+      if (!dead && (unsigned)(g >> 32) != tag) {
 #pragma nounroll
         for (;;) {
           g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -312,7 +319,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
+    float d = core.template finish<false>(s, acc1, acc2, in0, in1, q, pc);
+    core.refresh(s);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
     pc.mark(9);
