@@ -239,7 +239,13 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     pc.mark(3);                                             // partial r + publish
     // 30 MFMAs (L2B) give the partner time to publish; the first poll load goes out THEN and its L2 round trip
     // is covered by the other 30 MFMAs (L1H) -- in program order, a single wave issues in order
-    core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
+#ifndef L2O_PAIR_POLL_AT
+#define L2O_PAIR_POLL_AT 15   // measured: 0 -> 5.94, 5/10 -> 6.05, 15 -> 6.22, 30 -> 6.15, 45 -> 6.09 G (config 2)
+#endif
+    constexpr int kPollAt = L2O_PAIR_POLL_AT < Core::kTotal ? L2O_PAIR_POLL_AT : Core::kTotal;   // MFMAs before the first poll load
+    constexpr int kPollAt1 = L2O_PAIR_POLL_AT > Core::kTotal ? L2O_PAIR_POLL_AT - Core::kTotal : 0;
+    core.template issue_l2_prev<0, kPollAt>(s, acc2);
+    if (kPollAt1 > 0) core.template issue_l1_prev<0, kPollAt1>(s, acc1);
     const unsigned long long* src = theirs + par * SQ + (gq < 2 ? myrow : 0);
     unsigned long long g = 0;
 #ifdef L2O_ABLATE_EXCHANGE
@@ -248,7 +254,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     __builtin_amdgcn_sched_barrier(0);
     if (gq < 2 && !dead) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_sched_barrier(0);
-    core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
+    if (kPollAt < Core::kTotal) core.template issue_l2_prev<kPollAt, Core::kTotal>(s, acc2);
+    core.template issue_l1_prev<kPollAt1, Core::kTotal>(s, acc1);
     float contrib = 0.0f;
     if (gq < 2) {
       int spins = 0;
