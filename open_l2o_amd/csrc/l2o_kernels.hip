@@ -9,6 +9,7 @@
 // Written for gfx950 only: wave64, v_mfma_f32_16x16x4_f32, 160 KiB LDS per CU.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -987,6 +988,12 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     pa.ws = reinterpret_cast<PairWs*>(workspace);
     pa.xbuf = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + L.xbuf_off);
     pa.fx_half = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.fxh_off);
+    {
+      // tags carry a per-launch salt on top of the per-launch memset: a granule of an earlier launch that
+      // some cache level still held could otherwise match (same step number) and be taken for the partner's
+      static std::atomic<unsigned> launch_counter{0};
+      pa.salt = a.T + 1 < 0xffff ? ((launch_counter.fetch_add(1, std::memory_order_relaxed) + 1) & 0x7fffu) << 16 : 0u;
+    }
     void (*fn)(UnrollPairArgs) = nullptr;
     switch (g.CH) {
       case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : k_unroll_pair<PRE, KIND, 2, false>; break;

@@ -36,6 +36,7 @@ struct UnrollPairArgs {
   PairWs* ws;
   unsigned long long* xbuf;   // [B][2 halves][2 parities][SQ] granules (partial residuals)
   float* fx_half;             // [(T+1)][2*B]
+  unsigned salt;              // per-launch value in the tags' upper bits: a granule left by an earlier launch never matches
 };
 
 __device__ __forceinline__ unsigned long long pack_granule(float v, unsigned tag) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xfu;
-    constexpr unsigned kHsTag = 0x80000000u;
+    const unsigned kHsTag = 0x80000000u | pa.salt | 0xffffu;
     __hip_atomic_store(mine + SQ, ((unsigned long long)kHsTag << 32) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long g = 0;
     int spins = 0;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const size_t hist_n = (size_t)pp.B_local * D;
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
-    const unsigned tag = (unsigned)t + 1u;
+    const unsigned tag = pa.salt | ((unsigned)t + 1u);     // (T + 1 < 65 535 when salt != 0; the handshake tag ends in 0xffff)
     const int par = t & 1;
     if (q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
     if (HIST && t < a.T && tile_real)
