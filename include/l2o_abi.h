@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 3
+#define L2O_ABI_VERSION 4
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -307,8 +307,13 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device */,
                       int32_t T, int32_t step0, float* fx_part, void* workspace,
                       const l2o_unroll_hist* hist, void* stream);
 int l2o_unroll_status(const void* workspace_header_host /* host copy of the first 4 bytes */);
-/* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0. */
+/* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0: the LDS-resident forms
+ * (D <= 128, M <= 16 ceil(D/16)) or the streaming form (128 < D <= 512, D % 4 == 0, any M: one
+ * workgroup per problem, the matrix streamed once per step, x / LSTM state / moments on-chip). */
 int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);
+/* 1 if l2o_unroll_record (hist != NULL) has a kernel for the pair: the LDS-resident forms only
+ * (ABI v4).  Larger problems record their history on the step-granular path. */
+int l2o_unroll_record_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);
 
 /* ---- fx_array.stack() / tf.reduce_mean over the batch (DM/meta.py:345, 374-376):
  * fx[t] = (sum_b fx_part[t*B_local + b]) / B_global, fixed summation order

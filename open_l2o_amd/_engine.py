@@ -313,9 +313,11 @@ class HipEngine(object):
                              ptr(pn["sts"][t]), ptr(pn["dxs"][t]) if pn.get("dxs") else 0])
         return torch.tensor(rows, dtype=torch.int64).to(self.device, non_blocking=False)
 
-    def unroll_supported(self, spec: NetSpec, p: ProblemDesc):
+    def unroll_supported(self, spec: NetSpec, p: ProblemDesc, record=False):
+        """A fused kernel exists for the pair; record=True: one that also records the BPTT history."""
         cc, cp = spec.to_c(), self._cprob(p)
-        return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))
+        fn = self.lib.l2o_unroll_record_supported if record else self.lib.l2o_unroll_supported
+        return bool(fn(C.byref(cc), C.byref(cp)))
 
     def unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part, hist=None):
         """hist: None, or dict(st=[T, state_floats], g=[T, B*D], m=, v= (RNNProp), g_final=[B*D]) of

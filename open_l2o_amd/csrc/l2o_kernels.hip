@@ -818,6 +818,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_unroll_pair.h"
 
+#include "l2o_unroll_cu.h"
+
 #include "l2o_mlp.h"
 
 #include "l2o_bwd.h"
@@ -1034,6 +1036,25 @@ static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind
     case L2O_PROB_SQUARE_COS: return launch_unroll_ch<PRE, L2O_PROB_SQUARE_COS>(a, g, s, prob, workspace);
     default: return fail(L2O_ERR_UNSUPPORTED, "no fused kernel for problem kind %d", kind);
   }
+}
+
+// The streaming form (csrc/l2o_unroll_cu.h) takes the sizes the LDS-resident kernels cannot: one
+// workgroup per problem, matrix streamed once per step, LSTM state in LDS (+ registers).
+static bool unroll_cu_eligible(const l2o_problem* p) {
+  if (getenv("L2O_NO_UNROLL_CU")) return false;
+  if (p->D <= 128 || p->D > 512 || (p->D & 3) || p->M <= 0) return false;
+  return unroll_cu_layout(p->D).lds <= 160 * 1024;
+}
+template <int PRE>
+static int launch_unroll_cu(const UnrollArgs& a_in, hipStream_t s) {
+  const UnrollCuLayout L = unroll_cu_layout(a_in.pp.D);
+  const UnrollArgs& a = a_in;
+  void (*fn)(UnrollArgs) = a.pp.D <= 256 ? k_unroll_cu<PRE, 1> : k_unroll_cu<PRE, 2>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)L.lds));
+  hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(kCuThreads), L.lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
 }
 
 extern "C" {
@@ -1572,14 +1593,18 @@ int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
     return 0;
   if (prob->D <= 0 || prob->M <= 0) return 0;
   UnrollGeom g;
-  return unroll_geom(prob, &g) ? 1 : 0;
+  return (unroll_geom(prob, &g) || unroll_cu_eligible(prob)) ? 1 : 0;
+}
+
+int l2o_unroll_record_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
+  UnrollGeom g;
+  return (l2o_unroll_supported(cfg, prob) && unroll_geom(prob, &g)) ? 1 : 0;
 }
 
 size_t l2o_unroll_workspace_bytes(const l2o_net_cfg* cfg, const l2o_problem* prob, int32_t T) {
   if (!l2o_unroll_supported(cfg, prob) || T < 0) return 0;
   UnrollGeom g;
-  unroll_geom(prob, &g);
-  if (g.CH < 2) return 0;
+  if (!unroll_geom(prob, &g) || g.CH < 2) return 0;       // (the streaming form needs no workspace)
   return pair_layout(prob, g, T).total;
 }
 
@@ -1609,7 +1634,10 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
     return fail(L2O_ERR_UNSUPPORTED, "l2o_unroll: no fused kernel for kind=%d D=%d M=%d net(kind=%d,layers=%d)",
                 prob->kind, prob->D, prob->M, cfg->kind, cfg->n_layers);
   UnrollGeom g;
-  unroll_geom(prob, &g);
+  const bool lds_form = unroll_geom(prob, &g);
+  if (!lds_form && hist)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_unroll_record: no recording kernel for D=%d M=%d (l2o_unroll_record_supported)",
+                prob->D, prob->M);
   UnrollArgs a;
   a.np = make_net_params(cfg, wpack);
   a.pp = make_prob_params(prob);
@@ -1623,6 +1651,15 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
   pow_ff(cfg->beta1, step0, &a.p1_hi, &a.p1_lo);
   pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
   hipStream_t s = (hipStream_t)stream;
+  if (!lds_form) {
+    switch (cfg->preprocess) {
+      case L2O_PRE_IDENTITY: return launch_unroll_cu<L2O_PRE_IDENTITY>(a, s);
+      case L2O_PRE_LOGSIGN: return launch_unroll_cu<L2O_PRE_LOGSIGN>(a, s);
+      default:
+        if (!m || !v) return fail(L2O_ERR_ARG, "l2o_unroll: RNNProp needs m and v");
+        return launch_unroll_cu<L2O_PRE_FC_ELU>(a, s);
+    }
+  }
   switch (cfg->preprocess) {
     case L2O_PRE_IDENTITY: return launch_unroll_kind<L2O_PRE_IDENTITY>(a, g, prob->kind, s, prob, workspace);
     case L2O_PRE_LOGSIGN: return launch_unroll_kind<L2O_PRE_LOGSIGN>(a, g, prob->kind, s, prob, workspace);

@@ -367,7 +367,7 @@ class UnrollGraph(object):
             self.reset()
 
     # -- execution -------------------------------------------------------------
-    def _fused_ok(self, descs):
+    def _fused_ok(self, descs, record=False):
         if len(self.x) != 1 or len(self.slots) != 1 or len(self.terms) != 1 or descs[0] is None:
             return False
         s = self.slots[0]
@@ -375,7 +375,7 @@ class UnrollGraph(object):
             return False
         if os.environ.get("L2O_DISABLE_FUSED"):
             return False
-        return self.engine.unroll_supported(s.net.spec, descs[0])
+        return self.engine.unroll_supported(s.net.spec, descs[0], record=record)
 
     def execute(self, feed, commit):
         """Run one unroll from the current variables.  Returns dict(loss, fx, x) on the host."""
@@ -577,7 +577,7 @@ class UnrollGraph(object):
 
         if events is not None:
             events[0].record()
-        if record is not None and T > 0 and self._fused_ok(descs) and isinstance(states[0], PackedState) \
+        if record is not None and T > 0 and self._fused_ok(descs, record=True) and isinstance(states[0], PackedState) \
                 and states[0].packed is not None:
             # meta-gradient on a fused-size problem: ONE launch that also records the history
             # (state before, gradient at, moments after every step; gradient at x_T)

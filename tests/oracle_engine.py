@@ -267,12 +267,13 @@ class OracleEngine(object):
         if carry_out is not None:
             carry_out.copy_(cin)
 
-    def unroll_supported(self, spec, p):
+    def unroll_supported(self, spec, p, record=False):
         cc = spec.to_c()
         import ctypes as C
         cp = _abi.Problem()
         cp.kind, cp.B_local, cp.B_global, cp.D, cp.M = p.kind, p.B_local, p.B_global, p.D, p.M
-        return bool(self.lib.l2o_unroll_supported(C.byref(cc), C.byref(cp)))
+        fn = self.lib.l2o_unroll_record_supported if record else self.lib.l2o_unroll_supported
+        return bool(fn(C.byref(cc), C.byref(cp)))
 
     def unroll(self, spec, wpack, p, x, st, m, v, T, step0, fx_part, hist=None):
         self.calls.append("unroll")

@@ -398,7 +398,6 @@ def test_c3_lasso_rnnprop_full_size(eng):
     params = make_params(cfg, seed=17, trained_like=True)
     B, D, M = 256, 512, 256
     prob, x0, arrays = make_problem("lasso", B, D, seed=18, M=M)
-    assert not eng.unroll_supported(spec_of(cfg), device_problem(eng, arrays, B, D))
     fx_ref, _, _, _, _, _ = c_unroll("lasso", cfg, params, arrays, x0, 20)
     fx20, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 20)
     e = rel_err(fx20, fx_ref)
@@ -478,3 +477,100 @@ def test_fused_rejects_what_it_cannot_do(eng):
         fx, _ = _run_steps(eng, cfg, make_params(cfg, 1, trained_like=True), arrays, x0, B, D, 3)
         res = O.unroll(prob, cfg, make_params(cfg, 1, trained_like=True), x0, O.net_initial_state(cfg, B * D), 3)
         assert rel_err(fx, res.fx) < 1e-5
+
+
+# ---------------------------------------------------------------------------
+# the streaming form of the fused unroll (csrc/l2o_unroll_cu.h): 128 < D <= 512, any M
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kind,B,D,M,T", [
+    ("rnnprop", "lasso", 3, 512, 256, 20),        # BASELINE config 3's problem shape: 32 tiles, the 8th per wave in registers
+    ("dm", "quadratic", 2, 256, None, 20),        # one float4 chunk per lane (NV = 1)
+    ("dm_logsign", "rastrigin", 3, 200, None, 12),    # ragged last tile (200 = 12 x 16 + 8), tiles not a multiple of 4
+    ("rnnprop", "square_cos", 2, 132, None, 12),  # the smallest sizes: 9 tiles
+    ("dm", "lasso", 2, 452, 37, 8),               # odd row count (not a multiple of the 4-row groups), 29 tiles
+    ("dm_logsign", "lasso", 2, 480, 500, 8),      # more rows than columns, 30 tiles (8th slot on waves 0, 1 only)
+    ("rnnprop", "quadratic", 1, 512, None, 0),    # T = 0: only f(x_0)
+])
+def test_streaming_unroll_vs_oracle(eng, name, kind, B, D, M, T):
+    cfg = ORACLE_CFGS[name]
+    params = make_params(cfg, seed=31, trained_like=True)
+    prob, x0, arrays = make_problem(kind, B, D, seed=32, M=M)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=1)
+    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
+    e_fx = rel_err(fx, res.fx)
+    e_x = max_abs(x, res.x.reshape(B, D))
+    print("streaming %s/%s B=%d D=%d: rel fx=%.3g |dx|=%.3g fx0=%.4g fxT=%.4g"
+          % (name, kind, B, D, e_fx, e_x, res.fx[0], res.fx[-1]))
+    assert e_fx < 1e-5
+    assert e_x < 1e-5 * max(1.0, float(np.abs(res.x).max()))
+    for l in range(2):
+        for i in range(2):
+            assert max_abs(st[l][i], res.state[l][i]) < 1e-5 * max(1.0, float(np.abs(res.state[l][i]).max()))
+    if cfg.kind == "rnnprop":
+        assert max_abs(m, res.m.reshape(B, D)) < 1e-6 * max(1.0, np.abs(res.m).max())
+        assert max_abs(v, res.v.reshape(B, D)) < 1e-6 * max(1.0, np.abs(res.v).max())
+
+
+def test_streaming_unroll_continuation_and_step_path(eng):
+    """Streaming form: 16 steps == 2 x 8 steps with carried x / state / m / v (bit for bit: nothing
+    in the kernel depends on T), with a random x-scale and a batch that is a shard of a larger one;
+    and == the step-granular path (l2o_problem_fg + l2o_cwlstm_step) to fp32 summation-order accuracy."""
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=41, trained_like=True)
+    B, D, M = 5, 384, 96
+    prob, x0, arrays = make_problem("lasso", B, D, seed=42, M=M)
+    xs = np.exp(np.random.default_rng(43).uniform(-1, 1, (B, D))).astype(np.float32)
+    fx16, x16, st16, m16, v16 = _run_fused(eng, cfg, params, arrays, x0, B, D, 16, Bg=4 * B, x_scale=xs)
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D, B_global=4 * B, x_scale=xs)
+    st = eng.state_alloc(B, D)
+    x = eng.tensor(x0.reshape(B, D))
+    m, v = eng.zeros(B, D), eng.zeros(B, D)
+    fxs = []
+    for k in range(2):
+        fx_part, fx = eng.zeros(9 * B), eng.zeros(9)
+        eng.unroll(spec, wpack, pd, x, st, m, v, 8, 1 + 8 * k, fx_part)
+        eng.reduce_fx(fx_part, 9, B, pd.B_global, fx)
+        fxs.append(eng.to_numpy(fx))
+    # (not bit for bit: a launch starts beta^step0 from pow() and carries it as a running float-float product)
+    fx88 = np.concatenate([fxs[0], fxs[1][1:]])
+    assert fxs[0][8] == fxs[1][0] and rel_err(fx88, fx16) < 1e-6
+    for got, ref in ((eng.to_numpy(x), x16), (eng.to_numpy(m), m16), (eng.to_numpy(v), v16)):
+        assert max_abs(got, ref) < 1e-6 * max(1.0, float(np.abs(ref).max()))
+    # the step-granular path on the same (unscaled, unsharded) inputs
+    fxf, xf = _run_fused(eng, cfg, params, arrays, x0, B, D, 16)[:2]
+    fxs_, carry = _run_steps(eng, cfg, params, arrays, x0, B, D, 16)
+    assert rel_err(fxf, fxs_) < 1e-5
+    xs_ = eng.to_numpy(carry[0])
+    assert max_abs(xf, xs_) < 1e-5 * max(1.0, float(np.abs(xs_).max()))
+
+
+def test_c3_streaming_full_size(eng):
+    """Config 3 at full size (RNNProp, Lasso 256 x 512 per problem, batch 256, T = 200) through the
+    streaming fused unroll: the first 20 steps against the C oracle, the T = 200 trajectory through
+    the continuation property and against the step-granular path on the first 20 steps."""
+    from oracle.c_oracle import c_unroll
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=17, trained_like=True)
+    B, D, M = 256, 512, 256
+    prob, x0, arrays = make_problem("lasso", B, D, seed=18, M=M)
+    fx_ref, _, _, _, _, _ = c_unroll("lasso", cfg, params, arrays, x0, 20)
+    fx20 = _run_fused(eng, cfg, params, arrays, x0, B, D, 20)[0]
+    e = rel_err(fx20, fx_ref)
+    print("C3 streaming unroll vs C oracle (20 steps): rel fx=%.3g fx0=%.5g fx20=%.5g" % (e, fx_ref[0], fx_ref[-1]))
+    assert e < 1e-5
+    fx200 = _run_fused(eng, cfg, params, arrays, x0, B, D, 200)[0]
+    assert np.all(np.isfinite(fx200))
+    np.testing.assert_array_equal(fx200[:21], fx20)
+    fxs20, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 20)
+    assert rel_err(fx20, fxs20) < 1e-5
+
+
+def test_streaming_unroll_record_is_rejected(eng):
+    from open_l2o_amd import _abi
+    cfg = O.DM_IDENTITY
+    spec = spec_of(cfg)
+    prob, x0, arrays = make_problem("quadratic", 2, 256, seed=5)
+    pd = device_problem(eng, arrays, 2, 256)
+    assert eng.unroll_supported(spec, pd) and not eng.unroll_supported(spec, pd, record=True)
