@@ -16,10 +16,10 @@
 //           visits in registers between r_i = <row, x> - y_i and g += r_i row), nothing else:
 //           x / state / m / v never leave the CU between steps (the step-granular path moves
 //           664 B per coordinate-step of them through HBM, and pays 2 launches per step).
-//           The first row group of step t+1 is requested BEFORE the optimizer phase of step t
-//           (its address depends on nothing), so that the stream's start-up latency hides under
-//           the 8 network evaluations of a wave; in the GEMV phase a wave keeps 3 groups (24 KB)
-//           in flight while it reduces a fourth.
+//           A wave keeps 2-3 row groups (16-24 KB) in flight while it reduces another; the first
+//           groups of step t+1 are requested at the end of the optimizer phase of step t, ahead of
+//           the barrier (which waits for LDS traffic only), so the stream's start-up latency
+//           overlaps the barrier and the GEMV prologue.
 // Per step:  GEMV phase (4 waves x M/4 rows) -> partial g, partial f -> barrier ->
 //            optimizer phase (wave w: tiles w, w+4, ...) -> x, x*s in LDS -> barrier.
 #pragma once
@@ -30,10 +30,16 @@ constexpr int kCuWaves = 4;
 constexpr int kCuThreads = 64 * kCuWaves;
 constexpr int kCuMaxLdsSlots = 7;            // tile slots per wave whose state is LDS-resident
 constexpr int kCuSlotF4 = 5 * 64;            // float4 per tile slot (packed tile state)
-#ifndef L2O_CU_RING
-#define L2O_CU_RING 4
-#endif
-constexpr int kCuRing = L2O_CU_RING;         // row groups (4 rows each) per wave in the GEMV ring
+// Row groups (4 rows each) per wave in the GEMV ring.  RNNProp with two chunks per lane (D > 256) has 240
+// fragment registers + a 32-register group: a fourth group spills (measured: 4.29 vs 4.70 G on config 3).
+constexpr int cu_ring(int pre, int nv) { return (pre == L2O_PRE_FC_ELU && nv == 2) ? 3 : 4; }
+
+// Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS operations, not for its
+// global loads (__syncthreads() drains vmcnt as well, which would serialise the row groups requested
+// ahead of the barrier behind it).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 struct UnrollCuLayout { int tpp, nslots, nlds, DP; size_t lds; };
 static inline UnrollCuLayout unroll_cu_layout(int D) {
@@ -48,6 +54,7 @@ static inline UnrollCuLayout unroll_cu_layout(int D) {
 
 template <int PRE, int NV>
 __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_unroll_cu(UnrollArgs a) {
+  constexpr int kCuRing = cu_ring(PRE, NV);
   extern __shared__ float4 cu_smem[];
   const ProbParams& pp = a.pp;
   const int D = pp.D, M = pp.M;
@@ -97,11 +104,17 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int v = 0; v < NV; ++v) w4[k][v] = *reinterpret_cast<const float4*>(rowp + jcol[v]);
     }
   };
-  // wa crosses the optimizer phase (requested before it, used after it); wb / wc / wd are live in
-  // the GEMV phase only, where the registers the network's temporaries use are free
+  // the ring is live in the GEMV phase only (and across barrier B2), where the registers of the network's
+  // temporaries are free
   float4 wa[4][NV], wb[4][NV], wc[4][NV], wd[4][NV];
   const int i_first = 4 * wv;
-  if (i_first < M) load4(i_first, wa);
+  auto load_head = [&]() {                 // the ring's groups of a step's first trip
+    if (i_first < M) load4(i_first, wa);
+    if (i_first + kRowStep < M) load4(i_first + kRowStep, wb);
+    if (kCuRing >= 3 && i_first + 2 * kRowStep < M) load4(i_first + 2 * kRowStep, wc);
+    if (kCuRing >= 4 && i_first + 3 * kRowStep < M) load4(i_first + 3 * kRowStep, wd);
+  };
+  load_head();
 
   // ---- problem vectors and LSTM state into LDS ----------------------------------------------
   for (int j = tid; j < DP; j += kCuThreads) {
@@ -225,11 +238,8 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       }
     };
-    // kCuRing row groups in the ring, all but one in flight while that one is reduced; wa of the
-    // first trip was requested before the previous optimizer phase
-    if (i_first + kRowStep < M) load4(i_first + kRowStep, wb);
-    if (kCuRing >= 3 && i_first + 2 * kRowStep < M) load4(i_first + 2 * kRowStep, wc);
-    if (kCuRing >= 4 && i_first + 3 * kRowStep < M) load4(i_first + 3 * kRowStep, wd);
+    // kCuRing row groups in the ring, all but one in flight while that one is reduced; the first trip's
+    // were requested at the end of the previous optimizer phase, ahead of barrier B2
     for (int i0 = i_first; i0 < M; i0 += kCuRing * kRowStep) {
       use4(i0, wa);
       if (i0 + kCuRing * kRowStep < M) load4(i0 + kCuRing * kRowStep, wa);
@@ -253,12 +263,9 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     }
     const float fw = wave_sum64(facc);
     if (lane == 0) red[wv] = fw;
-    __syncthreads();                                          // B1: partial gradients and partial f complete
+    lds_barrier();                                            // B1: partial gradients and partial f complete
     if (tid == 0) a.fx_part[(size_t)t * pp.B_local + b] = ((red[0] + red[1]) + red[2]) + red[3];
     if (!want_g) break;
-
-    // ---- the next step's first row group: nothing it needs is still to be computed -----------
-    if (i_first < M) load4(i_first, wa);
 
     // ---- optimizer network on this wave's tiles ------------------------------------------------
     if (PRE == L2O_PRE_FC_ELU) { om1 = 1.0f - p1h; om2 = 1.0f - p2h; }
@@ -296,7 +303,8 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       lo = __builtin_fmaf(p2l, a.np.beta2, er); sum = hi + lo;
       p2l = lo - (sum - hi); p2h = sum;
     }
-    __syncthreads();                                          // B2: x s of the next step complete, `part` free
+    load_head();                                              // (the network's temporaries are dead: registers for the ring)
+    lds_barrier();                                            // B2: x s of the next step complete, `part` free
   }
 
   // ---- write back: x, moments, LSTM state ------------------------------------------------------
