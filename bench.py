@@ -258,12 +258,15 @@ def main():
                     "mnist": "MLP 784-20-10 (sigmoid) on synthetic MNIST-shaped data, minibatch %d" % B}[args.problem]
         is_c2 = (args.problem, args.net, D, B, T) == ("quadratic", "dm", 128, 128, 100)
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_c2.json")
-        if os.path.exists(pmc_file) and fused and is_c2 and world == 1:
+        for tag in ("c2", "c3"):                           # committed PMC passes of exactly this workload
+            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % tag)
+            if not (os.path.exists(pmc_file) and fused and world == 1 and not shared):
+                continue
             pmc = json.load(open(pmc_file))
-            traffic = pmc["traffic_bytes"]
-            traffic_src = ("profiles/r01_pmc_c2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                           "command, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)")
+            if pmc["workload"] == [args.problem, args.net, D, B, T] and (args.problem != "lasso" or Mrows == 256):
+                traffic = pmc["traffic_bytes"]
+                traffic_src = ("profiles/r01_pmc_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               "command, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)" % tag)
         out = {
             "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
             "value": value, "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
@@ -271,7 +274,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
                                    % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
-                       "kernel": ("l2o_unroll (fused persistent, 2 CUs per problem when 2*batch <= #CUs)" if fused
+                       "kernel": (("l2o_unroll, streaming form k_unroll_cu (one workgroup per problem, T steps in one "
+                                   "launch, matrix streamed once per step, x / LSTM state / moments on-chip)"
+                                   if D > 128 else
+                                   "l2o_unroll (fused persistent, 2 CUs per problem when 2*batch <= #CUs)") if fused
                                   else "l2o_problem_fg + l2o_cwlstm_step per step"),
                        "arithmetic": "fp32 state, inputs and outputs; the LSTM gate GEMM is a 6-product 3-way bf16 "
                                      "split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level error, "
@@ -288,9 +294,14 @@ def main():
                          "kernel_ms_avg": kern_ms, "kernel_ms_min": kern_ms_min,
                          "fp32_tflops": flops / (kern_ms * 1e-3) / 1e12,
                          "fp32_frac_of_157.3TF": flops / (kern_ms * 1e-3) / FP32_PEAK,
-                         "note": "step-granular algorithmic bytes (SURVEY 8d) over the HIP-event time of the "
-                                 "unroll kernels; the fused kernel keeps x, LSTM state and W on-chip, so real HBM "
-                                 "traffic is far below this figure (frac can exceed 1) and the kernel is bound by one wave's serial instruction stream -- DESIGN.md 5"},
+                         "note": ("step-granular algorithmic bytes (SURVEY 8d) over the HIP-event time of the "
+                                  "unroll kernels; the fused kernel keeps x, LSTM state and W on-chip, so real HBM "
+                                  "traffic is far below this figure (frac can exceed 1) and the kernel is bound by one "
+                                  "wave's serial instruction stream -- DESIGN.md 5") if not (fused and D > 128) else
+                                 ("step-granular algorithmic bytes (SURVEY 8d: matrix twice + x / state / moments "
+                                  "read and written per step) over the HIP-event time of the unroll kernel; the "
+                                  "streaming form reads the matrix ONCE per step and keeps everything else on-chip, "
+                                  "so frac can exceed 1 -- DESIGN.md 3.1c / 5")},
         }
         if world == 1 and not args.no_cpu_baseline and args.problem != "mnist" and not shared:
             names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
