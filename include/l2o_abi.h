@@ -284,7 +284,10 @@ int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, cons
  * through tagged 8-byte granules in the workspace; otherwise one workgroup per problem.
  * The first 4 bytes of the workspace are a status word the kernel raises if a partner
  * never showed up (bounded spin, no hang): after synchronising, copy them to the host and
- * pass them to l2o_unroll_status(). */
+ * pass them to l2o_unroll_status().
+ * Problems beyond the LDS-resident sizes (128 < D <= 512, D % 4 == 0, any M) run the streaming
+ * form: one workgroup per problem, the matrix streamed once per step, x / state / moments on-chip
+ * for the whole unroll; it needs no workspace (l2o_unroll_workspace_bytes() == 0). */
 size_t l2o_unroll_workspace_bytes(const l2o_net_cfg* cfg, const l2o_problem* prob, int32_t T);
 int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack /* device */,
                const l2o_problem* prob, float* x /* device [B_local,D] in-out */,
