@@ -285,7 +285,7 @@ int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, cons
  * The first 4 bytes of the workspace are a status word the kernel raises if a partner
  * never showed up (bounded spin, no hang): after synchronising, copy them to the host and
  * pass them to l2o_unroll_status().
- * Problems beyond the LDS-resident sizes (128 < D <= 512, D % 4 == 0, any M) run the streaming
+ * Problems beyond the LDS-resident sizes (D <= 512, D % 4 == 0, any M) run the streaming
  * form: one workgroup per problem, the matrix streamed once per step, x / state / moments on-chip
  * for the whole unroll; it needs no workspace (l2o_unroll_workspace_bytes() == 0). */
 size_t l2o_unroll_workspace_bytes(const l2o_net_cfg* cfg, const l2o_problem* prob, int32_t T);
@@ -311,8 +311,9 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device */,
                       const l2o_unroll_hist* hist, void* stream);
 int l2o_unroll_status(const void* workspace_header_host /* host copy of the first 4 bytes */);
 /* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0: the LDS-resident forms
- * (D <= 128, M <= 16 ceil(D/16)) or the streaming form (128 < D <= 512, D % 4 == 0, any M: one
- * workgroup per problem, the matrix streamed once per step, x / LSTM state / moments on-chip). */
+ * (D <= 128, M <= 16 ceil(D/16)) or the streaming form (everything else with D <= 512, D % 4 == 0,
+ * any M: one workgroup per problem, the matrix streamed once per step, x / LSTM state / moments
+ * on-chip). */
 int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);
 /* 1 if l2o_unroll_record (hist != NULL) has a kernel for the pair: the LDS-resident forms only
  * (ABI v4).  Larger problems record their history on the step-granular path. */

@@ -1042,7 +1042,7 @@ static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind
 // workgroup per problem, matrix streamed once per step, LSTM state in LDS (+ registers).
 static bool unroll_cu_eligible(const l2o_problem* p) {
   if (getenv("L2O_NO_UNROLL_CU")) return false;
-  if (p->D <= 128 || p->D > 512 || (p->D & 3) || p->M <= 0) return false;
+  if (p->D < 4 || p->D > 512 || (p->D & 3) || p->M <= 0) return false;   // (D <= 128: only when the rows do not fit the LDS forms)
   return unroll_cu_layout(p->D).lds <= 160 * 1024;
 }
 template <int PRE>

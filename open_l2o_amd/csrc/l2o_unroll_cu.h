@@ -1,5 +1,5 @@
 // l2o_unroll_cu.h -- the fused persistent unroll for optimizees that do NOT fit a CU's LDS
-// (128 < D <= 512, any M: BASELINE config 3 = Lasso 256 x 512 per problem).  Included by
+// (D <= 512 with D % 4 == 0, any M: BASELINE config 3 = Lasso 256 x 512 per problem).  Included by
 // l2o_kernels.hip after k_unroll; written for gfx950 only.
 //
 // Replaces, for these sizes, the step-granular pair {l2o_problem_fg, l2o_cwlstm_step} x T

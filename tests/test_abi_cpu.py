@@ -91,6 +91,9 @@ def test_bad_arguments_return_error_codes(lib):
     assert lib.l2o_unroll_workspace_bytes(C.byref(cc), C.byref(p), 10) == 0
     p.M = 37                                           # any row count
     assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
+    p.D, p.M = 16, 40                                  # few columns, more rows than the LDS forms take
+    assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
+    assert lib.l2o_unroll_record_supported(C.byref(cc), C.byref(p)) == 0
     for D in (516, 1024, 130, 129):                    # too large for the LDS-resident state / not float4 rows
         p.D = p.M = D
         assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 0

@@ -466,7 +466,7 @@ def test_fused_rejects_what_it_cannot_do(eng):
     from open_l2o_amd import _abi
     cfg = O.DM_IDENTITY
     spec = spec_of(cfg)
-    for kind, B, D, M in (("quadratic", 2, 129, None), ("lasso", 2, 16, 40)):
+    for kind, B, D, M in (("quadratic", 2, 129, None), ("lasso", 2, 18, 40), ("quadratic", 1, 516, None)):
         prob, x0, arrays = make_problem(kind, B, D, seed=92, M=M)
         pd = device_problem(eng, arrays, B, D)
         assert not eng.unroll_supported(spec, pd)
@@ -490,6 +490,8 @@ def test_fused_rejects_what_it_cannot_do(eng):
     ("dm", "lasso", 2, 452, 37, 8),               # odd row count (not a multiple of the 4-row groups), 29 tiles
     ("dm_logsign", "lasso", 2, 480, 500, 8),      # more rows than columns, 30 tiles (8th slot on waves 0, 1 only)
     ("rnnprop", "quadratic", 1, 512, None, 0),    # T = 0: only f(x_0)
+    ("dm", "lasso", 2, 16, 40, 6),                # D <= 128 with more rows than the LDS-resident forms take
+    ("rnnprop", "lasso", 3, 64, 200, 6),
 ])
 def test_streaming_unroll_vs_oracle(eng, name, kind, B, D, M, T):
     cfg = ORACLE_CFGS[name]

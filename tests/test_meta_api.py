@@ -177,6 +177,41 @@ def test_fused_and_step_paths_agree(engine, monkeypatch):
     assert rel_err(out["fused"][1], out["steps"][1]) < 1e-5
 
 
+def test_streaming_size_problem_through_the_api(engine, monkeypatch):
+    """A problem beyond the LDS-resident sizes (Lasso 40 x 160 per problem; RNNProp) takes the
+    streaming fused unroll through MetaOptimizer.meta_loss and agrees with the oracle and with the
+    step-granular path; meta_minimize on it records its history on the step-granular path."""
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=34, trained_like=True)
+    B, D, M, T = 3, 160, 40, 8
+    prob, x0, arrays = make_problem("lasso", B, D, seed=35, M=M)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=1)
+    out = {}
+    for mode in ("fused", "steps"):
+        if mode == "steps":
+            monkeypatch.setenv("L2O_DISABLE_FUSED", "1")
+        optimizer = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+        problem = problems.lasso(batch_size=B, num_dims=D, num_rows=M, l=prob.l,
+                                 data={"w": prob.w, "y": prob.y, "x": x0})
+        ml, _, _, step = optimizer.meta_loss(problem, T)
+        with Session() as sess:
+            sess.run(ml.reset)
+            out[mode] = sess.run([ml.loss, ml.fx, ml.x, ml.update], feed_dict={step: 1})[:3]
+        assert optimizer.graph.last_path == mode
+        assert rel_err(out[mode][0], res.loss) < 1e-5 and rel_err(out[mode][1], res.fx[-1]) < 1e-5
+    np.testing.assert_allclose(out["fused"][2][0], out["steps"][2][0], rtol=1e-4, atol=1e-6)
+    monkeypatch.delenv("L2O_DISABLE_FUSED", raising=False)
+    optimizer = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+    problem = problems.lasso(batch_size=B, num_dims=D, num_rows=M, l=prob.l, data={"w": prob.w, "y": prob.y, "x": x0})
+    mm = optimizer.meta_minimize(problem, T, learning_rate=1e-3)
+    ms, step_ph = mm[0], mm[3]
+    with Session() as sess:
+        sess.run(ms.reset)
+        cost = sess.run([ms.fx, ms.update, ms.step], feed_dict={step_ph: 1})[0]
+    assert optimizer.graph.last_path == "steps"            # no recording kernel for this size
+    assert rel_err(cost, res.fx[-1]) < 1e-5
+
+
 def test_evaluate_dm_flow(engine):
     """DM/evaluate_dm.py:70-91: util.get_config -> meta_loss(problem, 1) -> reset ->
     run_eval_epoch: the loss record is [f(x_1), ..., f(x_K)]."""
