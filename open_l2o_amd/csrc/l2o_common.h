@@ -129,6 +129,13 @@ __device__ __forceinline__ float quad_q_sum(float v) {
   return xor32_add(xor16_add(v));
 }
 
+// Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS operations, not for its
+// global loads (__syncthreads() drains vmcnt as well, which would serialise the row groups requested
+// ahead of the barrier behind it).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- weights in registers --------------------------------------------------
 template <int PRE>
 struct NetW {

@@ -34,13 +34,6 @@ constexpr int kCuSlotF4 = 5 * 64;            // float4 per tile slot (packed til
 // fragment registers + a 32-register group: a fourth group spills (measured: 4.29 vs 4.70 G on config 3).
 constexpr int cu_ring(int pre, int nv) { return (pre == L2O_PRE_FC_ELU && nv == 2) ? 3 : 4; }
 
-// Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS operations, not for its
-// global loads (__syncthreads() drains vmcnt as well, which would serialise the row groups requested
-// ahead of the barrier behind it).
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 struct UnrollCuLayout { int tpp, nslots, nlds, DP; size_t lds; };
 static inline UnrollCuLayout unroll_cu_layout(int D) {
   UnrollCuLayout L;
