@@ -42,6 +42,9 @@ KATS = {
 
 CASES = [(net, kind) for net in ("dm", "dm_logsign", "rnnprop") for kind in ("quadratic", "lasso", "rastrigin")]
 B, D, T = 4, 12, 10
+# wide problems (beyond the LDS-resident fused kernels: the streaming form / the step-granular path):
+# (net, problem file stem, kind, B, D, M, T, seed)
+WIDE = [("rnnprop", "lasso_wide", "lasso", 2, 160, 24, 8, 980), ("dm_logsign", "rastrigin_wide", "rastrigin", 2, 132, None, 6, 981)]
 
 
 def flat_params(params):
@@ -51,10 +54,14 @@ def flat_params(params):
 def main():
     with open(os.path.join(HERE, "reference_kats.json"), "w") as f:
         json.dump(KATS, f, indent=1, sort_keys=True)
-    for i, (net, kind) in enumerate(CASES):
+    only_wide = "--wide-only" in sys.argv            # (adds the wide fixtures without rewriting the others)
+    jobs = [] if only_wide else [(net, kind, kind, B, D, 9 if kind == "lasso" else None, T, 900 + i, 950 + i)
+                                 for i, (net, kind) in enumerate(CASES)]
+    jobs += [(net, stem, kind, b, d, m, t, seed, seed + 50) for net, stem, kind, b, d, m, t, seed in WIDE]
+    for net, stem, kind, B, D, M, T, pseed, dseed in jobs:
         cfg = ORACLE_CFGS[net]
-        params = make_params(cfg, seed=900 + i, trained_like=True)
-        prob, x0, arrays = make_problem(kind, B, D, seed=950 + i, M=9 if kind == "lasso" else None)
+        params = make_params(cfg, seed=pseed, trained_like=True)
+        prob, x0, arrays = make_problem(kind, B, D, seed=dseed, M=M)
         res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=1)
         out = {"B": B, "D": D, "T": T, "x0": x0, "fx": res.fx, "x_T": res.x.reshape(B, D),
                "h1": res.state[0][0], "c1": res.state[0][1], "h2": res.state[1][0], "c2": res.state[1][1]}
@@ -64,7 +71,7 @@ def main():
             out["prob_" + k] = np.asarray(a)
         for k, a in flat_params(params).items():
             out["param_" + k] = a
-        np.savez_compressed(os.path.join(HERE, "unroll_%s_%s.npz" % (net, kind)), **out)
+        np.savez_compressed(os.path.join(HERE, "unroll_%s_%s.npz" % (net, stem)), **out)
         print("%-10s %-10s fx0=%.6g fxT=%.6g" % (net, kind, res.fx[0], res.fx[-1]))
 
 
