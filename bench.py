@@ -14,6 +14,7 @@ One "step" of this benchmark = one complete unroll: rewind x / LSTM state -> T x
 HBM when the timed region starts; nothing is copied to the host inside it.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --config 3 --steps 5          (the other BASELINE configs: --config 3 / 4 / 5)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  value = coordinate-steps per second, whole job:
@@ -149,7 +150,17 @@ def main():
     ap.add_argument("--shared-matrix", dest="shared_matrix", action="store_true",
                     help="lasso: ONE sensing matrix for all problems (SURVEY 8d shared-A variant)")
     ap.add_argument("--net", default="dm", choices=["dm", "dm_logsign", "rnnprop"])
+    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
+                    help="preset = BASELINE.json configs[N-1] (per-GPU shard): 2 default; 3 RNNProp on Lasso 256x512, "
+                         "batch 256, T=200; 4 DM on Rastrigin d=100, 128 problems per GPU, T=100; 5 RNNProp on the "
+                         "MLP optimizee, minibatch 64, T=200 (forward unroll)")
     args = ap.parse_args()
+    if args.config == 3:
+        args.problem, args.net, args.dims, args.rows, args.batch, args.unroll = "lasso", "rnnprop", 512, 256, 256, 200
+    elif args.config == 4:
+        args.problem, args.net, args.dims, args.batch, args.unroll = "rastrigin", "dm", 100, 128, 100
+    elif args.config == 5:
+        args.problem, args.net, args.batch, args.unroll = "mnist", "rnnprop", 64, 200
 
     import torch
     import torch.distributed as dist
