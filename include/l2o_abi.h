@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 4
+#define L2O_ABI_VERSION 5
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -269,6 +269,19 @@ typedef struct l2o_bwd_unroll_seg {
 int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
                           int32_t nseg, const float* const* table, int32_t T, int64_t step0,
                           const float* carry_in, float* carry_out, float* A, float* Bm, void* stream);
+
+/* ---- the meta-step on the device (ABI v5): tf.train.AdamOptimizer(learning_rate).minimize(loss)
+ * (DM/meta.py:410-414) without a host round trip of the weights.
+ * l2o_adam_step: TF 1.x `_apply_dense` on one flat fp32 vector (all device pointers, n elements):
+ *   m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;  w <- w - lr_t m / (sqrt(v) + eps),
+ *   lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) computed by the caller; every operation rounded
+ *   separately (bit-equal to the NumPy expression of the host path).
+ * l2o_wpack_device: l2o_wpack_host for weights that live on the device (w: Sonnet layouts, `wpack`
+ *   member ignored); writes l2o_wpack_floats(cfg) floats, bit-equal to the host packer's output. */
+int l2o_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1,
+                  double beta2, double epsilon, void* stream);   /* fp32(beta), fp32(1 - beta), fp32(eps) are used */
+int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wpack_out /* device */,
+                     void* stream);
 
 /* ---- the fused unroll: MetaOptimizer.meta_loss's tf.while_loop
  * (DM/meta.py:338-376; RNNProp DM/meta_rnnprop_eval.py time_step) as ONE persistent

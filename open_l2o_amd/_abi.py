@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # L2O_HIP_LIB: alternative build of the SAME library (timing ablations, scripts/ablate.sh)
 LIB_PATH = os.environ.get("L2O_HIP_LIB") or os.path.join(_HERE, "libl2o_hip.so")
 
-L2O_ABI_VERSION = 4
+L2O_ABI_VERSION = 5
 L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
 
 NET_CW, NET_RNNPROP = 0, 1
@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats",
-    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
 
@@ -153,6 +153,10 @@ def lib():
     L.l2o_cwlstm_bwd_unroll.restype = C.c_int
     L.l2o_cwlstm_bwd_unroll.argtypes = [C.POINTER(NetCfg), C.POINTER(NetWeights), C.POINTER(BwdUnrollSeg), C.c_int32, vp,
                                         C.c_int32, i64, vp, vp, vp, vp, vp]
+    L.l2o_adam_step.restype = C.c_int
+    L.l2o_adam_step.argtypes = [vp, vp, vp, vp, i64, C.c_float, dbl, dbl, dbl, vp]
+    L.l2o_wpack_device.restype = C.c_int
+    L.l2o_wpack_device.argtypes = [C.POINTER(NetCfg), C.POINTER(NetWeights), vp, vp]
     L.l2o_unroll.restype = C.c_int
     L.l2o_unroll.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Problem), vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.l2o_unroll_record.restype = C.c_int

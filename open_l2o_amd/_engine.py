@@ -118,6 +118,20 @@ class HipEngine(object):
         host = pack_weights_host(self.lib, spec, params)
         return self.tensor(host) if key is None else self.upload(key, host)
 
+    def pack_weights_device(self, spec: NetSpec, weights: dict, out):
+        """Device Sonnet-layout weights (dict keyed like struct l2o_net_weights) -> `out` (device wpack),
+        without leaving the device (l2o_wpack_device; bit-equal to pack_weights)."""
+        cc = spec.to_c()
+        w = _abi.NetWeights()
+        for k, _ in _abi.NetWeights._fields_:
+            setattr(w, k, None if (k == "wpack" or weights.get(k) is None) else weights[k].data_ptr())
+        _abi.check(self.lib.l2o_wpack_device(C.byref(cc), C.byref(w), _ptr(out), self._stream()))
+
+    def adam_step(self, w, m, v, g, lr_t, beta1, beta2, epsilon):
+        """TF-1.x Adam on one flat device vector, in place (l2o_adam_step)."""
+        _abi.check(self.lib.l2o_adam_step(_ptr(w), _ptr(m), _ptr(v), _ptr(g), int(w.numel()), float(lr_t),
+                                          float(beta1), float(beta2), float(epsilon), self._stream()))
+
     def upload(self, key, a):
         """Host array -> a PERSISTENT device tensor per key, through a pinned staging buffer with an
         asynchronous copy (the meta-training step re-uploads the packed weights after every Adam update:

@@ -1070,23 +1070,145 @@ size_t l2o_wpack_floats(const l2o_net_cfg* cfg) {
 }
 
 // ---- bf16x3 section of wpack (l2o_lstm_bx3.h) --------------------------------
-static inline uint16_t bf16_rne(float f) {
-  uint32_t u;
-  std::memcpy(&u, &f, 4);
+__host__ __device__ static inline uint16_t bf16_rne(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-static inline double bf16_value(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float f;
-  std::memcpy(&f, &u, 4);
-  return (double)f;
+__host__ __device__ static inline double bf16_value(uint16_t h) {
+  return (double)__builtin_bit_cast(float, (uint32_t)h << 16);
 }
-static inline void bf16_split3(double v, uint16_t (&out)[3]) {
+__host__ __device__ static inline void bf16_split3(double v, uint16_t (&out)[3]) {
   for (int s = 0; s < 3; ++s) {
     out[s] = bf16_rne((float)v);
     v -= bf16_value(out[s]);
   }
+}
+
+// Lane l's share of the packed weights (the buffer is zero beforehand): the host packer runs it for
+// l = 0..63, the device packer (l2o_wpack_device, the meta-training step) with one thread per lane.
+// The lanes write disjoint words.
+__host__ __device__ static void wpack_lane(int pre, int l, const float* wg1, const float* bg1, const float* wg2,
+                                           const float* bg2, const float* wl, const float* bl, const float* wfc,
+                                           const float* bfc, float* out) {
+  const bool fc = pre == L2O_PRE_FC_ELU;
+  const int P = fc ? kH : (pre == L2O_PRE_LOGSIGN ? 2 : 1);
+  const int G = 4 * kH;
+  auto col = [](int t, int rho) { return (rho & 3) * kH + 4 * t + (rho >> 2); };
+  const int rho = l & 15, kq = l >> 4;   // A-fragment view of the lane
+  const int q = l >> 4;                  // C/D + B view of the lane
+  for (int t = 0; t < kNT; ++t) {
+    const int cA = col(t, rho);
+    // layer 1
+    if (fc) {
+      for (int kk = 0; kk < 10; ++kk) {
+        const int row = kk < 5 ? 4 * kk + kq : kH + 4 * (kk - 5) + kq;   // fc features, then h1
+        out[(wp_row_a1(pre) + kk * kNT + t) * 64 + l] = wg1[row * G + cA];
+      }
+    } else {
+      for (int kk = 0; kk < 5; ++kk)
+        out[(wp_row_a1(pre) + kk * kNT + t) * 64 + l] = wg1[(P + 4 * kk + kq) * G + cA];
+      float v = 0.0f;
+      if (kq == 0) v = wg1[0 * G + cA];
+      else if (kq == 1) v = P == 2 ? wg1[1 * G + cA] : 0.0f;
+      else if (kq == 2) v = bg1[cA];
+      out[(wp_row_a1(pre) + 5 * kNT + t) * 64 + l] = v;
+    }
+    // layer 2: kk 0..4 <- h1 (rows 0..19), kk 5..9 <- h2 (rows 20..39)
+    for (int kk = 0; kk < 10; ++kk) {
+      const int row = kk < 5 ? 4 * kk + kq : kH + 4 * (kk - 5) + kq;
+      out[(wp_row_a2(pre) + kk * kNT + t) * 64 + l] = wg2[row * G + cA];
+    }
+    for (int r = 0; r < 4; ++r) {
+      const int cD = col(t, 4 * q + r);
+      out[(wp_row_b1(pre) + t * 4 + r) * 64 + l] = fc ? bg1[cD] : 0.0f;
+      out[(wp_row_b2(pre) + t * 4 + r) * 64 + l] = bg2[cD];
+    }
+    out[(wp_row_wl(pre) + t) * 64 + l] = wl[4 * t + q];
+    if (fc) {
+      out[(wp_row_fc(pre) + t) * 64 + l] = wfc[0 * kH + 4 * t + q];
+      out[(wp_row_fc(pre) + kNT + t) * 64 + l] = wfc[1 * kH + 4 * t + q];
+      out[(wp_row_fc(pre) + 2 * kNT + t) * 64 + l] = bfc[4 * t + q];
+    }
+  }
+  out[wp_row_bl(pre) * 64 + l] = bl[0];
+  // ---- bf16x3 fragments: gate rows pre-scaled to exp2 arguments, split from float64 ----
+  {
+    uint32_t* ow = reinterpret_cast<uint32_t*>(out);
+    constexpr double kL2E = 1.4426950408889634074;
+    auto gscale = [&](int r) { return r == 1 ? 2.0 * kL2E : -kL2E; };      // rows i, j, f, o
+    for (int t = 0; t < kNT; ++t) {
+      const int cA = col(t, rho), r = rho & 3;
+      for (int ch = 0; ch < bx::nchunks(pre); ++ch) {
+        uint16_t sl[8][3];
+        for (int i = 0; i < 8; ++i)
+          for (int sp = 0; sp < 3; ++sp) sl[i][sp] = 0;
+        for (int i = 0; i < 5; ++i) {
+          const int u = 4 * i + kq;
+          double v;
+          if (ch == bx::kChL1H) v = wg1[(P + u) * G + cA];
+          else if (ch == bx::kChL2A) v = wg2[u * G + cA];
+          else if (ch == bx::kChL2B) v = wg2[(kH + u) * G + cA];
+          else v = wg1[u * G + cA];                              // kChL1X: the fc features
+          bf16_split3(v * gscale(r), sl[i]);
+        }
+        if (kq == 0 && (ch == bx::kChL1H || ch == bx::kChL2A)) {
+          const double bv = (double)(ch == bx::kChL1H ? bg1[cA] : bg2[cA]) + (r == 2 ? 1.0 : 0.0);   // forget_bias
+          bf16_split3(bv * gscale(r), sl[7]);
+        }
+        for (int sp = 0; sp < 3; ++sp)
+          for (int j = 0; j < 4; ++j)
+            ow[bx::frag_off(pre, ch, t, sp) + l * 4 + j] = (uint32_t)sl[2 * j][sp] | ((uint32_t)sl[2 * j + 1][sp] << 16);
+      }
+      if (!fc)
+        for (int rr = 0; rr < 4; ++rr) {
+          const int cD = col(t, 4 * q + rr);
+          out[bx::win_off(pre) + t * 256 + l * 4 + rr] = (float)((double)wg1[0 * G + cD] * gscale(rr));
+          out[bx::win_off(pre) + (kNT + t) * 256 + l * 4 + rr] =
+              P == 2 ? (float)((double)wg1[1 * G + cD] * gscale(rr)) : 0.0f;
+        }
+    }
+  }
+  // ---- bf16x3 fragments of the transposed products of the BPTT step (l2o_bwd_mfma.h): W itself,
+  //      unscaled; M-tile rows = input rows of W, K-chunk r = gate type r (Sonnet column block) ----
+  {
+    uint32_t* ow = reinterpret_cast<uint32_t*>(out) + bxb::base(pre);
+    for (int tile = 0; tile < bxb::ntiles(pre); ++tile) {
+      const bool l2 = tile < bxb::tiles2();
+      const int m = l2 ? tile : tile - bxb::tiles2();
+      const float* W = l2 ? wg2 : wg1;
+      const int first = l2 ? 0 : (fc ? 0 : -1), second = l2 ? kH : (fc ? kH : P);
+      const int row = bxb::src_row(m, rho, first, second);
+      if (row < 0) continue;
+      for (int r = 0; r < 4; ++r) {
+        uint16_t sl[8][3];
+        for (int i = 0; i < 8; ++i)
+          for (int sp = 0; sp < 3; ++sp) sl[i][sp] = 0;
+        for (int i = 0; i < 5; ++i) bf16_split3((double)W[row * G + r * kH + 4 * i + kq], sl[i]);
+        for (int sp = 0; sp < 3; ++sp)
+          for (int j = 0; j < 4; ++j)
+            ow[bxb::frag_rel(tile, r, sp) + l * 4 + j] = (uint32_t)sl[2 * j][sp] | ((uint32_t)sl[2 * j + 1][sp] << 16);
+      }
+    }
+  }
+}
+
+__global__ void k_wpack(int pre, const float* wg1, const float* bg1, const float* wg2, const float* bg2, const float* wl,
+                        const float* bl, const float* wfc, const float* bfc, float* out) {
+  wpack_lane(pre, threadIdx.x, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
+}
+
+// tf.train.AdamOptimizer._apply_dense (TF 1.x) on one flat fp32 vector, every operation rounded separately
+// like the NumPy expression it replaces (no contraction): bit-equal to the host update
+__global__ void k_adam(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                       long n, float lr_t, float b1, float omb1, float b2, float omb2, float eps) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = __fadd_rn(__fmul_rn(b1, m[i]), __fmul_rn(omb1, gi));
+  const float vi = __fadd_rn(__fmul_rn(b2, v[i]), __fmul_rn(__fmul_rn(omb2, gi), gi));
+  m[i] = mi; v[i] = vi;
+  w[i] = __fsub_rn(w[i], __fdiv_rn(__fmul_rn(lr_t, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
 }
 
 int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, const float* wg2,
@@ -1110,115 +1232,34 @@ int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, c
   const int pre = cfg->preprocess;
   const bool fc = pre == L2O_PRE_FC_ELU;
   if (fc && (!wfc || !bfc)) return fail(L2O_ERR_ARG, "l2o_wpack_host: fc preprocess needs input_projection");
-  const int P = fc ? kH : (pre == L2O_PRE_LOGSIGN ? 2 : 1);
-  const int G = 4 * kH;
-  std::memset(out, 0, sizeof(float) * wp_rows(pre) * 64);
-  auto col = [](int t, int rho) { return (rho & 3) * kH + 4 * t + (rho >> 2); };
-  for (int l = 0; l < 64; ++l) {
-    const int rho = l & 15, kq = l >> 4;   // A-fragment view of the lane
-    const int q = l >> 4;                  // C/D + B view of the lane
-    for (int t = 0; t < kNT; ++t) {
-      const int cA = col(t, rho);
-      // layer 1
-      if (fc) {
-        for (int kk = 0; kk < 10; ++kk) {
-          const int row = kk < 5 ? 4 * kk + kq : kH + 4 * (kk - 5) + kq;   // fc features, then h1
-          out[(wp_row_a1(pre) + kk * kNT + t) * 64 + l] = wg1[row * G + cA];
-        }
-      } else {
-        for (int kk = 0; kk < 5; ++kk)
-          out[(wp_row_a1(pre) + kk * kNT + t) * 64 + l] = wg1[(P + 4 * kk + kq) * G + cA];
-        float v = 0.0f;
-        if (kq == 0) v = wg1[0 * G + cA];
-        else if (kq == 1) v = P == 2 ? wg1[1 * G + cA] : 0.0f;
-        else if (kq == 2) v = bg1[cA];
-        out[(wp_row_a1(pre) + 5 * kNT + t) * 64 + l] = v;
-      }
-      // layer 2: kk 0..4 <- h1 (rows 0..19), kk 5..9 <- h2 (rows 20..39)
-      for (int kk = 0; kk < 10; ++kk) {
-        const int row = kk < 5 ? 4 * kk + kq : kH + 4 * (kk - 5) + kq;
-        out[(wp_row_a2(pre) + kk * kNT + t) * 64 + l] = wg2[row * G + cA];
-      }
-      for (int r = 0; r < 4; ++r) {
-        const int cD = col(t, 4 * q + r);
-        out[(wp_row_b1(pre) + t * 4 + r) * 64 + l] = fc ? bg1[cD] : 0.0f;
-        out[(wp_row_b2(pre) + t * 4 + r) * 64 + l] = bg2[cD];
-      }
-      out[(wp_row_wl(pre) + t) * 64 + l] = wl[4 * t + q];
-      if (fc) {
-        out[(wp_row_fc(pre) + t) * 64 + l] = wfc[0 * kH + 4 * t + q];
-        out[(wp_row_fc(pre) + kNT + t) * 64 + l] = wfc[1 * kH + 4 * t + q];
-        out[(wp_row_fc(pre) + 2 * kNT + t) * 64 + l] = bfc[4 * t + q];
-      }
-    }
-    out[wp_row_bl(pre) * 64 + l] = bl[0];
-  }
-  // ---- bf16x3 fragments: gate rows pre-scaled to exp2 arguments, split from float64 ----
-  {
-    uint32_t* ow = reinterpret_cast<uint32_t*>(out);
-    std::memset(ow + bx::base(pre), 0, sizeof(uint32_t) * bx::words(pre));
-    constexpr double kL2E = 1.4426950408889634074;
-    auto gscale = [&](int r) { return r == 1 ? 2.0 * kL2E : -kL2E; };      // rows i, j, f, o
-    for (int l = 0; l < 64; ++l) {
-      const int rho = l & 15, kq = l >> 4;
-      const int q = l >> 4;
-      for (int t = 0; t < kNT; ++t) {
-        const int cA = col(t, rho), r = rho & 3;
-        for (int ch = 0; ch < bx::nchunks(pre); ++ch) {
-          uint16_t sl[8][3];
-          std::memset(sl, 0, sizeof(sl));
-          for (int i = 0; i < 5; ++i) {
-            const int u = 4 * i + kq;
-            double v;
-            if (ch == bx::kChL1H) v = wg1[(P + u) * G + cA];
-            else if (ch == bx::kChL2A) v = wg2[u * G + cA];
-            else if (ch == bx::kChL2B) v = wg2[(kH + u) * G + cA];
-            else v = wg1[u * G + cA];                              // kChL1X: the fc features
-            bf16_split3(v * gscale(r), sl[i]);
-          }
-          if (kq == 0 && (ch == bx::kChL1H || ch == bx::kChL2A)) {
-            const double bv = (double)(ch == bx::kChL1H ? bg1[cA] : bg2[cA]) + (r == 2 ? 1.0 : 0.0);   // forget_bias
-            bf16_split3(bv * gscale(r), sl[7]);
-          }
-          for (int sp = 0; sp < 3; ++sp)
-            for (int j = 0; j < 4; ++j)
-              ow[bx::frag_off(pre, ch, t, sp) + l * 4 + j] = (uint32_t)sl[2 * j][sp] | ((uint32_t)sl[2 * j + 1][sp] << 16);
-        }
-        if (!fc)
-          for (int rr = 0; rr < 4; ++rr) {
-            const int cD = col(t, 4 * q + rr);
-            out[bx::win_off(pre) + t * 256 + l * 4 + rr] = (float)((double)wg1[0 * G + cD] * gscale(rr));
-            out[bx::win_off(pre) + (kNT + t) * 256 + l * 4 + rr] =
-                P == 2 ? (float)((double)wg1[1 * G + cD] * gscale(rr)) : 0.0f;
-          }
-      }
-    }
-  }
-  // ---- bf16x3 fragments of the transposed products of the BPTT step (l2o_bwd_mfma.h): W itself,
-  //      unscaled; M-tile rows = input rows of W, K-chunk r = gate type r (Sonnet column block) ----
-  {
-    uint32_t* ow = reinterpret_cast<uint32_t*>(out) + bxb::base(pre);
-    std::memset(ow, 0, sizeof(uint32_t) * bxb::words(pre));
-    for (int tile = 0; tile < bxb::ntiles(pre); ++tile) {
-      const bool l2 = tile < bxb::tiles2();
-      const int m = l2 ? tile : tile - bxb::tiles2();
-      const float* W = l2 ? wg2 : wg1;
-      const int first = l2 ? 0 : (fc ? 0 : -1), second = l2 ? kH : (fc ? kH : P);
-      for (int l = 0; l < 64; ++l) {
-        const int rho = l & 15, kq = l >> 4;
-        const int row = bxb::src_row(m, rho, first, second);
-        if (row < 0) continue;
-        for (int r = 0; r < 4; ++r) {
-          uint16_t sl[8][3];
-          std::memset(sl, 0, sizeof(sl));
-          for (int i = 0; i < 5; ++i) bf16_split3((double)W[row * G + r * kH + 4 * i + kq], sl[i]);
-          for (int sp = 0; sp < 3; ++sp)
-            for (int j = 0; j < 4; ++j)
-              ow[bxb::frag_rel(tile, r, sp) + l * 4 + j] = (uint32_t)sl[2 * j][sp] | ((uint32_t)sl[2 * j + 1][sp] << 16);
-        }
-      }
-    }
-  }
+  std::memset(out, 0, sizeof(float) * l2o_wpack_floats(cfg));
+  for (int l = 0; l < 64; ++l) wpack_lane(pre, l, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
+  return L2O_OK;
+}
+
+int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wpack, void* stream) {
+  if (!cfg || !w || !wpack) return fail(L2O_ERR_ARG, "l2o_wpack_device: NULL argument");
+  if (!net_ok_for_mfma(cfg) || cfg->n_layers == 0)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_wpack_device: layers=(20,20) nets only");
+  const bool fc = cfg->preprocess == L2O_PRE_FC_ELU;
+  if (!w->w_gates1 || !w->b_gates1 || !w->w_gates2 || !w->b_gates2 || !w->w_lin || !w->b_lin ||
+      (fc && (!w->w_fc || !w->b_fc)))
+    return fail(L2O_ERR_ARG, "l2o_wpack_device: NULL weight pointer");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(wpack, 0, sizeof(float) * l2o_wpack_floats(cfg), s));
+  hipLaunchKernelGGL(k_wpack, dim3(1), dim3(64), 0, s, (int)cfg->preprocess, w->w_gates1, w->b_gates1, w->w_gates2,
+                     w->b_gates2, w->w_lin, w->b_lin, w->w_fc, w->b_fc, wpack);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+int l2o_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1, double beta2,
+                  double epsilon, void* stream) {
+  if (!w || !m || !v || !g || n < 0) return fail(L2O_ERR_ARG, "l2o_adam_step: bad argument");
+  if (n == 0) return L2O_OK;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, m, v, g, (long)n,
+                     lr_t, (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)epsilon);
+  HIP_TRY(hipGetLastError());
   return L2O_OK;
 }
 

@@ -201,6 +201,19 @@ _DEFAULT_CONFIG = {
         }}}
 
 
+class _DevGrad(object):
+    """A weight gradient that stays on the device (the meta-step consumes it there); NumPy sees it as an
+    array (copied to the host on demand: tests, the host Adam path)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.t.detach().cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
 class _LazyHost(object):
     """res["x"]: the final iterates, copied device -> host when (and only when) one is fetched
     (every .cpu() is a stream synchronisation; sess.run([fx, update, step]) does not ask for x)."""
@@ -835,6 +848,9 @@ class UnrollGraph(object):
             for acc in out.values():
                 for k in sorted(acc):
                     dist.all_reduce(acc[k])
+        if all(self._device_adam(self.nets[key]) for key in out):
+            # the meta-step runs on the device: the gradients never visit the host
+            return {key: {k: _DevGrad(v) for k, v in acc.items()} for key, acc in out.items()}
         # ONE device-to-host copy for all weight gradients (each .cpu() is a stream sync + a transfer)
         items = [(key, k, v) for key, acc in out.items() for k, v in acc.items()]
         if not items:
@@ -847,6 +863,44 @@ class UnrollGraph(object):
             off += n
         return res
 
+    def _device_adam(self, net):
+        """Adam + weight re-pack on the device (l2o_adam_step, l2o_wpack_device) for the LSTM nets when the
+        engine has them; L2O_HOST_ADAM=1 keeps the NumPy meta-step."""
+        return (hasattr(self.engine, "adam_step") and isinstance(net, networks.StandardDeepLSTM)
+                and len(net.spec.layers) > 0 and not os.environ.get("L2O_HOST_ADAM"))
+
+    def _adam_apply_device(self, key, acc, st, lr_t, beta1, beta2, epsilon):
+        """One network's meta-step without a host round trip: the gradients are laid out like the flat
+        Sonnet-layout weight buffer (one torch.cat), l2o_adam_step updates that buffer in place and
+        l2o_wpack_device rebuilds the MFMA-fragment copy from it.  The host dict goes stale (lazy refresh)."""
+        import torch
+        eng, net = self.engine, self.nets[key]
+        wdev = net.device_weights(eng)
+        buf, offs, names = net._wdev_buf, net._wdev_offs, net._wdev_names
+        ds = st.setdefault("dev", {})
+        ent = ds.get(key)
+        if ent is None or ent["g"].numel() != buf.numel():
+            ent = ds[key] = {"g": eng.zeros(buf.numel()), "m": eng.zeros(buf.numel()), "v": eng.zeros(buf.numel()),
+                             "zeros": eng.zeros(8)}
+        parts, pos = [], 0
+        for k, (o, shp) in offs.items():                   # buffer order; 16-byte aligned parts
+            n = int(np.prod(shp))
+            if o > pos:
+                parts.append(ent["zeros"][:o - pos])
+            gk = acc.get(names[k])
+            if gk is None:
+                parts.append(torch.zeros(n, dtype=torch.float32, device=buf.device))
+            else:
+                t = gk.t if isinstance(gk, _DevGrad) else eng.tensor(np.asarray(gk, np.float32))
+                parts.append(t.reshape(-1))
+            pos = o + n
+        if buf.numel() > pos:
+            parts.append(ent["zeros"][:buf.numel() - pos])
+        torch.cat(parts, out=ent["g"])
+        eng.adam_step(buf, ent["m"], ent["v"], ent["g"], lr_t, beta1, beta2, epsilon)
+        eng.pack_weights_device(net.spec, wdev, wdev["wpack"])
+        net.mark_device_updated()
+
     def _adam_apply(self, grads, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, slot="_adam"):
         """tf.train.AdamOptimizer's update (TF 1.x `_apply_dense`): lr_t = lr sqrt(1-b2^t)/(1-b1^t);
         m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; var <- var - lr_t m / (sqrt(v) + eps).
@@ -858,6 +912,9 @@ class UnrollGraph(object):
         lr_t = f(learning_rate * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
         for key, acc in grads.items():                     # one flat vector per network: a handful of NumPy calls
             net = self.nets[key]
+            if self._device_adam(net):
+                self._adam_apply_device(key, acc, st, lr_t, beta1, beta2, epsilon)
+                continue
             names = list(acc.keys())
             g = np.concatenate([np.asarray(acc[k], np.float32).reshape(-1) for k in names])
             w = np.concatenate([net.variables[mod][var].reshape(-1) for mod, var in names])
@@ -1283,7 +1340,10 @@ class MtUnroll(object):
                     [r[si] for r in rec["st"]], [r[si] for r in rec["m"]], [r[si] for r in rec["v"]],
                     [r[si] for r in rec["dx"]])
         eng = self.engine
-        grads = {key: {k: eng.to_numpy(v) for k, v in acc.items()} for key, acc in out.items()}
+        if all(g._device_adam(g.nets[key]) for key in out):
+            grads = {key: {k: _DevGrad(v) for k, v in acc.items()} for key, acc in out.items()}
+        else:
+            grads = {key: {k: eng.to_numpy(v) for k, v in acc.items()} for key, acc in out.items()}
         g._adam_apply(grads, learning_rate, slot="_adam_mt%d" % self.mti)
         return {"loss": np.float32(eng.to_numpy(loss)[0])}
 

@@ -174,11 +174,39 @@ class StandardDeepLSTM(Network):
                               lambda: _truncated_normal((size_in, output_size), size_in)),
             "b": _materialize(init.get("b"), (output_size,), lambda: np.zeros((output_size,), np.float32)),
         }
+        self._host_stale = False
         self.variables = variables
         self.spec = NetSpec(kind=self._kind, preprocess=pre, layers=self._layers, scale=float(scale),
                             tanh_output=bool(tanh_output), logsign_k=k)
         self._wpack = None
         self._wpack_engine = None
+
+    # -- host view of the weights -------------------------------------------
+    # The .l2l dict {module: {variable: ndarray}} is the master copy until the meta-step runs on the
+    # device (MetaOptimizer.meta_minimize with the HIP engine: Adam + re-pack without a host round
+    # trip); from then on the flat device buffer of device_weights() is, and the dict is refreshed from
+    # it the next time somebody reads it (save, assign, tests).
+    @property
+    def variables(self):
+        if self._host_stale:
+            self._pull_from_device()
+        return self._variables
+
+    @variables.setter
+    def variables(self, value):
+        self._variables = value
+        self._host_stale = False
+
+    def _pull_from_device(self):
+        flat = self._wdev_engine.to_numpy(self._wdev_buf)
+        for k, (o, shp) in self._wdev_offs.items():
+            mod, var = self._wdev_names[k]
+            self._variables[mod][var] = flat[o:o + int(np.prod(shp))].reshape(shp).copy()
+        self._host_stale = False
+
+    def mark_device_updated(self):
+        """The flat device buffer (and the packed copy) were updated in place: the host dict is stale."""
+        self._host_stale = True
 
     # -- device weights ----------------------------------------------------
     def wpack(self, engine):
@@ -193,8 +221,8 @@ class StandardDeepLSTM(Network):
 
     def assign(self, module_name, variable_name, value):
         """Overwrite one weight (used by MetaOptimizer.restore and the Adam meta-step)."""
-        cur = self.variables[module_name][variable_name]
-        self.variables[module_name][variable_name] = np.asarray(value, np.float32).reshape(cur.shape).copy()
+        cur = self.variables[module_name][variable_name]          # (refreshes a stale host copy first)
+        self._variables[module_name][variable_name] = np.asarray(value, np.float32).reshape(cur.shape).copy()
         self._wpack = None
         self._wdev = None
 
@@ -221,6 +249,7 @@ class StandardDeepLSTM(Network):
             flat = np.concatenate(parts)
             buf = engine.upload((id(self), "wdev"), flat) if hasattr(engine, "upload") else engine.tensor(flat)
             self._wdev = {k: buf[o:o + int(np.prod(shp))].view(*shp) for k, (o, shp) in offs.items()}
+            self._wdev_buf, self._wdev_offs, self._wdev_names = buf, offs, names
             if len(self.spec.layers):
                 self._wdev["wpack"] = self.wpack(engine)      # selects the matrix-core BPTT kernel
             self._wdev_engine = engine

@@ -563,3 +563,87 @@ def test_planned_mlp_unroll_equals_step_path(name, monkeypatch):
                 assert float(np.abs(np.asarray(ga[key][k]) - np.asarray(gref)).max()) / scale < 1e-4, k
     finally:
         _engine.set_default_engine(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_device_weight_pack_equals_host_pack(name):
+    """l2o_wpack_device (weights that live on the device) == l2o_wpack_host, bit for bit."""
+    from open_l2o_amd._engine import HipEngine, pack_weights_host
+    from helpers import spec_of
+    eng = HipEngine()
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=123, trained_like=True)
+    host = pack_weights_host(eng.lib, spec, params)
+    names = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"), "w_gates2": ("lstm_2", "w_gates"),
+             "b_gates2": ("lstm_2", "b_gates"), "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+             "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+    wdev = {k: eng.tensor(params[m][v]) for k, (m, v) in names.items() if m in params}
+    out = eng.tensor(np.full(host.size, 7.0, np.float32))           # stale contents must be overwritten
+    eng.pack_weights_device(spec, wdev, out)
+    got = eng.to_numpy(out)
+    assert np.array_equal(got.view(np.uint32), host.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dm", "rnnprop"])
+def test_device_meta_step_equals_host_meta_step(name, monkeypatch):
+    """Three meta_minimize steps with Adam + re-pack on the device (l2o_adam_step, l2o_wpack_device) leave the
+    same weights, losses and packed copy as the NumPy meta-step (L2O_HOST_ADAM=1); the host dict is refreshed
+    lazily, and a host-side assign() after device steps is honoured."""
+    from open_l2o_amd import _engine
+    eng = _engine.HipEngine()
+    old = _engine._default_engine
+    _engine.set_default_engine(eng)
+    try:
+        cfg = ORACLE_CFGS[name]
+        rn = cfg.kind == "rnnprop"
+        params = make_params(cfg, seed=77, trained_like=True)
+        B, D, T = 4, 32, 5
+        prob, x0, _ = make_problem("quadratic", B, D, seed=78)
+        res = {}
+        for mode in ("device", "host"):
+            if mode == "host":
+                monkeypatch.setenv("L2O_HOST_ADAM", "1")
+            else:
+                monkeypatch.delenv("L2O_HOST_ADAM", raising=False)
+            problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+            if rn:
+                opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+                out = opt.meta_minimize(problem, T, learning_rate=1e-2)
+                ms, step_ph = out[0], out[3]
+            else:
+                opt = meta.MetaOptimizer(**_net_config(cfg, params))
+                ms, step_ph = opt.meta_minimize(problem, T, learning_rate=1e-2), None
+            net = opt.graph.nets["rp" if rn else "cw"]
+            costs = []
+            with Session() as sess:
+                sess.run(ms.reset)
+                for i in range(3):
+                    feed = {step_ph: 1 + i * T} if rn else {}
+                    costs.append(sess.run([ms.fx, ms.update, ms.step], feed_dict=feed)[0])
+                assert net._host_stale == (mode == "device")
+                w = {m: {v: a.copy() for v, a in d.items()} for m, d in net.variables.items()}
+                assert not net._host_stale
+                packed = eng.to_numpy(net.wpack(eng)).copy()
+                # a host-side write after device steps: picked up by the next unroll
+                net.assign("linear", "b", np.array([0.25], np.float32))
+                feed = {step_ph: 1 + 3 * T} if rn else {}
+                costs.append(sess.run([ms.fx, ms.update, ms.step], feed_dict=feed)[0])
+                w2 = {m: {v: a.copy() for v, a in d.items()} for m, d in net.variables.items()}
+            res[mode] = (costs, w, packed, w2)
+        for a, b in zip(res["device"][0], res["host"][0]):
+            assert rel_err(a, b) < 1e-6
+        for key in (1, 3):
+            for m, d in res["host"][key].items():
+                for v, a in d.items():
+                    assert max_abs(res["device"][key][m][v], a) <= 1e-7 * max(1.0, float(np.abs(a).max())), (m, v)
+        assert not np.array_equal(res["host"][1]["lstm_1"]["w_gates"], params["lstm_1"]["w_gates"])
+        # the packed copy the kernels read is the pack of the weights the host sees
+        from open_l2o_amd._engine import pack_weights_host
+        from helpers import spec_of
+        assert np.array_equal(pack_weights_host(eng.lib, spec_of(cfg), res["device"][1]).view(np.uint32),
+                              res["device"][2].view(np.uint32))
+    finally:
+        _engine.set_default_engine(old)
