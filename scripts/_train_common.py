@@ -19,6 +19,8 @@ import random
 import sys
 from timeit import default_timer as timer
 
+import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from open_l2o_amd import meta, meta_dm_train, meta_rnnprop_train, util  # noqa: E402
@@ -65,6 +67,10 @@ class Trainer(object):
         self.rnnprop = rnnprop
         if flags.seed:
             meta.set_random_seed(flags.seed)
+            # the harness' own draws (np.random in util.run_epoch's x-scale, random.random() for the
+            # imitation ratio -- DM/util.py:40-54, DM/train_dm.py) follow the flag too: a seeded run repeats
+            random.seed(flags.seed)
+            np.random.seed(flags.seed)
         if flags.save_path and not os.path.exists(flags.save_path):
             os.mkdir(flags.save_path)
         opts = {k: v for k, v in (("batch_size", flags.batch_size), ("num_dims", flags.num_dims)) if v is not None}
