@@ -67,6 +67,30 @@ class OracleEngine(object):
         t._l2l = {k: {v: np.array(a, np.float32) for v, a in d.items()} for k, d in params.items()}
         return t
 
+    # the meta-step "on the device" (HipEngine.adam_step / pack_weights_device): same contract on CPU
+    # tensors, so that the CPU suite runs the host logic of that path (gradient layout, lazy .l2l refresh)
+    _W_NAMES = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"),
+                "w_gates2": ("lstm_2", "w_gates"), "b_gates2": ("lstm_2", "b_gates"),
+                "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+                "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+
+    def adam_step(self, w, m, v, g, lr_t, beta1, beta2, epsilon):
+        self.calls.append("adam_step")
+        f = np.float32
+        wn, mn, vn, gn = w.numpy(), m.numpy(), v.numpy(), g.numpy()      # views: in place
+        mn[:] = f(beta1) * mn + f(1.0 - beta1) * gn
+        vn[:] = f(beta2) * vn + f(1.0 - beta2) * gn * gn
+        wn[:] = wn - f(lr_t) * mn / (np.sqrt(vn) + f(epsilon))
+
+    def pack_weights_device(self, spec, weights, out):
+        self.calls.append("pack_weights_device")
+        params = {}
+        for k, (mod, var) in self._W_NAMES.items():
+            if weights.get(k) is not None:
+                params.setdefault(mod, {})[var] = weights[k].numpy().copy()
+        out.copy_(torch.from_numpy(pack_weights_host(self.lib, spec, params)))
+        out._l2l = params
+
     def state_floats(self, B, D):
         return int(self.lib.l2o_state_floats(B, D))
 

@@ -647,3 +647,49 @@ def test_device_meta_step_equals_host_meta_step(name, monkeypatch):
                               res["device"][2].view(np.uint32))
     finally:
         _engine.set_default_engine(old)
+
+
+def test_device_meta_step_host_logic_on_cpu(monkeypatch):
+    """The host logic of the device meta-step (gradient layout = flat weight buffer, in-place update, lazy
+    refresh of the .l2l dict, assign() after device steps) on the oracle-backed engine: same weights as the
+    NumPy meta-step, bit for bit (the engine's adam_step is the same NumPy expression)."""
+    from oracle_engine import OracleEngine
+    cfg = ORACLE_CFGS["rnnprop"]
+    params = make_params(cfg, seed=61, trained_like=True)
+    B, D, T = 3, 10, 4
+    prob, x0, _ = make_problem("quadratic", B, D, seed=62)
+    res = {}
+    old = _engine._default_engine
+    try:
+        for mode in ("device", "host"):
+            eng = OracleEngine()
+            _engine.set_default_engine(eng)
+            if mode == "host":
+                monkeypatch.setenv("L2O_HOST_ADAM", "1")
+            else:
+                monkeypatch.delenv("L2O_HOST_ADAM", raising=False)
+            opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+            out = opt.meta_minimize(problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0}), T,
+                                    learning_rate=1e-2)
+            ms, step_ph = out[0], out[3]
+            net = opt.graph.nets["rp"]
+            with Session() as sess:
+                sess.run(ms.reset)
+                for i in range(2):
+                    sess.run([ms.fx, ms.update, ms.step], feed_dict={step_ph: 1 + i * T})
+                assert ("adam_step" in eng.calls) == (mode == "device")
+                assert net._host_stale == (mode == "device")
+                w = {m: {v: a.copy() for v, a in d.items()} for m, d in net.variables.items()}
+                assert not net._host_stale
+                net.assign("linear", "b", np.array([0.5], np.float32))
+                sess.run([ms.fx, ms.update, ms.step], feed_dict={step_ph: 1 + 2 * T})
+                w2 = {m: {v: a.copy() for v, a in d.items()} for m, d in net.variables.items()}
+            res[mode] = (w, w2)
+    finally:
+        _engine.set_default_engine(old)
+    for k in (0, 1):
+        for m, d in res["host"][k].items():
+            for v, a in d.items():
+                assert np.array_equal(res["device"][k][m][v], a), (m, v)
+    assert not np.array_equal(res["host"][0]["lstm_2"]["w_gates"], params["lstm_2"]["w_gates"])
+    assert abs(float(res["host"][1]["linear"]["b"][0]) - 0.5) < 0.05      # the assigned value, moved by one Adam step
