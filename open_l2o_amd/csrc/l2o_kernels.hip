@@ -1088,7 +1088,10 @@ __host__ __device__ static inline void bf16_split3(double v, uint16_t (&out)[3])
 // Lane l's share of the packed weights (the buffer is zero beforehand): the host packer runs it for
 // l = 0..63, the device packer (l2o_wpack_device, the meta-training step) with one thread per lane.
 // The lanes write disjoint words.
-__host__ __device__ static void wpack_lane(int pre, int l, const float* wg1, const float* bg1, const float* wg2,
+// [t_lo, t_hi): unit slices of the forward sections, [tile_lo, tile_hi): M-tiles of the BPTT section (the device
+// packer gives every (lane, slice) and (lane, tile) its own thread: the float64 splits are the cost).
+__host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, int tile_lo, int tile_hi,
+                                           const float* wg1, const float* bg1, const float* wg2,
                                            const float* bg2, const float* wl, const float* bl, const float* wfc,
                                            const float* bfc, float* out) {
   const bool fc = pre == L2O_PRE_FC_ELU;
@@ -1097,7 +1100,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, const float* wg1, con
   auto col = [](int t, int rho) { return (rho & 3) * kH + 4 * t + (rho >> 2); };
   const int rho = l & 15, kq = l >> 4;   // A-fragment view of the lane
   const int q = l >> 4;                  // C/D + B view of the lane
-  for (int t = 0; t < kNT; ++t) {
+  for (int t = t_lo; t < t_hi; ++t) {
     const int cA = col(t, rho);
     // layer 1
     if (fc) {
@@ -1131,13 +1134,13 @@ __host__ __device__ static void wpack_lane(int pre, int l, const float* wg1, con
       out[(wp_row_fc(pre) + 2 * kNT + t) * 64 + l] = bfc[4 * t + q];
     }
   }
-  out[wp_row_bl(pre) * 64 + l] = bl[0];
+  if (t_lo == 0 && t_hi > 0) out[wp_row_bl(pre) * 64 + l] = bl[0];
   // ---- bf16x3 fragments: gate rows pre-scaled to exp2 arguments, split from float64 ----
   {
     uint32_t* ow = reinterpret_cast<uint32_t*>(out);
     constexpr double kL2E = 1.4426950408889634074;
     auto gscale = [&](int r) { return r == 1 ? 2.0 * kL2E : -kL2E; };      // rows i, j, f, o
-    for (int t = 0; t < kNT; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
       const int cA = col(t, rho), r = rho & 3;
       for (int ch = 0; ch < bx::nchunks(pre); ++ch) {
         uint16_t sl[8][3];
@@ -1173,7 +1176,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, const float* wg1, con
   //      unscaled; M-tile rows = input rows of W, K-chunk r = gate type r (Sonnet column block) ----
   {
     uint32_t* ow = reinterpret_cast<uint32_t*>(out) + bxb::base(pre);
-    for (int tile = 0; tile < bxb::ntiles(pre); ++tile) {
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
       const bool l2 = tile < bxb::tiles2();
       const int m = l2 ? tile : tile - bxb::tiles2();
       const float* W = l2 ? wg2 : wg1;
@@ -1195,7 +1198,9 @@ __host__ __device__ static void wpack_lane(int pre, int l, const float* wg1, con
 
 __global__ void k_wpack(int pre, const float* wg1, const float* bg1, const float* wg2, const float* bg2, const float* wl,
                         const float* bl, const float* wfc, const float* bfc, float* out) {
-  wpack_lane(pre, threadIdx.x, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
+  const int b = blockIdx.x;                                   // kNT slice blocks, then one block per BPTT M-tile
+  if (b < kNT) wpack_lane(pre, threadIdx.x, b, b + 1, 0, 0, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
+  else wpack_lane(pre, threadIdx.x, 0, 0, b - kNT, b - kNT + 1, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
 }
 
 // tf.train.AdamOptimizer._apply_dense (TF 1.x) on one flat fp32 vector, every operation rounded separately
@@ -1233,7 +1238,7 @@ int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, c
   const bool fc = pre == L2O_PRE_FC_ELU;
   if (fc && (!wfc || !bfc)) return fail(L2O_ERR_ARG, "l2o_wpack_host: fc preprocess needs input_projection");
   std::memset(out, 0, sizeof(float) * l2o_wpack_floats(cfg));
-  for (int l = 0; l < 64; ++l) wpack_lane(pre, l, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
+  for (int l = 0; l < 64; ++l) wpack_lane(pre, l, 0, kNT, 0, bxb::ntiles(pre), wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
   return L2O_OK;
 }
 
@@ -1247,7 +1252,7 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
     return fail(L2O_ERR_ARG, "l2o_wpack_device: NULL weight pointer");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(wpack, 0, sizeof(float) * l2o_wpack_floats(cfg), s));
-  hipLaunchKernelGGL(k_wpack, dim3(1), dim3(64), 0, s, (int)cfg->preprocess, w->w_gates1, w->b_gates1, w->w_gates2,
+  hipLaunchKernelGGL(k_wpack, dim3(kNT + bxb::ntiles(cfg->preprocess)), dim3(64), 0, s, (int)cfg->preprocess, w->w_gates1, w->b_gates1, w->w_gates2,
                      w->b_gates2, w->w_lin, w->b_lin, w->w_fc, w->b_fc, wpack);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
