@@ -179,3 +179,22 @@ def test_product_path_fails_loudly_without_gpu():
     from open_l2o_amd._engine import HipEngine
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         HipEngine()
+
+
+def test_bench_cli_presets_parse():
+    """bench.py's command line (the driver's contract: --gpus / --steps / --warmup, plus the BASELINE presets)
+    parses without a GPU; the run itself needs one."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--no-cpu-baseline"):
+        assert flag in out.stdout
+
+
+def test_adam_and_device_pack_reject_bad_arguments(lib):
+    from open_l2o_amd import _abi
+    assert lib.l2o_adam_step(None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, None) == _abi.L2O_ERR_ARG
+    cc = spec_of(O.DM_IDENTITY).to_c()
+    assert lib.l2o_wpack_device(C.byref(cc), None, None, None) == _abi.L2O_ERR_ARG
