@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 5
+#define L2O_ABI_VERSION 6
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -99,6 +99,25 @@ typedef struct l2o_problem {
 /* ---- library info ------------------------------------------------------ */
 int l2o_abi_version(void);
 const char* l2o_last_error(void);
+
+/* ---- library options (ABI v6) -------------------------------------------
+ * Process-wide A/B switches between kernels that compute the same thing (all results stay within
+ * the parity tolerance).  The library never reads the environment: a host binding that wants
+ * L2O_* environment variables applies them once through this call (open_l2o_amd/_abi.py does).
+ * Apart from these switches the library keeps no state between calls: per-launch state (status
+ * word, launch sequence) lives in the caller-owned workspace. */
+#define L2O_OPT_PAIR 0               /* 1*: l2o_unroll may split every problem over two CUs; 0: one CU per problem        */
+#define L2O_OPT_PAIR_PLAIN_STORES 1  /* 1*: partners that CONFIRMED (XCC_ID handshake) they share an XCD publish their
+                                        exchange granules with plain stores (L2-resident); 0: agent-scope stores always    */
+#define L2O_OPT_UNROLL_CU 2          /* 1*: the streaming fused unroll for D > 128; 0: such sizes run step-granular         */
+#define L2O_OPT_FG_TWO_PASS 3        /* 0*: l2o_problem_fg reads a per-problem matrix once; 1: the two-pass kernel          */
+#define L2O_OPT_MLP_GENERIC 4        /* 0*: hidden width 20 uses the wave-per-sample MLP kernels; 1: the generic ones       */
+#define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups                 */
+#define L2O_OPT_BWD_KERNEL 6         /* 0*: matrix-core BPTT step (needs wpack); 1: fp32 tile kernel; 2: generic kernel     */
+#define L2O_OPT_MLP_UNROLL 7         /* 1*: l2o_mlp_unroll available to the host layer (0: it reports "unsupported")       */
+#define L2O_OPT_COUNT_ 8             /* (* = default) */
+int l2o_set_option(int32_t option, int64_t value);
+int64_t l2o_get_option(int32_t option);   /* -1 for an unknown option */
 
 /* ---- weights: networks.factory / networks.save (DM/networks.py:34-62) ---
  * The `.l2l` dict {lstm_1:{w_gates,b_gates}, lstm_2:{...}, linear:{w,b},
@@ -295,9 +314,12 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
  * With a workspace, and when 2*B_local workgroups are all co-resident on the device, every
  * problem is split over TWO workgroups (two CUs) that exchange the iterate once per step
  * through tagged 8-byte granules in the workspace; otherwise one workgroup per problem.
- * The first 4 bytes of the workspace are a status word the kernel raises if a partner
- * never showed up (bounded spin, no hang): after synchronising, copy them to the host and
- * pass them to l2o_unroll_status().
+ * The first 4 bytes of the workspace are a STICKY status word the kernel raises if a partner
+ * never showed up (bounded spin, no hang; the results of that launch are then invalid): after
+ * synchronising, copy them to the host and pass them to l2o_unroll_status(); the caller clears
+ * the word (writes 0) once it has handled the error.  The next 4 bytes are a launch sequence
+ * number the kernels maintain (the salt of the exchange tags).  A workspace must start zeroed
+ * and must not be shared by two streams at the same time.
  * Problems beyond the LDS-resident sizes (D <= 512, D % 4 == 0, any M) run the streaming
  * form: one workgroup per problem, the matrix streamed once per step, x / state / moments on-chip
  * for the whole unroll; it needs no workspace (l2o_unroll_workspace_bytes() == 0). */

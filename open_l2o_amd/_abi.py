@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # L2O_HIP_LIB: alternative build of the SAME library (timing ablations, scripts/ablate.sh)
 LIB_PATH = os.environ.get("L2O_HIP_LIB") or os.path.join(_HERE, "libl2o_hip.so")
 
-L2O_ABI_VERSION = 5
+L2O_ABI_VERSION = 6
 L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
 
 NET_CW, NET_RNNPROP = 0, 1
@@ -23,11 +23,28 @@ PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_M
 
 # every symbol include/l2o_abi.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "l2o_abi_version", "l2o_last_error", "l2o_wpack_floats", "l2o_wpack_host",
+    "l2o_abi_version", "l2o_last_error", "l2o_set_option", "l2o_get_option", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
+)
+
+
+# l2o_set_option ids (include/l2o_abi.h)
+OPT_PAIR, OPT_PAIR_PLAIN_STORES, OPT_UNROLL_CU, OPT_FG_TWO_PASS, OPT_MLP_GENERIC, OPT_BWD_BLOCKS, OPT_BWD_KERNEL, \
+    OPT_MLP_UNROLL = range(8)
+# The library never reads the environment; this binding applies these variables ONCE, when it loads it.
+_ENV_OPTIONS = (
+    ("L2O_NO_PAIR", OPT_PAIR, lambda v: 0),
+    ("L2O_PAIR_AGENT_STORES", OPT_PAIR_PLAIN_STORES, lambda v: 0),
+    ("L2O_NO_UNROLL_CU", OPT_UNROLL_CU, lambda v: 0),
+    ("L2O_FG_TWO_PASS", OPT_FG_TWO_PASS, lambda v: 1),
+    ("L2O_MLP_GENERIC", OPT_MLP_GENERIC, lambda v: 1),
+    ("L2O_BWD_BLOCKS", OPT_BWD_BLOCKS, lambda v: int(v)),
+    ("L2O_BWD_TILE", OPT_BWD_KERNEL, lambda v: 1),
+    ("L2O_BWD_GENERIC", OPT_BWD_KERNEL, lambda v: 2),
+    ("L2O_NO_MLP_UNROLL", OPT_MLP_UNROLL, lambda v: 0),
 )
 
 
@@ -124,6 +141,10 @@ def lib():
     L.l2o_abi_version.argtypes = []
     L.l2o_last_error.restype = C.c_char_p
     L.l2o_last_error.argtypes = []
+    L.l2o_set_option.restype = C.c_int
+    L.l2o_set_option.argtypes = [C.c_int32, C.c_int64]
+    L.l2o_get_option.restype = C.c_int64
+    L.l2o_get_option.argtypes = [C.c_int32]
     L.l2o_wpack_floats.restype = C.c_size_t
     L.l2o_wpack_floats.argtypes = [C.POINTER(NetCfg)]
     L.l2o_wpack_host.restype = C.c_int
@@ -175,8 +196,23 @@ def lib():
     if L.l2o_abi_version() != L2O_ABI_VERSION:
         raise RuntimeError("libl2o_hip.so ABI version %d != binding version %d"
                            % (L.l2o_abi_version(), L2O_ABI_VERSION))
+    for name, opt, conv in _ENV_OPTIONS:
+        if os.environ.get(name):
+            L.l2o_set_option(opt, conv(os.environ[name]))
     _lib = L
     return L
+
+
+def set_option(opt, value):
+    """l2o_set_option; returns the previous value (tests restore it)."""
+    L = lib()
+    old = int(L.l2o_get_option(opt))
+    check(L.l2o_set_option(opt, int(value)))
+    return old
+
+
+def get_option(opt):
+    return int(lib().l2o_get_option(opt))
 
 
 def check(rc):

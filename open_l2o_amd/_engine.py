@@ -361,6 +361,8 @@ class HipEngine(object):
         ws = self._last_ws
         if ws is not None:
             hdr = ws[:4].cpu().numpy().tobytes()
+            if hdr != b"\0\0\0\0":
+                ws[:4].zero_()                               # the status word is sticky: handled here, cleared here
             _abi.check(self.lib.l2o_unroll_status(hdr))
 
     def reduce_fx(self, fx_part, T1, B_local, B_global, fx):

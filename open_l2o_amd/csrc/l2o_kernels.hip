@@ -947,24 +947,41 @@ static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
   return g->lds <= 160 * 1024;
 }
 
-static int device_cu_count() {
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-      cus = n;
-    else
-      cus = 0;
+// ---------------------------------------------------------------------------
+// library options (l2o_set_option): process-wide A/B switches, read on the launch paths as plain
+// relaxed atomics.  The library itself never calls getenv(); the Python binding applies the L2O_*
+// environment variables ONCE when it loads the library (open_l2o_amd/_abi.py).
+// ---------------------------------------------------------------------------
+static std::atomic<int64_t> g_opt[L2O_OPT_COUNT_] = {
+    /* L2O_OPT_PAIR */ {1}, /* L2O_OPT_PAIR_PLAIN_STORES */ {1}, /* L2O_OPT_UNROLL_CU */ {1},
+    /* L2O_OPT_FG_TWO_PASS */ {0}, /* L2O_OPT_MLP_GENERIC */ {0}, /* L2O_OPT_BWD_BLOCKS */ {0},
+    /* L2O_OPT_BWD_KERNEL */ {0}, /* L2O_OPT_MLP_UNROLL */ {1}};
+static inline int64_t opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
+
+// CUs of the device the call runs on (the stream's device; the current device for the null stream).
+// Immutable hardware facts cached per device ordinal -- not launch state.
+static int device_cu_count(hipStream_t s) {
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> cache[kMaxDev];
+  int dev = -1;
+  if (s == nullptr || hipStreamGetDevice(s, &dev) != hipSuccess || dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
   }
-  return cus;
+  if (dev < kMaxDev) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (dev < kMaxDev) cache[dev].store(n, std::memory_order_relaxed);
+  return n;
 }
 
 // Split every problem over two workgroups when that still leaves all of them co-resident.
-static bool pair_eligible(const l2o_problem* p, const UnrollGeom& g) {
-  if (getenv("L2O_NO_PAIR")) return false;
+static bool pair_eligible(const l2o_problem* p, const UnrollGeom& g, hipStream_t s) {
+  if (!opt(L2O_OPT_PAIR)) return false;
   if (g.CH < 2) return false;
-  return 2 * p->B_local <= device_cu_count();
+  return 2 * p->B_local <= device_cu_count(s);
 }
 struct PairLayout { size_t xbuf_off, xbuf_bytes, fxh_off, total; int npg; size_t lds; };
 static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) {
@@ -983,32 +1000,31 @@ template <int PRE, int KIND>
 static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s, const l2o_problem* prob,
                             void* workspace) {
   const bool hist = a.hist_st != nullptr;
-  if (workspace && pair_eligible(prob, g)) {
+  if (workspace && pair_eligible(prob, g, s)) {
     const PairLayout L = pair_layout(prob, g, a.T);
     UnrollPairArgs pa;
     pa.u = a;
     pa.ws = reinterpret_cast<PairWs*>(workspace);
     pa.xbuf = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + L.xbuf_off);
     pa.fx_half = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.fxh_off);
-    {
-      // tags carry a per-launch salt on top of the per-launch memset: a granule of an earlier launch that
-      // some cache level still held could otherwise match (same step number) and be taken for the partner's
-      static std::atomic<unsigned> launch_counter{0};
-      pa.salt = a.T + 1 < 0xffff ? ((launch_counter.fetch_add(1, std::memory_order_relaxed) + 1) & 0x7fffu) << 16 : 0u;
-    }
+    // (the per-launch salt of the granule tags is the device-side sequence word ws->seq, which
+    //  k_combine_halves advances after every launch: no host-side launch state)
+    pa.use_salt = a.T + 1 < 0xffff ? 1u : 0u;
+    pa.plain_stores = opt(L2O_OPT_PAIR_PLAIN_STORES) ? 1u : 0u;
     void (*fn)(UnrollPairArgs) = nullptr;
     switch (g.CH) {
       case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : k_unroll_pair<PRE, KIND, 2, false>; break;
       case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
       default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
     }
-    HIP_TRY(hipMemsetAsync(workspace, 0, L.fxh_off, s));
+    // the granules only: the header (sticky status, launch sequence) survives
+    HIP_TRY(hipMemsetAsync(static_cast<char*>(workspace) + L.xbuf_off, 0, L.xbuf_bytes, s));
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
     const int groups = (a.pp.B_local + 7) / 8;
     hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
     HIP_TRY(hipGetLastError());
     const int n = (a.T + 1) * a.pp.B_local;
-    hipLaunchKernelGGL(k_combine_halves, dim3((n + 255) / 256), dim3(256), 0, s, pa.fx_half, a.fx_part, n);
+    hipLaunchKernelGGL(k_combine_halves, dim3((n + 255) / 256), dim3(256), 0, s, pa.fx_half, a.fx_part, n, pa.ws);
     HIP_TRY(hipGetLastError());
     return L2O_OK;
   }
@@ -1041,7 +1057,7 @@ static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind
 // The streaming form (csrc/l2o_unroll_cu.h) takes the sizes the LDS-resident kernels cannot: one
 // workgroup per problem, matrix streamed once per step, LSTM state in LDS (+ registers).
 static bool unroll_cu_eligible(const l2o_problem* p) {
-  if (getenv("L2O_NO_UNROLL_CU")) return false;
+  if (!opt(L2O_OPT_UNROLL_CU)) return false;
   if (p->D < 4 || p->D > 512 || (p->D & 3) || p->M <= 0) return false;   // (D <= 128: only when the rows do not fit the LDS forms)
   return unroll_cu_layout(p->D).lds <= 160 * 1024;
 }
@@ -1061,6 +1077,16 @@ extern "C" {
 
 int l2o_abi_version(void) { return L2O_ABI_VERSION; }
 const char* l2o_last_error(void) { return g_err; }
+
+int l2o_set_option(int32_t option, int64_t value) {
+  if (option < 0 || option >= L2O_OPT_COUNT_) return fail(L2O_ERR_ARG, "l2o_set_option: unknown option %d", option);
+  g_opt[option].store(value, std::memory_order_relaxed);
+  return L2O_OK;
+}
+int64_t l2o_get_option(int32_t option) {
+  if (option < 0 || option >= L2O_OPT_COUNT_) return -1;
+  return opt(option);
+}
 
 size_t l2o_wpack_floats(const l2o_net_cfg* cfg) {
   if (!cfg) return 0;
@@ -1302,7 +1328,7 @@ int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float
   if (lds > 160 * 1024) return fail(L2O_ERR_UNSUPPORTED, "problem too large for k_problem_fg (D=%d M=%d)", pp.D, pp.M);
   const bool vec = pp.kind != L2O_PROB_SIMPLE && (pp.D & 3) == 0 && ((uintptr_t)pp.W & 15) == 0;
   if (vec && pp.D >= 64 && pp.D <= 2048 && ((uintptr_t)x & 15) == 0 && (!pp.x_scale || ((uintptr_t)pp.x_scale & 15) == 0) &&
-      !pp.w_shared && !getenv("L2O_FG_TWO_PASS")) {         // single pass over the matrix (a shared, L2-resident
+      !pp.w_shared && !opt(L2O_OPT_FG_TWO_PASS)) {         // single pass over the matrix (a shared, L2-resident
                                                             // matrix is faster in two passes: 20 vs 28 us for config 3)
     const size_t lds1 = sizeof(float) * ((size_t)kFgWaves * pp.D + kFgWaves);
     void (*f1)(ProbParams, const float*, float*, float*) =
@@ -1348,7 +1374,7 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
   if (lds_small > lds_b) lds_b = lds_small;
   if (lds_f > 160 * 1024 || lds_b > 160 * 1024)
     return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_fg: needs %zu / %zu bytes of LDS", lds_f, lds_b);
-  if (p.H == kMlp20 && !getenv("L2O_MLP_GENERIC")) {       // the reference's width: barrier-free forward, scalar-operand backward
+  if (p.H == kMlp20 && !opt(L2O_OPT_MLP_GENERIC)) {       // the reference's width: barrier-free forward, scalar-operand backward
     hipLaunchKernelGGL(k_mlp_fwd20, dim3(p.batch), dim3(64), 0, s, p);
     HIP_TRY(hipGetLastError());
     const int nkb20 = (p.n_in + 63) / 64;
@@ -1444,13 +1470,13 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, 
 
 static int launch_bwd_tile(const BwdParams& p, int pre, hipStream_t s) {
   size_t nblk = ((size_t)p.tile_end[p.nseg - 1] + 3) / 4;
-  size_t cap = (size_t)device_cu_count();               // persistent: one workgroup per CU walks the tile groups
-  if (const char* e = getenv("L2O_BWD_BLOCKS")) cap = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : cap;
+  size_t cap = (size_t)device_cu_count(s);              // persistent: one workgroup per CU walks the tile groups
+  if (opt(L2O_OPT_BWD_BLOCKS) > 0) cap = (size_t)opt(L2O_OPT_BWD_BLOCKS);
   if (nblk > cap && p.T <= 1) nblk = cap;                  // (a T-step launch keeps one workgroup per four tiles: each lives T steps)
   const dim3 grid((unsigned)nblk), block(256);
   void (*fn)(BwdParams) = nullptr;
   size_t lds = 0;
-  if (p.wpack && !getenv("L2O_BWD_TILE")) {                // the matrix-core form needs the packed weights
+  if (p.wpack && opt(L2O_OPT_BWD_KERNEL) == 0) {                // the matrix-core form needs the packed weights
     switch (pre) {
       case L2O_PRE_IDENTITY: fn = k_cwlstm_bwd_mfma<L2O_PRE_IDENTITY>; lds = BwdMfmaGeom<L2O_PRE_IDENTITY>::kLdsFloats; break;
       case L2O_PRE_LOGSIGN: fn = k_cwlstm_bwd_mfma<L2O_PRE_LOGSIGN>; lds = BwdMfmaGeom<L2O_PRE_LOGSIGN>::kLdsFloats; break;
@@ -1608,7 +1634,7 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
                         (pre != L2O_PRE_FC_ELU || (io->feats == io->act1 + K1q + 3 * kH && io->du == io->dz1 + 8 * kH + 1 &&
                                                    io->m && io->v && w->w_fc && w->b_fc));
     if (layout && (D % kTile == 0 || B == 1) && ((uintptr_t)io->act1 & 15) == 0 && ((uintptr_t)io->dz1 & 15) == 0 &&
-        !getenv("L2O_BWD_GENERIC")) {
+        opt(L2O_OPT_BWD_KERNEL) != 2) {
       p.nseg = 1;
       p.tile_end[0] = (int)((N + kTile - 1) / kTile);
       p.seg_n[0] = (long)N;

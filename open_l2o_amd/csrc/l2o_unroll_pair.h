@@ -25,9 +25,11 @@
 // (1 KB per wave ds_read_b128 x 32 per wave per pass = 1024 cycles per CU).
 #pragma once
 
-struct PairWs {               // header of the caller-owned workspace
-  unsigned status;            // 0 ok, 1 = partner timeout
-  unsigned pad[15];
+struct PairWs {               // header of the caller-owned workspace (never cleared by the library)
+  unsigned status;            // 0 ok, 1 = partner timeout.  STICKY: raised by the kernel, cleared by the caller
+  unsigned seq;               // launch sequence number: read by every workgroup of a launch (tag salt), advanced
+                              // by k_combine_halves after it -- the library keeps no host-side launch state
+  unsigned pad[14];
   long long phases[16];       // phase clock dump of the -DL2O_PROFILE_PHASES build (else unused)
 };
 
@@ -36,7 +38,9 @@ struct UnrollPairArgs {
   PairWs* ws;
   unsigned long long* xbuf;   // [B][2 halves][2 parities][SQ] granules (partial residuals)
   float* fx_half;             // [(T+1)][2*B]
-  unsigned salt;              // per-launch value in the tags' upper bits: a granule left by an earlier launch never matches
+  unsigned use_salt;          // tags carry the launch sequence in their upper bits (T + 1 < 65 535): a granule left by an
+                              // earlier launch never matches, on top of the memset of the granule area ahead of every launch
+  unsigned plain_stores;      // L2O_OPT_PAIR_PLAIN_STORES: a confirmed same-XCD pair publishes with plain stores
 };
 
 __device__ __forceinline__ unsigned long long pack_granule(float v, unsigned tag) {
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   // partner workgroups are blockIdx b and b + 8 inside a group of 16 (same XCD under the
   // observed round-robin placement -- a speed choice only)
   const int bid = blockIdx.x;
+  const unsigned salt = pa.use_salt ? ((pa.ws->seq + 1u) & 0x7fffu) << 16 : 0u;
   const int half = (bid >> 3) & 1;
   const int b = ((bid >> 4) << 3) | (bid & 7);          // problem index
   if (b >= pp.B_local) return;                          // padding blocks of the last group of 16 (both halves)
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xfu;
-    const unsigned kHsTag = 0x80000000u | pa.salt | 0xffffu;
+    const unsigned kHsTag = 0x80000000u | salt | 0xffffu;
     __hip_atomic_store(mine + SQ, ((unsigned long long)kHsTag << 32) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long g = 0;
     int spins = 0;
@@ -186,10 +191,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       if (++spins > (1 << 20)) { ok = false; break; }       // (the step loop reports a missing partner)
       __builtin_amdgcn_s_sleep(1);
     }
-#ifdef L2O_PAIR_AGENT_STORES
-    ok = false;
-#endif
-    same_xcd_s = ok && ((unsigned)g & 0xfu) == my_xcc;
+    same_xcd_s = ok && pa.plain_stores && ((unsigned)g & 0xfu) == my_xcc;
   }
   __syncthreads();
   const bool same_xcd = same_xcd_s != 0;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const size_t hist_n = (size_t)pp.B_local * D;
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
-    const unsigned tag = pa.salt | ((unsigned)t + 1u);     // (T + 1 < 65 535 when salt != 0; the handshake tag ends in 0xffff)
+    const unsigned tag = salt | ((unsigned)t + 1u);     // (T + 1 < 65 535 when salt != 0; the handshake tag ends in 0xffff)
     const int par = t & 1;
     if (q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
     if (HIST && t < a.T && tile_real)
@@ -344,8 +346,10 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   if (tile_real) store_tile_state(s, st_tile, lane);
 }
 
-// fx_part[t][b] = fx_half[t][2b] + fx_half[t][2b+1]
-__global__ void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part, int n) {
+// fx_part[t][b] = fx_half[t][2b] + fx_half[t][2b+1]; runs after every workgroup of the unroll has
+// finished, so it also advances the launch sequence word the next launch salts its tags with
+__global__ void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part, int n, PairWs* ws) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) fx_part[i] = fx_half[2 * i] + fx_half[2 * i + 1];
+  if (i == 0) ws->seq = ws->seq + 1u;
 }

@@ -89,11 +89,11 @@ class data_loader(object):
         opt = _OPTIMIZERS[self.optimizers[task_i]]()
         graph.reset()                                       # reset_x: fresh x and problem data
         if if_scale:
-            r_scale = [np.exp(np.random.uniform(-rd_scale_bound, rd_scale_bound, size=k.shape)) for k in self.scale]
+            from . import meta
+            r_scale = [meta.synced_scale(k.shape, rd_scale_bound) for k in self.scale]   # same factors on every rank
             feed_rs = {p: v for p, v in zip(self.scale, r_scale)}
-            k_value_list = [sess.run(self.x[k_id]) / r_scale[k_id] for k_id in range(len(self.scale))]
             assert assign_func is not None
-            assign_func(k_value_list)
+            assign_func([sess.run(v) / meta.local_slice(v, r) for v, r in zip(self.x, r_scale)])
         else:
             feed_rs = {}
         xs = [v.value for v in self.x]

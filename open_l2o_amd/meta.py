@@ -113,8 +113,13 @@ class Variable(object):
         self.value = self._graph.engine.tensor(self._local(self.initial_value()))
 
     def load(self, value, session=None):
-        """tf.Variable.load: assign a (global-shape) value."""
-        self.value = self._graph.engine.tensor(self._local(value))
+        """tf.Variable.load: assign a value -- the GLOBAL shape, or (sharded) this rank's shard, i.e.
+        what ``eval`` / ``sess.run(var)`` returned."""
+        value = np.asarray(value, np.float32)
+        if self.sharded and value.shape == self._graph._local_shape(self) and value.shape != tuple(self.shape):
+            self.value = self._graph.engine.tensor(np.ascontiguousarray(value))
+        else:
+            self.value = self._graph.engine.tensor(self._local(value))
 
     def eval(self, session=None):
         """This rank's shard as an ndarray."""
@@ -242,6 +247,23 @@ def _world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def synced_scale(shape, bound):
+    """exp(U[-bound, bound]) of the given (GLOBAL) shape from ``np.random`` (DM/util.py:44), identical on
+    every rank: drawn on rank 0 and broadcast when torch.distributed is initialised."""
+    arr = np.exp(np.random.uniform(-bound, bound, size=tuple(shape)))
+    if _world()[1] > 1:
+        import torch.distributed as dist
+        box = [arr]
+        dist.broadcast_object_list(box, src=0)
+        arr = box[0]
+    return arr
+
+
+def local_slice(var, arr):
+    """This rank's part of a global-shape array that belongs to ``var`` (the whole array when unsharded)."""
+    return var._local(arr).reshape(var._graph._local_shape(var)) if isinstance(var, Variable) else np.asarray(arr)
 
 
 # ---------------------------------------------------------------------------
@@ -706,7 +728,9 @@ class UnrollGraph(object):
         T = self.len_unroll
         grads = self._backward(T, record)                   # (launched before the host reads anything back)
         self.wait_fx()
-        fx_host = eng.to_numpy(fx)
+        fx_host = eng.to_numpy(fx)                          # host sync
+        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
+            eng.check_unroll_status()                       # a partner timeout leaves a garbage history: raise BEFORE the Adam update
         x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
         self._adam_apply(grads, learning_rate)
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
@@ -766,8 +790,8 @@ class UnrollGraph(object):
         KA = K1 + 2 * H + H + (2 if fc else 0) + 1
         KB = 4 * H + 4 * H + 1 + (H if fc else 0)
         multi = all(pn["D"] % 16 == 0 or pn["B"] == 1 for pn in panels) and len(panels) <= 8
-        fused = multi and wdev.get("wpack") is not None and not any(
-            os.environ.get(k) for k in ("L2O_BWD_STEPWISE", "L2O_BWD_GENERIC", "L2O_BWD_TILE"))   # A/B switches of the tests
+        fused = (multi and wdev.get("wpack") is not None and not os.environ.get("L2O_BWD_STEPWISE")
+                 and _abi.get_option(_abi.OPT_BWD_KERNEL) == 0)                                   # A/B switches of the tests
         groups = [panels] if multi else [[pn] for pn in panels]
         if not fused:
             need_dxs()
@@ -844,10 +868,19 @@ class UnrollGraph(object):
         for key, (net, panels) in by_net.items():      # rec["plan"]: buffers of a planned unroll are reused, so is the table
             self._bptt_panels(net, out.setdefault(key, {}), T, step0, panels, cache=rec.get("plan"))
         if self.sharded:
+            # sum of the shards' weight gradients (1/B_global is already in every gradient): ONE collective
+            # per network on a contiguous buffer -- the entries of `acc` are column blocks of A^T Bm, i.e.
+            # NON-contiguous views, which RCCL rejects and gloo silently mis-reduces
             import torch.distributed as dist
             for acc in out.values():
-                for k in sorted(acc):
-                    dist.all_reduce(acc[k])
+                keys = sorted(acc)
+                flat = torch.cat([acc[k].reshape(-1) for k in keys])
+                dist.all_reduce(flat)
+                off = 0
+                for k in keys:
+                    n = acc[k].numel()
+                    acc[k] = flat[off:off + n].view(acc[k].shape)
+                    off += n
         if all(self._device_adam(self.nets[key]) for key in out):
             # the meta-step runs on the device: the gradients never visit the host
             return {key: {k: _DevGrad(v) for k, v in acc.items()} for key, acc in out.items()}

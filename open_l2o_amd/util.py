@@ -15,49 +15,51 @@ import numpy as np
 from . import problems
 
 
+def _rescale_iterate(sess, scale, bound, assign_func, var_x):
+    """The random x-scaling augmentation of the train drivers (DM/util.py:40-54): draw
+    r = exp(U[-bound, bound]) per coordinate, restart from x / r and feed r to the scale
+    placeholders, so that the optimizee sees x * r == the sampled x0.  Returns the feed dict.
+
+    The factors are drawn with the variables' GLOBAL shapes on rank 0 and broadcast
+    (meta.synced_scale), a rank divides ITS shard of x by ITS slice of r."""
+    from . import meta
+    if scale is None or var_x is None or assign_func is None:
+        raise ValueError("rd_scale=True needs scale, var_x and assign_func")
+    factors = [meta.synced_scale(ph.shape, bound) for ph in scale]
+    assign_func([sess.run(v) / meta.local_slice(v, r) for v, r in zip(var_x, factors)])
+    return dict(zip(scale, factors))
+
+
 def run_epoch(sess, cost_op, ops, reset, num_unrolls,
               scale=None, rd_scale=False, rd_scale_bound=3.0, assign_func=None, var_x=None,
               step=None, unroll_len=None,
               task_i=-1, data=None, label_pl=None, input_pl=None):
-    """Runs one optimization epoch.  DM/util.py:31-75."""
+    """Runs one optimization epoch: `reset`, then `num_unrolls` x {cost_op + ops}; returns
+    (seconds, cost of the last unroll).  Same signature and feeds as DM/util.py:31-75:
+    task_i == -1 is a meta-training epoch on the optimizee (optionally with the random x-scaling
+    of :40-54), task_i >= 0 an imitation epoch that feeds unroll i of a recorded teacher
+    trajectory (`data`, :62-74); RNNProp's `step` placeholder gets i * unroll_len + 1 (:59-60)."""
     start = timer()
     sess.run(reset)
-    cost = None
     if task_i == -1:
-        if rd_scale:
-            assert scale is not None
-            r_scale = []
-            for k in scale:
-                r_scale.append(np.exp(np.random.uniform(-rd_scale_bound, rd_scale_bound, size=k.shape)))
-            assert var_x is not None
-            k_value_list = []
-            for k_id in range(len(var_x)):
-                k_value = sess.run(var_x[k_id])
-                k_value = k_value / r_scale[k_id]
-                k_value_list.append(k_value)
-            assert assign_func is not None
-            assign_func(k_value_list)
-            feed_rs = {p: v for p, v in zip(scale, r_scale)}
-        else:
-            feed_rs = {}
-        feed_dict = feed_rs
-        for i in range(num_unrolls):
-            if step is not None:
-                feed_dict[step] = i * unroll_len + 1
-            cost = sess.run([cost_op] + ops, feed_dict=feed_dict)[0]
-    else:                                               # imitation epoch, DM/util.py:62-74
-        assert data is not None
-        assert input_pl is not None
-        assert label_pl is not None
-        feed_dict = {}
-        for ri in range(num_unrolls):
-            for pl, dat in zip(label_pl, data["labels"][ri]):
-                feed_dict[pl] = dat
-            for pl, dat in zip(input_pl, data["inputs"][ri]):
-                feed_dict[pl] = dat
-            if step is not None:
-                feed_dict[step] = ri * unroll_len + 1
-            cost = sess.run([cost_op] + ops, feed_dict=feed_dict)[0]
+        base = _rescale_iterate(sess, scale, rd_scale_bound, assign_func, var_x) if rd_scale else {}
+
+        def feed_of(i):
+            return dict(base)
+    else:
+        if data is None or input_pl is None or label_pl is None:
+            raise ValueError("an imitation epoch needs data, input_pl and label_pl")
+
+        def feed_of(i):
+            f = dict(zip(label_pl, data["labels"][i]))
+            f.update(zip(input_pl, data["inputs"][i]))
+            return f
+    cost = None
+    for i in range(num_unrolls):
+        feed = feed_of(i)
+        if step is not None:
+            feed[step] = i * unroll_len + 1
+        cost = sess.run([cost_op] + ops, feed_dict=feed)[0]
     return timer() - start, cost
 
 

@@ -79,3 +79,17 @@ def rel_err(a, b):
 
 def max_abs(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def lib_option(opt, value):
+    """Set a libl2o_hip option (l2o_set_option) for the duration of a with-block."""
+    from open_l2o_amd import _abi
+    old = _abi.set_option(opt, value)
+    try:
+        yield
+    finally:
+        _abi.set_option(opt, old)

@@ -98,3 +98,115 @@ def test_two_rank_sharding_matches_single_process(kind, netname):
         # every rank sees the GLOBAL loss (all-reduce), equal to the single-process value
         np.testing.assert_allclose(np.array(out), np.array(ref_out), rtol=2e-6)
         np.testing.assert_allclose(x, ref_x[rank * 4:(rank + 1) * 4], rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------
+# sharded meta-TRAINING: the weight gradients are summed over ranks (one flat all-reduce per
+# network) and every replica takes the same Adam step as the single-process run
+# ---------------------------------------------------------------------------
+def _train(netname, B, D, T, nsteps, if_scale=False):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import ORACLE_CFGS, make_params, make_problem
+    from open_l2o_amd import _engine, meta, meta_dm_train, meta_rnnprop_eval, problems, util
+    from open_l2o_amd.session import Session
+    from oracle_engine import OracleEngine
+    from test_meta_api import _net_config
+
+    _engine.set_default_engine(OracleEngine())
+    cfg = ORACLE_CFGS[netname]
+    params = make_params(cfg, seed=60, trained_like=True)
+    prob, x0, _ = make_problem("quadratic", B, D, seed=61)
+    problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+    np.random.seed(7 + (dist.get_rank() if dist.is_initialized() else 0))     # ranks start UNSYNCHRONISED on purpose
+    if if_scale:
+        opt = meta_dm_train.MetaOptimizer(0, **_net_config(cfg, params))
+        out = opt.meta_minimize(problem, T, learning_rate=1e-2)
+        ms, scale, var_x = out[0], out[1], out[2]
+        costs = []
+        with Session() as sess:
+            for _ in range(nsteps):
+                _, cost = util.run_epoch(sess, ms.fx, [ms.update, ms.step], ms.reset, 2, scale=scale, rd_scale=True,
+                                         rd_scale_bound=1.0, var_x=var_x,
+                                         assign_func=lambda vals: [v.load(a) for v, a in zip(var_x, vals)])
+                costs.append(float(cost))
+        return opt.save(), costs
+    feed = {}
+    if cfg.kind == "rnnprop":
+        opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+        out = opt.meta_minimize(problem, T, learning_rate=1e-2)
+        ms, step = out[0], out[3]
+        feed = {step: 1}
+    else:
+        opt = meta.MetaOptimizer(**_net_config(cfg, params))
+        ms = opt.meta_minimize(problem, T, learning_rate=1e-2)
+    costs = []
+    with Session() as sess:
+        sess.run(ms.reset)
+        for i in range(nsteps):
+            if feed:
+                feed[step] = 1 + i * T
+            costs.append(float(sess.run([ms.fx, ms.update, ms.step], feed_dict=feed)[0]))
+    return opt.save(), costs
+
+
+def _train_worker(rank, world, port, args, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _train(*args))
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_ranks(args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, args, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(2):
+        rank, weights, costs = q.get(timeout=300)
+        results[rank] = (weights, costs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def _assert_same_weights(a, b, tol):
+    assert a.keys() == b.keys()
+    for net in a:
+        for mod in a[net]:
+            for var in a[net][mod]:
+                ref = np.asarray(a[net][mod][var])
+                np.testing.assert_allclose(np.asarray(b[net][mod][var]), ref, rtol=0, atol=tol * max(1.0, float(np.abs(ref).max())),
+                                           err_msg="%s/%s/%s" % (net, mod, var))
+
+
+@pytest.mark.parametrize("netname", ["dm", "rnnprop"])
+def test_two_rank_meta_training_matches_single_process(netname):
+    """the per-block weight gradients are non-contiguous views of A^T Bm; they must be
+    reduced as one contiguous buffer.  lr = 1e-2: a sign flip of one gradient entry moves a weight by
+    2e-2, four orders of magnitude above the tolerance."""
+    args = (netname, 8, 16, 4, 2)
+    ref_w, ref_c = _train(*args)
+    results = _two_ranks(args)
+    for rank in (0, 1):
+        w, c = results[rank]
+        np.testing.assert_allclose(c, ref_c, rtol=5e-6)
+        _assert_same_weights(ref_w, w, 2e-6)
+    _assert_same_weights(results[0][0], results[1][0], 0.0)      # the replicas stay bit-identical
+
+
+def test_two_rank_random_scaling_epoch():
+    """util.run_epoch(rd_scale=True) under batch sharding: the scale factors are drawn with the global
+    shape on rank 0 and broadcast, each rank rescales its own shard; the replicas agree bit for bit."""
+    args = ("dm", 8, 16, 3, 2, True)
+    results = _two_ranks(args)
+    np.testing.assert_allclose(results[0][1], results[1][1], rtol=0)
+    _assert_same_weights(results[0][0], results[1][0], 0.0)

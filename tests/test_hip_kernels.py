@@ -7,8 +7,9 @@ import numpy as np
 import pytest
 
 import oracle as O
-from helpers import (ORACLE_CFGS, device_problem, make_params, make_problem, max_abs, random_state,
+from helpers import (ORACLE_CFGS, device_problem, lib_option, make_params, make_problem, max_abs, random_state,
                      rel_err, spec_of)
+from open_l2o_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
@@ -259,12 +260,8 @@ def test_fused_unroll_random_shapes(eng):
         T = 6
         res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=3)
         for no_pair in (False, True):
-            if no_pair:
-                os.environ["L2O_NO_PAIR"] = "1"
-            try:
+            with lib_option(_abi.OPT_PAIR, 0 if no_pair else 1):
                 fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T, step0=3)
-            finally:
-                os.environ.pop("L2O_NO_PAIR", None)
             e = rel_err(fx, res.fx)
             worst = max(worst, e)
             assert e < 1e-5, (kind, B, D, M, name, no_pair, e)
@@ -449,14 +446,13 @@ def test_mlp_fg_kernel(eng, activation, batch):
     ("lasso", 5, 128, 128, 3),           # the largest fused size (8 tiles, 128 x 128 in LDS)
 ])
 @pytest.mark.parametrize("pair", [True, False])
-def test_fused_edge_cases(eng, monkeypatch, kind, B, D, M, T, pair):
-    if not pair:
-        monkeypatch.setenv("L2O_NO_PAIR", "1")
+def test_fused_edge_cases(eng, kind, B, D, M, T, pair):
     cfg = O.DM_LOGSIGN
     params = make_params(cfg, seed=90, trained_like=True)
     prob, x0, arrays = make_problem(kind, B, D, seed=91, M=M)
     res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
-    fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
+    with lib_option(_abi.OPT_PAIR, 1 if pair else 0):
+        fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
     assert fx.shape == (T + 1,)
     assert rel_err(fx, res.fx) < 1e-5
     assert max_abs(x, res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max()))

@@ -12,7 +12,7 @@ import torch
 
 import oracle as O
 from helpers import ORACLE_CFGS, make_params, make_problem, max_abs, random_state, rel_err, spec_of
-from open_l2o_amd import _engine, meta, meta_rnnprop_eval, problems
+from open_l2o_amd import _abi, _engine, meta, meta_rnnprop_eval, problems
 from open_l2o_amd.session import Session
 from test_meta_api import _net_config, engine  # noqa: F401  (fixture)
 from test_oracle_kat import _torch_lstm_from_sonnet  # noqa: F401
@@ -323,10 +323,7 @@ def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
         prob, x0, _ = make_problem("quadratic", B, D, seed=82)
         got = {}
         for mode in ("tile", "generic"):
-            if mode == "generic":
-                monkeypatch.setenv("L2O_BWD_GENERIC", "1")
-            else:
-                monkeypatch.delenv("L2O_BWD_GENERIC", raising=False)
+            _abi.set_option(_abi.OPT_BWD_KERNEL, 2 if mode == "generic" else 0)
             problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
             if rn:
                 opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
@@ -347,6 +344,7 @@ def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
             scale = max(float(np.abs(gref).max()), 1e-12)
             assert float(np.abs(np.asarray(got["tile"][k]) - np.asarray(gref)).max()) / scale < 1e-4, k
     finally:
+        _abi.set_option(_abi.OPT_BWD_KERNEL, 0)
         _engine.set_default_engine(old)
 
 
