@@ -13,19 +13,26 @@ One "step" of this benchmark = one complete unroll: rewind x / LSTM state -> T x
 (-> all-reduce of the T+1 partial losses over ranks when N > 1).  Inputs are resident in
 HBM when the timed region starts; nothing is copied to the host inside it.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python bench.py --config 3 --steps 5          (the other BASELINE configs: --config 3 / 4 / 5)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W     (N > 1 without WORLD_SIZE: re-launches itself under
+                                                       torch.distributed.run, one rank per GPU, 127.0.0.1)
+    python bench.py --config 3 --steps 5              (the other BASELINE configs: --config 3 / 4 / 5)
+    python bench.py --gpus 8 --scaling strong         (the global batch stays what --batch says)
 
 Prints ONE JSON line (rank 0).  value = coordinate-steps per second, whole job:
-    N_gpus * B_local * D * T * steps / wall_time.
-Weak scaling: every GPU holds its own 128 problems of a global batch 128*N, the loss mean
-is over the global batch (DM/problems.py:99), the only collective is the all-reduce of
-T+1 floats per unroll.  The oracle is imported by the cpu_baseline leg only.
+    sum over ranks of B_local * D * T * steps / wall_time (max over ranks).
+--scaling weak (default): every GPU holds `--batch` problems of a global batch batch*N;
+--scaling strong: the global batch is `--batch`, every GPU holds batch/N of it.  Either way the
+loss mean is over the global batch (DM/problems.py:99) and the only collective is the all-reduce
+of T+1 floats per unroll.  For N > 1 the line also carries, under "also", the config-2 strong-scaling
+run (global batch 128) and the config-4 run (Rastrigin d=100, global batch 1024 sharded over the N
+GPUs) measured in the same job.  The oracle is imported by the cpu_baseline leg only.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,11 +43,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK = 157.3e12
+N_SIMD = 256 * 4           # 256 CUs x 4 SIMDs
+PARITY_PIN = ("reference KATs (tests/golden/reference_kats.json: meta_test / problems_test / preprocess_test / "
+              "networks_test values) + torch.nn.LSTMCell for the LSTM cell; dm-sonnet 1.11 / TF 1.14 are absent, so "
+              "the cell's gate order and forget bias are pinned to Sonnet's published source, not to a reference run")
 
 
 def alg_bytes_per_coord_step(problem, net, D, M):
     """x r+w + LSTM state r+w (+ RNNProp m, v r+w) + the optimizee's matrix
-    streamed for the forward and for the gradient."""
+    streamed for the forward and for the gradient (the step-granular contract figure)."""
     base = 8 + 640 + (16 if net == "rnnprop" else 0)
     if problem == "quadratic":
         return base + 8 * D + 4
@@ -95,6 +106,40 @@ def cpu_baseline(problem, net, arrays, weights, x0, T, max_seconds=20.0):
     return out
 
 
+def cpu_baseline_mnist(weights, batch, T, max_seconds=15.0):
+    """Config 5's CPU leg: the NumPy oracle (oracle/l2o_oracle.py: MnistMLP.fg + the RNNProp inputs of
+    DM/meta_rnnprop_train.py:383-388 + net_apply, the four variables stepped by one net) for a bounded
+    number of steps on synthetic MNIST-shaped data; multi-threaded BLAS."""
+    import oracle as O
+    rng = np.random.default_rng(5)
+    n_data = 1024
+    prob = O.MnistMLP(rng.random((n_data, 784), dtype=np.float32), rng.integers(0, 10, n_data).astype(np.int32))
+    xs = prob.init_vars(np.random.default_rng(6))
+    cfg = O.RNNPROP
+    f = np.float32
+    b1 = b2 = f(0.95)
+    states = [O.net_initial_state(cfg, x.size) for x in xs]
+    ms, vs = [np.zeros_like(x) for x in xs], [np.zeros_like(x) for x in xs]
+    steps = 0
+    t0 = time.perf_counter()
+    while steps < T and time.perf_counter() - t0 < max_seconds:
+        _, grads = prob.fg(xs, rng.integers(0, n_data, size=batch))
+        k = f(steps + 1)
+        for j, g in enumerate(grads):
+            ms[j] = b1 * ms[j] + f(1.0 - 0.95) * g
+            vs[j] = b2 * vs[j] + f(1.0 - 0.95) * g * g
+            den = np.sqrt(vs[j] / (f(1) - np.power(b2, k))) + f(1e-8)
+            delta, states[j] = O.net_apply(cfg, weights, (ms[j] / (f(1) - np.power(b1, k)) / den, g / den), states[j])
+            xs[j] = xs[j] + delta
+        steps += 1
+    dt = time.perf_counter() - t0
+    ncoord = sum(int(x.size) for x in xs)
+    return {"value": ncoord * steps / dt, "unit": "coordinate-steps/s", "cores": os.cpu_count(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d steps of the NumPy oracle (MnistMLP.fg + RNNProp inputs + net_apply, multi-threaded BLAS) on "
+                      "the 784-20-10 MLP, minibatch %d, %.1f s" % (steps, batch, dt)}
+
+
 def build_workload(args, Bg):
     """Problem + optimizer through the product API."""
     from open_l2o_amd import meta, meta_rnnprop_eval, networks, util
@@ -136,69 +181,136 @@ def build_workload(args, Bg):
     return optimizer, ml, feed, weights
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dims", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=128, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="problems per GPU (--scaling weak) / in the whole job (--scaling strong)")
     ap.add_argument("--unroll", type=int, default=100, help="T")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="N > 1: skip the extra strong-scaling / config-4 runs")
     ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin", "mnist"])
     ap.add_argument("--rows", type=int, default=None, help="lasso rows M (default: dims)")
     ap.add_argument("--shared-matrix", dest="shared_matrix", action="store_true",
                     help="lasso: ONE sensing matrix for all problems (SURVEY 8d shared-A variant)")
     ap.add_argument("--net", default="dm", choices=["dm", "dm_logsign", "rnnprop"])
     ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
-                    help="preset = BASELINE.json configs[N-1] (per-GPU shard): 2 default; 3 RNNProp on Lasso 256x512, "
-                         "batch 256, T=200; 4 DM on Rastrigin d=100, 128 problems per GPU, T=100; 5 RNNProp on the "
-                         "MLP optimizee, minibatch 64, T=200 (forward unroll)")
-    args = ap.parse_args()
+                    help="preset = BASELINE.json configs[N-1]: 2 default; 3 RNNProp on Lasso 256x512, batch 256, T=200; "
+                         "4 DM on Rastrigin d=100, global batch 1024 sharded over the GPUs (strong), T=100; 5 RNNProp on "
+                         "the MLP optimizee, minibatch 64, T=200 (forward unroll)")
+    args = ap.parse_args(argv)
     if args.config == 3:
         args.problem, args.net, args.dims, args.rows, args.batch, args.unroll = "lasso", "rnnprop", 512, 256, 256, 200
     elif args.config == 4:
-        args.problem, args.net, args.dims, args.batch, args.unroll = "rastrigin", "dm", 100, 128, 100
+        args.problem, args.net, args.dims, args.batch, args.unroll, args.scaling = "rastrigin", "dm", 100, 1024, 100, "strong"
     elif args.config == 5:
         args.problem, args.net, args.batch, args.unroll = "mnist", "rnnprop", 64, 200
+    return args
 
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and relay the JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.call(cmd, env=env)
+
+
+def counters_for(workload, kernel_hint):
+    """The newest committed PMC summary of exactly this workload (profiles/r*_counters_*.json, written by
+    scripts/counters_to_json.py from rocprofv3 --pmc passes of this command), or None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters_*.json"))):
+        try:
+            c = json.load(open(path))
+        except Exception:
+            continue
+        if c.get("workload") == list(workload) and (not kernel_hint or kernel_hint in c.get("kernel", "")):
+            best = (path, c)
+    return best
+
+
+def roofline_block(case, args, counters):
+    """The binding roofline of the dominant kernel of this workload.
+
+    bound == "hbm": achieved = HBM bytes per launch (PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, committed
+    under profiles/) / the kernel time measured live with HIP events.  bound == "valu_issue" (the
+    LDS/register-resident fused kernels: ~20 MB of HBM traffic per launch): achieved = the share of the SIMDs'
+    issue cycles spent on VALU + MFMA work = (SQ_ACTIVE_INST_VALU x 4 + SQ_VALU_MFMA_BUSY_CYCLES) per launch
+    (PMC, committed) / (SIMDs in use x kernel cycles, live time x the profiled clock).  The step-granular
+    algorithmic-bytes figure of SURVEY.md 8(d) is kept as alg_bytes_frac (it exceeds 1 for a fused kernel:
+    those bytes never move) and the fp32-equivalent FLOP fraction as fp32_frac."""
+    kern_s = case["kern_ms"] * 1e-3
+    out = {"kernel": case["kernel"], "kernel_ms_avg": case["kern_ms"], "kernel_ms_min": case["kern_ms_min"],
+           "algorithmic_bytes_per_launch": case["alg_bytes"], "alg_bytes_per_coord_step": case["bpc"],
+           "alg_bytes_GBps": case["alg_bytes"] / kern_s / 1e9, "alg_bytes_frac": case["alg_bytes"] / kern_s / HBM_PEAK,
+           "fp32_tflops": case["flops"] / kern_s / 1e12, "fp32_frac": case["flops"] / kern_s / FP32_PEAK}
+    hbm_bound = case["hbm_bound"]
+    src = None
+    traffic = None
+    issue = None
+    if counters is not None:
+        path, c = counters
+        src = os.path.relpath(path, ROOT)
+        pl = c.get("per_launch", {})
+        if "FETCH_SIZE_KiB" in pl and "WRITE_SIZE_KiB" in pl:
+            traffic = (2.0 * pl["FETCH_SIZE_KiB"] + pl["WRITE_SIZE_KiB"]) * 1024.0
+        if all(k in pl for k in ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES")):
+            busy = 4.0 * pl["SQ_ACTIVE_INST_VALU"] + pl["SQ_VALU_MFMA_BUSY_CYCLES"]   # cycles, summed over SIMDs
+            simds = min(N_SIMD, pl["SQ_WAVES"]) if c.get("one_wave_per_simd") else N_SIMD
+            clock = c.get("clock_hz_profiled") or 2.4e9
+            issue = {"busy_cycles": busy, "simds": simds, "clock_hz": clock,
+                     "valu_quad_cycles": pl["SQ_ACTIVE_INST_VALU"], "mfma_busy_cycles": pl["SQ_VALU_MFMA_BUSY_CYCLES"],
+                     "wave_quad_cycles": pl["SQ_WAVE_CYCLES"],
+                     "frac_profiled": busy / (4.0 * pl["SQ_WAVE_CYCLES"]) if c.get("one_wave_per_simd") else None}
+    if hbm_bound:
+        out.update(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, traffic=traffic)
+        if traffic is not None:
+            out.update(achieved=traffic / kern_s / 1e9, frac=traffic / kern_s / HBM_PEAK)
+        else:   # no PMC pass of this workload committed: the matrix-once-per-evaluation model of the streaming kernels
+            model = case["hbm_model_bytes"]
+            out.update(achieved=model / kern_s / 1e9, frac=model / kern_s / HBM_PEAK, traffic_model_bytes=model)
+    else:
+        out.update(bound="valu_issue", unit="busy SIMD-cycles/s (VALU + MFMA)", traffic=traffic)
+        if issue is not None:
+            peak = issue["simds"] * issue["clock_hz"]
+            ach = issue["busy_cycles"] / kern_s
+            out.update(achieved=ach, peak=peak, frac=min(ach / peak, 1.0), issue=issue)
+        else:   # no SQ pass committed for this workload: the fp32-equivalent FLOP fraction stands in
+            out.update(bound="fp32_flops", unit="TFLOP/s", achieved=out["fp32_tflops"], peak=FP32_PEAK / 1e12,
+                       frac=out["fp32_frac"])
+        if traffic is not None:
+            out["hbm_frac_measured"] = traffic / kern_s / HBM_PEAK
+    out["counters_source"] = src
+    return out
+
+
+def run_case(args, eng, world, rank, Bg, B, label):
+    """Build one workload, time `steps` unrolls; returns the measurements (all ranks) or None for a
+    configuration that does not apply (batch not divisible by the world size)."""
     import torch
     import torch.distributed as dist
-    from open_l2o_amd import _engine
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hook: L2O_BENCH_BACKEND=gloo L2O_BENCH_ONE_DEVICE=1 runs the N > 1 code path with all
-    # ranks on cuda:0 (a 1-GPU box cannot host two RCCL ranks); the driver never sets these
-    backend = os.environ.get("L2O_BENCH_BACKEND", "nccl")
-    if os.environ.get("L2O_BENCH_ONE_DEVICE"):
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda:%d" % local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    eng = _engine.HipEngine("cuda:%d" % local_rank)        # raises without GPU / built extension
-    _engine.set_default_engine(eng)
-
-    D, B, T = args.dims, args.batch, args.unroll
+    D, T = args.dims, args.unroll
     if args.problem == "mnist":                    # 784-20-10 MLP: 15 910 coordinates, `batch` = minibatch
         D = 784 * 20 + 20 + 20 * 10 + 10
-    Bg = B * world
     optimizer, ml, feed, weights = build_workload(args, Bg)
     graph = optimizer.graph
     graph.reset()                                           # (first call: allocator / context warm-up)
-    if eng.device.type == "cuda":
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     t_reset = time.perf_counter()
     graph.reset()                                           # sample x0, W, y on the host (NumPy), upload this rank's shard
-    if eng.device.type == "cuda":
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     t_reset = time.perf_counter() - t_reset
     x0 = [v.value.clone() for v in graph.x]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -231,12 +343,109 @@ def main():
         dt = float(tt.item())
     fx_host = eng.to_numpy(fx)
     eng.check_unroll_status()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    kern_ms_min = float(np.min([a.elapsed_time(b) for a, b in ev]))
+    kt = [a.elapsed_time(b) for a, b in ev]
+    coord_steps = (1 if args.problem == "mnist" else B) * D * T     # per GPU per unroll
+    Mrows = B if args.problem == "mnist" else (args.rows or D)
+    shared = args.problem == "lasso" and args.shared_matrix
+    bpc = (alg_bytes_lasso_shared(args.net, B, D, Mrows) if shared
+           else alg_bytes_per_coord_step(args.problem, args.net, D, Mrows))
     fused = graph.last_path == "fused"
+    streaming = fused and D > 128
+    if args.problem == "mnist":
+        kernel = "l2o_mlp_unroll (persistent)" if graph.last_path == "mlp_unroll" else "l2o_mlp_fg + l2o_cwlstm_step_multi per step"
+    elif streaming:
+        kernel = "k_unroll_cu"
+    elif fused:
+        kernel = "k_unroll_pair" if 2 * B <= 256 and D > 16 else "k_unroll"
+    else:
+        kernel = "k_problem_fg1 + k_cwlstm_step per step"
+    # HBM bytes per launch that a kernel of this form MUST move (used only when no PMC pass is committed):
+    # the per-problem matrices once per evaluation (T + 1) + x / state once each way
+    mat_bytes = 0 if args.problem == "mnist" else 4.0 * (1 if shared else B) * Mrows * D
+    hbm_model = mat_bytes * ((T + 1) if (streaming or not fused) else 2) + 2 * 4.0 * B * D * 81
+    return {"label": label, "graph": graph, "weights": weights, "x0": x0, "fx_host": fx_host, "dt": dt,
+            "value": world * coord_steps * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+            "kern_ms": float(np.mean(kt)), "kern_ms_min": float(np.min(kt)), "coord_steps": coord_steps,
+            "bpc": bpc, "alg_bytes": bpc * coord_steps,
+            "flops": alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps,
+            "fused": fused, "kernel": kernel, "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
+            "hbm_model_bytes": hbm_model, "t_reset": t_reset, "D": D, "B": B, "Bg": Bg, "T": T, "Mrows": Mrows,
+            "shared": shared}
+
+
+def workload_names(args, D, B, Bg, T, Mrows, shared):
+    netname = {"dm": "L2O-DM CoordinateWiseDeepLSTM(20,20)", "dm_logsign": "L2O-DM (LogAndSign k=5)",
+               "rnnprop": "L2O-RNNProp (fc+ELU, tanh, 0.01)"}[args.net]
+    probname = {"quadratic": "Quadratic d=%d" % D,
+                "lasso": "Lasso A in R^{%dx%d} l=0.1%s" % (Mrows, D, " (one A shared by the batch)" if shared else ""),
+                "rastrigin": "Rastrigin d=%d" % D,
+                "mnist": "MLP 784-20-10 (sigmoid) on synthetic MNIST-shaped data, minibatch %d" % B}[args.problem]
+    return netname, probname
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+
+    import torch
+    import torch.distributed as dist
+    from open_l2o_amd import _engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
+                         "or without a launcher: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
+    # test hook: L2O_BENCH_BACKEND=gloo L2O_BENCH_ONE_DEVICE=1 runs the N > 1 code path with all
+    # ranks on cuda:0 (a 1-GPU box cannot host two RCCL ranks); the driver never sets these
+    backend = os.environ.get("L2O_BENCH_BACKEND", "nccl")
+    if os.environ.get("L2O_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda:%d" % local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    eng = _engine.HipEngine("cuda:%d" % local_rank)        # raises without GPU / built extension
+    _engine.set_default_engine(eng)
+
+    def sizes(a):
+        """(global batch, per-GPU batch) of a run; None when the batch does not divide."""
+        if a.problem == "mnist":
+            return a.batch, a.batch
+        if a.scaling == "strong":
+            return (a.batch, a.batch // world) if a.batch % world == 0 and a.batch >= world else None
+        return a.batch * world, a.batch
+
+    sz = sizes(args)
+    if sz is None:
+        raise SystemExit("bench.py: --scaling strong needs --batch divisible by --gpus")
+    Bg, B = sz
+    case = run_case(args, eng, world, rank, Bg, B, "primary")
+
+    also = {}
+    if world > 1 and not args.no_also and args.problem == "quadratic" and args.config in (None, 2):
+        for name, extra_argv in (("config2_strong", ["--config", "2", "--scaling", "strong"]), ("config4", ["--config", "4"])):
+            a2 = parse_args(extra_argv + ["--gpus", str(world), "--steps", str(max(5, args.steps // 2)), "--warmup", "2"])
+            s2 = sizes(a2)
+            if s2 is None:
+                continue
+            c2 = run_case(a2, eng, world, rank, s2[0], s2[1], name)
+            n2, p2 = workload_names(a2, c2["D"], c2["B"], c2["Bg"], c2["T"], c2["Mrows"], False)
+            also[name] = {"workload": "%s on %s, global batch %d = %d per GPU x %d, T=%d" % (n2, p2, c2["Bg"], c2["B"], world, c2["T"]),
+                          "scaling": "strong", "value": c2["value"], "unit": "coordinate-steps/s",
+                          "ms_per_step": c2["ms_per_step"], "steps": a2.steps, "kernel": c2["kernel"],
+                          "kernel_ms_avg": c2["kern_ms"], "final_loss_fx_T": float(c2["fx_host"][-1])}
+            del c2
 
     copy_gbps = None
-    if rank == 0 and eng.device.type == "cuda":
+    if rank == 0:
         # achievable-copy figure of this box (SURVEY 8d): device-to-device copy of 512 MiB, read + write counted
         src = torch.empty(128 << 20, dtype=torch.float32, device=eng.device).normal_()
         dst = torch.empty_like(src)
@@ -252,79 +461,57 @@ def main():
         del src, dst
 
     if rank == 0:
-        coord_steps = (1 if args.problem == "mnist" else B) * D * T     # per GPU per unroll
-        value = world * coord_steps * args.steps / dt
-        Mrows = B if args.problem == "mnist" else (args.rows or D)
-        shared = args.problem == "lasso" and args.shared_matrix
-        bpc = (alg_bytes_lasso_shared(args.net, B, D, Mrows) if shared
-               else alg_bytes_per_coord_step(args.problem, args.net, D, Mrows))
-        alg = bpc * coord_steps                            # algorithmic bytes per unroll
-        achieved = alg / (kern_ms * 1e-3)
-        flops = alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps
-        netname = {"dm": "L2O-DM CoordinateWiseDeepLSTM(20,20)", "dm_logsign": "L2O-DM (LogAndSign k=5)",
-                   "rnnprop": "L2O-RNNProp (fc+ELU, tanh, 0.01)"}[args.net]
-        probname = {"quadratic": "Quadratic d=%d" % D,
-                    "lasso": "Lasso A in R^{%dx%d} l=0.1%s" % (Mrows, D, " (one A shared by the batch)" if shared else ""),
-                    "rastrigin": "Rastrigin d=%d" % D,
-                    "mnist": "MLP 784-20-10 (sigmoid) on synthetic MNIST-shaped data, minibatch %d" % B}[args.problem]
+        D, T, Mrows, shared = case["D"], case["T"], case["Mrows"], case["shared"]
+        netname, probname = workload_names(args, D, B, Bg, T, Mrows, shared)
         is_c2 = (args.problem, args.net, D, B, T) == ("quadratic", "dm", 128, 128, 100)
-        traffic, traffic_src = None, None
-        for tag in ("c2", "c3"):                           # committed PMC passes of exactly this workload
-            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % tag)
-            if not (os.path.exists(pmc_file) and fused and world == 1 and not shared):
-                continue
-            pmc = json.load(open(pmc_file))
-            if pmc["workload"] == [args.problem, args.net, D, B, T] and (args.problem != "lasso" or Mrows == 256):
-                traffic = pmc["traffic_bytes"]
-                traffic_src = ("profiles/r01_pmc_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                               "command, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)" % tag)
+        counters = None
+        if world == 1 and not shared:
+            counters = counters_for([args.problem, args.net, D, B, T] + ([Mrows] if args.problem == "lasso" else []),
+                                    case["kernel"] if case["fused"] else "")
+        roof = roofline_block(case, args, counters)
+        roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms_host_sampling_plus_h2d=case["t_reset"] * 1e3)
+        scaling_note = None
+        if world > 1 or args.scaling == "strong":
+            scaling_note = ("weak: %d problems per GPU, global batch %d (config 2 cannot strong-scale: a T-step unroll "
+                            "is a serial chain of T x ~2.4 us per problem whatever the number of problems per GPU -- "
+                            "see also.config2_strong; config 4's 1024 problems do, see also.config4)" % (B, Bg)
+                            if args.scaling == "weak" else "strong: global batch %d, %d per GPU" % (Bg, B))
         out = {
             "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
-            "value": value, "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value": case["value"], "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": case["ms_per_step"], "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
                                    % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
-                       "kernel": (("l2o_unroll, streaming form k_unroll_cu (one workgroup per problem, T steps in one "
-                                   "launch, matrix streamed once per step, x / LSTM state / moments on-chip)"
-                                   if D > 128 else
-                                   "l2o_unroll (fused persistent, 2 CUs per problem when 2*batch <= #CUs)") if fused
-                                  else "l2o_problem_fg + l2o_cwlstm_step per step"),
+                       "kernel": case["kernel"],
                        "arithmetic": "fp32 state, inputs and outputs; the LSTM gate GEMM is a 6-product 3-way bf16 "
                                      "split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level error, "
                                      "DESIGN.md 2); everything else fp32 VALU",
                        "api": "open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> UnrollGraph.launch",
-                       "parallelism": "problem-batch sharding x%d, all-reduce of T+1 floats" % world},
-            "final_loss_fx_T": float(fx_host[-1]), "fx_0": float(fx_host[0]),
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "hbm_copy_measured_GBps": copy_gbps,
-                         "reset_ms_host_sampling_plus_h2d": t_reset * 1e3,
-                         "frac_of_measured_copy": None if not copy_gbps else achieved / 1e9 / copy_gbps,
-                         "algorithmic_bytes_per_launch": alg, "alg_bytes_per_coord_step": bpc,
-                         "kernel_ms_avg": kern_ms, "kernel_ms_min": kern_ms_min,
-                         "fp32_tflops": flops / (kern_ms * 1e-3) / 1e12,
-                         "fp32_frac_of_157.3TF": flops / (kern_ms * 1e-3) / FP32_PEAK,
-                         "note": ("step-granular algorithmic bytes (SURVEY 8d) over the HIP-event time of the "
-                                  "unroll kernels; the fused kernel keeps x, LSTM state and W on-chip, so real HBM "
-                                  "traffic is far below this figure (frac can exceed 1) and the kernel is bound by one "
-                                  "wave's serial instruction stream -- DESIGN.md 5") if not (fused and D > 128) else
-                                 ("step-granular algorithmic bytes (SURVEY 8d: matrix twice + x / state / moments "
-                                  "read and written per step) over the HIP-event time of the unroll kernel; the "
-                                  "streaming form reads the matrix ONCE per step and keeps everything else on-chip, "
-                                  "so frac can exceed 1 -- DESIGN.md 3.1c / 5")},
+                       "parallelism": "problem-batch sharding x%d, one all-reduce of T+1 floats per unroll" % world,
+                       "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                       "backend": (dist.get_backend() if world > 1 else None),
+                       "scaling_note": scaling_note},
+            "final_loss_fx_T": float(case["fx_host"][-1]), "fx_0": float(case["fx_host"][0]),
+            "parity_pin": PARITY_PIN,
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.problem != "mnist" and not shared:
-            names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
-                     "rastrigin": ("A", "B", "C")}[args.problem]
-            g = graph._by_name
-            arrays = {"W": g[names[0]].eval(), "y": g[names[1]].eval().reshape(B, -1)}
-            if names[2]:
-                arrays["C"] = g[names[2]].eval().reshape(B, -1)
-            arrays["l1"], arrays["alpha"] = 0.1, 10.0
-            out["cpu_baseline"] = cpu_baseline(args.problem, args.net, arrays, weights,
-                                               eng.to_numpy(x0[0]).reshape(B, D), T)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if also:
+            out["also"] = also
+        if world == 1 and not args.no_cpu_baseline and not shared:
+            if args.problem == "mnist":
+                out["cpu_baseline"] = cpu_baseline_mnist(case["weights"], B, T)
+            else:
+                names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
+                         "rastrigin": ("A", "B", "C")}[args.problem]
+                g = case["graph"]._by_name
+                arrays = {"W": g[names[0]].eval(), "y": g[names[1]].eval().reshape(B, -1)}
+                if names[2]:
+                    arrays["C"] = g[names[2]].eval().reshape(B, -1)
+                arrays["l1"], arrays["alpha"] = 0.1, 10.0
+                out["cpu_baseline"] = cpu_baseline(args.problem, args.net, arrays, case["weights"],
+                                                   eng.to_numpy(case["x0"][0]).reshape(B, D), T)
+            out["speedup_vs_cpu_baseline"] = case["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

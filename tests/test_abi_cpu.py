@@ -189,8 +189,31 @@ def test_bench_cli_presets_parse():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
                          timeout=120)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--config", "--no-cpu-baseline"):
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--no-cpu-baseline", "--scaling"):
         assert flag in out.stdout
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--config", "4", "--gpus", "8"])
+    assert (a.problem, a.dims, a.batch, a.unroll, a.scaling) == ("rastrigin", 100, 1024, 100, "strong")
+    a = bench.parse_args([])
+    assert (a.gpus, a.problem, a.net, a.dims, a.batch, a.unroll, a.scaling) == (1, "quadratic", "dm", 128, 128, 100, "weak")
+
+
+def test_bench_cpu_baseline_legs_run():
+    """The cpu_baseline legs of bench.py (the oracle, timed) on tiny inputs: they are the only place outside tests/
+    and smoke() that may touch oracle/."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from helpers import make_params
+    w = make_params(O.RNNPROP, seed=1, trained_like=True)
+    out = bench.cpu_baseline_mnist(w, batch=8, T=2, max_seconds=5.0)
+    assert out["value"] > 0 and out["kind"] == "port" and "2 steps" in out["sample"]
+    rng = np.random.default_rng(0)
+    arrays = {"W": rng.random((4, 10, 10), dtype=np.float32), "y": rng.random((4, 10), dtype=np.float32), "l1": 0.1, "alpha": 10.0}
+    out = bench.cpu_baseline("quadratic", "dm", arrays, make_params(O.DM_IDENTITY, seed=2, trained_like=True),
+                             (rng.standard_normal((4, 10)) * 0.01).astype(np.float32), 5, max_seconds=1.0)
+    assert out["value"] > 0 and out["cores"] >= 1 and np.isfinite(out["fx_T"])
 
 
 def test_adam_and_device_pack_reject_bad_arguments(lib):

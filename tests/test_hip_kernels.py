@@ -385,28 +385,40 @@ def _run_steps(eng, cfg, params, arrays, x0, B, D, T, step0=1, carry=None):
     return eng.to_numpy(fx), (xd, std, md, vd)
 
 
+_C3_REF = {}
+
+
+def _c3_reference(cfg, params, arrays, x0):
+    """The C oracle's full T = 200 unroll of config 3 (a few seconds on the box's cores), shared by the two
+    full-size tests."""
+    if "fx" not in _C3_REF:
+        from oracle.c_oracle import c_unroll
+        fx, x, _, _, _, _ = c_unroll("lasso", cfg, params, arrays, x0, 200)
+        _C3_REF.update(fx=fx, x=x)
+    return _C3_REF["fx"], _C3_REF["x"]
+
+
 def test_c3_lasso_rnnprop_full_size(eng):
     """Config 3: L2O-RNNProp on Lasso A in R^{256x512}, lambda=0.1, batch=256, T=200
-    (per-problem A: 128 MiB streamed twice per step; step-granular kernels).
-    Parity vs the C oracle on the first 20 steps; the full T=200 trajectory through the
-    continuation property (200 steps == 2 x 100 steps with carried x/state/m/v)."""
-    from oracle.c_oracle import c_unroll
+    (per-problem A: 128 MiB streamed once per step; step-granular kernels).
+    The WHOLE T=200 loss trajectory and x_T against the C oracle (1e-5 relative, the north_star
+    tolerance), plus the continuation property (200 steps == 2 x 100 steps with carried
+    x/state/m/v, bit for bit)."""
     cfg = O.RNNPROP
     params = make_params(cfg, seed=17, trained_like=True)
     B, D, M = 256, 512, 256
     prob, x0, arrays = make_problem("lasso", B, D, seed=18, M=M)
-    fx_ref, _, _, _, _, _ = c_unroll("lasso", cfg, params, arrays, x0, 20)
-    fx20, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 20)
-    e = rel_err(fx20, fx_ref)
-    print("C3 step path vs C oracle (20 steps): rel fx=%.3g fx0=%.5g fx20=%.5g" % (e, fx_ref[0], fx_ref[-1]))
-    assert e < 1e-5
-    fx200, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 200)
+    fx_ref, x_ref = _c3_reference(cfg, params, arrays, x0)
+    fx200, carry200 = _run_steps(eng, cfg, params, arrays, x0, B, D, 200)
+    e = rel_err(fx200, fx_ref)
+    ex = max_abs(eng.to_numpy(carry200[0]), x_ref) / max(1.0, float(np.abs(x_ref).max()))
+    print("C3 step path vs C oracle (all 200 steps): rel fx=%.3g |dx_T|=%.3g fx0=%.5g fx200=%.5g"
+          % (e, ex, fx_ref[0], fx_ref[-1]))
+    assert e < 1e-5 and ex < 1e-5
     fxa, carry = _run_steps(eng, cfg, params, arrays, x0, B, D, 100)
     fxb, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 100, step0=101, carry=carry)
-    assert np.all(np.isfinite(fx200))
     np.testing.assert_array_equal(fx200[:101], fxa)
     np.testing.assert_array_equal(fx200[100:], fxb)
-    np.testing.assert_allclose(fx200[:21], fx_ref, rtol=1e-5)
 
 
 @pytest.mark.parametrize("activation,batch", [("sigmoid", 128), ("relu", 100), ("sigmoid", 7)])
@@ -546,23 +558,21 @@ def test_streaming_unroll_continuation_and_step_path(eng):
 
 def test_c3_streaming_full_size(eng):
     """Config 3 at full size (RNNProp, Lasso 256 x 512 per problem, batch 256, T = 200) through the
-    streaming fused unroll: the first 20 steps against the C oracle, the T = 200 trajectory through
-    the continuation property and against the step-granular path on the first 20 steps."""
-    from oracle.c_oracle import c_unroll
+    streaming fused unroll: the WHOLE T = 200 loss trajectory and x_T against the C oracle, and a
+    20-step launch equal to the head of the 200-step one bit for bit."""
     cfg = O.RNNPROP
     params = make_params(cfg, seed=17, trained_like=True)
     B, D, M = 256, 512, 256
     prob, x0, arrays = make_problem("lasso", B, D, seed=18, M=M)
-    fx_ref, _, _, _, _, _ = c_unroll("lasso", cfg, params, arrays, x0, 20)
+    fx_ref, x_ref = _c3_reference(cfg, params, arrays, x0)
+    fx200, x200 = _run_fused(eng, cfg, params, arrays, x0, B, D, 200)[:2]
+    e = rel_err(fx200, fx_ref)
+    ex = max_abs(x200, x_ref) / max(1.0, float(np.abs(x_ref).max()))
+    print("C3 streaming unroll vs C oracle (all 200 steps): rel fx=%.3g |dx_T|=%.3g fx0=%.5g fx200=%.5g"
+          % (e, ex, fx_ref[0], fx_ref[-1]))
+    assert e < 1e-5 and ex < 1e-5
     fx20 = _run_fused(eng, cfg, params, arrays, x0, B, D, 20)[0]
-    e = rel_err(fx20, fx_ref)
-    print("C3 streaming unroll vs C oracle (20 steps): rel fx=%.3g fx0=%.5g fx20=%.5g" % (e, fx_ref[0], fx_ref[-1]))
-    assert e < 1e-5
-    fx200 = _run_fused(eng, cfg, params, arrays, x0, B, D, 200)[0]
-    assert np.all(np.isfinite(fx200))
     np.testing.assert_array_equal(fx200[:21], fx20)
-    fxs20, _ = _run_steps(eng, cfg, params, arrays, x0, B, D, 20)
-    assert rel_err(fx20, fxs20) < 1e-5
 
 
 def test_streaming_unroll_record_is_rejected(eng):
@@ -572,3 +582,29 @@ def test_streaming_unroll_record_is_rejected(eng):
     prob, x0, arrays = make_problem("quadratic", 2, 256, seed=5)
     pd = device_problem(eng, arrays, 2, 256)
     assert eng.unroll_supported(spec, pd) and not eng.unroll_supported(spec, pd, record=True)
+
+
+def test_long_horizon_T1000(eng):
+    """The curriculum's longest training horizon (DM/train_dm.py:66: num_unrolls up to 50 x unroll_length 20 =
+    1000 steps) and a tenth of the evaluation drivers' 10 000 (DM/evaluate_dm.py:43) in ONE launch of the
+    fused kernel: L2O-DM on Quadratic d = 128 (config-2 shape, 16 problems), T = 1000.  fp32 trajectories
+    drift from the exact one; the bound is the drift of the fp32 ORACLE from its own float64 evaluation
+    (x 3), and never looser than 1e-4: measured 6e-7 for the oracle."""
+    from oracle.c_oracle import c_unroll
+    cfg = O.DM_IDENTITY
+    params = make_params(cfg, seed=3, trained_like=True)
+    B, D, T = 16, 128, 1000
+    prob, x0, arrays = make_problem("quadratic", B, D, seed=4)
+    fx32 = c_unroll("quadratic", cfg, params, arrays, x0, T)[0]
+    p64 = {k: {v: a.astype(np.float64) for v, a in d.items()} for k, d in params.items()}
+    r64 = O.unroll(O.Quadratic(prob.w.astype(np.float64), prob.y.astype(np.float64)), cfg, p64, x0.astype(np.float64),
+                   O.net_initial_state(cfg, B * D, np.float64), T)
+    envelope = rel_err(fx32, r64.fx)
+    for pair in (1, 0):
+        with lib_option(_abi.OPT_PAIR, pair):
+            fx = _run_fused(eng, cfg, params, arrays, x0, B, D, T)[0]
+        e64, e32 = rel_err(fx, r64.fx), rel_err(fx, fx32)
+        print("T=1000 (pair=%d): rel fx vs float64 oracle %.3g, vs fp32 C oracle %.3g (fp32 oracle's own drift %.3g)"
+              % (pair, e64, e32, envelope))
+        assert e64 < min(1e-4, max(1e-5, 3 * envelope))
+        assert rel_err(fx[:101], r64.fx[:101]) < 1e-5
