@@ -991,7 +991,7 @@ static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) 
   L.xbuf_off = sizeof(PairWs);
   L.xbuf_bytes = (size_t)p->B_local * 2 * 2 * L.npg * sizeof(unsigned long long);
   L.fxh_off = L.xbuf_off + L.xbuf_bytes;
-  L.total = L.fxh_off + sizeof(float) * (size_t)(T + 1) * 2 * p->B_local;
+  L.total = L.fxh_off + sizeof(float) * (size_t)(T + 1) * g.CH * p->B_local;   // one partial per (step, problem, wave)
   L.lds = 0;                          // static LDS only (xs, rs, fpart)
   return L;
 }
@@ -1024,7 +1024,7 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
     HIP_TRY(hipGetLastError());
     const int n = (a.T + 1) * a.pp.B_local;
-    hipLaunchKernelGGL(k_combine_halves, dim3((n + 255) / 256), dim3(256), 0, s, pa.fx_half, a.fx_part, n, pa.ws);
+    hipLaunchKernelGGL(k_combine_halves, dim3((n + 255) / 256), dim3(256), 0, s, pa.fx_half, a.fx_part, n, g.CH, pa.ws);
     HIP_TRY(hipGetLastError());
     return L2O_OK;
   }

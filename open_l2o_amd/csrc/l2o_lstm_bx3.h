@@ -214,6 +214,38 @@ __device__ __forceinline__ void gates5(const f32x4 (&acc)[kNT], float (&c)[kNT],
   h[4] = __builtin_copysignf((1.0f - E_c) * ro, cn);
 }
 
+// The same nonlinearities with plain (non-packed) fp32 VALU instructions, stage-major over the five units.  Used
+// where bf16 MFMAs are interleaved with the gate math: beside MFMAs a v_pk_*_f32 costs its issue slot plus ~13
+// cycles (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), a plain VALU instruction only its slot.
+__device__ __forceinline__ void gates5_scalar(const f32x4 (&acc)[kNT], float (&c)[kNT], float (&h)[kNT]) {
+  constexpr float k2 = 2.0f * 1.4426950408889634f;
+  float e_i[kNT], E_j[kNT], e_f[kNT], e_o[kNT], ij[kNT], rf[kNT], cn[kNT], E_c[kNT], ro[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) e_i[t] = fast_exp2(acc[t][0]);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) E_j[t] = fast_exp2(-__builtin_fabsf(acc[t][1]));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) e_f[t] = fast_exp2(acc[t][2]);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) e_o[t] = fast_exp2(acc[t][3]);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) ij[t] = fast_rcp((1.0f + e_i[t]) * (1.0f + E_j[t]));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) rf[t] = fast_rcp(1.0f + e_f[t]);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+    cn[t] = __builtin_fmaf(rf[t], c[t], __builtin_copysignf((1.0f - E_j[t]) * ij[t], acc[t][1]));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) E_c[t] = fast_exp2(-__builtin_fabsf(cn[t] * k2));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) ro[t] = fast_rcp((1.0f + E_c[t]) * (1.0f + e_o[t]));
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    c[t] = cn[t];
+    h[t] = __builtin_copysignf((1.0f - E_c[t]) * ro[t], cn[t]);
+  }
+}
+
 // Everything that needs this step's gradient (see l2o::lstm_finish for the contract):
 // acc1 must hold chunk L1H (h1(t-1), bias), acc2 chunk L2B (h2(t-1)).  On return s holds the
 // new state, b1 / b2 the split h1(t) / h2(t) (the next step's L1H / L2B operands) and, with
@@ -250,14 +282,19 @@ __device__ __forceinline__ float finish(const NetWB<PRE>& w, TileState& s, BOp& 
   // a single wave issues in order, so the MFMAs must be interleaved with the VALU stream in
   // program order (30 back-to-back MFMAs stall the wave for 30 x 17 cycles)
   __builtin_amdgcn_sched_barrier(0);
-  if (NEXT) issue<PRE, kChL1H, 0, kChunkMfmas, true>(w, b1, acc1);
-  gates5(acc2, s.c2, s.h2);
   if (NEXT) {
+#ifndef L2O_NEXT_VALU_PER_MFMA
+#define L2O_NEXT_VALU_PER_MFMA 3
+#endif
+    issue<PRE, kChL1H, 0, kChunkMfmas, true>(w, b1, acc1);
+    gates5_scalar(acc2, s.c2, s.h2);
 #pragma unroll
     for (int i = 0; i < kChunkMfmas; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // three VALU / transcendental
+      __builtin_amdgcn_sched_group_barrier(0x402, L2O_NEXT_VALU_PER_MFMA, 0);    // VALU | transcendental
     }
+  } else {
+    gates5(acc2, s.c2, s.h2);
   }
   __builtin_amdgcn_sched_barrier(0);
   pc.mark(8);
@@ -300,6 +337,7 @@ struct LstmCore<PRE, false> {
   static constexpr int kTotal = 25, kHalf = 12;
   NetW<PRE> w;
   __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { load_netw<PRE>(w, wpack, lane); }
+  __device__ __forceinline__ void pin() {}
   __device__ __forceinline__ void init(const TileState&, int) {}
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState& s, f32x4 (&acc1)[kNT]) {
@@ -325,6 +363,19 @@ struct LstmCore<PRE, true> {
   bx::BOp b1, b2;          // split h1(t-1), h2(t-1): the recurrent chunks' B operands
   unsigned one;
   __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE>(w, wpack, lane); }
+  // Pin the 180-240 fragment registers to the accumulation half of the register file.  MFMA reads its A operand
+  // from AGPRs directly; left to itself the allocator parks whatever does not fit the 256 VGPRs (fragments AND
+  // VALU operands) there and pays a v_accvgpr_read per use (126 of the 618 VALU instructions of a config-2 step).
+  __device__ __forceinline__ void pin() {
+#ifndef L2O_NO_AGPR_PIN
+#pragma unroll
+    for (int ch = 0; ch < bx::NetWB<PRE>::NCH; ++ch)
+#pragma unroll
+      for (int t = 0; t < kNT; ++t)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) asm volatile("" : "+a"(w.a[ch][t][s3]));
+#endif
+  }
   __device__ __forceinline__ void init(const TileState& s, int q) {
     one = q == 0 ? 0x3f800000u : 0u;
     bx::split5(s.h1, one, b1);

@@ -37,7 +37,7 @@ struct UnrollPairArgs {
   UnrollArgs u;
   PairWs* ws;
   unsigned long long* xbuf;   // [B][2 halves][2 parities][SQ] granules (partial residuals)
-  float* fx_half;             // [(T+1)][2*B]
+  float* fx_half;             // [(T+1)][B][2 * NWH]: one partial per (step, problem, wave)
   unsigned use_salt;          // tags carry the launch sequence in their upper bits (T + 1 < 65 535): a granule left by an
                               // earlier launch never matches, on top of the memset of the granule area ahead of every launch
   unsigned plain_stores;      // L2O_OPT_PAIR_PLAIN_STORES: a confirmed same-XCD pair publishes with plain stores
@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   constexpr int NC = 16 * NWH;           // columns (coordinates) owned by a half = SQ / 2
   __shared__ float xs[NC];               // this half's scaled iterate
   __shared__ float rs[SQ];               // the full residual
-  __shared__ float fpart[8];
   const UnrollArgs& a = pa.u;
   const ProbParams& pp = a.pp;
   const int D = pp.D, M = pp.M;
@@ -92,7 +91,10 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const int b = ((bid >> 4) << 3) | (bid & 7);          // problem index
   if (b >= pp.B_local) return;                          // padding blocks of the last group of 16 (both halves)
   const int tile_in_prob = half * NWH + wv;             // this wave's coordinate tile
-  const int gq = lane & 3, gr = lane >> 2;              // GEMV role: quarter gq of row / column gr
+  // GEMV role of a lane = its LSTM role: row / column gr = c, 16-byte chunk gq = q.  The four chunk partial sums
+  // of a row / column then sit on the lanes (c, 0..3) and two permlane swaps add them INTO the lanes that feed
+  // the gradient to the network -- no ds_bpermute (an LDS round trip) between the g pass and the gate math.
+  const int gq = q, gr = c;
 
   // ---- the matrix lives in registers: no LDS bandwidth in the two GEMV passes -------------
   //  wr[p][m] : row (2 wv + p) 16 + gr, own columns 16 m + 4 gq + {0..3}     (partial r = W xs)
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 #endif
   Core core;
   core.load(a.np.wpack, lane);
+  core.pin();   // fragments -> AGPRs (MFMA reads them there): the VGPRs hold W, the state and the gate math
   const int j = tile_in_prob * kTile + c;
   const bool live = j < D;
   const size_t idx = (size_t)b * D + j;
@@ -166,7 +169,6 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const float kTwoPi = pp.twopi;
   const float* xsq = xs + 4 * gq;
   const float* rsq = rs + 4 * gq;
-  const int perm_src = (4 * c) << 2;
   unsigned long long* mine = pa.xbuf + ((size_t)b * 2 + half) * 2 * SQ;
   const unsigned long long* theirs = pa.xbuf + ((size_t)b * 2 + (half ^ 1)) * 2 * SQ;
   bool dead = false;                                             // partner timed out
@@ -198,6 +200,11 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 
   f32x4 acc1[kNT], acc2[kNT];
   core.init(s, q);
+#ifdef L2O_PAIR_L1H_UNDER_GATES
+  // variant: chunk L1H of step t+1 (fed by h1(t)) rides underneath the layer-2 gate block of step t
+  // (Core::finish<true>); only the first step's is issued up front
+  core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
+#endif
   // (both recurrent chunks -- L1H: h1(t-1) -> layer 1, L2B: h2(t-1) -> layer 2 -- are issued inside the step loop,
   //  in the window where the wave waits for its partner's partial residuals)
   PhaseClock pc;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
         dot4(wr[0][m], x4[m], r0);
         dot4(wr[1][m], x4[m], r1);
       }
-      const float p0 = quad_sum(hsum4(r0)), p1 = quad_sum(hsum4(r1));
+      const float p0 = quad_q_sum(hsum4(r0)), p1 = quad_q_sum(hsum4(r1));
       part = (gq & 1) ? p1 : p0;
     }
     // ---- exchange the partial sums (one granule per row), the previous-h2 matrix work covers the latency
@@ -248,7 +255,9 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     constexpr int kPollAt = L2O_PAIR_POLL_AT < Core::kTotal ? L2O_PAIR_POLL_AT : Core::kTotal;   // MFMAs before the first poll load
     constexpr int kPollAt1 = L2O_PAIR_POLL_AT > Core::kTotal ? L2O_PAIR_POLL_AT - Core::kTotal : 0;
     core.template issue_l2_prev<0, kPollAt>(s, acc2);
+#ifndef L2O_PAIR_L1H_UNDER_GATES
     if (kPollAt1 > 0) core.template issue_l1_prev<0, kPollAt1>(s, acc1);
+#endif
     const unsigned long long* src = theirs + par * SQ + (gq < 2 ? myrow : 0);
     unsigned long long g = 0;
 #ifdef L2O_ABLATE_EXCHANGE
@@ -258,7 +267,9 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     if (gq < 2 && !dead) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_sched_barrier(0);
     if (kPollAt < Core::kTotal) core.template issue_l2_prev<kPollAt, Core::kTotal>(s, acc2);
+#ifndef L2O_PAIR_L1H_UNDER_GATES
     core.template issue_l1_prev<kPollAt1, Core::kTotal>(s, acc1);
+#endif
     float contrib = 0.0f;
     if (gq < 2) {
       int spins = 0;
@@ -282,14 +293,14 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       if (kCos) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
     }
     pc.mark(1);                                             // previous-h2 MFMAs + partner poll
-    contrib = wave_sum64(contrib);
-    if (lane == 0) fpart[wv] = contrib;
-    __syncthreads();                                        // B2: rs, fpart complete
+    __syncthreads();                                        // B2: rs complete
     pc.mark(4);
-    if (tid == 0) {
-      float f = fpart[0];
-      for (int k = 1; k < NWH; ++k) f += fpart[k];
-      pa.fx_half[(size_t)t * 2 * pp.B_local + 2 * b + half] = f;
+    // this wave's share of f_b(x_t): reduced AFTER the barrier (the DPP chain fills the LDS latency of the g
+    // pass instead of sitting in front of the barrier) and written straight to HBM -- no LDS round, no
+    // thread-0 sum on the step's critical path; k_combine_halves adds the 2 x NWH partials per (step, problem)
+    {
+      const float fw = wave_sum64(contrib);
+      if (lane == 0) pa.fx_half[((size_t)t * pp.B_local + b) * (2 * NWH) + half * NWH + wv] = fw;
     }
     if (t == a.T && !HIST) break;
 
@@ -301,8 +312,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < CH; ++m) dot4(wt[m], rv4[m], gacc4);
-    const float gacc = quad_sum(hsum4(gacc4));
-    float gv = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(gacc)));
+    float gv = quad_q_sum(hsum4(gacc4));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
@@ -329,8 +339,14 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
+#ifdef L2O_PAIR_L1H_UNDER_GATES
+    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);
+#else
     float d = core.template finish<false>(s, acc1, acc2, in0, in1, q, pc);
+#endif
+#ifndef L2O_PAIR_L1H_UNDER_GATES
     core.refresh(s);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
+#endif
     if (a.np.tanh_output) d = tanhf_(d);
     xv = __builtin_fmaf(d, a.np.scale, xv);
     pc.mark(9);
@@ -346,10 +362,16 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   if (tile_real) store_tile_state(s, st_tile, lane);
 }
 
-// fx_part[t][b] = fx_half[t][2b] + fx_half[t][2b+1]; runs after every workgroup of the unroll has
-// finished, so it also advances the launch sequence word the next launch salts its tags with
-__global__ void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part, int n, PairWs* ws) {
+// fx_part[t][b] = sum of the 2 x NWH per-wave partials of (step t, problem b), fixed order; runs after every
+// workgroup of the unroll has finished, so it also advances the launch sequence word the next launch salts
+// its tags with
+__global__ void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part, int n, int nparts,
+                                 PairWs* ws) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) fx_part[i] = fx_half[2 * i] + fx_half[2 * i + 1];
+  if (i < n) {
+    float f = fx_half[(size_t)i * nparts];
+    for (int k = 1; k < nparts; ++k) f += fx_half[(size_t)i * nparts + k];
+    fx_part[i] = f;
+  }
   if (i == 0) ws->seq = ws->seq + 1u;
 }
