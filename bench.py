@@ -244,49 +244,53 @@ def counters_for(workload, kernel_hint):
 def roofline_block(case, args, counters):
     """The binding roofline of the dominant kernel of this workload.
 
-    bound == "hbm": achieved = HBM bytes per launch (PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, committed
-    under profiles/) / the kernel time measured live with HIP events.  bound == "valu_issue" (the
-    LDS/register-resident fused kernels: ~20 MB of HBM traffic per launch): achieved = the share of the SIMDs'
-    issue cycles spent on VALU + MFMA work = (SQ_ACTIVE_INST_VALU x 4 + SQ_VALU_MFMA_BUSY_CYCLES) per launch
-    (PMC, committed) / (SIMDs in use x kernel cycles, live time x the profiled clock).  The step-granular
-    algorithmic-bytes figure of SURVEY.md 8(d) is kept as alg_bytes_frac (it exceeds 1 for a fused kernel:
-    those bytes never move) and the fp32-equivalent FLOP fraction as fp32_frac."""
+    bound == "hbm" (streaming / step-granular kernels): achieved = HBM bytes per launch (PMC: FETCH_SIZE x 2 on
+    gfx950 + WRITE_SIZE, committed under profiles/) / the kernel time measured live with HIP events.
+    bound == "valu_issue" (the LDS/register-resident fused kernels: ~20 MB of HBM traffic per launch, one wave per
+    SIMD issuing in order): achieved = VALU-active SIMD-cycles per second = 4 x SQ_ACTIVE_INST_VALU per launch
+    (quad-cycles -> cycles; MFMA issue slots included; PMC, committed) / live kernel time; peak = SIMDs in use x
+    the clock the profiled run sustained.  frac is the share of the SIMDs' cycles in which the VALU issued; the
+    matrix-pipe share (SQ_VALU_MFMA_BUSY_CYCLES) and the sum of the two (an upper bound: they overlap) ride along.
+    The step-granular algorithmic-bytes figure of SURVEY.md 8(d) is kept as alg_bytes_frac (it exceeds 1 for a
+    fused kernel: those bytes never move) and the fp32-equivalent FLOP fraction as fp32_frac."""
     kern_s = case["kern_ms"] * 1e-3
     out = {"kernel": case["kernel"], "kernel_ms_avg": case["kern_ms"], "kernel_ms_min": case["kern_ms_min"],
            "algorithmic_bytes_per_launch": case["alg_bytes"], "alg_bytes_per_coord_step": case["bpc"],
            "alg_bytes_GBps": case["alg_bytes"] / kern_s / 1e9, "alg_bytes_frac": case["alg_bytes"] / kern_s / HBM_PEAK,
            "fp32_tflops": case["flops"] / kern_s / 1e12, "fp32_frac": case["flops"] / kern_s / FP32_PEAK}
-    hbm_bound = case["hbm_bound"]
-    src = None
-    traffic = None
-    issue = None
+    src, traffic, issue = None, None, None
     if counters is not None:
         path, c = counters
         src = os.path.relpath(path, ROOT)
         pl = c.get("per_launch", {})
         if "FETCH_SIZE_KiB" in pl and "WRITE_SIZE_KiB" in pl:
             traffic = (2.0 * pl["FETCH_SIZE_KiB"] + pl["WRITE_SIZE_KiB"]) * 1024.0
-        if all(k in pl for k in ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES")):
-            busy = 4.0 * pl["SQ_ACTIVE_INST_VALU"] + pl["SQ_VALU_MFMA_BUSY_CYCLES"]   # cycles, summed over SIMDs
+        if all(k in pl for k in ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVES")):
             simds = min(N_SIMD, pl["SQ_WAVES"]) if c.get("one_wave_per_simd") else N_SIMD
-            clock = c.get("clock_hz_profiled") or 2.4e9
-            issue = {"busy_cycles": busy, "simds": simds, "clock_hz": clock,
-                     "valu_quad_cycles": pl["SQ_ACTIVE_INST_VALU"], "mfma_busy_cycles": pl["SQ_VALU_MFMA_BUSY_CYCLES"],
-                     "wave_quad_cycles": pl["SQ_WAVE_CYCLES"],
-                     "frac_profiled": busy / (4.0 * pl["SQ_WAVE_CYCLES"]) if c.get("one_wave_per_simd") else None}
-    if hbm_bound:
+            issue = {"simds": simds, "clock_hz": c.get("clock_hz_profiled") or 2.4e9,
+                     "valu_active_cycles": 4.0 * pl["SQ_ACTIVE_INST_VALU"],
+                     "mfma_busy_cycles": pl["SQ_VALU_MFMA_BUSY_CYCLES"],
+                     "mfma_issue_cycles": 4.0 * pl.get("SQ_INSTS_MFMA", 0.0),
+                     "kernel_us_profiled": (sum(c["kernel_ns_profiled"].values()) / max(1, len(c["kernel_ns_profiled"])) / 1e3
+                                            if c.get("kernel_ns_profiled") else None)}
+    if case["hbm_bound"]:
         out.update(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, traffic=traffic)
         if traffic is not None:
             out.update(achieved=traffic / kern_s / 1e9, frac=traffic / kern_s / HBM_PEAK)
         else:   # no PMC pass of this workload committed: the matrix-once-per-evaluation model of the streaming kernels
             model = case["hbm_model_bytes"]
             out.update(achieved=model / kern_s / 1e9, frac=model / kern_s / HBM_PEAK, traffic_model_bytes=model)
+        if issue is not None:
+            out["valu_issue_frac"] = issue["valu_active_cycles"] / (issue["simds"] * issue["clock_hz"] * kern_s)
     else:
-        out.update(bound="valu_issue", unit="busy SIMD-cycles/s (VALU + MFMA)", traffic=traffic)
+        out.update(bound="valu_issue", unit="VALU-active SIMD-cycles/s", traffic=traffic)
         if issue is not None:
             peak = issue["simds"] * issue["clock_hz"]
-            ach = issue["busy_cycles"] / kern_s
-            out.update(achieved=ach, peak=peak, frac=min(ach / peak, 1.0), issue=issue)
+            ach = issue["valu_active_cycles"] / kern_s
+            both = (issue["valu_active_cycles"] + issue["mfma_busy_cycles"] - issue["mfma_issue_cycles"]) / kern_s
+            out.update(achieved=ach, peak=peak, frac=min(ach / peak, 1.0),
+                       mfma_busy_frac=issue["mfma_busy_cycles"] / kern_s / peak,
+                       valu_plus_mfma_frac=min(both / peak, 1.0), issue=issue)
         else:   # no SQ pass committed for this workload: the fp32-equivalent FLOP fraction stands in
             out.update(bound="fp32_flops", unit="TFLOP/s", achieved=out["fp32_tflops"], peak=FP32_PEAK / 1e12,
                        frac=out["fp32_frac"])

@@ -4,10 +4,12 @@ bench.py's roofline block reads (profiles/rNN_counters_<tag>.json) + a text summ
 
     python scripts/counters_to_json.py OUT.json KERNEL_SUBSTRING '["quadratic","dm",128,128,100]' db1 [db2 ...]
 
-Per counter: the average over the dispatches of the dominant kernel (the one whose name contains
-KERNEL_SUBSTRING).  FETCH_SIZE / WRITE_SIZE are stored as reported (KiB; bench.py doubles FETCH_SIZE,
-MI355X_MICROARCH.md "HBM").  clock_hz_profiled = GRBM_GUI_ACTIVE / kernel duration when that counter
-was collected."""
+Per counter: the per-launch TOTAL of the dominant kernel (the one whose name contains KERNEL_SUBSTRING), i.e. the
+sum over the counter's hardware instances (rocprofv3 reports one row per shader engine for SQ_*: 32 rows per
+dispatch on MI355X; one per XCD for GRBM_*), averaged over the kernel's dispatches.  GRBM_GUI_ACTIVE is kept as
+the per-instance average (cycles the XCD was active).  FETCH_SIZE / WRITE_SIZE are stored as reported (KiB;
+bench.py doubles FETCH_SIZE, MI355X_MICROARCH.md "HBM").  clock_hz_profiled = GRBM_GUI_ACTIVE / kernel duration
+when that counter was collected."""
 import glob
 import json
 import os
@@ -24,16 +26,17 @@ def main(out, kernel, workload, dbs):
             cur = con.cursor()
             try:
                 rows = list(cur.execute(
-                    "select name, counter_name, count(*), avg(counter_value) from pmc_events "
+                    "select name, counter_name, count(distinct dispatch_id), sum(counter_value), count(*) from pmc_events "
                     "where name like ? group by name, counter_name", ("%" + kernel + "%",)))
             except Exception as e:
                 print("skip %s: %s" % (db, e))
                 continue
-            for name, cname, n, avg in rows:
+            for name, cname, n, total, nrows in rows:
                 key = cname + ("_KiB" if cname in ("FETCH_SIZE", "WRITE_SIZE") else "")
-                per[key] = avg
+                per[key] = total / nrows if cname.startswith("GRBM_") else total / n
                 meta["kernel"] = name
                 meta.setdefault("dispatches", {})[cname] = n
+                meta.setdefault("instances", {})[cname] = nrows // n
             try:
                 r = list(cur.execute("select name, count(*), avg(duration), vgpr_count, accum_vgpr_count, sgpr_count, "
                                      "workgroup_x, grid_x from kernels where name like ? group by name", ("%" + kernel + "%",)))
@@ -46,7 +49,7 @@ def main(out, kernel, workload, dbs):
             meta["dbs"].append(os.path.relpath(db))
     res = {"workload": json.loads(workload), "kernel": meta.get("kernel", kernel), "per_launch": per,
            "kernel_ns_profiled": dur, "launch": {k: meta.get(k) for k in ("vgpr", "agpr", "sgpr", "workgroup_x", "grid_x")},
-           "dispatches": meta.get("dispatches", {}),
+           "dispatches": meta.get("dispatches", {}), "instances_per_dispatch": meta.get("instances", {}),
            "source": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py ... (one pass per counter group; "
                      "scripts/gpu_counters.sh), averaged over the timed + warm-up launches of the kernel"}
     # one wave per SIMD when the kernel's register budget exceeds 256 per lane
