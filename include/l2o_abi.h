@@ -176,6 +176,27 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices /* device [batch] rows
                float* loss /* device [1] */, float* gw1, float* gb1, float* gw2, float* gb2,
                float* scratch /* device [l2o_mlp_scratch_floats] */, void* stream);
 
+/* ---- the fused unroll for the neural optimizee (ABI v6): MetaOptimizer.meta_loss's tf.while_loop
+ * (DM/meta.py:338-376; RNNProp DM/meta_rnnprop_eval.py time_step) over problems.mnist (DM/problems.py:246-288) as ONE
+ * persistent launch: T x { fx_t = loss(minibatch_t; x_t * s); g = s * grad; delta, state = net(g, state) for each of
+ * the four variables (one shared net, DM/meta.py:330-336); x += delta } then fx_T on minibatch_T.
+ *   indices   device int32 [T + 1][batch]: the minibatch of every evaluation (DM/problems.py:282-286 draws one per
+ *             evaluation of the loss; the host draws them up front in the reference's order)
+ *   x, st, m, v, x_scale   HOST arrays of 4 device pointers in the order w1 [n_in, H], b1 [H], w2 [H, O], b2 [O]
+ *             (st: packed state of l2o_state_floats(1, n) floats; m, v: RNNProp only; x_scale may be NULL or
+ *             hold NULLs); all updated in place == the harness' `update` op
+ *   fx        device [T + 1]: the scalar loss of every evaluation
+ *   workspace caller-owned device scratch of l2o_mlp_unroll_workspace_bytes() bytes, zeroed once by the caller;
+ *             header as for l2o_unroll (sticky status word -> l2o_unroll_status, launch sequence word)
+ * One workgroup per 64 coordinates, all co-resident (n_tiles / 4 <= #CUs): l2o_mlp_unroll_supported() == 0
+ * otherwise (and for n_in * H % 64 != 0, H outside [8, 32], O > 16, batch > 128) -- callers then run
+ * l2o_mlp_fg + l2o_cwlstm_step_multi per step. */
+int l2o_mlp_unroll_supported(const l2o_net_cfg* cfg, const l2o_mlp* mlp, void* stream);
+size_t l2o_mlp_unroll_workspace_bytes(const l2o_mlp* mlp);
+int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_mlp* mlp,
+                   const int32_t* indices, float* const* x, float* const* st, float* const* m, float* const* v,
+                   const float* const* x_scale, int32_t T, int32_t step0, float* fx, void* workspace, void* stream);
+
 /* ---- one optimizer step on a gradient panel: the closure `update`
  * (DM/meta.py:319-336; RNNProp DM/meta_rnnprop_train.py:371-395) for ONE variable:
  * preprocess -> 2-layer coordinate-wise LSTM -> Linear -> (tanh) * scale -> x += delta

@@ -25,7 +25,7 @@ PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_M
 SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_set_option", "l2o_get_option", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
-    "l2o_mlp_scratch_floats",
+    "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
@@ -161,6 +161,12 @@ def lib():
     L.l2o_mlp_fg.argtypes = [C.POINTER(Mlp)] + [vp] * 12
     L.l2o_mlp_scratch_floats.restype = C.c_size_t
     L.l2o_mlp_scratch_floats.argtypes = [C.POINTER(Mlp)]
+    L.l2o_mlp_unroll_supported.restype = C.c_int
+    L.l2o_mlp_unroll_supported.argtypes = [C.POINTER(NetCfg), C.POINTER(Mlp), vp]
+    L.l2o_mlp_unroll_workspace_bytes.restype = C.c_size_t
+    L.l2o_mlp_unroll_workspace_bytes.argtypes = [C.POINTER(Mlp)]
+    L.l2o_mlp_unroll.restype = C.c_int
+    L.l2o_mlp_unroll.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Mlp), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
     L.l2o_cwlstm_step_multi.restype = C.c_int

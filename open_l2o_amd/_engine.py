@@ -197,6 +197,38 @@ class HipEngine(object):
         _abi.check(self.lib.l2o_mlp_fg(C.byref(c), C.c_void_p(indices.data_ptr()), _ptr(w1), _ptr(b1), _ptr(w2),
                                        _ptr(b2), _ptr(loss), *g, _ptr(self._mlp_scratch), self._stream()))
 
+    def _cmlp(self, d: MlpDesc):
+        c = _abi.Mlp()
+        c.n_in, c.n_hidden, c.n_out, c.batch = d.n_in, d.n_hidden, d.n_out, d.batch
+        c.activation, c.n_data = d.activation, int(d.images.shape[0])
+        c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
+        return c
+
+    def mlp_unroll_supported(self, spec: NetSpec, d: MlpDesc):
+        """A fused persistent unroll exists for this (net, MLP optimizee) pair on this device (l2o_mlp_unroll)."""
+        cc, cm = spec.to_c(), self._cmlp(d)
+        return bool(self.lib.l2o_mlp_unroll_supported(C.byref(cc), C.byref(cm), self._stream()))
+
+    def mlp_unroll(self, spec: NetSpec, wpack, d: MlpDesc, indices, xs, sts, ms, vs, scales, T, step0, fx):
+        """T optimizer steps on the MLP optimizee in ONE launch.  indices: device int32 [T + 1, batch]; xs / sts /
+        ms / vs / scales: lists of 4 device tensors (w1, b1, w2, b2; ms / vs / scales entries may be None)."""
+        cc, cm = spec.to_c(), self._cmlp(d)
+        n = int(self.lib.l2o_mlp_unroll_workspace_bytes(C.byref(cm)))
+        ws = self.__dict__.get("_mlp_ws")
+        if ws is None or ws.numel() < n:
+            ws = self._mlp_ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._last_ws = ws
+
+        def arr(ts):
+            a = (C.c_void_p * 4)()
+            for k, t in enumerate(ts):
+                a[k] = None if t is None else t.data_ptr()
+            return a
+        ax, ast, am, av, asc = arr(xs), arr(sts), arr(ms), arr(vs), arr(scales)
+        _abi.check(self.lib.l2o_mlp_unroll(C.byref(cc), _ptr(wpack), C.byref(cm), C.c_void_p(indices.data_ptr()), ax, ast,
+                                           am, av, asc, int(T), int(step0), _ptr(fx), C.c_void_p(ws.data_ptr()),
+                                           self._stream()))
+
     # -- prepared calls: the ctypes argument objects are built ONCE for launches that repeat with the same
     #    buffers (the T steps of a recorded unroll); per call only what changes is passed ------------------
     def prepared_mlp_fg(self, d: MlpDesc, indices, w1, b1, w2, b2, grads):

@@ -822,6 +822,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_mlp.h"
 
+#include "l2o_mlp_unroll.h"
+
 #include "l2o_bwd.h"
 
 #include "l2o_bwd_mfma.h"
@@ -1403,6 +1405,92 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
 size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp) {
   if (!mlp || mlp->batch < 1) return 0;
   return (size_t)mlp->batch * (2 * (size_t)mlp->n_hidden + mlp->n_out + 1);
+}
+
+// ---- the fused persistent unroll of the MLP optimizee (csrc/l2o_mlp_unroll.h) ---------------------------
+struct MlpUnrollLayout { int n[4], tile_begin[5], nwg, nw1, R; bool fast; size_t NO, NSM, p_off, s_off, sm_off, total; };
+static bool mlp_unroll_layout(const l2o_mlp* mlp, MlpUnrollLayout* L) {
+  if (!mlp) return false;
+  const int H = mlp->n_hidden, O = mlp->n_out;
+  if (H < kMuMinH || H > kMuMaxH || O < 1 || O > kMuMaxO || mlp->batch < 1 || mlp->batch > kMuMaxBatch || mlp->n_in < 1)
+    return false;
+  L->n[0] = mlp->n_in * H; L->n[1] = H; L->n[2] = H * O; L->n[3] = O;
+  if (L->n[0] % 64) return false;                        // the w1 coordinates fill whole workgroups
+  L->tile_begin[0] = 0;
+  for (int v = 0; v < 4; ++v) L->tile_begin[v + 1] = L->tile_begin[v] + tiles_per_problem(L->n[v]);
+  L->nwg = (L->tile_begin[4] + 3) / 4;
+  L->nw1 = L->n[0] / 64;
+  L->NO = (size_t)mlp->batch * H;
+  L->NSM = (size_t)H + (size_t)H * O + O;
+  L->R = (int)((L->NO + L->nwg - 1) / L->nwg);
+  L->R = (L->R + 1) & ~1;                                // even: the fast path moves granules in pairs
+  if (L->R > kMuMaxR) return false;
+  L->fast = H == 20 && O == 10 && mlp->batch == 64;
+  L->p_off = sizeof(MlpWs);
+  // P: generic [nw1][NO]; fast path: one inbox per reducing workgroup, [nwg][nw1][R]
+  const size_t pg = (size_t)L->nw1 * L->NO, pf = (size_t)L->nwg * L->nw1 * L->R;
+  L->s_off = L->p_off + sizeof(unsigned long long) * (pg > pf ? pg : pf);
+  L->sm_off = L->s_off + sizeof(unsigned long long) * 2 * L->NO;
+  L->total = L->sm_off + sizeof(unsigned long long) * 2 * ((L->NSM + 1) & ~(size_t)1);
+  return true;
+}
+
+int l2o_mlp_unroll_supported(const l2o_net_cfg* cfg, const l2o_mlp* mlp, void* stream) {
+  MlpUnrollLayout L;
+  if (!cfg || !net_ok_for_mfma(cfg) || !opt(L2O_OPT_MLP_UNROLL) || !mlp_unroll_layout(mlp, &L)) return 0;
+  return L.nwg <= device_cu_count((hipStream_t)stream) ? 1 : 0;   // one workgroup per CU, all co-resident
+}
+
+size_t l2o_mlp_unroll_workspace_bytes(const l2o_mlp* mlp) {
+  MlpUnrollLayout L;
+  return mlp_unroll_layout(mlp, &L) ? L.total : 0;
+}
+
+int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* mlp, const int32_t* indices,
+                   float* const* x, float* const* st, float* const* m, float* const* v, const float* const* x_scale,
+                   int32_t T, int32_t step0, float* fx, void* workspace, void* stream) {
+  if (!cfg || !wpack || !mlp || !indices || !x || !st || !fx || !workspace || T < 0 || !mlp->images || !mlp->labels)
+    return fail(L2O_ERR_ARG, "l2o_mlp_unroll: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  MlpUnrollLayout L;
+  if (!net_ok_for_mfma(cfg) || !mlp_unroll_layout(mlp, &L) || L.nwg > device_cu_count(s))
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_unroll: no fused kernel for n_in=%d hidden=%d out=%d batch=%d net(layers=%d)",
+                mlp->n_in, mlp->n_hidden, mlp->n_out, mlp->batch, cfg->n_layers);
+  const bool rn = cfg->preprocess == L2O_PRE_FC_ELU;
+  MlpUnrollArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.np = make_net_params(cfg, wpack);
+  a.n_in = mlp->n_in; a.H = mlp->n_hidden; a.O = mlp->n_out; a.batch = mlp->batch; a.act = mlp->activation;
+  a.images = mlp->images; a.labels = mlp->labels; a.idx = indices;
+  for (int k = 0; k < 4; ++k) {
+    if (!x[k] || !st[k] || (rn && (!m || !v || !m[k] || !v[k]))) return fail(L2O_ERR_ARG, "l2o_mlp_unroll: NULL buffer of variable %d", k);
+    a.x[k] = x[k]; a.st[k] = st[k]; a.m[k] = rn ? m[k] : nullptr; a.v[k] = rn ? v[k] : nullptr;
+    a.xscale[k] = x_scale ? x_scale[k] : nullptr;
+    a.n[k] = L.n[k];
+  }
+  for (int k = 0; k < 5; ++k) a.tile_begin[k] = L.tile_begin[k];
+  a.T = T;
+  pow_ff(cfg->beta1, step0, &a.p1_hi, &a.p1_lo);
+  pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
+  a.fx = fx;
+  char* wsb = static_cast<char*>(workspace);
+  a.ws = reinterpret_cast<MlpWs*>(wsb);
+  a.P = reinterpret_cast<unsigned long long*>(wsb + L.p_off);
+  a.S = reinterpret_cast<unsigned long long*>(wsb + L.s_off);
+  a.Sm = reinterpret_cast<unsigned long long*>(wsb + L.sm_off);
+  a.nwg = L.nwg; a.nw1 = L.nw1; a.R = L.R;
+  a.use_salt = T + 1 < 0xffff ? 1u : 0u;
+  HIP_TRY(hipMemsetAsync(wsb + L.p_off, 0, L.total - L.p_off, s));   // the granules only: the header survives
+  const dim3 grid(L.nwg), block(256);
+  void (*fn)(MlpUnrollArgs) = nullptr;
+  switch (cfg->preprocess) {
+    case L2O_PRE_IDENTITY: fn = L.fast ? k_mlp_unroll<L2O_PRE_IDENTITY, true> : k_mlp_unroll<L2O_PRE_IDENTITY, false>; break;
+    case L2O_PRE_LOGSIGN: fn = L.fast ? k_mlp_unroll<L2O_PRE_LOGSIGN, true> : k_mlp_unroll<L2O_PRE_LOGSIGN, false>; break;
+    default: fn = L.fast ? k_mlp_unroll<L2O_PRE_FC_ELU, true> : k_mlp_unroll<L2O_PRE_FC_ELU, false>;
+  }
+  hipLaunchKernelGGL(fn, grid, block, 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
 }
 
 int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_step_seg* segs, int32_t nseg,

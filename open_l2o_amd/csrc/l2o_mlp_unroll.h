@@ -1,0 +1,563 @@
+// l2o_mlp_unroll.h -- the fused persistent unroll for the neural optimizee problems.mnist
+// (DM/problems.py:246-288: a [n_in -> H -> O] MLP, mean sparse-softmax cross-entropy on a fresh
+// minibatch per evaluation, DM/problems.py:282-286) stepped by ONE coordinate-wise LSTM optimizer shared by
+// its four variables (DM/meta.py:338-359; RNNProp DM/meta_rnnprop_train.py:371-423): T steps in ONE launch.
+// Included by l2o_kernels.hip.
+//
+// Why: the step-granular path spends 22 us per step in three latency-bound launches (forward, backward,
+// LSTM step) and re-reads the 5 MB of LSTM state and the weight fragments every step.  Here every
+// 16-coordinate tile of the 15 910 coordinates (996 tiles) lives on its own SIMD for the whole unroll --
+// LSTM state, Adam moments and the iterate in registers, bf16x3 fragments in AGPRs -- and the optimizee is
+// evaluated by the same workgroups:
+//
+//   workgroup i (4 waves) owns the flat w1 coordinates [64 i, 64 i + 64) (the last workgroups own b1, w2, b2)
+//   per step
+//     publish   b1 / w2 / b2 owners broadcast their coordinates as {value, tag} granules        (230 values)
+//     partial   P_i[s][h] = sum over the workgroup's OWN w1 coordinates (k, h) of img[s][k] w1[k][h]
+//               -- the hidden pre-activation split over K; published as granules                (batch x H)
+//     reduce    workgroup r sums outputs [r R, r R + R) over all partials in a FIXED order and publishes them
+//     gather    every workgroup polls the batch x H sums and the small parameters, then computes the rest of
+//               the forward (sigmoid / relu, layer 2, softmax, loss) and dZ, dH redundantly in LDS   (30 kMAC)
+//     gradient  every lane forms the gradient of ITS coordinate from LDS (64 MACs), RNNProp / LogAndSign
+//               inputs, LSTM tile step, x += delta
+//
+// i.e. one all-reduce of batch x H floats per step through self-validating granules (no flag, no fence, no
+// grid barrier object; MI355X_MICROARCH.md "valid forms": 8-byte agent-scope atomics on both sides).  Buffer
+// reuse: P is single-buffered (a workgroup can only overwrite P_i(t) after it holds all sums of step t, each of
+// which was published after its reducer had consumed every P(t)); the sums and the small parameters are
+// double-buffered by step parity (their publishers run at most one evaluation ahead of the slowest reader).
+// Every spin is bounded; a timeout raises the sticky status word of the workspace header.
+#pragma once
+
+#ifndef L2O_MU_SLEEP2
+#define L2O_MU_SLEEP2 1    // back-off between two polls of a granule pair (x 64 clocks)
+#endif
+#ifndef L2O_MU_SLEEP1
+#define L2O_MU_SLEEP1 1
+#endif
+constexpr int kMuMaxBatch = 128;
+constexpr int kMuMaxH = 32;
+constexpr int kMuMaxO = 16;
+constexpr int kMuMinH = 8;                 // (bounds the k-rows a workgroup's 64 w1 coordinates touch)
+constexpr int kMuMaxKR = 64 / kMuMinH + 2; // k-rows of the image a workgroup needs per sample
+constexpr int kMuMaxR = 16;                // outputs per reducing workgroup: batch * H <= 16 * workgroups
+constexpr int kMuMaxG = (kMuMaxBatch * kMuMaxH + 255) / 256;   // sums gathered per thread
+
+struct MlpWs {                 // header of the caller-owned workspace (never cleared by the library)
+  unsigned status;             // STICKY: 1 = a publisher never showed up
+  unsigned seq;                // launch sequence number (tag salt), advanced by workgroup 0 at the end of a launch
+  unsigned pad[14];
+  long long phases[16];        // phase clock dump of the -DL2O_PROFILE_PHASES build (else unused)
+};
+
+struct MlpUnrollArgs {
+  NetParams np;
+  int n_in, H, O, batch, act;
+  const float* images;
+  const int* labels;
+  const int* idx;              // [T + 1][batch]
+  float* x[4];                 // w1 [n_in, H], b1 [H], w2 [H, O], b2 [O]   in-out
+  float* st[4];                // packed LSTM state per variable            in-out
+  float* m[4];                 // RNNProp moments per variable              in-out
+  float* v[4];
+  const float* xscale[4];      // per-coordinate scale or NULL
+  int n[4];                    // coordinates per variable
+  int tile_begin[5];           // running tile count
+  int T;
+  float p1_hi, p1_lo, p2_hi, p2_lo;
+  float* fx;                   // [T + 1]
+  MlpWs* ws;
+  unsigned long long* P;       // [nw1][batch * H]        partial pre-activations
+  unsigned long long* S;       // [2][batch * H]          their sums, by step parity
+  unsigned long long* Sm;      // [2][H + H * O + O]      b1, w2, b2 (scaled), by step parity
+  int nwg, nw1, R;             // workgroups; workgroups that own w1 coordinates; outputs per reducer
+  unsigned use_salt;
+};
+
+__device__ __forceinline__ unsigned long long mu_granule(float v, unsigned tag) {
+  return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+// bounded poll of one granule; returns the value, raises *dead on timeout
+__device__ __forceinline__ float mu_poll(const unsigned long long* p, unsigned tag, bool& dead, unsigned* status) {
+  unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while ((unsigned)(g >> 32) != tag && !dead) {
+    if (++spins > (1 << 20)) { dead = true; atomicExch(status, 1u); break; }
+    __builtin_amdgcn_s_sleep(L2O_MU_SLEEP1);
+    g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __uint_as_float((unsigned)g);
+}
+
+// 16-byte (two-granule) write-through store / L1-bypassing load: MI355X_MICROARCH.md "valid forms" (16-B sc1 on both sides)
+typedef unsigned mu_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mu_store2(unsigned long long* p, float v0, float v1, unsigned tag) {
+  mu_u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ mu_u32x4 mu_load2(const unsigned long long* p) {
+  mu_u32x4 d;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory");
+  return d;
+}
+__device__ __forceinline__ void mu_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// two granules at p until both carry `tag` (bounded, with back-off: a failed poll is a fabric request that competes
+// with the stores it waits for)
+__device__ __forceinline__ mu_u32x4 mu_poll2(const unsigned long long* p, mu_u32x4 d, unsigned tag, bool& dead, unsigned* status) {
+  int spins = 0;
+  while ((d[1] != tag || d[3] != tag) && !dead) {
+    if (++spins > (1 << 17)) { dead = true; atomicExch(status, 1u); break; }
+    __builtin_amdgcn_s_sleep(L2O_MU_SLEEP2);
+    d = mu_load2(p);
+    mu_wait_loads();
+  }
+  return d;
+}
+
+// FAST: the reference's shape (hidden 20, 10 classes, minibatch 64 = one sample per lane) with static loop bounds,
+// pairwise 16-byte granule traffic and a barrier-free forward tail; else the generic loops.
+template <int PRE, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_unroll(MlpUnrollArgs a) {
+  __shared__ float xwg_p[32 + 64 + 64];               // the workgroup's 64 scaled coordinates, zero margins (w1 owners)
+  float* xwg = xwg_p + 32;
+  __shared__ float imgs[2][kMuMaxBatch][kMuMaxKR];    // the image columns the workgroup's w1 rows touch, by step parity
+  __shared__ int labs[2][kMuMaxBatch];
+  __shared__ float Hs[kMuMaxBatch][kMuMaxH];          // hidden activations
+  __shared__ float dHs[kMuMaxBatch][kMuMaxH];
+  __shared__ float dZs[kMuMaxBatch][kMuMaxO];         // logits, then dZ
+  __shared__ float small[kMuMaxH + kMuMaxH * kMuMaxO + kMuMaxO];   // b1 | w2 | b2 (scaled)
+  __shared__ __attribute__((aligned(16))) float w2p[kMuMaxH][12];   // FAST: w2 rows padded to 48 bytes
+  __shared__ float red[4][kMuMaxR];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int wg = blockIdx.x;
+  const int H = a.H, O = a.O, Bn = a.batch, n_in = a.n_in;
+  const int NO = Bn * H;                              // all-reduced outputs per evaluation
+  const int NSM = H + H * O + O;
+  const unsigned salt = a.use_salt ? ((a.ws->seq + 1u) & 0x7fffu) << 16 : 0u;
+  unsigned* status = &a.ws->status;
+
+  // ---- this wave's tile ---------------------------------------------------
+  const int ti = wg * 4 + wv;
+  const int ntiles = a.tile_begin[4];
+  const bool tile_real = ti < ntiles;
+  int var = 0;
+  while (var < 3 && ti >= a.tile_begin[var + 1]) ++var;
+  const int tile_in_var = tile_real ? ti - a.tile_begin[var] : 0;
+  const int jl = tile_in_var * kTile + c;             // coordinate index inside the variable
+  const bool live = tile_real && jl < a.n[var];
+  // workgroup's w1 range: flat [j0, j0 + 64) -> image columns [k0, k0 + KR)
+  const int j0 = wg * 64;
+  const bool owns_w1 = wg < a.nw1;
+  const int k0 = j0 / H;
+  const int k_end = (min(j0 + 64, a.n[0]) - 1) / H;   // inclusive
+  const int KR = owns_w1 ? k_end - k0 + 1 : 0;
+
+  using Core = LstmCore<PRE, true>;                    // bf16x3 gate GEMM, fragments pinned to AGPRs
+  Core core;
+  core.load(a.np.wpack, lane);
+  core.pin();
+  f32x4 acc1[kNT], acc2[kNT];
+  TileState s;
+  float* st_tile = a.st[var] + (size_t)tile_in_var * kStateFloatsPerTile;
+  if (tile_real) load_tile_state(s, st_tile, lane);
+  else {
+#pragma unroll
+    for (int t5 = 0; t5 < kNT; ++t5) s.h1[t5] = s.c1[t5] = s.h2[t5] = s.c2[t5] = 0.0f;
+  }
+  float xv = live ? a.x[var][jl] : 0.0f;
+  const float sc = (live && a.xscale[var]) ? a.xscale[var][jl] : 1.0f;
+  float mv = 0.0f, vv = 0.0f;
+  if (PRE == L2O_PRE_FC_ELU && live) { mv = a.m[var][jl]; vv = a.v[var][jl]; }
+  float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
+  const int sm_off = var == 1 ? 0 : (var == 2 ? H : H + H * O);        // slot of a small-parameter coordinate
+  bool dead = false;
+
+  // image columns + labels of evaluation `t` into the parity buffer (synchronous form: prologue)
+  auto load_eval = [&](int t, int par) {
+    const int* ix = a.idx + (size_t)t * Bn;
+    for (int e = tid; e < Bn * KR; e += 256) {
+      const int sidx = e / KR, kk = e - sidx * KR;
+      imgs[par][sidx][kk] = a.images[(size_t)ix[sidx] * n_in + k0 + kk];
+    }
+    for (int sidx = tid; sidx < Bn; sidx += 256) labs[par][sidx] = a.labels[ix[sidx]];
+  };
+  for (int e = tid; e < 160; e += 256) xwg_p[e] = 0.0f;
+  for (int e = tid; e < 2 * kMuMaxBatch * kMuMaxKR; e += 256) (&imgs[0][0][0])[e] = 0.0f;
+  for (int e = tid; e < kMuMaxH * 12; e += 256) (&w2p[0][0])[e] = 0.0f;
+  __syncthreads();
+  load_eval(0, 0);
+  __syncthreads();
+
+  const float invB = 1.0f / (float)Bn;
+  core.init(s, q);
+  PhaseClock pc;
+  pc.start();
+  for (int t = 0;; ++t) {
+    const int par = t & 1;
+    const unsigned tag = salt | ((unsigned)t + 1u);
+    const float xsv = xv * sc;
+    // ---- publish: w1 owners into the workgroup's LDS row, small-parameter owners as granules
+    if (q == 0 && tile_real) {
+      if (var == 0) xwg[wv * kTile + c] = live ? xsv : 0.0f;
+      else if (live)
+        __hip_atomic_store(a.Sm + (size_t)par * NSM + sm_off + jl, mu_granule(xsv, tag), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (q == 0 && !tile_real && owns_w1) xwg[wv * kTile + c] = 0.0f;
+    // prefetch the next evaluation's image columns / labels into registers (landed long before the step ends)
+    float pre_img[(kMuMaxBatch * kMuMaxKR + 255) / 256];
+    int pre_lab = 0;
+    const bool have_next = t < a.T;
+    if (have_next) {
+      const int* ix = a.idx + (size_t)(t + 1) * Bn;
+#pragma unroll
+      for (int u = 0; u < (kMuMaxBatch * kMuMaxKR + 255) / 256; ++u) {
+        const int e = tid + 256 * u;
+        pre_img[u] = 0.0f;
+        if (e < Bn * KR) {
+          const int sidx = e / KR, kk = e - sidx * KR;
+          pre_img[u] = a.images[(size_t)ix[sidx] * n_in + k0 + kk];
+        }
+      }
+      if (tid < Bn) pre_lab = a.labels[ix[tid]];
+    }
+    __syncthreads();                                   // xwg complete
+    pc.mark(0);
+    if constexpr (FAST) {
+      constexpr int FH = 20, FO = 10, FB = 64, FNO = FB * FH;
+      const int R = a.R;                               // even (host check)
+      // ---- partial hidden pre-activations, two adjacent outputs (s, h), (s, h + 1) per 16-byte granule pair,
+      // stored into the INBOX of the workgroup that reduces them: P[r][source][R]
+      if (owns_w1) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int pr = tid + 256 * u;
+          if (pr < FNO / 2) {
+            const int o = 2 * pr, sidx = o / FH, h = o - sidx * FH;
+            float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 5; ++kk) {           // (k-rows beyond KR: zero image columns AND zero margin of xwg)
+              const float im = imgs[par][sidx][kk];
+              const int jj = (k0 + kk) * FH + h - j0;  // in [-19, 99]: inside the zero margins of xwg_p
+              acc0 = __builtin_fmaf(im, xwg[jj], acc0);
+              acc1 = __builtin_fmaf(im, xwg[jj + 1], acc1);
+            }
+            const int r = o / R;
+            mu_store2(a.P + ((size_t)r * a.nw1 + wg) * R + (o - r * R), acc0, acc1, tag);
+          }
+        }
+      }
+      // the 60 recurrent MFMAs of the optimizer step (chunks L2B, L1H: fed by the previous step's h2, h1) ride under
+      // the first hop of the all-reduce -- the first poll below would only fail anyway
+      core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
+      core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
+      // ---- the small parameters (published at the start of the step: one hop, long under way)
+      if (tid < FH + FH * FO + FO) {
+        const float val = mu_poll(a.Sm + (size_t)par * NSM + tid, tag, dead, status);
+        small[tid] = val;
+        if (tid >= FH && tid < FH + FH * FO) { const int e = tid - FH; w2p[e / FO][e % FO] = val; }
+      }
+      pc.mark(1);
+      // ---- reduce-scatter: thread = source workgroup, R granules contiguous in this workgroup's inbox
+      {
+        const int o0 = wg * R;
+        const int nr = min(R, FNO - o0);               // <= 0: nothing to reduce here (workgroup-uniform, even)
+        if (nr > 0) {
+          float part[kMuMaxR];
+#pragma unroll
+          for (int r = 0; r < kMuMaxR; ++r) part[r] = 0.0f;
+          for (int src = tid; src < a.nw1; src += 256) {
+            const unsigned long long* pp = a.P + ((size_t)wg * a.nw1 + src) * R;
+            mu_u32x4 g[kMuMaxR / 2];
+#pragma unroll
+            for (int r = 0; r < kMuMaxR / 2; ++r)
+              if (2 * r < nr) g[r] = mu_load2(pp + 2 * r);
+            mu_wait_loads();
+#pragma unroll
+            for (int r = 0; r < kMuMaxR / 2; ++r)
+              if (2 * r < nr) {
+                g[r] = mu_poll2(pp + 2 * r, g[r], tag, dead, status);
+                part[2 * r] += __uint_as_float(g[r][0]);
+                part[2 * r + 1] += __uint_as_float(g[r][2]);
+              }
+          }
+#pragma unroll
+          for (int r = 0; r < kMuMaxR; ++r)
+            if (r < nr) {
+              const float ws_ = wave_sum64(part[r]);
+              if (lane == 0) red[wv][r] = ws_;
+            }
+          __syncthreads();
+          if (2 * tid < nr)
+            mu_store2(a.S + (size_t)par * FNO + o0 + 2 * tid,
+                      (red[0][2 * tid] + red[1][2 * tid]) + (red[2][2 * tid] + red[3][2 * tid]),
+                      (red[0][2 * tid + 1] + red[1][2 * tid + 1]) + (red[2][2 * tid + 1] + red[3][2 * tid + 1]), tag);
+        } else {
+          __syncthreads();
+        }
+      }
+      pc.mark(2);
+      // ---- gather the sums (pairs), bias + activation fused into the LDS write
+      {
+        const unsigned long long* Sp = a.S + (size_t)par * FNO;
+        mu_u32x4 g[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int pr = tid + 256 * u;
+          if (pr < FNO / 2) g[u] = mu_load2(Sp + 2 * pr);
+        }
+        mu_wait_loads();
+        // (small[] was written before the barrier inside the reduce phase)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int pr = tid + 256 * u;
+          if (pr < FNO / 2) {
+            g[u] = mu_poll2(Sp + 2 * pr, g[u], tag, dead, status);
+            const int o = 2 * pr, sidx = o / FH, h = o - sidx * FH;
+            const float a0 = __uint_as_float(g[u][0]) + small[h], a1 = __uint_as_float(g[u][2]) + small[h + 1];
+            Hs[sidx][h] = a.act == 0 ? sigmoidf_(a0) : fmaxf(a0, 0.0f);
+            Hs[sidx][h + 1] = a.act == 0 ? sigmoidf_(a1) : fmaxf(a1, 0.0f);
+          }
+        }
+      }
+      __syncthreads();
+      pc.mark(3);
+      // ---- forward tail, every wave for all 64 samples (lane = sample): logits, softmax, loss, dZ in registers
+      float hrow[FH], dz[FO];
+      {
+        const float4* hp = reinterpret_cast<const float4*>(&Hs[lane][0]);
+#pragma unroll
+        for (int j4 = 0; j4 < FH / 4; ++j4) {
+          const float4 v4 = hp[j4];
+          hrow[4 * j4] = v4.x; hrow[4 * j4 + 1] = v4.y; hrow[4 * j4 + 2] = v4.z; hrow[4 * j4 + 3] = v4.w;
+        }
+        float z[FO];
+#pragma unroll
+        for (int o = 0; o < FO; ++o) z[o] = small[FH + FH * FO + o];
+#pragma unroll
+        for (int h = 0; h < FH; ++h) {
+          const float4* wp = reinterpret_cast<const float4*>(&w2p[h][0]);
+          const float4 wa = wp[0], wb = wp[1], wc = wp[2];
+          const float wr[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+          for (int o = 0; o < FO; ++o) z[o] = __builtin_fmaf(hrow[h], wr[o], z[o]);
+        }
+        const int lab = labs[par][lane];
+        constexpr float kLog2e = 1.4426950408889634f;
+        float zmax = z[0];
+#pragma unroll
+        for (int o = 1; o < FO; ++o) zmax = fmaxf(zmax, z[o]);
+        float se = 0.0f, zl = 0.0f;
+#pragma unroll
+        for (int o = 0; o < FO; ++o) { se += fast_exp2((z[o] - zmax) * kLog2e); zl = o == lab ? z[o] : zl; }
+        const float lse = zmax + __builtin_amdgcn_logf(se) * 0.6931471805599453f;      // v_log_f32 (log2), 1 ulp
+#pragma unroll
+        for (int o = 0; o < FO; ++o) dz[o] = (fast_exp2((z[o] - lse) * kLog2e) - (o == lab ? 1.0f : 0.0f)) * invB;
+        const float lsum = wave_sum64(lse - zl);
+        if (wg == 0 && tid == 0) a.fx[t] = lsum * invB;
+        if (wv == 0) {
+#pragma unroll
+          for (int o = 0; o < FO; ++o) dZs[lane][o] = dz[o];
+        }
+      }
+      pc.mark(4);
+      if (t == a.T) break;
+      // ---- dH for hidden units 5 wv .. 5 wv + 4 of the lane's sample
+#pragma unroll
+      for (int hh = 0; hh < 5; ++hh) {
+        const int h = 5 * wv + hh;
+        const float4* wp = reinterpret_cast<const float4*>(&w2p[h][0]);
+        const float4 wa = wp[0], wb = wp[1], wc = wp[2];
+        const float wr[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
+        float d = 0.0f;
+#pragma unroll
+        for (int o = 0; o < FO; ++o) d = __builtin_fmaf(dz[o], wr[o], d);
+        const float hv = Hs[lane][h];
+        dHs[lane][h] = a.act == 0 ? d * hv * (1.0f - hv) : (hv > 0.0f ? d : 0.0f);
+      }
+    } else {
+    // ---- partial hidden pre-activations over the workgroup's own w1 coordinates
+    if (owns_w1) {
+      unsigned long long* Pw = a.P + (size_t)wg * NO;
+      for (int o = tid; o < NO; o += 256) {
+        const int sidx = o / H, h = o - sidx * H;
+        float acc = 0.0f;
+        for (int kk = 0; kk < KR; ++kk) {
+          const int jj = (k0 + kk) * H + h - j0;       // position inside the workgroup's 64 coordinates
+          if (jj >= 0 && jj < 64) acc = __builtin_fmaf(imgs[par][sidx][kk], xwg[jj], acc);
+        }
+        __hip_atomic_store(Pw + o, mu_granule(acc, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
+    core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
+    pc.mark(1);                                        // partial + publish
+    // ---- reduce-scatter: this workgroup sums outputs [wg R, wg R + R) over all partials, fixed order.
+    // All R granules of a source are requested before the first tag is checked (one L2 / fabric round trip
+    // per source, not R of them)
+    {
+      const int o0 = wg * a.R;
+      const int nr = min(a.R, NO - o0);                // <= 0: nothing to reduce here (workgroup-uniform)
+      if (nr > 0) {
+        float part[kMuMaxR];
+#pragma unroll
+        for (int r = 0; r < kMuMaxR; ++r) part[r] = 0.0f;
+        for (int src = tid; src < a.nw1; src += 256) { // (ascending source order per thread, then a fixed tree)
+          const unsigned long long* pp = a.P + (size_t)src * NO + o0;
+          unsigned long long g[kMuMaxR];
+#pragma unroll
+          for (int r = 0; r < kMuMaxR; ++r)
+            if (r < nr) g[r] = __hip_atomic_load(pp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int r = 0; r < kMuMaxR; ++r)
+            if (r < nr) {
+              if ((unsigned)(g[r] >> 32) != tag) g[r] = mu_granule(mu_poll(pp + r, tag, dead, status), tag);
+              part[r] += __uint_as_float((unsigned)g[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kMuMaxR; ++r)
+          if (r < nr) {
+            const float ws_ = wave_sum64(part[r]);
+            if (lane == 0) red[wv][r] = ws_;
+          }
+        __syncthreads();
+        if (tid < nr)
+          __hip_atomic_store(a.S + (size_t)par * NO + o0 + tid,
+                             mu_granule((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]), tag),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    pc.mark(2);                                        // reduce-scatter
+    // ---- gather the sums and the small parameters (all requests first, then the tag checks)
+    {
+      const unsigned long long* Sp = a.S + (size_t)par * NO;
+      const unsigned long long* Smp = a.Sm + (size_t)par * NSM;
+      unsigned long long g[kMuMaxG], gs = 0;
+#pragma unroll
+      for (int u = 0; u < kMuMaxG; ++u) {
+        const int o = tid + 256 * u;
+        if (o < NO) g[u] = __hip_atomic_load(Sp + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int e = tid; e < NSM; e += 256) {
+        gs = __hip_atomic_load(Smp + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        small[e] = (unsigned)(gs >> 32) == tag ? __uint_as_float((unsigned)gs) : mu_poll(Smp + e, tag, dead, status);
+      }
+#pragma unroll
+      for (int u = 0; u < kMuMaxG; ++u) {
+        const int o = tid + 256 * u;
+        if (o < NO) {
+          const float val = (unsigned)(g[u] >> 32) == tag ? __uint_as_float((unsigned)g[u]) : mu_poll(Sp + o, tag, dead, status);
+          const int sidx = o / H;
+          Hs[sidx][o - sidx * H] = val;
+        }
+      }
+    }
+    __syncthreads();
+    pc.mark(3);                                        // gather
+    const float* b1s = small;
+    const float* w2s = small + H;
+    const float* b2s = small + H + H * O;
+    for (int o = tid; o < NO; o += 256) {
+      const int sidx = o / H, h = o - sidx * H;
+      const float av = Hs[sidx][h] + b1s[h];
+      Hs[sidx][h] = a.act == 0 ? 1.0f / (1.0f + expf(-av)) : fmaxf(av, 0.0f);
+    }
+    __syncthreads();
+    for (int e = tid; e < Bn * O; e += 256) {          // logits
+      const int sidx = e / O, o = e - sidx * O;
+      float z = b2s[o];
+      for (int h = 0; h < H; ++h) z = __builtin_fmaf(Hs[sidx][h], w2s[h * O + o], z);
+      dZs[sidx][o] = z;
+    }
+    __syncthreads();
+    float lossn = 0.0f;
+    if (tid < Bn) {                                    // softmax cross-entropy of sample tid
+      const int lab = labs[par][tid];
+      float zmax = dZs[tid][0];
+      for (int o = 1; o < O; ++o) zmax = fmaxf(zmax, dZs[tid][o]);
+      float se = 0.0f;
+      for (int o = 0; o < O; ++o) se += expf(dZs[tid][o] - zmax);
+      const float lse = zmax + logf(se);
+      lossn = lse - dZs[tid][lab];
+      for (int o = 0; o < O; ++o) dZs[tid][o] = (expf(dZs[tid][o] - lse) - (o == lab ? 1.0f : 0.0f)) * invB;
+    }
+    lossn = wave_sum64(lossn);
+    if (lane == 0) red[wv][0] = lossn;
+    __syncthreads();
+    if (wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
+    pc.mark(4);                                        // activation, layer 2, softmax, loss
+    if (t == a.T) break;
+    for (int o = tid; o < NO; o += 256) {              // dH = (dZ w2^T) * act'
+      const int sidx = o / H, h = o - sidx * H;
+      float d = 0.0f;
+      for (int oo = 0; oo < O; ++oo) d = __builtin_fmaf(dZs[sidx][oo], w2s[h * O + oo], d);
+      const float hv = Hs[sidx][h];
+      dHs[sidx][h] = a.act == 0 ? d * hv * (1.0f - hv) : (hv > 0.0f ? d : 0.0f);
+    }
+    }
+    __syncthreads();
+    pc.mark(5);                                        // dH
+    // ---- the gradient of this lane's coordinate: a sum over the samples, split over the four q lanes
+    float gv = 0.0f;
+    if (live) {
+      if (var == 0) {
+        const int k = jl / H, h = jl - k * H;
+        for (int sidx = q; sidx < Bn; sidx += 4) gv = __builtin_fmaf(imgs[par][sidx][k - k0], dHs[sidx][h], gv);
+      } else if (var == 1) {
+        for (int sidx = q; sidx < Bn; sidx += 4) gv += dHs[sidx][jl];
+      } else if (var == 2) {
+        const int h = jl / O, o = jl - h * O;
+        for (int sidx = q; sidx < Bn; sidx += 4) gv = __builtin_fmaf(Hs[sidx][h], dZs[sidx][o], gv);
+      } else {
+        for (int sidx = q; sidx < Bn; sidx += 4) gv += dZs[sidx][jl];
+      }
+    }
+    gv = quad_q_sum(gv);
+    gv = live ? gv * sc : 0.0f;
+    pc.mark(6);                                        // gradient
+    // ---- optimizer step on the tile
+    float in0, in1;
+    if (PRE == L2O_PRE_FC_ELU) {
+      rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, 1.0f - p1h, 1.0f - p2h, in0, in1);
+      if (!live) { in0 = 0.0f; in1 = 0.0f; }
+      float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
+      float lo = __builtin_fmaf(p1l, a.np.beta1, er), sum = hi + lo;
+      p1l = lo - (sum - hi); p1h = sum;
+      hi = p2h * a.np.beta2; er = __builtin_fmaf(p2h, a.np.beta2, -hi);
+      lo = __builtin_fmaf(p2l, a.np.beta2, er); sum = hi + lo;
+      p2l = lo - (sum - hi); p2h = sum;
+    } else {
+      preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
+    }
+    float d = core.template finish<false>(s, acc1, acc2, in0, in1, q, pc);
+    core.refresh(s);
+    if (a.np.tanh_output) d = tanhf_(d);
+    xv = __builtin_fmaf(d, a.np.scale, xv);
+    pc.mark(7);                                        // LSTM tile step
+    // ---- the prefetched next evaluation -> the other parity buffer (its previous readers finished two barriers ago)
+#pragma unroll
+    for (int u = 0; u < (kMuMaxBatch * kMuMaxKR + 255) / 256; ++u) {
+      const int e = tid + 256 * u;
+      if (e < Bn * KR) {
+        const int sidx = e / KR, kk = e - sidx * KR;
+        imgs[par ^ 1][sidx][kk] = pre_img[u];
+      }
+    }
+    if (tid < Bn) labs[par ^ 1][tid] = pre_lab;
+    pc.mark(8);
+  }
+#ifdef L2O_PROFILE_PHASES
+  if (wg == L2O_PROFILE_WG && tid == 0) pc.dump(a.ws->phases);
+#endif
+
+  if (live && q == 0) {
+    a.x[var][jl] = xv;
+    if (PRE == L2O_PRE_FC_ELU) { a.m[var][jl] = mv; a.v[var][jl] = vv; }
+  }
+  if (tile_real) store_tile_state(s, st_tile, lane);
+  // every workgroup read ws->seq at its start and none can finish before all have started (the first
+  // all-reduce needs every partial): workgroup 0 may advance the sequence word now
+  if (wg == 0 && tid == 0) a.ws->seq = a.ws->seq + 1u;
+}

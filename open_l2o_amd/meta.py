@@ -419,7 +419,7 @@ class UnrollGraph(object):
         T = self.len_unroll
         self.wait_fx()
         fx_host = eng.to_numpy(fx)                       # host sync
-        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
+        if self.last_path in ("fused", "mlp_unroll") and hasattr(eng, "check_unroll_status"):
             eng.check_unroll_status()
         x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
@@ -655,6 +655,21 @@ class UnrollGraph(object):
             if events is not None:
                 events[1].record()
             eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
+        elif self._mlp_unroll_ok(slots, states, scales):
+            # the neural optimizee, all four variables stepped by one LSTM net: T steps in ONE persistent launch
+            self.last_path = "mlp_unroll"
+            self._draw_minibatches(T)
+            term = self.terms[0]
+            index_of = {v.decl.name: j for j, v in enumerate(self.x)}
+            js = [index_of[tv.name] for tv in _term_vars(term)]
+            slot_of = {s.var_index: si for si, s in enumerate(slots)}
+            sis = [slot_of[j] for j in js]
+            net = slots[sis[0]].net
+            eng.mlp_unroll(net.spec, net.wpack(eng), self._mlp_desc(term), self._mlp_idx[0],
+                           [panels[j] for j in js], [states[si].packed for si in sis], [ms[si] for si in sis],
+                           [vs[si] for si in sis], [scales[j] for j in js], T, step0, fx)
+            if events is not None:
+                events[1].record()
         else:
             self.last_path = "steps"
             self._draw_minibatches(T)                      # host RNG -> persistent device index buffers
@@ -686,6 +701,24 @@ class UnrollGraph(object):
             for s, st in zip(slots, states):
                 s.state = st
         return fx, xs
+
+    def _mlp_unroll_ok(self, slots, states, scales):
+        """l2o_mlp_unroll applies: ONE problems.mnist term of weight 1 whose four variables are all stepped by the
+        same (20, 20) LSTM net, on an engine / device that has the fused kernel."""
+        eng = self.engine
+        if not hasattr(eng, "mlp_unroll") or os.environ.get("L2O_DISABLE_FUSED") or self.sharded:
+            return False
+        if len(self.terms) != 1 or self.terms[0].kind != _abi.PROB_MLP or self.terms[0].weight != 1.0:
+            return False
+        tv = _term_vars(self.terms[0])
+        if len(tv) != 4 or len(self.x) != 4 or len(slots) != 4:
+            return False
+        net = slots[0].net
+        for s, st in zip(slots, states):
+            if s.net is not net or not isinstance(net, networks.StandardDeepLSTM) or not isinstance(st, PackedState) \
+                    or st.packed is None:
+                return False
+        return eng.mlp_unroll_supported(net.spec, self._mlp_desc(self.terms[0]))
 
     def wait_fx(self):
         """Make the current stream (NCCL) / the host (gloo) wait for the loss all-reduces in flight."""

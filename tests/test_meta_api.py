@@ -431,7 +431,8 @@ def test_mnist_mlp_optimizee(engine, activation):
         assert 0.005 < v0[0].std() < 0.02                       # _nn_initializers: N(0, 0.01)
         loss1, fx1, x1, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
         loss2, fx2, x2, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
-    assert optimizer.graph.last_path == "steps"
+    # (the HIP engine runs the T steps as ONE persistent launch, l2o_mlp_unroll; the oracle engine per step)
+    assert optimizer.graph.last_path == ("mlp_unroll" if engine.name == "hip" else "steps")
     ref = O.MnistMLP(data["images"], data["labels"].astype(np.int32), activation)
     states = [O.net_initial_state(cfg, a.size) for a in v0]
     fx_a, va, sa = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[t], wg), cfg, params, v0, states, T)
