@@ -210,6 +210,34 @@ int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack /* device */,
                     float* st /* device, packed, in-out */, float* x /* device [B,D] in-out */,
                     int64_t B, int64_t D, void* stream);
 
+/* ---- the same step for ANY `layers` tuple (ABI v6): StandardDeepLSTM(layers=...) builds one snt.LSTM per entry
+ * (DM/networks.py:192-200); the matrix-core kernels above implement the harness' (20, 20), this entry point every
+ * other stack of 1..3 layers with hidden sizes <= 64 (the reference's own tests use layers=(1,) and (1, 1),
+ * L2O-Swarm/src/networks_test.py:33-47), one thread per coordinate, plain fp32.  Weights stay in their Sonnet
+ * layouts (device pointers).  State: l2o_gen_state_floats(net, N) floats -- per layer hidden [N][H_l] then cell
+ * [N][H_l]; zero memory is the zero state.
+ * direct_inputs = 1 (L2O_NET_RNNPROP only): the plugin contract of RNNprop._build, `net(m, g, prev_state)`
+ * (DM/networks.py:287-295): g holds g~, m_tilde holds m~, no moments are read or written. */
+typedef struct l2o_gen_net {
+  int32_t n_layers;            /* len(layers): 1..3                                           */
+  int32_t hidden[3];           /* layers[l] <= 64                                             */
+  int32_t in_dim;              /* width after preprocessing: 1 identity, 2 LogAndSign, fc dim */
+  int32_t direct_inputs;
+  const float* w_gates[3];     /* device [in_l + H_l, 4 H_l], gate order i, j, f, o           */
+  const float* b_gates[3];     /* device [4 H_l]                                              */
+  const float* w_lin;          /* device [H_last, 1]                                          */
+  const float* b_lin;          /* device [1]                                                  */
+  const float* w_fc;           /* device [2, in_dim] (fc) or NULL                             */
+  const float* b_fc;           /* device [in_dim]                                             */
+} l2o_gen_net;
+size_t l2o_gen_state_floats(const l2o_gen_net* net, int64_t N);
+int l2o_cwlstm_step_generic(const l2o_net_cfg* cfg /* kind, preprocess, tanh_output, scale, logsign_k, betas */,
+                            const l2o_gen_net* net, const float* g /* device [N] */,
+                            const float* m_tilde /* device [N], direct_inputs only */,
+                            float* m, float* v /* device [N], RNNProp without direct_inputs */,
+                            double pow1, double pow2, float* state /* device, in-out */,
+                            float* x /* device [N] in-out: x += delta */, int64_t N, void* stream);
+
 /* The same update for several variables that share one network in ONE launch (the reference
  * applies `net` to every variable of a subset inside the same time step, DM/meta.py:330-336;
  * problems.mnist has four: mlp/linear_{0,1}/{w,b}).  `segs` is a HOST array of 1..8 panels. */

@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_set_option", "l2o_get_option", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
-    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
 )
 
@@ -74,6 +74,13 @@ class Mlp(C.Structure):
         ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32), ("batch", C.c_int32),
         ("activation", C.c_int32), ("n_data", C.c_int32), ("images", C.c_void_p), ("labels", C.c_void_p),
     ]
+
+
+class GenNet(C.Structure):
+    """struct l2o_gen_net"""
+    _fields_ = [("n_layers", C.c_int32), ("hidden", C.c_int32 * 3), ("in_dim", C.c_int32), ("direct_inputs", C.c_int32),
+                ("w_gates", C.c_void_p * 3), ("b_gates", C.c_void_p * 3), ("w_lin", C.c_void_p), ("b_lin", C.c_void_p),
+                ("w_fc", C.c_void_p), ("b_fc", C.c_void_p)]
 
 
 class NetWeights(C.Structure):
@@ -169,6 +176,10 @@ def lib():
     L.l2o_mlp_unroll.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Mlp), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
+    L.l2o_gen_state_floats.restype = C.c_size_t
+    L.l2o_gen_state_floats.argtypes = [C.POINTER(GenNet), i64]
+    L.l2o_cwlstm_step_generic.restype = C.c_int
+    L.l2o_cwlstm_step_generic.argtypes = [C.POINTER(NetCfg), C.POINTER(GenNet), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, vp]
     L.l2o_cwlstm_step_multi.restype = C.c_int
     L.l2o_cwlstm_step_multi.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(StepSeg), C.c_int32, dbl, dbl, vp]
     L.l2o_cwlstm_bwd_step.restype = C.c_int

@@ -32,6 +32,12 @@ class NetSpec:
     beta1: float = 0.95
     beta2: float = 0.95
 
+    @property
+    def generic(self):
+        """An LSTM stack the matrix-core kernels do not implement (they cover the harness' (20, 20)): stepped by
+        l2o_cwlstm_step_generic, state in the per-layer [N, H] layout (l2o_gen_state_floats)."""
+        return len(self.layers) > 0 and tuple(int(h) for h in self.layers) != (20, 20)
+
     def to_c(self):
         c = _abi.NetCfg()
         c.kind, c.preprocess = self.kind, self.preprocess
@@ -273,7 +279,47 @@ class HipEngine(object):
                 check(rc)
         return call
 
+    # -- generic-`layers` nets (l2o_cwlstm_step_generic) --------------------------------
+    class GenNet(object):
+        """Device weights of an LSTM stack in their Sonnet layouts + the struct l2o_gen_net that points at them."""
+
+        def __init__(self, engine, spec, params, direct=False):
+            layers = tuple(int(h) for h in spec.layers)
+            self.tensors = []
+            c = _abi.GenNet()
+            c.n_layers = len(layers)
+            for l, H in enumerate(layers):
+                c.hidden[l] = H
+                for name, field in (("w_gates", c.w_gates), ("b_gates", c.b_gates)):
+                    t = engine.tensor(params["lstm_%d" % (l + 1)][name])
+                    self.tensors.append(t)
+                    field[l] = t.data_ptr()
+            wl, bl = engine.tensor(params["linear"]["w"]), engine.tensor(params["linear"]["b"])
+            self.tensors += [wl, bl]
+            c.w_lin, c.b_lin = wl.data_ptr(), bl.data_ptr()
+            c.in_dim = 2 if spec.preprocess == _abi.PRE_LOGSIGN else 1
+            if spec.preprocess == _abi.PRE_FC_ELU:
+                wf, bf = engine.tensor(params["input_projection"]["w"]), engine.tensor(params["input_projection"]["b"])
+                self.tensors += [wf, bf]
+                c.w_fc, c.b_fc = wf.data_ptr(), bf.data_ptr()
+                c.in_dim = int(wf.shape[1])
+            c.direct_inputs = 1 if direct else 0
+            self.c, self.layers = c, layers
+
+    def gen_net(self, spec: NetSpec, params: dict, direct=False):
+        return HipEngine.GenNet(self, spec, params, direct)
+
+    def gen_state_alloc(self, gen, N):
+        return self.zeros(int(self.lib.l2o_gen_state_floats(C.byref(gen.c), int(N))))
+
+    def lstm_step_generic(self, spec: NetSpec, gen, g, m_tilde, m, v, pow1, pow2, st, x, N):
+        cc = spec.to_c()
+        _abi.check(self.lib.l2o_cwlstm_step_generic(C.byref(cc), C.byref(gen.c), _ptr(g), _ptr(m_tilde), _ptr(m), _ptr(v),
+                                                    float(pow1), float(pow2), _ptr(st), _ptr(x), int(N), self._stream()))
+
     def lstm_step(self, spec: NetSpec, wpack, g, m, v, pow1, pow2, st, x, B, D):
+        if isinstance(wpack, HipEngine.GenNet):
+            return self.lstm_step_generic(spec, wpack, g, None, m, v, pow1, pow2, st, x, B * D)
         cc = spec.to_c()
         _abi.check(self.lib.l2o_cwlstm_step(C.byref(cc), _ptr(wpack), _ptr(g), _ptr(m), _ptr(v),
                                             float(pow1), float(pow2), _ptr(st), _ptr(x), B, D,
@@ -284,6 +330,13 @@ class HipEngine(object):
     def lstm_step_multi(self, spec: NetSpec, wpack, segs, pow1, pow2):
         """One launch for several variables that share a network.  segs: list of
         (g, m, v, st, x, B, D[, st_out, m_out, v_out]) with device tensors (m, v, st may be None)."""
+        if isinstance(wpack, HipEngine.GenNet):              # generic-`layers` net: one launch per variable
+            for seg in segs:
+                g, m, v, st, x, B, D = seg[:7]
+                if len(seg) > 7 and seg[7] is not None:
+                    raise NotImplementedError("history chaining (st_out) is implemented for the (20, 20) nets")
+                self.lstm_step_generic(spec, wpack, g, None, m, v, pow1, pow2, st, x, B * D)
+            return
         for i in range(0, len(segs), self.MAX_STEP_SEGS):
             chunk = segs[i:i + self.MAX_STEP_SEGS]
             arr = (_abi.StepSeg * len(chunk))()

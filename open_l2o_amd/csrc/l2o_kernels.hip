@@ -824,6 +824,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_mlp_unroll.h"
 
+#include "l2o_generic.h"
+
 #include "l2o_bwd.h"
 
 #include "l2o_bwd_mfma.h"
@@ -1405,6 +1407,58 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
 size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp) {
   if (!mlp || mlp->batch < 1) return 0;
   return (size_t)mlp->batch * (2 * (size_t)mlp->n_hidden + mlp->n_out + 1);
+}
+
+// ---- generic-`layers` optimizer step (csrc/l2o_generic.h) --------------------------------------------------
+static int check_gen_net(const l2o_net_cfg* cfg, const l2o_gen_net* net) {
+  if (!cfg || !net) return fail(L2O_ERR_ARG, "generic net: NULL argument");
+  if (net->n_layers < 1 || net->n_layers > kGenMaxL)
+    return fail(L2O_ERR_UNSUPPORTED, "generic net: 1..%d LSTM layers (got %d)", kGenMaxL, net->n_layers);
+  for (int l = 0; l < net->n_layers; ++l) {
+    if (net->hidden[l] < 1 || net->hidden[l] > kGenMaxH)
+      return fail(L2O_ERR_UNSUPPORTED, "generic net: hidden sizes 1..%d (layer %d has %d)", kGenMaxH, l, net->hidden[l]);
+    if (!net->w_gates[l] || !net->b_gates[l]) return fail(L2O_ERR_ARG, "generic net: NULL weights of layer %d", l);
+  }
+  if (!net->w_lin || !net->b_lin) return fail(L2O_ERR_ARG, "generic net: NULL output Linear");
+  const int want = cfg->preprocess == L2O_PRE_FC_ELU ? net->in_dim : (cfg->preprocess == L2O_PRE_LOGSIGN ? 2 : 1);
+  if (net->in_dim != want || net->in_dim < 1 || net->in_dim > kGenMaxH)
+    return fail(L2O_ERR_ARG, "generic net: in_dim %d does not match the preprocessing (%d)", net->in_dim, want);
+  if (cfg->preprocess == L2O_PRE_FC_ELU && (!net->w_fc || !net->b_fc)) return fail(L2O_ERR_ARG, "generic net: fc weights");
+  return L2O_OK;
+}
+
+size_t l2o_gen_state_floats(const l2o_gen_net* net, int64_t N) {
+  if (!net || N <= 0 || net->n_layers < 1 || net->n_layers > kGenMaxL) return 0;
+  size_t n = 0;
+  for (int l = 0; l < net->n_layers; ++l) n += 2 * (size_t)N * (size_t)net->hidden[l];
+  return n;
+}
+
+int l2o_cwlstm_step_generic(const l2o_net_cfg* cfg, const l2o_gen_net* net, const float* g, const float* m_tilde, float* m,
+                            float* v, double pow1, double pow2, float* state, float* x, int64_t N, void* stream) {
+  int rc = check_gen_net(cfg, net);
+  if (rc) return rc;
+  if (!g || !state || !x || N <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_step_generic: bad argument");
+  const bool fc = cfg->preprocess == L2O_PRE_FC_ELU;
+  if (fc && net->direct_inputs && !m_tilde) return fail(L2O_ERR_ARG, "l2o_cwlstm_step_generic: direct inputs need m_tilde");
+  if (fc && !net->direct_inputs && (!m || !v)) return fail(L2O_ERR_ARG, "l2o_cwlstm_step_generic: RNNProp needs m and v");
+  GenParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.n_layers = net->n_layers;
+  for (int l = 0; l < net->n_layers; ++l) { p.H[l] = net->hidden[l]; p.wg[l] = net->w_gates[l]; p.bg[l] = net->b_gates[l]; }
+  p.in_dim = net->in_dim; p.pre = cfg->preprocess; p.direct = net->direct_inputs; p.tanh_output = cfg->tanh_output;
+  p.scale = (float)cfg->scale;
+  p.k_inv = cfg->logsign_k != 0.0 ? (float)(1.0 / cfg->logsign_k) : 0.0f;
+  p.exp_k = (float)std::exp(cfg->logsign_k);
+  p.beta1 = (float)cfg->beta1; p.beta2 = (float)cfg->beta2;
+  p.omb1 = (float)(1.0 - cfg->beta1); p.omb2 = (float)(1.0 - cfg->beta2);
+  p.om1 = (float)(1.0 - pow1); p.om2 = (float)(1.0 - pow2);
+  p.wl = net->w_lin; p.bl = net->b_lin; p.wfc = net->w_fc; p.bfc = net->b_fc;
+  p.g = g; p.m_in = m_tilde; p.m = m; p.v = v; p.state = state; p.x = x; p.N = (long)N;
+  hipLaunchKernelGGL(k_cwlstm_generic, dim3((unsigned)((N + kGenThreads - 1) / kGenThreads)), dim3(kGenThreads), 0,
+                     (hipStream_t)stream, p);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
 }
 
 // ---- the fused persistent unroll of the MLP optimizee (csrc/l2o_mlp_unroll.h) ---------------------------

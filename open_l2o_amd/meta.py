@@ -136,13 +136,20 @@ class PackedState(object):
     (DM/networks.py:234-236; index [l][0] = hidden, [l][1] = cell)."""
 
     def __init__(self, engine, packed, B, D, layers):
-        self.engine, self.packed, self.B, self.D, self.layers = engine, packed, B, D, tuple(layers)
+        self.engine, self.packed, self.B, self.D, self.layers = engine, packed, B, D, tuple(int(h) for h in layers)
+
+    @property
+    def generic(self):
+        """layers other than (20, 20): the per-layer [N, H] layout of l2o_cwlstm_step_generic, not the tile-major one."""
+        return len(self.layers) > 0 and self.layers != (20, 20)
 
     @classmethod
     def zeros(cls, engine, B, D, layers):
-        layers = tuple(layers)
+        layers = tuple(int(h) for h in layers)
         if len(layers) == 0:
             return cls(engine, None, B, D, layers)
+        if layers != (20, 20):
+            return cls(engine, engine.zeros(2 * B * D * sum(layers)), B, D, layers)
         return cls(engine, engine.state_alloc(B, D), B, D, layers)
 
     def clone(self):
@@ -156,12 +163,21 @@ class PackedState(object):
     def unpack(self):
         if self.packed is None:
             return ()
+        if self.generic:
+            N, out, off = self.B * self.D, [], 0
+            for H in self.layers:
+                out.append((self.packed[off:off + N * H].view(N, H), self.packed[off + N * H:off + 2 * N * H].view(N, H)))
+                off += 2 * N * H
+            return tuple(out)
         h1, c1, h2, c2 = self.engine.state_unpack(self.packed, self.B, self.D)
         return ((h1, c1), (h2, c2))
 
     def load(self, state):
-        (h1, c1), (h2, c2) = state
         t = self.engine.tensor
+        if self.generic:
+            self.packed = torch.cat([t(a).reshape(-1) for hc in state for a in hc])
+            return
+        (h1, c1), (h2, c2) = state
         self.packed = self.engine.state_pack(t(h1), t(c1), t(h2), t(c2), self.B, self.D)
 
 
@@ -802,6 +818,9 @@ class UnrollGraph(object):
                         pn["dxs"][t] = acc_g
                         acc_g = acc_g + pn["gs"][t].reshape(N)
 
+        if spec.generic:
+            raise NotImplementedError("meta_minimize (BPTT) is implemented for the layers=(20, 20) and () optimizer nets; "
+                                      "layers=%r runs forward only (l2o_cwlstm_step_generic)" % (spec.layers,))
         if not nl:                                         # Linear-only net: two tiny products per step
             need_dxs()
             for pn in panels:

@@ -210,7 +210,12 @@ class StandardDeepLSTM(Network):
 
     # -- device weights ----------------------------------------------------
     def wpack(self, engine):
-        """Device copy of the weights in MFMA-fragment order (cached until invalidated)."""
+        """Device copy of the weights in MFMA-fragment order (cached until invalidated); for a generic `layers`
+        tuple the Sonnet-layout device weights behind a struct l2o_gen_net."""
+        if self.spec.generic and hasattr(engine, "gen_net"):
+            if self._wpack is None or self._wpack_engine is not engine:
+                self._wpack, self._wpack_engine = engine.gen_net(self.spec, self.variables), engine
+            return self._wpack
         if self._wpack is None or self._wpack_engine is not engine:
             if hasattr(engine, "upload"):                 # persistent device buffer, pinned staging
                 self._wpack = engine.pack_weights(self.spec, self.variables, key=(id(self), "wpack"))
@@ -293,10 +298,33 @@ class RNNprop(StandardDeepLSTM):
     def __init__(self, name="RNNprop", **kwargs):
         super(RNNprop, self).__init__(1, name=name, **kwargs)
 
-    def __call__(self, m, g, prev_state=None):
-        raise NotImplementedError(
-            "RNNprop is evaluated inside the fused kernels (l2o_cwlstm_step / l2o_unroll consume the raw "
-            "gradient and carry the Adam moments); use MetaOptimizer from meta_rnnprop_eval")
+    def __call__(self, m, g, prev_state):
+        """The plugin contract of DM/networks.py:287-295: ``net(m, g, prev_state) -> (delta shaped like g,
+        next_state)`` on the pre-normalised pair (m~, g~) -- no moments are read or written here (the unroll
+        kernels consume the raw gradient and carry them; this is the eager form).  One launch of
+        l2o_cwlstm_step_generic with direct inputs; the arguments are not modified."""
+        from .meta import PackedState
+        import torch
+        engine = prev_state.engine
+        n = self._panel(g)
+        gen = self.__dict__.get("_gen_direct")
+        if gen is None or gen[0] is not engine or gen[2] is not self._variables:
+            gen = self._gen_direct = (engine, engine.gen_net(self.spec, self.variables, direct=True), self._variables)
+        if prev_state.generic:
+            st = prev_state.packed.clone()
+        else:                                              # (20, 20): tile-major packed -> per-layer [N, H] -> back
+            st = torch.cat([t.reshape(-1) for t in engine.state_unpack(prev_state.packed, prev_state.B, prev_state.D)])
+        delta = engine.zeros(n)
+        engine.lstm_step_generic(self.spec, gen[1], g.reshape(n).contiguous(), m.reshape(n).contiguous(), None, None,
+                                 0.0, 0.0, st, delta, n)
+        if prev_state.generic:
+            nxt = PackedState(engine, st, prev_state.B, prev_state.D, self._layers)
+        else:
+            H = 20
+            parts = [st[k * n * H:(k + 1) * n * H].view(n, H) for k in range(4)]
+            nxt = PackedState(engine, engine.state_pack(*parts, prev_state.B, prev_state.D), prev_state.B, prev_state.D,
+                              self._layers)
+        return delta.reshape(g.shape), nxt
 
 
 class KernelDeepLSTM(StandardDeepLSTM):
