@@ -154,6 +154,15 @@ int l2o_problem_fg(const l2o_problem* prob, const float* x /* device [B_local,D]
                    float* f_part /* device [B_local] */, float* g /* device [B_local,D] or NULL */,
                    void* stream);
 
+/* ---- Hessian-vector product of the analytic optimizees (ABI v6): out = (d g / d x) u with g what l2o_problem_fg
+ * returns (1/B_global and the x_scale chain rule included), i.e. the term MetaOptimizer.meta_loss(...,
+ * second_derivatives=True) adds to dL/dx_t when the optimizee gradient is NOT held constant (DM/meta.py:328-329):
+ *   quadratic 2 s W^T W (s u) / B;  lasso s A^T A (s u) / B (the l1 term has no curvature);  rastrigin / square_cos
+ *   additionally s (2 pi)^2 alpha C cos(2 pi x s) s u / B;  simple 2 s^2 u.
+ * scratch: device [B_local] floats. */
+int l2o_problem_hvp(const l2o_problem* prob, const float* x /* device [B_local,D] */, const float* u /* [B_local,D] */,
+                    float* out /* device [B_local,D] */, float* scratch, void* stream);
+
 /* ---- neural optimizee: problems.mnist (DM/problems.py:246-288) = mean sparse-softmax
  * cross-entropy of snt.nets.MLP([n_hidden, n_out]) on a minibatch gathered from a resident
  * dataset; forward + tf.gradients w.r.t. the four variables (DM/meta.py:322, 344).
@@ -294,6 +303,9 @@ typedef struct l2o_bwd_io {
    * offsets into them) and obtains EVERY weight gradient from the single product A^T Bm. */
   int64_t a_stride;        /* act1, act2, h2, feats */
   int64_t b_stride;        /* dz1, dz2, dd, du      */
+  float* dg;               /* optional, device [N]: dL/d(the gradient fed to the net at this step), through the
+                            * preprocessing -- what second_derivatives=True back-propagates into the optimizee
+                            * (DM/meta.py:328-329 skips the stop_gradient); DM nets (identity / LogAndSign) only */
 } l2o_bwd_io;
 int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io,
                         double pow1, double pow2, int64_t B, int64_t D, void* stream);

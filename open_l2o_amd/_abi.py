@@ -24,7 +24,7 @@ PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_M
 # every symbol include/l2o_abi.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_set_option", "l2o_get_option", "l2o_wpack_floats", "l2o_wpack_host",
-    "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_mlp_fg",
+    "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx",
@@ -93,7 +93,7 @@ class BwdIO(C.Structure):
     """struct l2o_bwd_io"""
     _fields_ = [(n, C.c_void_p) for n in ("g", "m", "v", "st_prev", "dx_next", "carry_in", "carry_out", "act1",
                                           "dz1", "act2", "dz2", "h2", "dd", "feats", "du")] + \
-               [("a_stride", C.c_int64), ("b_stride", C.c_int64)]
+               [("a_stride", C.c_int64), ("b_stride", C.c_int64), ("dg", C.c_void_p)]
 
 
 PROB_W_SHARED = 1     # l2o_problem.flags: W is one [M, D] matrix for every problem
@@ -164,6 +164,8 @@ def lib():
     L.l2o_state_unpack.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
     L.l2o_problem_fg.restype = C.c_int
     L.l2o_problem_fg.argtypes = [C.POINTER(Problem), vp, vp, vp, vp]
+    L.l2o_problem_hvp.restype = C.c_int
+    L.l2o_problem_hvp.argtypes = [C.POINTER(Problem), vp, vp, vp, vp, vp]
     L.l2o_mlp_fg.restype = C.c_int
     L.l2o_mlp_fg.argtypes = [C.POINTER(Mlp)] + [vp] * 12
     L.l2o_mlp_scratch_floats.restype = C.c_size_t

@@ -187,6 +187,14 @@ class HipEngine(object):
         cp = self._cprob(p)
         _abi.check(self.lib.l2o_problem_fg(C.byref(cp), _ptr(x), _ptr(f_part), _ptr(g), self._stream()))
 
+    def problem_hvp(self, p: ProblemDesc, x, u, out):
+        """out = (d g / d x) u of the analytic optimizee at x (l2o_problem_hvp), g as problem_fg returns it."""
+        cp = self._cprob(p)
+        scr = self.__dict__.get("_hvp_scratch")
+        if scr is None or scr.numel() < p.B_local:
+            scr = self._hvp_scratch = self.empty(max(p.B_local, 1))
+        _abi.check(self.lib.l2o_problem_hvp(C.byref(cp), _ptr(x), _ptr(u), _ptr(out), _ptr(scr), self._stream()))
+
     def int_tensor(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
 
@@ -360,6 +368,8 @@ class HipEngine(object):
         for k, _ in _abi.BwdIO._fields_:
             if k in ("a_stride", "b_stride"):
                 setattr(b, k, int(io.get(k) or 0))
+            elif k == "dg":
+                b.dg = None if io.get("dg") is None else io["dg"].data_ptr()
             else:
                 setattr(b, k, None if io.get(k) is None else io[k].data_ptr())
         _abi.check(self.lib.l2o_cwlstm_bwd_step(C.byref(cc), C.byref(w), C.byref(b), float(pow1), float(pow2),

@@ -20,6 +20,7 @@ struct BwdParams {
   const float *wg1, *bg1, *wg2, *bg2, *wl, *bl, *wfc, *bfc;
   const float *g, *m, *v, *st_prev, *dx_next, *carry_in;
   float *carry_out, *act1, *dz1, *act2, *dz2, *h2o, *dd, *feats, *du;
+  float* dg;                          // optional: dL/d(network input gradient) per coordinate (second derivatives)
   long s_act1, s_dz1, s_act2, s_dz2, s_h2, s_dd, s_feats, s_du;   // row strides (floats) of the emitted rows
   // tile kernel only: up to 8 panels that share the network in ONE launch (l2o_cwlstm_bwd_multi);
   // panel s covers the tiles [tile_end[s-1], tile_end[s]) and the rows 16 * tile of A / Bm / the carries
@@ -218,6 +219,16 @@ __global__ __launch_bounds__(64) void k_cwlstm_bwd_step(BwdParams p) {
   if (valid) {
 #pragma unroll
     for (int u = 0; u < kH; ++u) p.carry_out[(0 * N + n) * kH + u] = xi[(P + u) * NT];
+    if (PRE != L2O_PRE_FC_ELU && p.dg) {                   // chain through the preprocessing: dL/dg
+      float dgv = xi[0];
+      if (PRE == L2O_PRE_LOGSIGN) {                        // DM/preprocess.py:63-70, both clamps
+        const float gv = p.g[n], ag = fabsf(gv) + 1.1920928955078125e-07f;
+        const float d0 = logf(ag) * p.k_inv > -1.0f ? copysignf(p.k_inv / ag, gv) : 0.0f;
+        const float d1 = fabsf(gv * p.exp_k) < 1.0f ? p.exp_k : 0.0f;
+        dgv = xi[0] * d0 + xi[1 * NT] * d1;
+      }
+      p.dg[n] = dgv;
+    }
     if (PRE == L2O_PRE_FC_ELU) {
       p.feats[n * p.s_feats] = f0;
       p.feats[n * p.s_feats + 1] = f1;
@@ -594,4 +605,14 @@ __global__ void k_linear_bwd_step(BwdParams p) {
     ddv *= 1.0f - th * th;
   }
   p.dd[n * p.s_dd] = ddv;
+  if (p.dg) {                                             // dL/dg through Linear and the preprocessing
+    float dgv = ddv * p.wl[0];
+    if (PRE == L2O_PRE_LOGSIGN) {
+      const float ag = fabsf(gv) + 1.1920928955078125e-07f;
+      const float d0 = logf(ag) * p.k_inv > -1.0f ? copysignf(p.k_inv / ag, gv) : 0.0f;
+      const float d1 = fabsf(gv * p.exp_k) < 1.0f ? p.exp_k : 0.0f;
+      dgv = ddv * (p.wl[0] * d0 + p.wl[1] * d1);
+    }
+    p.dg[n] = dgv;
+  }
 }

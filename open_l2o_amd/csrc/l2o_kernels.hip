@@ -56,6 +56,7 @@ struct NetParams {
 struct ProbParams {
   int kind, B_local, D, M;
   int w_shared;      // W is one [M, D] matrix for every problem
+  int hvp;           // Hessian-vector mode (l2o_problem_hvp): the residual is W xs (no y), no separable terms
   float inv_bg;      // 1 / B_global
   float l1, alpha;
   float twopi;       // 2*pi (rastrigin) or 2*3.1415926 (square_cos, DM/problems.py:989)
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
         for (int k = 0; k < 4; ++k) {
           const float a = wave_sum64(acc[k]);
           if (lane == 0 && i0 + k < M) {
-            const float r = a - yb[i0 + k];
+            const float r = a - (pp.hvp ? 0.0f : yb[i0 + k]);
             rs[i0 + k] = r;
             facc += coef * r * r;
           }
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
         for (int j = lane; j < D; j += 64) acc = __builtin_fmaf(row[j], xs[j], acc);
         acc = wave_sum64(acc);
         if (lane == 0) {
-          const float r = acc - yb[i];
+          const float r = acc - (pp.hvp ? 0.0f : yb[i]);
           rs[i] = r;
           facc += coef * r * r;
         }
@@ -397,9 +398,11 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
   auto finish = [&](int j, float s) {
     float gj = cg * s;
     const float xv = xs[j];
-    if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f));
-    if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
-      gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xv);
+    if (!pp.hvp) {
+      if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f));
+      if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
+        gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xv);
+    }
     gb[j] = gj * pp.inv_bg * (sb ? sb[j] : 1.0f);
   };
   if (VEC) {
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg1(ProbParams pp, const
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const bool ok = i0 + k < M;
-      const float r = ok ? wave_sum64(acc[k]) - yb[ok ? i0 + k : 0] : 0.0f;
+      const float r = ok ? wave_sum64(acc[k]) - (pp.hvp ? 0.0f : yb[ok ? i0 + k : 0]) : 0.0f;
       if (lane == 0) facc += coef * r * r;
       if (want_g) {
 #pragma unroll
@@ -598,9 +601,11 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg1(ProbParams pp, const
     const float sc = sb ? sb[j] : 1.0f;
     const float xj = xb[j] * sc;
     float gj = cg * s;
-    if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xj > 0.f ? 1.f : (xj < 0.f ? -1.f : 0.f));
-    if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
-      gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xj);
+    if (!pp.hvp) {
+      if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xj > 0.f ? 1.f : (xj < 0.f ? -1.f : 0.f));
+      if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
+        gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xj);
+    }
     gb[j] = gj * pp.inv_bg * sc;
   }
 }
@@ -901,6 +906,7 @@ static ProbParams make_prob_params(const l2o_problem* p) {
   pp.D = p->D;
   pp.M = p->kind == L2O_PROB_SIMPLE ? 0 : p->M;
   pp.w_shared = (p->flags & L2O_PROB_W_SHARED) ? 1 : 0;
+  pp.hvp = 0;
   pp.inv_bg = 1.0f / (float)p->B_global;
   pp.l1 = (float)p->l1;
   pp.alpha = p->kind == L2O_PROB_SQUARE_COS ? 10.0f : (float)p->alpha;
@@ -1323,11 +1329,7 @@ int l2o_state_unpack(const float* st, float* h1, float* c1, float* h2, float* c2
   return state_repack(h1, c1, h2, c2, const_cast<float*>(st), B, D, stream, 0);
 }
 
-int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float* g, void* stream) {
-  int rc = check_problem(prob);
-  if (rc) return rc;
-  if (!x || !f_part) return fail(L2O_ERR_ARG, "l2o_problem_fg: NULL x / f_part");
-  const ProbParams pp = make_prob_params(prob);
+static int launch_problem_fg(const ProbParams& pp, const float* x, float* f_part, float* g, void* stream) {
   const size_t lds = sizeof(float) * ((size_t)((pp.D + 3) & ~3) + ((pp.M + 3) & ~3) + 4 * kFgThreads + kFgWaves);
   if (lds > 160 * 1024) return fail(L2O_ERR_UNSUPPORTED, "problem too large for k_problem_fg (D=%d M=%d)", pp.D, pp.M);
   const bool vec = pp.kind != L2O_PROB_SIMPLE && (pp.D & 3) == 0 && ((uintptr_t)pp.W & 15) == 0;
@@ -1347,6 +1349,38 @@ int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float
                               (int)lds));
   hipLaunchKernelGGL(fn, dim3(pp.B_local), dim3(kFgThreads), lds, (hipStream_t)stream, pp, x, f_part, g);
   HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float* g, void* stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!x || !f_part) return fail(L2O_ERR_ARG, "l2o_problem_fg: NULL x / f_part");
+  return launch_problem_fg(make_prob_params(prob), x, f_part, g, stream);
+}
+
+// out += s * inv_bg * f''(x s) * s * u for the separable cosine term (rastrigin / square_cos)
+__global__ void k_hvp_sep(ProbParams pp, const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sc = pp.x_scale ? pp.x_scale[i] : 1.0f;
+  const float xs = x[i] * sc;
+  out[i] += sc * pp.inv_bg * (pp.twopi * pp.twopi * pp.alpha * pp.C[i] * cosf(pp.twopi * xs)) * sc * u[i];
+}
+
+int l2o_problem_hvp(const l2o_problem* prob, const float* x, const float* u, float* out, float* scratch, void* stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!x || !u || !out || !scratch) return fail(L2O_ERR_ARG, "l2o_problem_hvp: NULL argument");
+  ProbParams pp = make_prob_params(prob);
+  pp.hvp = 1;
+  rc = launch_problem_fg(pp, u, scratch, out, stream);     // cg s inv_bg W^T (W (s u))  (simple: 2 s^2 u)
+  if (rc) return rc;
+  if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS) {
+    const size_t n = (size_t)pp.B_local * pp.D;
+    hipLaunchKernelGGL(k_hvp_sep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pp, x, u, out, n);
+    HIP_TRY(hipGetLastError());
+  }
   return L2O_OK;
 }
 
@@ -1742,6 +1776,9 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
   p.g = io->g; p.m = io->m; p.v = io->v; p.st_prev = io->st_prev; p.dx_next = io->dx_next;
   p.carry_in = io->carry_in; p.carry_out = io->carry_out; p.act1 = io->act1; p.dz1 = io->dz1;
   p.act2 = io->act2; p.dz2 = io->dz2; p.h2o = io->h2; p.dd = io->dd; p.feats = io->feats; p.du = io->du;
+  p.dg = io->dg;
+  if (io->dg && cfg->preprocess == L2O_PRE_FC_ELU)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_step: the input adjoint (dg) is implemented for the DM nets (identity / LogAndSign)");
   {
     const int pre_ = cfg->preprocess;
     const long P_ = cfg->n_layers == 0 ? 2 : (pre_ == L2O_PRE_FC_ELU ? kH : (pre_ == L2O_PRE_LOGSIGN ? 2 : 1));
@@ -1776,7 +1813,7 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
                         (pre != L2O_PRE_FC_ELU || (io->feats == io->act1 + K1q + 3 * kH && io->du == io->dz1 + 8 * kH + 1 &&
                                                    io->m && io->v && w->w_fc && w->b_fc));
     if (layout && (D % kTile == 0 || B == 1) && ((uintptr_t)io->act1 & 15) == 0 && ((uintptr_t)io->dz1 & 15) == 0 &&
-        opt(L2O_OPT_BWD_KERNEL) != 2) {
+        opt(L2O_OPT_BWD_KERNEL) != 2 && !io->dg) {           // (the input adjoint is emitted by the generic kernel)
       p.nseg = 1;
       p.tile_end[0] = (int)((N + kTile - 1) / kTile);
       p.seg_n[0] = (long)N;

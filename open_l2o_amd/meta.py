@@ -361,6 +361,7 @@ class UnrollGraph(object):
         self._initialized = False
         self._fx_cache = {}
         self.last_path = None
+        self.second_derivatives = False
 
     # -- geometry helpers ----------------------------------------------------
     def _panel_shape(self, var):
@@ -628,8 +629,11 @@ class UnrollGraph(object):
 
         if events is not None:
             events[0].record()
-        if record is not None and T > 0 and self._fused_ok(descs, record=True) and isinstance(states[0], PackedState) \
-                and states[0].packed is not None:
+        if record is not None and self.second_derivatives:
+            record["x"] = []                              # the Hessian needs the iterates: step-granular recording
+            record["descs"] = descs
+        if record is not None and T > 0 and not self.second_derivatives and self._fused_ok(descs, record=True) \
+                and isinstance(states[0], PackedState) and states[0].packed is not None:
             # meta-gradient on a fused-size problem: ONE launch that also records the history
             # (state before, gradient at, moments after every step; gradient at x_T)
             self.last_path = "fused"
@@ -808,7 +812,21 @@ class UnrollGraph(object):
             k = (mod, var)
             acc[k] = val if k not in acc else acc[k] + val
 
+        second = any(pn.get("second") for pn in panels)
+
+        def hess_update(pn, t, N):
+            """second_derivatives: lam_t = g_t + lam_{t+1} + (d g_t / d x_t) u_t with u_t = dL/dg_t just emitted."""
+            hv = pn.setdefault("hv", eng.empty(N))
+            eng.problem_hvp(pn["desc"], pn["xs"][t], pn["dg"].view(pn["B"], pn["D"]), hv.view(pn["B"], pn["D"]))
+            pn["lam"] = pn["gs"][t].reshape(N) + pn["lam"] + hv      # (a new tensor: hv is reused)
+
         def need_dxs():
+            if second:                                      # running adjoint instead of the precomputed prefix sums
+                for pn in panels:
+                    N = pn["B"] * pn["D"]
+                    pn["lam"] = pn["g_final"].reshape(N).clone()
+                    pn["dg"] = eng.empty(N)
+                return
             for pn in panels:                               # loss = sum_t fx_t: dL/d(delta_t) = g_final + sum_{tau > t} g_tau
                 if pn.get("dxs") is None:
                     N = pn["B"] * pn["D"]
@@ -827,8 +845,10 @@ class UnrollGraph(object):
                 N = pn["B"] * pn["D"]
                 io = {"dd": eng.empty(N), "act1": eng.empty(N, 2)}
                 for t in reversed(range(T)):
-                    io.update(g=pn["gs"][t], dx_next=pn["dxs"][t])
+                    io.update(g=pn["gs"][t], dx_next=pn["lam"] if second else pn["dxs"][t], dg=pn.get("dg"))
                     eng.bwd_step(spec, wdev, io, b1 ** (step0 + t), b2 ** (step0 + t), pn["B"], pn["D"])
+                    if second:
+                        hess_update(pn, t, N)
                     dd = io["dd"].view(N, 1)
                     add("linear", "w", io["act1"][:, :P].t() @ dd)
                     add("linear", "b", dd.sum(0))
@@ -841,7 +861,7 @@ class UnrollGraph(object):
         K1 = P + H
         KA = K1 + 2 * H + H + (2 if fc else 0) + 1
         KB = 4 * H + 4 * H + 1 + (H if fc else 0)
-        multi = all(pn["D"] % 16 == 0 or pn["B"] == 1 for pn in panels) and len(panels) <= 8
+        multi = all(pn["D"] % 16 == 0 or pn["B"] == 1 for pn in panels) and len(panels) <= 8 and not second
         fused = (multi and wdev.get("wpack") is not None and not os.environ.get("L2O_BWD_STEPWISE")
                  and _abi.get_option(_abi.OPT_BWD_KERNEL) == 0)                                   # A/B switches of the tests
         groups = [panels] if multi else [[pn] for pn in panels]
@@ -876,7 +896,8 @@ class UnrollGraph(object):
                     eng.bwd_multi(spec, wdev, segs, carry_in, carry_out, At, Bt, b1 ** k, b2 ** k)
                 else:
                     pn, N = grp[0], Ns[0]
-                    io = dict(g=pn["gs"][t], dx_next=pn["dxs"][t], st_prev=pn["sts"][t], carry_in=carry_in[:, :N],
+                    io = dict(g=pn["gs"][t], dx_next=pn["lam"] if second else pn["dxs"][t], dg=pn.get("dg"),
+                              st_prev=pn["sts"][t], carry_in=carry_in[:, :N],
                               carry_out=carry_out[:, :N], m=pn["ms"][t], v=pn["vs"][t], a_stride=KA, b_stride=KB,
                               act1=At[:N, 0:K1], act2=At[:N, K1:K1 + 2 * H], h2=At[:N, K1 + 2 * H:K1 + 3 * H],
                               dz1=Bt[:N, 0:4 * H], dz2=Bt[:N, 4 * H:8 * H], dd=Bt[:N, 8 * H:8 * H + 1])
@@ -887,6 +908,8 @@ class UnrollGraph(object):
                     eng.bwd_step(spec, wdev, io, b1 ** k, b2 ** k, pn["B"], pn["D"])
                     if R != N:
                         carry_out[:, :N] = io["carry_out"]
+                    if second:
+                        hess_update(pn, t, N)
                 carry_in, carry_out = carry_out, carry_in
             Gm = _chunked_atb(A.view(T * R, KA), Bm.view(T * R, KB))
             add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
@@ -913,10 +936,14 @@ class UnrollGraph(object):
             N = B * D
             # loss = sum_t fx_t and x_{t+1} = x_t + delta_t  =>  dL/d(delta_t) = sum_{tau > t} g_tau
             # (accumulated inside the fused BPTT kernel, or by _bptt_panels for the step-wise kernels)
-            by_net.setdefault(s.key, (net, []))[1].append(
-                dict(B=B, D=D, gs=[g[j] for g in rec["g"]], sts=[st[si] for st in rec["st"]],
-                     ms=[m[si] for m in rec["m"]], vs=[v[si] for v in rec["v"]], dxs=None,
-                     g_final=rec["g_final"][j].reshape(N)))
+            pn = dict(B=B, D=D, gs=[g[j] for g in rec["g"]], sts=[st[si] for st in rec["st"]],
+                      ms=[m[si] for m in rec["m"]], vs=[v[si] for v in rec["v"]], dxs=None,
+                      g_final=rec["g_final"][j].reshape(N))
+            if self.second_derivatives:                    # dL/dx_t picks up H(x_t) . dL/dg_t (DM/meta.py:328-329)
+                if rec["descs"][j] is None:
+                    raise NotImplementedError("second_derivatives=True is implemented for the analytic optimizees")
+                pn.update(second=True, desc=rec["descs"][j], xs=[x[j] for x in rec["x"]])
+            by_net.setdefault(s.key, (net, []))[1].append(pn)
         for key, (net, panels) in by_net.items():      # rec["plan"]: buffers of a planned unroll are reused, so is the table
             self._bptt_panels(net, out.setdefault(key, {}), T, step0, panels, cache=rec.get("plan"))
         if self.sharded:
@@ -1151,6 +1178,8 @@ class UnrollGraph(object):
             forward(t, True)
             k = step0 + t
             if record is not None:
+                if "x" in record:
+                    record["x"].append([pn.clone() for pn in panels])
                 record["g"].append(list(grads))
                 record["st"].append([chain[si][0][t] if si in chain else
                                      (None if not isinstance(st, PackedState) or st.packed is None else st.packed.clone())
@@ -1507,10 +1536,14 @@ class MetaOptimizer(object):
 
     # -- the unroll ------------------------------------------------------------
     def _build_graph(self, make_loss, len_unroll, net_assignments, second_derivatives):
-        if second_derivatives:
-            raise NotImplementedError("second_derivatives=True needs the meta-gradient path (SURVEY.md 8f)")
+        if second_derivatives and self._rnnprop:
+            raise NotImplementedError("second_derivatives=True is implemented for the L2O-DM nets (identity / LogAndSign "
+                                      "preprocessing); RNNProp's inputs depend on the gradient through the Adam moments")
         graph = UnrollGraph(self, make_loss, len_unroll, net_assignments, rnnprop=self._rnnprop,
                             beta1=self.beta1, beta2=self.beta2)
+        # DM/meta.py:328-329: without the flag the optimizee gradients are constants of the meta-gradient
+        # (tf.stop_gradient); with it dL/dx_t also receives H(x_t) . dL/dg_t (l2o_problem_hvp)
+        graph.second_derivatives = bool(second_derivatives)
         self._graph = graph
         return graph
 
