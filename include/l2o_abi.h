@@ -411,8 +411,8 @@ int l2o_unroll_status(const void* workspace_header_host /* host copy of the firs
  * any M: one workgroup per problem, the matrix streamed once per step, x / LSTM state / moments
  * on-chip). */
 int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);
-/* 1 if l2o_unroll_record (hist != NULL) has a kernel for the pair: the LDS-resident forms only
- * (ABI v4).  Larger problems record their history on the step-granular path. */
+/* 1 if l2o_unroll_record (hist != NULL) has a kernel for the pair: every fused form records (ABI v6: the
+ * streaming form for D <= 512 too; v4 / v5: the LDS-resident forms only). */
 int l2o_unroll_record_supported(const l2o_net_cfg* cfg, const l2o_problem* prob);
 
 /* ---- fx_array.stack() / tf.reduce_mean over the batch (DM/meta.py:345, 374-376):

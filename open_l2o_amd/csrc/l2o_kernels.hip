@@ -1075,7 +1075,9 @@ template <int PRE>
 static int launch_unroll_cu(const UnrollArgs& a_in, hipStream_t s) {
   const UnrollCuLayout L = unroll_cu_layout(a_in.pp.D);
   const UnrollArgs& a = a_in;
-  void (*fn)(UnrollArgs) = a.pp.D <= 256 ? k_unroll_cu<PRE, 1> : k_unroll_cu<PRE, 2>;
+  const bool hist = a.hist_st != nullptr;
+  void (*fn)(UnrollArgs) = a.pp.D <= 256 ? (hist ? k_unroll_cu<PRE, 1, true> : k_unroll_cu<PRE, 1, false>)
+                                         : (hist ? k_unroll_cu<PRE, 2, true> : k_unroll_cu<PRE, 2, false>);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)L.lds));
   hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(kCuThreads), L.lds, s, a);
@@ -1848,8 +1850,7 @@ int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
 }
 
 int l2o_unroll_record_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
-  UnrollGeom g;
-  return (l2o_unroll_supported(cfg, prob) && unroll_geom(prob, &g)) ? 1 : 0;
+  return l2o_unroll_supported(cfg, prob);                   // every fused form records (ABI v6: the streaming form too)
 }
 
 size_t l2o_unroll_workspace_bytes(const l2o_net_cfg* cfg, const l2o_problem* prob, int32_t T) {
@@ -1886,9 +1887,6 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
                 prob->kind, prob->D, prob->M, cfg->kind, cfg->n_layers);
   UnrollGeom g;
   const bool lds_form = unroll_geom(prob, &g);
-  if (!lds_form && hist)
-    return fail(L2O_ERR_UNSUPPORTED, "l2o_unroll_record: no recording kernel for D=%d M=%d (l2o_unroll_record_supported)",
-                prob->D, prob->M);
   UnrollArgs a;
   a.np = make_net_params(cfg, wpack);
   a.pp = make_prob_params(prob);

@@ -45,7 +45,9 @@ static inline UnrollCuLayout unroll_cu_layout(int D) {
   return L;
 }
 
-template <int PRE, int NV>
+// HIST: also record what back-propagation through time needs (l2o_unroll_record): the packed state BEFORE each
+// step, the gradient fed to the network, RNNProp's moments after the step, and the gradient at x_T.
+template <int PRE, int NV, bool HIST>
 __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_unroll_cu(UnrollArgs a) {
   constexpr int kCuRing = cu_ring(PRE, NV);
   extern __shared__ float4 cu_smem[];
@@ -150,25 +152,44 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   float om1 = 1.0f, om2 = 1.0f;
   __syncthreads();
 
-  // one optimizer step for a 16-coordinate tile whose state is in `s`
-  auto do_tile = [&](int tile, TileState& s) {
+  int tcur = 0;                                             // the step being computed (history slots)
+  const size_t hist_n = (size_t)pp.B_local * D;
+  // the gradient of coordinate j = tile * 16 + c from the four waves' partial sums
+  auto grad_of = [&](int tile, float& xsv_out) {
     const int j = tile * kTile + c;
     const bool live = j < D;
     const int jc = live ? j : D - 1;
     float sum = part[jc];
 #pragma unroll
     for (int p = 1; p < kCuWaves; ++p) sum += part[p * D + jc];
-    const float xsv = xsL[j], sc = scL[j], xj = xL[j];
+    const float xsv = xsL[j], sc = scL[j];
     float gj = cg * sum;
     if (kind == L2O_PROB_LASSO) gj += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (kCos) gj += pp.twopi * pp.alpha * Cb[jc] * sinf(pp.twopi * xsv);
-    const float gv = live ? gj * pp.inv_bg * sc : 0.0f;
+    xsv_out = xsv;
+    return live ? gj * pp.inv_bg * sc : 0.0f;
+  };
+  // one optimizer step for a 16-coordinate tile whose state is in `s`
+  auto do_tile = [&](int tile, TileState& s) {
+    const int j = tile * kTile + c;
+    const bool live = j < D;
+    float xsv;
+    const float gv = grad_of(tile, xsv);
+    const float sc = scL[j], xj = xL[j];
+    if (HIST) {
+      store_tile_state(s, a.hist_st + (((size_t)tcur * pp.B_local + b) * tpp + tile) * kStateFloatsPerTile, lane);
+      if (live && q == 0) a.hist_g[(size_t)tcur * hist_n + (size_t)b * D + j] = gv;
+    }
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
       float m = mL[j], v = vL[j];
       rnnprop_inputs(gv, m, v, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, om1, om2, in0, in1);
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       if (q == 0) { mL[j] = m; vL[j] = v; }
+      if (HIST && live && q == 0) {
+        a.hist_m[(size_t)tcur * hist_n + (size_t)b * D + j] = m;
+        a.hist_v[(size_t)tcur * hist_n + (size_t)b * D + j] = v;
+      }
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
@@ -180,7 +201,8 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   };
 
   for (int t = 0;; ++t) {
-    const bool want_g = t < a.T;
+    const bool want_g = t < a.T || HIST;                      // (history mode: the gradient at x_T is recorded too)
+    tcur = t;
     // ---- optimizee: f_b(x s) and the partial gradients of this wave's rows -------------------
     float4 xv[NV], ga[NV];
     float facc = 0.0f;
@@ -259,6 +281,15 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     lds_barrier();                                            // B1: partial gradients and partial f complete
     if (tid == 0) a.fx_part[(size_t)t * pp.B_local + b] = ((red[0] + red[1]) + red[2]) + red[3];
     if (!want_g) break;
+    if (HIST && t == a.T) {                                   // the gradient at x_T, then done
+      for (int tile = wv; tile < tpp; tile += kCuWaves) {
+        float xsv;
+        const float gv = grad_of(tile, xsv);
+        const int j = tile * kTile + c;
+        if (j < D && q == 0) a.hist_gfinal[(size_t)b * D + j] = gv;
+      }
+      break;
+    }
 
     // ---- optimizer network on this wave's tiles ------------------------------------------------
     if (PRE == L2O_PRE_FC_ELU) { om1 = 1.0f - p1h; om2 = 1.0f - p2h; }

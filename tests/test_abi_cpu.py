@@ -85,15 +85,15 @@ def test_bad_arguments_return_error_codes(lib):
     p.D = p.M = 128
     assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
     assert lib.l2o_unroll_record_supported(C.byref(cc), C.byref(p)) == 1
-    p.D = p.M = 512                                    # > 8 tiles: the streaming form (no history recording)
+    p.D = p.M = 512                                    # > 8 tiles: the streaming form (records its history too, ABI v6)
     assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
-    assert lib.l2o_unroll_record_supported(C.byref(cc), C.byref(p)) == 0
+    assert lib.l2o_unroll_record_supported(C.byref(cc), C.byref(p)) == 1
     assert lib.l2o_unroll_workspace_bytes(C.byref(cc), C.byref(p), 10) == 0
     p.M = 37                                           # any row count
     assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
     p.D, p.M = 16, 40                                  # few columns, more rows than the LDS forms take
     assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 1
-    assert lib.l2o_unroll_record_supported(C.byref(cc), C.byref(p)) == 0
+    assert lib.l2o_unroll_record_supported(C.byref(cc), C.byref(p)) == 1
     for D in (516, 1024, 130, 129):                    # too large for the LDS-resident state / not float4 rows
         p.D = p.M = D
         assert lib.l2o_unroll_supported(C.byref(cc), C.byref(p)) == 0

@@ -575,13 +575,47 @@ def test_c3_streaming_full_size(eng):
     np.testing.assert_array_equal(fx200[:21], fx20)
 
 
-def test_streaming_unroll_record_is_rejected(eng):
-    from open_l2o_amd import _abi
-    cfg = O.DM_IDENTITY
+@pytest.mark.parametrize("name,kind,B,D,M", [("dm", "quadratic", 2, 256, None), ("rnnprop", "lasso", 3, 512, 40),
+                                             ("dm_logsign", "lasso", 2, 200, 24)])
+def test_streaming_unroll_records_history(eng, name, kind, B, D, M):
+    """l2o_unroll_record on the streaming form (D > 128): the recorded history -- packed state BEFORE each step,
+    the gradient fed to the network, RNNProp moments AFTER the step, the gradient at x_T -- equals what the
+    step-granular kernels see along the same trajectory, and the recording launch leaves the same x / fx as
+    the plain one."""
+    cfg = ORACLE_CFGS[name]
     spec = spec_of(cfg)
-    prob, x0, arrays = make_problem("quadratic", 2, 256, seed=5)
-    pd = device_problem(eng, arrays, 2, 256)
-    assert eng.unroll_supported(spec, pd) and not eng.unroll_supported(spec, pd, record=True)
+    params = make_params(cfg, seed=61, trained_like=True)
+    prob, x0, arrays = make_problem(kind, B, D, seed=62, M=M)
+    pd = device_problem(eng, arrays, B, D)
+    assert eng.unroll_supported(spec, pd) and eng.unroll_supported(spec, pd, record=True)
+    T, N = 5, B * D
+    wpack = eng.pack_weights(spec, params)
+    x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
+    m, v = eng.zeros(B, D), eng.zeros(B, D)
+    fx_part = eng.zeros((T + 1) * B)
+    hist = {"st": eng.zeros(T, st.numel()), "g": eng.zeros(T, N), "g_final": eng.zeros(N)}
+    if name == "rnnprop":
+        hist.update(m=eng.zeros(T, N), v=eng.zeros(T, N))
+    eng.unroll(spec, wpack, pd, x, st, m, v, T, 2, fx_part, hist=hist)
+    fx_plain, x_plain = _run_fused(eng, cfg, params, arrays, x0, B, D, T, step0=2)[:2]
+    # (the recording variant is a different instantiation: same arithmetic, the compiler may contract differently)
+    np.testing.assert_allclose(eng.to_numpy(x), x_plain, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(eng.to_numpy(fx_part).reshape(T + 1, B).sum(1) / np.float32(B), fx_plain, rtol=1e-6)
+    # replay with the step-granular kernels
+    xd, std, md, vd = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D), eng.zeros(B, D), eng.zeros(B, D)
+    f, g = eng.zeros(B), eng.zeros(B, D)
+    b95 = float(np.float32(0.95))
+    for t in range(T):
+        eng.problem_fg(pd, xd, f, g)
+        assert max_abs(eng.to_numpy(hist["st"][t]), eng.to_numpy(std)) < 2e-6, t
+        gs = float(np.abs(eng.to_numpy(g)).max())
+        assert max_abs(eng.to_numpy(hist["g"][t]), eng.to_numpy(g).reshape(-1)) < 2e-5 * gs, t
+        eng.lstm_step(spec, wpack, g, md, vd, b95 ** (2 + t), b95 ** (2 + t), std, xd, B, D)
+        if name == "rnnprop":
+            assert max_abs(eng.to_numpy(hist["m"][t]), eng.to_numpy(md).reshape(-1)) < 2e-5 * gs
+            assert max_abs(eng.to_numpy(hist["v"][t]), eng.to_numpy(vd).reshape(-1)) < 4e-5 * gs * gs
+    eng.problem_fg(pd, xd, f, g)
+    assert max_abs(eng.to_numpy(hist["g_final"]), eng.to_numpy(g).reshape(-1)) < 2e-5 * float(np.abs(eng.to_numpy(g)).max())
 
 
 def test_long_horizon_T1000(eng):
