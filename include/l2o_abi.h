@@ -350,6 +350,15 @@ int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, cons
                           int32_t nseg, const float* const* table, int32_t T, int64_t step0,
                           const float* carry_in, float* carry_out, float* A, float* Bm, void* stream);
 
+/* ---- the weight-gradient contraction (ABI v6): out [KA][KB] = A^T B for A [R][KA], B [R][KB] dense row-major device
+ * matrices (KA <= 112, KB <= 192, any R): with A = [act1 | act2 | h2 | feats | 1] and B = [dz1 | dz2 | dd | du] as
+ * written by l2o_cwlstm_bwd_unroll / _multi / _step, every weight gradient of the unroll is a block of `out`
+ * (what tf.gradients accumulates over the while_loop, DM/meta.py:398-414).  fp32 products and sums
+ * (v_mfma_f32_16x16x4_f32), split over the rows with a fixed-order reduction: bit-reproducible.
+ * workspace: l2o_atb_workspace_bytes() bytes of device scratch. */
+size_t l2o_atb_workspace_bytes(int64_t R, int32_t KA, int32_t KB);
+int l2o_atb(const float* A, const float* B, int64_t R, int32_t KA, int32_t KB, float* out, void* workspace, void* stream);
+
 /* ---- the meta-step on the device (ABI v5): tf.train.AdamOptimizer(learning_rate).minimize(loss)
  * (DM/meta.py:410-414) without a host round trip of the weights.
  * l2o_adam_step: TF 1.x `_apply_dense` on one flat fp32 vector (all device pointers, n elements):

@@ -27,7 +27,7 @@ SYMBOLS = (
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
-    "l2o_unroll_status", "l2o_reduce_fx",
+    "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
 )
 
 
@@ -210,6 +210,10 @@ def lib():
     L.l2o_unroll_supported.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem)]
     L.l2o_unroll_record_supported.restype = C.c_int
     L.l2o_unroll_record_supported.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem)]
+    L.l2o_atb_workspace_bytes.restype = C.c_size_t
+    L.l2o_atb_workspace_bytes.argtypes = [i64, i32, i32]
+    L.l2o_atb.restype = C.c_int
+    L.l2o_atb.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp]
     L.l2o_reduce_fx.restype = C.c_int
     L.l2o_reduce_fx.argtypes = [vp, i32, i32, i32, vp, vp]
     if L.l2o_abi_version() != L2O_ABI_VERSION:

@@ -460,6 +460,19 @@ class HipEngine(object):
                 ws[:4].zero_()                               # the status word is sticky: handled here, cleared here
             _abi.check(self.lib.l2o_unroll_status(hdr))
 
+    def atb(self, A, B):
+        """A^T B for tall-skinny fp32 device matrices A [R, KA], B [R, KB] (l2o_atb: split-K over the rows on the
+        matrix cores, fixed-order reduction) -> new [KA, KB] device tensor."""
+        R, KA = A.shape
+        KB = B.shape[1]
+        n = int(self.lib.l2o_atb_workspace_bytes(int(R), int(KA), int(KB)))
+        ws = self.__dict__.get("_atb_ws")
+        if ws is None or ws.numel() * 4 < n:
+            ws = self._atb_ws = self.empty((n + 3) // 4)
+        out = self.empty(KA, KB)
+        _abi.check(self.lib.l2o_atb(_ptr(A), _ptr(B), int(R), int(KA), int(KB), _ptr(out), _ptr(ws), self._stream()))
+        return out
+
     def reduce_fx(self, fx_part, T1, B_local, B_global, fx):
         _abi.check(self.lib.l2o_reduce_fx(_ptr(fx_part), int(T1), int(B_local), int(B_global), _ptr(fx),
                                           self._stream()))

@@ -1,0 +1,147 @@
+// l2o_atb.h -- G = A^T B for tall-skinny fp32 operands: A [R][KA], B [R][KB], R up to millions of rows,
+// KA <= 112, KB <= 192.  Every weight gradient of a recorded unroll is a block of this one product
+// (meta_minimize, DM/meta.py:398-414: A = [act1 | act2 | h2 | feats | 1], B = [dz1 | dz2 | dd | du] as emitted by
+// l2o_cwlstm_bwd_unroll; KA x KB = 82 x 161 (L2O-DM), 83 x 161 (LogAndSign), 103 x 181 (RNNProp)).
+// Included by l2o_kernels.hip.
+//
+// Split-K over the rows: a persistent workgroup walks row blocks of 32, keeps the WHOLE KA x KB result in its
+// accumulators (MT x NT tiles of 16 x 16 over 4 waves, v_mfma_f32_16x16x4_f32: exact fp32 products and sums, like
+// the library GEMM it replaces) and writes one partial per workgroup; a second kernel adds the partials in a
+// fixed order.  Operands: each 32-row block of A and B is contiguous in memory; it is read once, coalesced, staged
+// in registers while the previous block is being multiplied, and laid out in LDS with a row stride = 16 mod 32
+// floats so that the per-lane operand reads (ds_read_b32: lanes (m, k) -> row k, column 16 tile + m) are
+// bank-conflict free.  Both operands stream from HBM exactly once: 4 (KA + KB) bytes per row.
+#pragma once
+
+constexpr int kAtbRows = 32;               // rows per block (8 k-steps of the 16x16x4 MFMA)
+constexpr int kAtbMaxGroups = 512;         // split-K partials (persistent workgroups)
+
+__host__ __device__ constexpr int atb_ld(int tiles) { return (16 * tiles) % 32 == 16 ? 16 * tiles : 16 * tiles + 16; }
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_atb(const float* __restrict__ A, const float* __restrict__ B, long R, int KA,
+                                             int KB, float* __restrict__ part) {
+  constexpr int LDA = atb_ld(MT), LDB = atb_ld(NT);
+  constexpr int NTILES = MT * NT, TPW = (NTILES + 3) / 4;          // tiles per wave
+  __shared__ float sA[2][kAtbRows * LDA];
+  __shared__ float sB[2][kAtbRows * LDB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ml = lane & 15, kq = lane >> 4;
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // zero the padding columns once (never overwritten)
+  for (int e = tid; e < 2 * kAtbRows * LDA; e += 256) (&sA[0][0])[e] = 0.0f;
+  for (int e = tid; e < 2 * kAtbRows * LDB; e += 256) (&sB[0][0])[e] = 0.0f;
+  __syncthreads();
+  const long nblk = (R + kAtbRows - 1) / kAtbRows;
+  // global -> registers -> LDS: wave w fetches rows w * 8 .. w * 8 + 7 of the block, one dword per (row, column)
+  // and lane (coalesced 256-byte pieces of a row); measured against dwordx4 pieces of the contiguous block scattered
+  // through a multiply-high row/column split: 723 vs 894 us at R = 1.6 M rows (the scatter costs more than it saves)
+  constexpr int NLA = (16 * MT + 63) / 64, NLB = (16 * NT + 63) / 64;   // dword loads per lane and row
+  constexpr int RPW = kAtbRows / 4;                                 // rows of a block loaded by one wave
+  float ra[RPW][NLA], rb[RPW][NLB];
+  auto fetch = [&](long blk) {                                      // this wave's 8 rows of the block -> registers
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const long row = blk * kAtbRows + wv * RPW + i;
+      const bool ok = row < R;
+#pragma unroll
+      for (int u = 0; u < NLA; ++u) {
+        const int col = lane + 64 * u;
+        ra[i][u] = (ok && col < KA) ? A[row * KA + col] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < NLB; ++u) {
+        const int col = lane + 64 * u;
+        rb[i][u] = (ok && col < KB) ? B[row * KB + col] : 0.0f;
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wv * RPW + i;
+#pragma unroll
+      for (int u = 0; u < NLA; ++u) {
+        const int col = lane + 64 * u;
+        if (col < 16 * MT) sA[buf][r * LDA + col] = ra[i][u];
+      }
+#pragma unroll
+      for (int u = 0; u < NLB; ++u) {
+        const int col = lane + 64 * u;
+        if (col < 16 * NT) sB[buf][r * LDB + col] = rb[i][u];
+      }
+    }
+  };
+  long blk = blockIdx.x;
+  int buf = 0;
+  if (blk < nblk) { fetch(blk); stage(0); }
+  __syncthreads();
+  for (; blk < nblk; blk += gridDim.x) {
+    const long nxt = blk + gridDim.x;
+    if (nxt < nblk) fetch(nxt);                                     // in flight while this block is multiplied
+    const float* pa = sA[buf] + kq * LDA + ml;
+    const float* pb = sB[buf] + kq * LDB + ml;
+    // the tile list of a wave is static once the wave index is a compile-time constant: tile W + 4 i -> (mt, nt)
+    // fold into immediate LDS offsets, and operands shared by consecutive tiles are read once
+    auto compute = [&](auto wc) {
+      constexpr int W = decltype(wc)::value;
+#pragma unroll
+      for (int ks = 0; ks < kAtbRows / 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          constexpr int dummy = 0; (void)dummy;
+          const int ti = W + 4 * i;
+          if (ti < NTILES) {
+            const int mt = ti / NT, nt = ti - mt * NT;
+            const float av = pa[(4 * ks) * LDA + 16 * mt];
+            const float bv = pb[(4 * ks) * LDB + 16 * nt];
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    };
+    switch (wv) {
+      case 0: compute(std::integral_constant<int, 0>{}); break;
+      case 1: compute(std::integral_constant<int, 1>{}); break;
+      case 2: compute(std::integral_constant<int, 2>{}); break;
+      default: compute(std::integral_constant<int, 3>{});
+    }
+    if (nxt < nblk) stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // ---- this workgroup's partial: D[16 mt + 4 kq + r][16 nt + ml]
+  float* out = part + (size_t)blockIdx.x * KA * KB;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int ti = wv + 4 * i;
+    if (ti < NTILES) {
+      const int mt = ti / NT, nt = ti - mt * NT;
+      const int col = 16 * nt + ml;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + 4 * kq + r;
+        if (row < KA && col < KB) out[(size_t)row * KB + col] = acc[i][r];
+      }
+    }
+  }
+}
+
+// out[e] = sum_g part[g][e], ascending g (bit-reproducible)
+__global__ void k_atb_reduce(const float* __restrict__ part, int groups, int n, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int g = 0;
+  for (; g + 3 < groups; g += 4) {
+    s0 += part[(size_t)g * n + e];
+    s1 += part[(size_t)(g + 1) * n + e];
+    s2 += part[(size_t)(g + 2) * n + e];
+    s3 += part[(size_t)(g + 3) * n + e];
+  }
+  for (; g < groups; ++g) s0 += part[(size_t)g * n + e];
+  out[e] = (s0 + s1) + (s2 + s3);
+}

@@ -831,6 +831,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_generic.h"
 
+#include "l2o_atb.h"
+
 #include "l2o_bwd.h"
 
 #include "l2o_bwd_mfma.h"
@@ -1443,6 +1445,36 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, cons
 size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp) {
   if (!mlp || mlp->batch < 1) return 0;
   return (size_t)mlp->batch * (2 * (size_t)mlp->n_hidden + mlp->n_out + 1);
+}
+
+// ---- G = A^T B, the weight-gradient contraction of the meta-gradient (csrc/l2o_atb.h) ----------------------
+static int atb_groups(int64_t R, hipStream_t s) {
+  const int64_t nblk = (R + kAtbRows - 1) / kAtbRows;
+  int g = 2 * device_cu_count(s);                         // two workgroups per CU (72 KB of LDS each)
+  if (g <= 0 || g > kAtbMaxGroups) g = kAtbMaxGroups;
+  return (int)(nblk < g ? nblk : g);
+}
+size_t l2o_atb_workspace_bytes(int64_t R, int32_t KA, int32_t KB) {
+  if (R <= 0 || KA <= 0 || KB <= 0) return 0;
+  return sizeof(float) * (size_t)kAtbMaxGroups * KA * KB;
+}
+int l2o_atb(const float* A, const float* B, int64_t R, int32_t KA, int32_t KB, float* out, void* workspace, void* stream) {
+  if (!A || !B || !out || !workspace || R <= 0 || KA <= 0 || KB <= 0) return fail(L2O_ERR_ARG, "l2o_atb: bad argument");
+  if (KA > 112 || KB > 192) return fail(L2O_ERR_UNSUPPORTED, "l2o_atb: KA <= 112 and KB <= 192 (got %d x %d)", KA, KB);
+  hipStream_t s = (hipStream_t)stream;
+  const int groups = atb_groups(R, s);
+  float* part = static_cast<float*>(workspace);
+  const int MT = (KA + 15) / 16, NT = (KB + 15) / 16;
+  void (*fn)(const float*, const float*, long, int, int, float*) = nullptr;
+  if (MT <= 1 && NT <= 1) fn = k_atb<1, 1>;
+  else if (MT <= 6 && NT <= 11) fn = k_atb<6, 11>;
+  else fn = k_atb<7, 12>;
+  hipLaunchKernelGGL(fn, dim3(groups), dim3(256), 0, s, A, B, (long)R, (int)KA, (int)KB, part);
+  HIP_TRY(hipGetLastError());
+  const int n = KA * KB;
+  hipLaunchKernelGGL(k_atb_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, groups, n, out);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
 }
 
 // ---- generic-`layers` optimizer step (csrc/l2o_generic.h) --------------------------------------------------

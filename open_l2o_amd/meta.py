@@ -850,7 +850,7 @@ class UnrollGraph(object):
                     if second:
                         hess_update(pn, t, N)
                     dd = io["dd"].view(N, 1)
-                    add("linear", "w", io["act1"][:, :P].t() @ dd)
+                    add("linear", "w", eng.atb(io["act1"], dd)[:P])
                     add("linear", "b", dd.sum(0))
             return
         # The kernel emits, per step and coordinate, one row of  A = [act1 | act2 | h2 | feats | 1]
@@ -911,7 +911,7 @@ class UnrollGraph(object):
                     if second:
                         hess_update(pn, t, N)
                 carry_in, carry_out = carry_out, carry_in
-            Gm = _chunked_atb(A.view(T * R, KA), Bm.view(T * R, KB))
+            Gm = eng.atb(A.view(T * R, KA), Bm.view(T * R, KB))      # l2o_atb: every weight gradient is a block of A^T Bm
             add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
             add("lstm_1", "b_gates", Gm[KA - 1, 0:4 * H])
             add("lstm_2", "w_gates", Gm[K1:K1 + 2 * H, 4 * H:8 * H])
@@ -1328,24 +1328,6 @@ class UnrollGraph(object):
             states[si].packed.copy_(hs[T])
             if hm is not None:
                 ms[si].copy_(hm[T].view(ms[si].shape)); vs[si].copy_(hv[T].view(vs[si].shape))
-
-
-def _chunked_atb(A, B, chunk=None):
-    """A^T B for tall-skinny A [R, ka], B [R, kb] as ONE batched GEMM over row chunks + a sum
-    (library GEMMs; rocBLAS' plain skinny-K path is ~4x slower).  Chunk size by measurement
-    (scripts/microbench/skinny_gemm_big.py: R = 0.33 M rows: 1024 -> 173 us, 4096 -> 147 us;
-    R = 1.6 M rows: 1024 -> 854 us, 8192 -> 602 us)."""
-    R = A.shape[0]
-    if chunk is None:
-        chunk = 1024 if R < (1 << 16) else (4096 if R < (1 << 20) else 8192)
-    n = R // chunk
-    out = None
-    if n:
-        out = torch.bmm(A[:n * chunk].view(n, chunk, -1).transpose(1, 2), B[:n * chunk].view(n, chunk, -1)).sum(0)
-    if n * chunk < R:
-        tail = A[n * chunk:].t() @ B[n * chunk:]
-        out = tail if out is None else out + tail
-    return out
 
 
 # ---------------------------------------------------------------------------

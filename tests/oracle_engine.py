@@ -49,6 +49,10 @@ class OracleEngine(object):
         self.lib = _abi.lib()
         self.calls = []
 
+    def atb(self, A, B):
+        """A^T B (the HIP engine's l2o_atb), CPU torch."""
+        return A.t().contiguous() @ B
+
     def tensor(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).copy())
 

@@ -642,3 +642,21 @@ def test_long_horizon_T1000(eng):
               % (pair, e64, e32, envelope))
         assert e64 < min(1e-4, max(1e-5, 3 * envelope))
         assert rel_err(fx[:101], r64.fx[:101]) < 1e-5
+
+
+@pytest.mark.parametrize("R,KA,KB", [(16384 * 5, 82, 161), (4000, 83, 161), (16384 * 3 + 7, 103, 181), (50, 2, 1),
+                                     (31, 82, 161), (100000, 21, 80)])
+def test_atb_weight_gradient_contraction(eng, R, KA, KB):
+    """l2o_atb (split-K A^T B on the fp32 matrix cores) against a float64 product, for the three (KA, KB) of the
+    BPTT rows, ragged row counts and the tiny Linear-only case; two runs are bit-identical (fixed-order reduction)."""
+    import torch
+    rng = np.random.default_rng(R + KA)
+    A = rng.standard_normal((R, KA)).astype(np.float32)
+    B = rng.standard_normal((R, KB)).astype(np.float32)
+    Ad, Bd = eng.tensor(A), eng.tensor(B)
+    got = eng.to_numpy(eng.atb(Ad, Bd))
+    again = eng.to_numpy(eng.atb(Ad, Bd))
+    want = A.astype(np.float64).T @ B.astype(np.float64)
+    scale = np.sqrt(R)
+    assert got.shape == (KA, KB) and np.array_equal(got, again)
+    assert float(np.abs(got - want).max()) < 2e-5 * scale, float(np.abs(got - want).max())
