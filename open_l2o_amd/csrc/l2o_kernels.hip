@@ -1546,6 +1546,9 @@ static bool mlp_unroll_layout(const l2o_mlp* mlp, MlpUnrollLayout* L) {
   L->NSM = (size_t)H + (size_t)H * O + O;
   L->R = (int)((L->NO + L->nwg - 1) / L->nwg);
   L->R = (L->R + 1) & ~1;                                // even: the fast path moves granules in pairs
+  // one 64-byte line per (source, reducer): R = 8 measured best (profiles/r02l: R = 6 / 8 / 12 / 16 -> 1.32 / 1.35 /
+  // 1.28 / 1.24 G on config 5)
+  if (L->R < 8 && L->NO >= 8 * 32) L->R = 8;
   if (L->R > kMuMaxR) return false;
   L->fast = H == 20 && O == 10 && mlp->batch == 64;
   L->p_off = sizeof(MlpWs);

@@ -9,15 +9,17 @@
 // the halves swap the partial residuals (one granule per row, 128 each way for d = 128).
 //
 // Exchange protocol (placement independent, MI355X_MICROARCH.md "valid forms"): data-tagged
-// 8-byte granules {float x, uint tag = step + 1} written with ONE agent-scope relaxed atomic
+// 8-byte granules {float x, uint tag = launch salt | step + 1} written with ONE agent-scope relaxed atomic
 // 64-bit store (global_store_dwordx2 sc1: write-through) and polled with agent-scope relaxed
 // 64-bit loads (sc1: L1 bypass).  A granule is self-validating, so no flag, no fence.  Two
 // parity buffers: a workgroup can publish step t+2 only after it has consumed the partner's
 // step t+1, which the partner publishes only after it consumed ours of step t+1 -- the
-// buffer of parity (t+2)&1 = t&1 is therefore free.  The whole buffer is zeroed by a
-// hipMemsetAsync ahead of every launch (tag 0 is never valid).  Every spin is bounded: on
-// timeout the kernel raises ws->status and stops waiting (results are then garbage and the
-// host reports L2O_ERR_HIP) -- a non-resident partner can never hang the GPU.
+// buffer of parity (t+2)&1 = t&1 is therefore free.  The granule area is zeroed by a
+// hipMemsetAsync ahead of every launch (tag 0 is never valid) and the tags carry the launch
+// sequence number of the workspace header on top.  Every spin is bounded: on timeout the kernel
+// raises the STICKY ws->status and stops waiting (results are then garbage and the host reports
+// L2O_ERR_HIP) -- a non-resident partner can never hang the GPU.  Confirmed same-XCD partners
+// publish with plain stores (see the handshake below; L2O_OPT_PAIR_PLAIN_STORES).
 //
 // The matrix never touches LDS: a half keeps its SQ x SQ/2 column block of W twice in
 // registers (row-major for the partial residual, column-major for the gradient: 2 x SQ/4
