@@ -389,7 +389,7 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
  * synchronising, copy them to the host and pass them to l2o_unroll_status(); the caller clears
  * the word (writes 0) once it has handled the error.  The next 4 bytes are a launch sequence
  * number the kernels maintain (the salt of the exchange tags).  A workspace must start zeroed
- * and must not be shared by two streams at the same time.
+ * (see l2o_unroll_workspace_init / _layout below) and must not be shared by two streams at the same time.
  * Problems beyond the LDS-resident sizes (D <= 512, D % 4 == 0, any M) run the streaming
  * form: one workgroup per problem, the matrix streamed once per step, x / state / moments on-chip
  * for the whole unroll; it needs no workspace (l2o_unroll_workspace_bytes() == 0). */
@@ -414,6 +414,26 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device */,
                       const l2o_problem* prob, float* x, float* st, float* m, float* v,
                       int32_t T, int32_t step0, float* fx_part, void* workspace,
                       const l2o_unroll_hist* hist, void* stream);
+/* The same unroll with the passes around it folded in (ABI v6); hist may be NULL:
+ *   fx     also leaves fx[t] = (sum_b fx_part[t][b]) / B_global, t = 0..T (== l2o_reduce_fx, same summation order) --
+ *          for the two-CU form inside the unroll's own epilogue kernel;
+ *   x0     if not NULL the unroll starts from x0 [B_local, D] (read-only) and writes x_T to x: the `reset` of the
+ *          iterate (DM/meta.py:379-383 re-runs the x initializer; a driver that restarts the SAME instance keeps x0);
+ *   flags  L2O_UNROLL_ZERO_STATE: start from the zero LSTM state and zero RNNProp moments (what `reset` leaves,
+ *          DM/meta.py:381, DM/meta_rnnprop_train.py:559-566) instead of reading st, m, v; they are still written.
+ * i.e. `reset` + the first unroll of an epoch + fx_array.stack() in one call, without memset / copy passes. */
+#define L2O_UNROLL_ZERO_STATE 1
+int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_problem* prob,
+                      const float* x0 /* device or NULL */, float* x, float* st, float* m, float* v, int32_t T,
+                      int32_t step0, int32_t flags, float* fx_part, float* fx /* device [T+1] */, void* workspace,
+                      const l2o_unroll_hist* hist, void* stream);
+/* Workspace contract (ABI v6).  The workspace of l2o_unroll must be ZERO before its first use and whenever
+ * l2o_unroll_workspace_layout(cfg, prob) differs from the previous launch on it (another batch size / padded problem
+ * size: the exchange granules move); l2o_unroll_workspace_init zeroes `bytes` bytes asynchronously (a hipMemsetAsync).
+ * Between launches of one layout the library keeps the granule area clean itself (the epilogue kernel of a launch
+ * re-zeroes it), so there is no memset per unroll.  layout == 0: the pair has no workspace-using kernel. */
+int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream);
+int64_t l2o_unroll_workspace_layout(const l2o_net_cfg* cfg, const l2o_problem* prob);
 int l2o_unroll_status(const void* workspace_header_host /* host copy of the first 4 bytes */);
 /* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0: the LDS-resident forms
  * (D <= 128, M <= 16 ceil(D/16)) or the streaming form (everything else with D <= 512, D % 4 == 0,

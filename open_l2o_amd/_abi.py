@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_set_option", "l2o_get_option", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
-    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
 )
 
@@ -96,6 +96,7 @@ class BwdIO(C.Structure):
                [("a_stride", C.c_int64), ("b_stride", C.c_int64), ("dg", C.c_void_p)]
 
 
+UNROLL_ZERO_STATE = 1     # l2o_unroll_reduce flags
 PROB_W_SHARED = 1     # l2o_problem.flags: W is one [M, D] matrix for every problem
 
 
@@ -202,6 +203,13 @@ def lib():
     L.l2o_unroll_record.restype = C.c_int
     L.l2o_unroll_record.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Problem), vp, vp, vp, vp, i32, i32, vp, vp,
                                     C.POINTER(UnrollHist), vp]
+    L.l2o_unroll_reduce.restype = C.c_int
+    L.l2o_unroll_reduce.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Problem), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp,
+                                    vp, C.POINTER(UnrollHist), vp]
+    L.l2o_unroll_workspace_init.restype = C.c_int
+    L.l2o_unroll_workspace_init.argtypes = [vp, C.c_size_t, vp]
+    L.l2o_unroll_workspace_layout.restype = C.c_int64
+    L.l2o_unroll_workspace_layout.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem)]
     L.l2o_unroll_workspace_bytes.restype = C.c_size_t
     L.l2o_unroll_workspace_bytes.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem), i32]
     L.l2o_unroll_status.restype = C.c_int

@@ -428,25 +428,42 @@ class HipEngine(object):
         fn = self.lib.l2o_unroll_record_supported if record else self.lib.l2o_unroll_supported
         return bool(fn(C.byref(cc), C.byref(cp)))
 
-    def unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part, hist=None):
+    def unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part, hist=None, fx=None, x0=None,
+               zero_state=False):
         """hist: None, or dict(st=[T, state_floats], g=[T, B*D], m=, v= (RNNProp), g_final=[B*D]) of
-        device tensors that receive the per-step history the meta-gradient needs (l2o_unroll_record)."""
+        device tensors that receive the per-step history the meta-gradient needs (l2o_unroll_record).
+        fx: None, or a device tensor [T + 1] that receives the batch-mean loss of every step (l2o_unroll_reduce:
+        the reduction rides in the unroll's epilogue kernel where there is one).  x0 / zero_state (with fx): start
+        from x0 and the zero LSTM state / moments instead of the contents of x / st / m / v (`reset` folded in)."""
+        assert fx is not None or (x0 is None and not zero_state)
         cc, cp = spec.to_c(), self._cprob(p)
         nbytes = int(self.lib.l2o_unroll_workspace_bytes(C.byref(cc), C.byref(cp), int(T)))
         ws = None
         if nbytes:
             ws = self._workspace
+            layout = int(self.lib.l2o_unroll_workspace_layout(C.byref(cc), C.byref(cp)))
             if ws is None or ws.numel() < nbytes:
                 ws = self._workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            elif layout != self.__dict__.get("_ws_layout"):
+                # the granule area moved: zero the workspace once (the library keeps it clean between launches)
+                _abi.check(self.lib.l2o_unroll_workspace_init(C.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
+            self._ws_layout = layout
         self._last_ws = ws
         wsp = None if ws is None else C.c_void_p(ws.data_ptr())
-        if hist is None:
-            _abi.check(self.lib.l2o_unroll(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
-                                           _ptr(v), int(T), int(step0), _ptr(fx_part), wsp, self._stream()))
-        else:
+        h = None
+        if hist is not None:
             h = _abi.UnrollHist()
             for k, _ in _abi.UnrollHist._fields_:
                 setattr(h, k, None if hist.get(k) is None else hist[k].data_ptr())
+        if fx is not None:
+            _abi.check(self.lib.l2o_unroll_reduce(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x0), _ptr(x), _ptr(st), _ptr(m),
+                                                  _ptr(v), int(T), int(step0),
+                                                  _abi.UNROLL_ZERO_STATE if zero_state else 0, _ptr(fx_part), _ptr(fx),
+                                                  wsp, None if h is None else C.byref(h), self._stream()))
+        elif hist is None:
+            _abi.check(self.lib.l2o_unroll(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
+                                           _ptr(v), int(T), int(step0), _ptr(fx_part), wsp, self._stream()))
+        else:
             _abi.check(self.lib.l2o_unroll_record(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),
                                                   _ptr(v), int(T), int(step0), _ptr(fx_part), wsp, C.byref(h),
                                                   self._stream()))

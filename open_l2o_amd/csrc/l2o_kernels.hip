@@ -642,6 +642,10 @@ struct UnrollArgs {
   // step t, the gradient fed to the network at step t, RNNProp moments AFTER step t, and the
   // gradient at x_T.  All NULL for a plain unroll.
   float *hist_st, *hist_g, *hist_m, *hist_v, *hist_gfinal;
+  // restart (l2o_unroll_reduce): read the iterate from x_in (x receives x_T) / start from the zero LSTM state and
+  // zero moments instead of reading st, m, v -- `reset` + the first unroll in one launch, no memset / copy pass
+  const float* x_in;
+  int zero_state;
 };
 
 #ifdef L2O_ABLATE_BARRIER
@@ -706,14 +710,19 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   const int tile = b * nw + wv;
   TileState s;
   float* st_tile = a.st + (size_t)tile * kStateFloatsPerTile;
-  load_tile_state(s, st_tile, lane);
-  float xv = live ? a.x[idx] : 0.0f;
+  if (a.zero_state) {
+#pragma unroll
+    for (int t5 = 0; t5 < kNT; ++t5) s.h1[t5] = s.c1[t5] = s.h2[t5] = s.c2[t5] = 0.0f;
+  } else {
+    load_tile_state(s, st_tile, lane);
+  }
+  float xv = live ? (a.x_in ? a.x_in : a.x)[idx] : 0.0f;
   const float sc = (live && pp.x_scale) ? pp.x_scale[idx] : 1.0f;
   float cj = 0.0f;
   constexpr bool kCos = KIND == L2O_PROB_RASTRIGIN || KIND == L2O_PROB_SQUARE_COS;
   if (kCos) cj = live ? pp.C[idx] : 0.0f;
   float mv = 0.0f, vv = 0.0f;
-  if (PRE == L2O_PRE_FC_ELU) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
+  if (PRE == L2O_PRE_FC_ELU && !a.zero_state) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   constexpr bool kSq = KIND == L2O_PROB_QUADRATIC || KIND == L2O_PROB_SQUARE_COS;
   const float coef = kSq ? 1.0f : 0.5f;
@@ -1010,7 +1019,7 @@ static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) 
 
 template <int PRE, int KIND>
 static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s, const l2o_problem* prob,
-                            void* workspace) {
+                            void* workspace, float* fx, bool* fx_done) {
   const bool hist = a.hist_st != nullptr;
   if (workspace && pair_eligible(prob, g, s)) {
     const PairLayout L = pair_layout(prob, g, a.T);
@@ -1029,15 +1038,16 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
       case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
       default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
     }
-    // the granules only: the header (sticky status, launch sequence) survives
-    HIP_TRY(hipMemsetAsync(static_cast<char*>(workspace) + L.xbuf_off, 0, L.xbuf_bytes, s));
+    // (no memset here: the workspace starts zeroed -- l2o_unroll_workspace_init -- and the epilogue kernel of every
+    //  launch leaves the granule area zeroed for the next one)
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
     const int groups = (a.pp.B_local + 7) / 8;
     hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
     HIP_TRY(hipGetLastError());
-    const int n = (a.T + 1) * a.pp.B_local;
-    hipLaunchKernelGGL(k_combine_halves, dim3((n + 255) / 256), dim3(256), 0, s, pa.fx_half, a.fx_part, n, g.CH, pa.ws);
+    hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(64), 0, s, pa.fx_half, a.fx_part, a.pp.B_local, g.CH,
+                       a.pp.inv_bg, fx, pa.xbuf, (long)(L.xbuf_bytes / sizeof(unsigned long long)), pa.ws);
     HIP_TRY(hipGetLastError());
+    if (fx_done) *fx_done = fx != nullptr;
     return L2O_OK;
   }
   void (*fn)(UnrollArgs) = nullptr;
@@ -1056,12 +1066,12 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
 
 template <int PRE>
 static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind, hipStream_t s,
-                              const l2o_problem* prob, void* workspace) {
+                              const l2o_problem* prob, void* workspace, float* fx, bool* fx_done) {
   switch (kind) {
-    case L2O_PROB_QUADRATIC: return launch_unroll_ch<PRE, L2O_PROB_QUADRATIC>(a, g, s, prob, workspace);
-    case L2O_PROB_LASSO: return launch_unroll_ch<PRE, L2O_PROB_LASSO>(a, g, s, prob, workspace);
-    case L2O_PROB_RASTRIGIN: return launch_unroll_ch<PRE, L2O_PROB_RASTRIGIN>(a, g, s, prob, workspace);
-    case L2O_PROB_SQUARE_COS: return launch_unroll_ch<PRE, L2O_PROB_SQUARE_COS>(a, g, s, prob, workspace);
+    case L2O_PROB_QUADRATIC: return launch_unroll_ch<PRE, L2O_PROB_QUADRATIC>(a, g, s, prob, workspace, fx, fx_done);
+    case L2O_PROB_LASSO: return launch_unroll_ch<PRE, L2O_PROB_LASSO>(a, g, s, prob, workspace, fx, fx_done);
+    case L2O_PROB_RASTRIGIN: return launch_unroll_ch<PRE, L2O_PROB_RASTRIGIN>(a, g, s, prob, workspace, fx, fx_done);
+    case L2O_PROB_SQUARE_COS: return launch_unroll_ch<PRE, L2O_PROB_SQUARE_COS>(a, g, s, prob, workspace, fx, fx_done);
     default: return fail(L2O_ERR_UNSUPPORTED, "no fused kernel for problem kind %d", kind);
   }
 }
@@ -1903,14 +1913,44 @@ int l2o_unroll_status(const void* workspace_header_host) {
                            "were not co-resident; rerun with L2O_NO_PAIR=1", st);
 }
 
+static int unroll_impl(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st,
+                       float* m, float* v, int32_t T, int32_t step0, float* fx_part, void* workspace,
+                       const l2o_unroll_hist* hist, float* fx, void* stream, const float* x0 = nullptr, int flags = 0);
+
 int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st, float* m,
                float* v, int32_t T, int32_t step0, float* fx_part, void* workspace, void* stream) {
-  return l2o_unroll_record(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, nullptr, stream);
+  return unroll_impl(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, nullptr, nullptr, stream);
 }
 
 int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st,
                       float* m, float* v, int32_t T, int32_t step0, float* fx_part, void* workspace,
                       const l2o_unroll_hist* hist, void* stream) {
+  return unroll_impl(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, hist, nullptr, stream);
+}
+
+int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, const float* x0, float* x,
+                      float* st, float* m, float* v, int32_t T, int32_t step0, int32_t flags, float* fx_part, float* fx,
+                      void* workspace, const l2o_unroll_hist* hist, void* stream) {
+  if (!fx) return fail(L2O_ERR_ARG, "l2o_unroll_reduce: NULL fx");
+  if (flags & ~L2O_UNROLL_ZERO_STATE) return fail(L2O_ERR_ARG, "l2o_unroll_reduce: unknown flags %d", flags);
+  return unroll_impl(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, hist, fx, stream, x0, flags);
+}
+
+int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream) {
+  if (!workspace && bytes) return fail(L2O_ERR_ARG, "l2o_unroll_workspace_init: NULL workspace");
+  if (bytes) HIP_TRY(hipMemsetAsync(workspace, 0, bytes, (hipStream_t)stream));
+  return L2O_OK;
+}
+
+int64_t l2o_unroll_workspace_layout(const l2o_net_cfg* cfg, const l2o_problem* prob) {
+  UnrollGeom g;
+  if (!cfg || !prob || !l2o_unroll_supported(cfg, prob) || !unroll_geom(prob, &g) || g.CH < 2) return 0;
+  return ((int64_t)prob->B_local << 8) | g.CH;            // changes whenever the granule area's layout does
+}
+
+static int unroll_impl(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st,
+                       float* m, float* v, int32_t T, int32_t step0, float* fx_part, void* workspace,
+                       const l2o_unroll_hist* hist, float* fx, void* stream, const float* x0, int flags) {
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!cfg || !wpack || !x || !st || !fx_part || T < 0) return fail(L2O_ERR_ARG, "l2o_unroll: bad argument");
@@ -1926,6 +1966,7 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
   a.np = make_net_params(cfg, wpack);
   a.pp = make_prob_params(prob);
   a.x = x; a.st = st; a.m = m; a.v = v; a.fx_part = fx_part;
+  a.x_in = x0; a.zero_state = (flags & L2O_UNROLL_ZERO_STATE) ? 1 : 0;
   a.T = T;
   a.hist_st = hist ? hist->st : nullptr;
   a.hist_g = hist ? hist->g : nullptr;
@@ -1935,22 +1976,26 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
   pow_ff(cfg->beta1, step0, &a.p1_hi, &a.p1_lo);
   pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
   hipStream_t s = (hipStream_t)stream;
+  bool fx_done = false;
+  rc = L2O_OK;
+  if (cfg->preprocess == L2O_PRE_FC_ELU && (!m || !v)) return fail(L2O_ERR_ARG, "l2o_unroll: RNNProp needs m and v");
   if (!lds_form) {
     switch (cfg->preprocess) {
-      case L2O_PRE_IDENTITY: return launch_unroll_cu<L2O_PRE_IDENTITY>(a, s);
-      case L2O_PRE_LOGSIGN: return launch_unroll_cu<L2O_PRE_LOGSIGN>(a, s);
-      default:
-        if (!m || !v) return fail(L2O_ERR_ARG, "l2o_unroll: RNNProp needs m and v");
-        return launch_unroll_cu<L2O_PRE_FC_ELU>(a, s);
+      case L2O_PRE_IDENTITY: rc = launch_unroll_cu<L2O_PRE_IDENTITY>(a, s); break;
+      case L2O_PRE_LOGSIGN: rc = launch_unroll_cu<L2O_PRE_LOGSIGN>(a, s); break;
+      default: rc = launch_unroll_cu<L2O_PRE_FC_ELU>(a, s);
+    }
+  } else {
+    switch (cfg->preprocess) {
+      case L2O_PRE_IDENTITY: rc = launch_unroll_kind<L2O_PRE_IDENTITY>(a, g, prob->kind, s, prob, workspace, fx, &fx_done); break;
+      case L2O_PRE_LOGSIGN: rc = launch_unroll_kind<L2O_PRE_LOGSIGN>(a, g, prob->kind, s, prob, workspace, fx, &fx_done); break;
+      default: rc = launch_unroll_kind<L2O_PRE_FC_ELU>(a, g, prob->kind, s, prob, workspace, fx, &fx_done);
     }
   }
-  switch (cfg->preprocess) {
-    case L2O_PRE_IDENTITY: return launch_unroll_kind<L2O_PRE_IDENTITY>(a, g, prob->kind, s, prob, workspace);
-    case L2O_PRE_LOGSIGN: return launch_unroll_kind<L2O_PRE_LOGSIGN>(a, g, prob->kind, s, prob, workspace);
-    default:
-      if (!m || !v) return fail(L2O_ERR_ARG, "l2o_unroll: RNNProp needs m and v");
-      return launch_unroll_kind<L2O_PRE_FC_ELU>(a, g, prob->kind, s, prob, workspace);
-  }
+  if (rc) return rc;
+  if (fx && !fx_done)                                       // forms without the fused epilogue: the separate reduction
+    return l2o_reduce_fx(fx_part, T + 1, prob->B_local, prob->B_global, fx, stream);
+  return L2O_OK;
 }
 
 int l2o_reduce_fx(const float* fx_part, int32_t T1, int32_t B_local, int32_t B_global, float* fx, void* stream) {

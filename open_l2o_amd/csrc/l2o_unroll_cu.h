@@ -115,11 +115,11 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   for (int j = tid; j < DP; j += kCuThreads) {
     const bool live = j < D;
     const size_t idx = (size_t)b * D + (live ? j : D - 1);
-    const float xv = live ? a.x[idx] : 0.0f;
+    const float xv = live ? (a.x_in ? a.x_in : a.x)[idx] : 0.0f;
     const float sc = (live && pp.x_scale) ? pp.x_scale[idx] : 1.0f;
     xL[j] = xv; scL[j] = sc; xsL[j] = xv * sc;
-    mL[j] = (PRE == L2O_PRE_FC_ELU && live) ? a.m[idx] : 0.0f;
-    vL[j] = (PRE == L2O_PRE_FC_ELU && live) ? a.v[idx] : 0.0f;
+    mL[j] = (PRE == L2O_PRE_FC_ELU && live && !a.zero_state) ? a.m[idx] : 0.0f;
+    vL[j] = (PRE == L2O_PRE_FC_ELU && live && !a.zero_state) ? a.v[idx] : 0.0f;
   }
   float* st_b = a.st + (size_t)b * tpp * kStateFloatsPerTile;
   for (int k = 0; k < nlds; ++k) {
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     if (tile < tpp) {
       const float4* src = reinterpret_cast<const float4*>(st_b + (size_t)tile * kStateFloatsPerTile);
 #pragma unroll
-      for (int jj = 0; jj < 5; ++jj) stL[k * kCuSlotF4 + jj * 64 + lane] = src[jj * 64 + lane];
+      for (int jj = 0; jj < 5; ++jj)
+        stL[k * kCuSlotF4 + jj * 64 + lane] = a.zero_state ? float4{0.f, 0.f, 0.f, 0.f} : src[jj * 64 + lane];
     }
   }
   const int tile7 = wv + kCuWaves * kCuMaxLdsSlots;            // the register-resident eighth tile
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   TileState s7;
 #pragma unroll
   for (int t5 = 0; t5 < kNT; ++t5) { s7.h1[t5] = 0.f; s7.c1[t5] = 0.f; s7.h2[t5] = 0.f; s7.c2[t5] = 0.f; }
-  if (has7) load_tile_state(s7, st_b + (size_t)tile7 * kStateFloatsPerTile, lane);
+  if (has7 && !a.zero_state) load_tile_state(s7, st_b + (size_t)tile7 * kStateFloatsPerTile, lane);
 
   bx::NetWB<PRE> w;
   bx::load_netw<PRE>(w, a.np.wpack, lane);

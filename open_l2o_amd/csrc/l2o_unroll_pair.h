@@ -152,18 +152,18 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const bool tile_real = tile_in_prob < tpp;            // the padded tile of an odd tile count is idle
   TileState s;
   float* st_tile = a.st + ((size_t)b * tpp + (tile_real ? tile_in_prob : 0)) * kStateFloatsPerTile;
-  if (tile_real) load_tile_state(s, st_tile, lane);
+  if (tile_real && !a.zero_state) load_tile_state(s, st_tile, lane);
   else {
 #pragma unroll
     for (int t = 0; t < kNT; ++t) s.h1[t] = s.c1[t] = s.h2[t] = s.c2[t] = 0.0f;
   }
-  float xv = live ? a.x[idx] : 0.0f;
+  float xv = live ? (a.x_in ? a.x_in : a.x)[idx] : 0.0f;
   const float sc = (live && pp.x_scale) ? pp.x_scale[idx] : 1.0f;
   float cj = 0.0f;
   constexpr bool kCos = KIND == L2O_PROB_RASTRIGIN || KIND == L2O_PROB_SQUARE_COS;
   if (kCos) cj = live ? pp.C[idx] : 0.0f;
   float mv = 0.0f, vv = 0.0f;
-  if (PRE == L2O_PRE_FC_ELU) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
+  if (PRE == L2O_PRE_FC_ELU && !a.zero_state) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   constexpr bool kSq = KIND == L2O_PROB_QUADRATIC || KIND == L2O_PROB_SQUARE_COS;
   const float coef = kSq ? 1.0f : 0.5f;
@@ -364,16 +364,30 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   if (tile_real) store_tile_state(s, st_tile, lane);
 }
 
-// fx_part[t][b] = sum of the 2 x NWH per-wave partials of (step t, problem b), fixed order; runs after every
-// workgroup of the unroll has finished, so it also advances the launch sequence word the next launch salts
-// its tags with
-__global__ void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part, int n, int nparts,
-                                 PairWs* ws) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    float f = fx_half[(size_t)i * nparts];
-    for (int k = 1; k < nparts; ++k) f += fx_half[(size_t)i * nparts + k];
-    fx_part[i] = f;
+// The epilogue of a two-CU unroll, one workgroup (64 threads) per step t; runs after every workgroup of the unroll
+// has finished:
+//   fx_part[t][b] = sum of the 2 x NWH per-wave partials of (step t, problem b), fixed order
+//   fx[t]         = (sum_b fx_part[t][b]) / B_global, the summation order of k_reduce_fx (optional)
+//   the exchange granules are zeroed for the NEXT launch (tag 0 is never valid; no memset launch per unroll)
+//   the launch sequence word the next launch salts its tags with advances
+__global__ __launch_bounds__(64) void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part,
+                                                       int B_local, int nparts, float inv_bg, float* __restrict__ fx,
+                                                       unsigned long long* __restrict__ xbuf, long xwords, PairWs* ws) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  float acc = 0.0f;
+  for (int b = lane; b < B_local; b += 64) {
+    const float* p = fx_half + ((size_t)t * B_local + b) * nparts;
+    float f = p[0];
+    for (int k = 1; k < nparts; ++k) f += p[k];
+    fx_part[(size_t)t * B_local + b] = f;
+    acc += f;
   }
-  if (i == 0) ws->seq = ws->seq + 1u;
+  if (fx) {
+    acc = l2o::wave_sum64(acc);
+    if (lane == 0) fx[t] = acc * inv_bg;
+  }
+  const long per = (xwords + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)t * per, hi = lo + per < xwords ? lo + per : xwords;
+  for (long e = lo + lane; e < hi; e += 64) xbuf[e] = 0ull;
+  if (t == 0 && lane == 0) ws->seq = ws->seq + 1u;
 }

@@ -546,7 +546,7 @@ class UnrollGraph(object):
         out = eng.to_numpy(fxbuf).reshape(n, L + 1)
         return [np.float32(out[k, L]) for k in range(n)]
 
-    def launch(self, feed=None, commit=True, events=None, use_graph=False, record=None):
+    def launch(self, feed=None, commit=True, events=None, use_graph=False, record=None, restart=None):
         """Enqueue one unroll on the current stream WITHOUT synchronising the host; returns
         (device tensor fx[0..T] -- already all-reduced when sharded --, list of device x_T).
         ``events`` = (start, end) torch.cuda.Event pair recorded around the unroll kernels.
@@ -557,6 +557,15 @@ class UnrollGraph(object):
         eng = self.engine
         T = self.len_unroll
         feed = feed or {}
+        # restart = list of device tensors x0: run this unroll from x0 and the zero LSTM state / moments on the SAME
+        # problem instance (rewind(x0) + launch); the fused kernels fold it in (no copy / memset pass), every other
+        # path rewinds first
+        restart_fused = False
+        if restart is not None:
+            if commit and record is None and len(self.x) == 1 and hasattr(eng, "mlp_unroll"):
+                restart_fused = True                        # (decided for good below, once the path is known)
+            else:
+                self.rewind(restart)
         # placeholders
         # (persistent device buffers, re-uploaded only when a NEW array is fed: util.run_epoch feeds the same
         #  random scaling to every unroll of an epoch, DM/util.py:40-54; stable addresses keep plans valid)
@@ -618,6 +627,9 @@ class UnrollGraph(object):
             n = 4 if self.sharded else 1
             ring = self._fx_cache[key] = {"bufs": [eng.zeros(T + 1) for _ in range(n)], "work": [None] * n, "i": 0}
         fused_path = record is None and self._fused_ok(descs)
+        if restart_fused and not fused_path:
+            self.rewind(restart)                            # (panels / states are views of the live tensors: still valid)
+            restart_fused = False
         if not fused_path:
             ring["i"] = 0                                  # a captured launch sequence owns buffer 0
         i = ring["i"]
@@ -657,8 +669,7 @@ class UnrollGraph(object):
             hist = fp["hist"]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
             eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
-                       fx_part, hist=hist)
-            eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
+                       fx_part, hist=hist, fx=fx)
             record.update(step0=step0, shapes=[tuple(pn.shape) for pn in panels], g=fp["g"], st=fp["st"],
                           m=fp["m"], v=fp["v"], g_final=fp["g_final"], plan=fp)
         elif record is not None:                           # meta-gradient: needs the per-step history
@@ -670,11 +681,14 @@ class UnrollGraph(object):
             self.last_path = "fused"
             s, d = slots[0], descs[0]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
-            eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
-                       fx_part)
+            if restart_fused:
+                eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
+                           fx_part, fx=fx, x0=restart[0].view(panels[0].shape), zero_state=True)
+            else:
+                eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
+                           fx_part, fx=fx)                  # (the batch-mean reduction rides in the unroll's epilogue)
             if events is not None:
                 events[1].record()
-            eng.reduce_fx(fx_part, T + 1, d.B_local, d.B_global, fx)
         elif self._mlp_unroll_ok(slots, states, scales):
             # the neural optimizee, all four variables stepped by one LSTM net: T steps in ONE persistent launch
             self.last_path = "mlp_unroll"
@@ -1065,14 +1079,25 @@ class UnrollGraph(object):
         """Device-side restart of the SAME problem instance: x <- x0 (list of device tensors),
         LSTM state / moments <- 0, without re-sampling the problem data (bench.py)."""
         self._ensure_init()
-        for v, t in zip(self.x, x0):
-            v.value.copy_(t)
+        dst, src = [v.value for v in self.x], list(x0)
+        zeros = self.__dict__.setdefault("_rewind_zeros", {})
         for s in self.slots:
-            if isinstance(s.state, PackedState):
-                s.state.zero_()
+            ts = []
+            if isinstance(s.state, PackedState) and s.state.packed is not None:
+                ts.append(s.state.packed)
             if s.m is not None:
-                s.m.zero_()
-                s.v.zero_()
+                ts += [s.m, s.v]
+            for t in ts:
+                z = zeros.get(tuple(t.shape))
+                if z is None or z.device != t.device:
+                    z = zeros[tuple(t.shape)] = torch.zeros_like(t)
+                dst.append(t)
+                src.append(z)
+        if hasattr(torch, "_foreach_copy_") and len(dst) > 1:
+            torch._foreach_copy_(dst, src)                  # ONE launch for x, LSTM state and moments
+        else:
+            for d_, s_ in zip(dst, src):
+                d_.copy_(s_)
 
     def _local_shape(self, var):
         if self.sharded:

@@ -113,8 +113,9 @@ int main(int argc, char** argv) {
   HIP(hipStreamCreate(&s));
   /* (a) the fused unroll */
   HIP(hipMemcpy(dx, x0, sizeof x0, hipMemcpyHostToDevice)); HIP(hipMemset(dst, 0, nst * 4));
-  L2O(l2o_unroll(&cfg, dwp, &prob, dx, dst, NULL, NULL, T, 1, dfxp, dws, s));
-  L2O(l2o_reduce_fx(dfxp, T + 1, B, B, dfx, s));
+  CHECK(l2o_unroll_workspace_layout(&cfg, &prob) == (wsb ? (((long long)B << 8) | 2) : 0), "workspace layout id");
+  if (dws) L2O(l2o_unroll_workspace_init(dws, wsb, s));      /* (already zero: the call a caller makes when the layout changes) */
+  L2O(l2o_unroll_reduce(&cfg, dwp, &prob, NULL, dx, dst, NULL, NULL, T, 1, 0, dfxp, dfx, dws, NULL, s));
   HIP(hipStreamSynchronize(s));
   HIP(hipMemcpy(fx_fused, dfx, sizeof fx_fused, hipMemcpyDeviceToHost)); HIP(hipMemcpy(x_fused, dx, sizeof x_fused, hipMemcpyDeviceToHost));
   if (dws) {

@@ -303,7 +303,18 @@ class OracleEngine(object):
         fn = self.lib.l2o_unroll_record_supported if record else self.lib.l2o_unroll_supported
         return bool(fn(C.byref(cc), C.byref(cp)))
 
-    def unroll(self, spec, wpack, p, x, st, m, v, T, step0, fx_part, hist=None):
+    def unroll(self, spec, wpack, p, x, st, m, v, T, step0, fx_part, hist=None, fx=None, x0=None, zero_state=False):
+        if x0 is not None:
+            x.copy_(x0)
+        if zero_state:
+            st.zero_()
+            if m is not None:
+                m.zero_(); v.zero_()
+        self._unroll(spec, wpack, p, x, st, m, v, T, step0, fx_part, hist)
+        if fx is not None:                                         # l2o_unroll_reduce
+            self.reduce_fx(fx_part, T + 1, p.B_local, p.B_global, fx)
+
+    def _unroll(self, spec, wpack, p, x, st, m, v, T, step0, fx_part, hist=None):
         self.calls.append("unroll")
         cfg = _cfg_of(spec)
         prob, shape = self._oracle_problem(p)

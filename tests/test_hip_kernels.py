@@ -5,6 +5,7 @@ reference CPU path; teacher-forced single steps within ~1e-6 absolute on O(1) st
 """
 import numpy as np
 import pytest
+import torch
 
 import oracle as O
 from helpers import (ORACLE_CFGS, device_problem, lib_option, make_params, make_problem, max_abs, random_state,
@@ -660,3 +661,33 @@ def test_atb_weight_gradient_contraction(eng, R, KA, KB):
     scale = np.sqrt(R)
     assert got.shape == (KA, KB) and np.array_equal(got, again)
     assert float(np.abs(got - want).max()) < 2e-5 * scale, float(np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("name,kind,B,D,M", [("dm", "quadratic", 128, 128, None), ("rnnprop", "rastrigin", 128, 100, None),
+                                             ("dm_logsign", "lasso", 200, 48, None), ("rnnprop", "lasso", 4, 384, 40)])
+def test_unroll_reduce_restart_equals_rewind_then_unroll(eng, name, kind, B, D, M):
+    """l2o_unroll_reduce(x0, L2O_UNROLL_ZERO_STATE): `reset` of the iterate and of the LSTM state / moments folded into
+    the unroll (no copy / memset pass) == an unroll from buffers that hold x0 and zeros, bit for bit -- for the
+    two-CU form, the one-CU form (B > #CUs / 2) and the streaming form; fx == l2o_reduce_fx of fx_part."""
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=41, trained_like=True)
+    prob, x0, arrays = make_problem(kind, B, D, seed=42, M=M)
+    pd = device_problem(eng, arrays, B, D)
+    wpack = eng.pack_weights(spec, params)
+    T = 7
+    x0d = eng.tensor(x0.reshape(B, D))
+    # reference: clean buffers, separate reduction
+    x, st, m, v = x0d.clone(), eng.state_alloc(B, D), eng.zeros(B, D), eng.zeros(B, D)
+    fx_part, fx = eng.zeros((T + 1) * B), eng.zeros(T + 1)
+    eng.unroll(spec, wpack, pd, x, st, m, v, T, 3, fx_part)
+    eng.reduce_fx(fx_part, T + 1, B, B, fx)
+    # restart form: the in-out buffers start with garbage
+    g = torch.Generator(device="cpu").manual_seed(1)
+    junk = lambda t: torch.randn(t.shape, generator=g).to(t.device)
+    x2, st2, m2, v2 = junk(x), junk(st), junk(m).abs(), junk(v).abs()
+    fx_part2, fx2 = eng.zeros((T + 1) * B), eng.zeros(T + 1)
+    eng.unroll(spec, wpack, pd, x2, st2, m2, v2, T, 3, fx_part2, fx=fx2, x0=x0d, zero_state=True)
+    for a, b in ((x, x2), (st, st2), (fx_part, fx_part2), (fx, fx2)) + (((m, m2), (v, v2)) if name == "rnnprop" else ()):
+        assert torch.equal(a, b)
+    assert torch.equal(x0d, eng.tensor(x0.reshape(B, D)))                # x0 is read-only
