@@ -205,23 +205,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     if (q == 0 && !tile_real && owns_w1) xwg[wv * kTile + c] = 0.0f;
-    // prefetch the next evaluation's image columns / labels into registers (landed long before the step ends)
     float pre_img[(kMuMaxBatch * kMuMaxKR + 255) / 256];
     int pre_lab = 0;
     const bool have_next = t < a.T;
-    if (have_next) {
-      const int* ix = a.idx + (size_t)(t + 1) * Bn;
+    // the next evaluation's image columns / labels -> registers: requested once the sums of THIS evaluation are in
+    // (vector-memory returns in order: ahead of the polls the gather would delay them, and in front of the step's
+    // first barrier its two dependent latencies sat on the critical path), completed under the forward tail
+    auto prefetch_next = [&]() {
+      if (have_next) {
+        const int* ix = a.idx + (size_t)(t + 1) * Bn;
 #pragma unroll
-      for (int u = 0; u < (kMuMaxBatch * kMuMaxKR + 255) / 256; ++u) {
-        const int e = tid + 256 * u;
-        pre_img[u] = 0.0f;
-        if (e < Bn * KR) {
-          const int sidx = e / KR, kk = e - sidx * KR;
-          pre_img[u] = a.images[(size_t)ix[sidx] * n_in + k0 + kk];
+        for (int u = 0; u < (kMuMaxBatch * kMuMaxKR + 255) / 256; ++u) {
+          const int e = tid + 256 * u;
+          pre_img[u] = 0.0f;
+          if (e < Bn * KR) {
+            const int sidx = e / KR, kk = e - sidx * KR;
+            pre_img[u] = a.images[(size_t)ix[sidx] * n_in + k0 + kk];
+          }
         }
+        if (tid < Bn) pre_lab = a.labels[ix[tid]];
       }
-      if (tid < Bn) pre_lab = a.labels[ix[tid]];
-    }
+    };
     __syncthreads();                                   // xwg complete
     pc.mark(0);
     if constexpr (FAST) {
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       __syncthreads();
       pc.mark(3);
+      prefetch_next();
       // ---- forward tail, every wave for all 64 samples (lane = sample): logits, softmax, loss, dZ in registers
       float hrow[FH], dz[FO];
       {
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
     pc.mark(3);                                        // gather
+    prefetch_next();
     const float* b1s = small;
     const float* w2s = small + H;
     const float* b2s = small + H + H * O;
