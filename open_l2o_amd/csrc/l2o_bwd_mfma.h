@@ -28,7 +28,6 @@
 namespace l2o {
 namespace bxb {
 
-using bx::BOp;
 using bx::u32x4;
 
 __host__ __device__ constexpr int tiles2() { return 3; }
@@ -88,6 +87,8 @@ __device__ __forceinline__ void gate_grads(const Gates& g, const float (&cp)[kNT
   }
 }
 
+// The transposed products keep the one-MFMA-per-product form (six per M-tile, 5 of 8 K-slots used): their fragments
+// live in LDS next to the carries, and the packed form of l2o_lstm_bx3.h would need 4/3 of the space.
 // acc[m] = sum over the four gate chunks of  W-fragment(m, r) x split(dz[r])
 template <int NTL>
 __device__ __forceinline__ void tgemm(const unsigned* fr, int lane, const float (&dz)[4][kNT], f32x4 (&acc)[NTL]) {
@@ -96,8 +97,8 @@ __device__ __forceinline__ void tgemm(const unsigned* fr, int lane, const float 
   for (int m = 0; m < NTL; ++m) acc[m] = zero;
   static_for<0, 4>([&](auto rc) {
     constexpr int r = decltype(rc)::value;
-    BOp b;
-    bx::split5(dz[r], 0u, b);
+    bx::BOp<false> b;
+    bx::split5<false>(dz[r], 0u, b);
     u32x4 a[NTL][3];
 #pragma unroll
     for (int m = 0; m < NTL; ++m)
@@ -106,7 +107,7 @@ __device__ __forceinline__ void tgemm(const unsigned* fr, int lane, const float 
     static_for<0, bx::kProducts>([&](auto pc) {
       constexpr int pp = decltype(pc)::value;
 #pragma unroll
-      for (int m = 0; m < NTL; ++m) acc[m] = bx::mfma_bf(a[m][bx::prod_w(pp)], b.l[bx::prod_x(pp)], acc[m]);
+      for (int m = 0; m < NTL; ++m) acc[m] = bx::mfma_bf(a[m][bx::prod_w(pp)], b.m[bx::prod_x(pp)], acc[m]);
     });
   });
 }
@@ -158,9 +159,11 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
       }
     }
   }
-  bx::NetWB<PRE> w;
-  bx::load_netw<PRE>(w, p.wpack, lane);
-  const unsigned one = q == 0 ? 0x3f800000u : 0u;
+  constexpr bool PK = bx::packed_default(PRE);       // the forward recomputation uses the net's default gate-GEMM form
+  constexpr int kN = bx::chunk_mfmas(PK);
+  bx::NetWB<PRE, PK> w;
+  bx::load_netw<PRE, true, PK>(w, p.wpack, lane);
+  const unsigned one = bx::bias_one<PK>(q);
   const size_t ntiles = (size_t)p.tile_end[p.nseg - 1];
   const size_t ngrp4 = (ntiles + 3) / 4;
   const size_t RT = (size_t)p.rows_total;
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     // ---- forward recompute --------------------------------------------------------------------------
     f32x4 acc1[kNT], acc2[kNT];
     {
-      bx::BOp b;
-      bx::split5(s.h2, one, b);
-      bx::issue<PRE, bx::kChL2B, 0, bx::kChunkMfmas, true>(w, b, acc2);
-      bx::split5(s.h1, one, b);
-      bx::issue<PRE, bx::kChL1H, 0, bx::kChunkMfmas, true>(w, b, acc1);
+      bx::BOp<PK> b;
+      bx::split5<PK>(s.h2, one, b);
+      bx::issue<PRE, bx::kChL2B, 0, kN, true>(w, b, acc2);
+      bx::split5<PK>(s.h1, one, b);
+      bx::issue<PRE, bx::kChL1H, 0, kN, true>(w, b, acc1);
       if constexpr (FC) {
-        bx::split5(fcv, 0u, b);
-        bx::issue<PRE, bx::kChL1X, 0, bx::kChunkMfmas, false>(w, b, acc1);
+        bx::split5<PK>(fcv, 0u, b);
+        bx::issue<PRE, bx::kChL1X, 0, kN, false>(w, b, acc1);
       } else {
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
@@ -276,9 +279,9 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     float h1n[kNT], h2n[kNT];
     bxb::gates_full(acc1, s.c1, g1, h1n);
     {
-      bx::BOp b;
-      bx::split5(h1n, one, b);
-      bx::issue<PRE, bx::kChL2A, 0, bx::kChunkMfmas, false>(w, b, acc2);
+      bx::BOp<PK> b;
+      bx::split5<PK>(h1n, one, b);
+      bx::issue<PRE, bx::kChL2A, 0, kN, false>(w, b, acc2);
     }
     bxb::gates_full(acc2, s.c2, g2, h2n);
     float dl = 0.0f;

@@ -124,14 +124,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = blockIdx.x * (blockDim.x >> 6) + wv;
   const int nwaves = gridDim.x * (blockDim.x >> 6);
   const int ntiles = sg.tile_end[sg.n - 1];
-  // ---- the bf16x3 weight fragments (46 / 61 KB) reach the four waves through LDS: one DMA copy per
+  // ---- the bf16x3 weight fragments (60 / 80 KB) reach the four waves through LDS: one DMA copy per
   // workgroup instead of four L2 reads; the staging area is the (not yet used) prefetch ring
-  bx::NetWB<PRE> w;
+  constexpr bool PK = bx::packed_default(PRE);
+  bx::NetWB<PRE, PK> w;
   {
-    constexpr int kFrags = bx::nchunks(PRE) * kNT * 3;             // 1 KB each = one wave-wide dwordx4
+    constexpr int kFrags = bx::nchunks(PRE) * kNT * bx::frags(PK);   // 1 KB each = one wave-wide dwordx4
     static_assert(kFrags * 1024 <= (int)sizeof(sbuf), "staging area");
     float4* stage = &sbuf[0][0][0];
-    const float* src = np.wpack + bx::base(PRE) + lane * 4;
+    const float* src = np.wpack + bx::frag_off(PRE, PK, 0, 0, 0) + lane * 4;
 #pragma unroll
     for (int f = 0; f < (kFrags + 3) / 4; ++f) {
       const int fr = 4 * f + wv;
@@ -141,12 +142,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int ch = 0; ch < bx::NetWB<PRE>::NCH; ++ch)
+    for (int ch = 0; ch < bx::NetWB<PRE, PK>::NCH; ++ch)
 #pragma unroll
       for (int t = 0; t < kNT; ++t)
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
-          const float4 v4 = stage[((ch * kNT + t) * 3 + s3) * 64 + lane];
+        for (int s3 = 0; s3 < bx::frags(PK); ++s3) {
+          const float4 v4 = stage[((ch * kNT + t) * bx::frags(PK) + s3) * 64 + lane];
           w.a[ch][t][s3] = __builtin_bit_cast(bx::u32x4, v4);
         }
     __syncthreads();                                               // everyone holds its copy: the ring may be used
@@ -1193,9 +1194,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
     for (int t = t_lo; t < t_hi; ++t) {
       const int cA = col(t, rho), r = rho & 3;
       for (int ch = 0; ch < bx::nchunks(pre); ++ch) {
-        uint16_t sl[8][3];
-        for (int i = 0; i < 8; ++i)
-          for (int sp = 0; sp < 3; ++sp) sl[i][sp] = 0;
+        uint16_t sl[5][3], bs[3] = {0, 0, 0};
         for (int i = 0; i < 5; ++i) {
           const int u = 4 * i + kq;
           double v;
@@ -1205,13 +1204,30 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
           else v = wg1[u * G + cA];                              // kChL1X: the fc features
           bf16_split3(v * gscale(r), sl[i]);
         }
-        if (kq == 0 && (ch == bx::kChL1H || ch == bx::kChL2A)) {
+        if (ch == bx::kChL1H || ch == bx::kChL2A) {
           const double bv = (double)(ch == bx::kChL1H ? bg1[cA] : bg2[cA]) + (r == 2 ? 1.0 : 0.0);   // forget_bias
-          bf16_split3(bv * gscale(r), sl[7]);
+          bf16_split3(bv * gscale(r), bs);
         }
+        // 6-product form: K-slots 0..4 = the units, slot 7 = the bias (q == 0), one fragment per split level
         for (int sp = 0; sp < 3; ++sp)
-          for (int j = 0; j < 4; ++j)
-            ow[bx::frag_off(pre, ch, t, sp) + l * 4 + j] = (uint32_t)sl[2 * j][sp] | ((uint32_t)sl[2 * j + 1][sp] << 16);
+          for (int rg = 0; rg < 4; ++rg) {
+            auto slot = [&](int i) -> uint32_t { return i < 5 ? sl[i][sp] : (i == 7 && kq == 0 ? bs[sp] : 0); };
+            ow[bx::frag_off(pre, false, ch, t, sp) + l * 4 + rg] = slot(2 * rg) | (slot(2 * rg + 1) << 16);
+          }
+        // packed K-slots (l2o_lstm_bx3.h, slot_desc): the weight level that multiplies the slot's activation level
+        if (bx::packed_default(pre))
+          for (int j = 0; j < bx::kPack; ++j)
+            for (int rg = 0; rg < 4; ++rg) {
+              uint32_t word = 0;
+              for (int h = 0; h < 2; ++h) {
+                const bx::SlotDesc d = bx::slot_desc(j, rg, h);
+                uint16_t v16 = 0;
+                if (d.unit < 5) v16 = sl[d.unit][d.w];
+                else if (bx::bias_level(kq, h) >= 0) v16 = bs[bx::bias_level(kq, h)];
+                word |= (uint32_t)v16 << (16 * h);
+              }
+              ow[bx::frag_off(pre, true, ch, t, j) + l * 4 + rg] = word;
+            }
       }
       if (!fc)
         for (int rr = 0; rr < 4; ++rr) {

@@ -7,21 +7,30 @@
 // bf16 terms  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
 // 24 mantissa bits), the weights likewise on the host (from float64), and
 //      x.w  =  x1w1 + x1w2 + x1w3 + x2w1 + x2w2 + x3w1      (dropped terms < 2^-24)
-// is accumulated by six v_mfma_f32_16x16x32_bf16 per (16 gate rows x 16 coordinates x K=32)
-// block: bf16 x bf16 products are exact in fp32 and the accumulator is fp32, so the result
-// carries an fp32-level error (measured rms 1.7e-8 vs 7.7e-8 of a sequential fp32 fmaf chain).
+// is accumulated on the matrix pipe: bf16 x bf16 products are exact in fp32 and the accumulator
+// is fp32, so the result carries an fp32-level error (measured rms 1.7e-8 vs 7.7e-8 of a
+// sequential fp32 fmaf chain).
 //
 // Layout.  Same tile decomposition as l2o_common.h: lane (c, q) owns the units u = 4t + q of
-// coordinate c; the D operand row rho = 4q + r of M-tile t is gate r of unit 4t + q.  K = 32
-// per chunk: lane group q supplies the slots k = 8q + i,
-//      i = 0..4 : unit 4i + q of the chunk's input vector,   i = 5, 6 : zero,
-//      i = 7    : the constant 1.0 on q == 0 (bias row of the chunk), zero elsewhere
-// so the B operand of a chunk is 4 VGPRs {slot 2j | slot 2j+1 << 16} per split level, built
-// from the five values the lane already owns -- no cross-lane traffic, like the fp32 form.
+// coordinate c; the D operand row rho = 4q + r of M-tile t is gate r of unit 4t + q.  A chunk
+// (one 20-vector times the 80 gate rows of a layer) has K = 20 inputs x 6 products + 3 bias
+// levels = 123 (term, input) pairs.  A lane group q supplies 8 K-slots per MFMA, all of them
+// values the lane already owns (its five units) -- no cross-lane traffic -- so the 6 x 5 = 30
+// (product, unit) pairs of a lane group are PACKED into the 32 slots of FOUR
+// v_mfma_f32_16x16x32_bf16 per M-tile (round 1: one MFMA per product with 5 of 8 slots used,
+// six per M-tile) and the two slots left over carry the bias (B = 1.0: levels 1, 2 on q == 0,
+// level 3 on q == 1).  Register r of MFMA j holds slots (2r, 2r + 1) = the table slot_*() below:
+//      j = 0: (u0,u1) x1w1 | (u2,u3) x1w1 | u4: x1w1, x1w2 | bias
+//      j = 1: (u0,u1) x1w2 | (u2,u3) x1w2 | (u0,u1) x1w3   | (u2,u3) x1w3
+//      j = 2: (u0,u1) x2w1 | (u2,u3) x2w1 | u4: x1w3, x2w1 | (u0,u1) x2w2
+//      j = 3: (u2,u3) x2w2 | (u0,u1) x3w1 | (u2,u3) x3w1   | u4: x2w2, x3w1
+// (u_i = unit 4i + q; a unit pair of one split level is one v_cvt_pk_bf16_f32 result, so the B
+// operand is 16 registers built with the same conversions as before plus 6 copies; MFMA 0 and 1
+// need the first split level only and start while the residuals are still being computed.)
 // Chunks: L1H = h1(t-1) -> layer 1 (+ b_gates1), L2A = h1(t) -> layer 2 (+ b_gates2),
 //         L2B = h2(t-1) -> layer 2, L1X = the 20 ELU features of RNNProp -> layer 1.
 // The 1-2 gradient features of the DM nets are applied with 20-40 VALU FMAs instead (they
-// arrive last; a chunk of their own would put 30 MFMAs on the critical path).
+// arrive last; a chunk of their own would put 20 MFMAs on the critical path).
 //
 // The gate weights are pre-scaled on the host so that the accumulators ARE the exp2
 // arguments: rows i, f, o by -log2(e) (f including forget_bias = 1), rows j by +2 log2(e);
@@ -40,26 +49,65 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kChL1H = 0, kChL2A = 1, kChL2B = 2, kChL1X = 3;
 constexpr int kFragWords = 256;     // 64 lanes x 4 dwords
-constexpr int kProducts = 6;        // (x level, w level) pairs below
-constexpr int kChunkMfmas = kProducts * kNT;   // 30
+// PK (template parameter below): true = the packed form (4 MFMAs per chunk and M-tile, 80 fragment registers per
+// chunk), false = one MFMA per product (6 per chunk and M-tile, 60 fragment registers per chunk).  The packed form is
+// the default wherever its fragments fit the 256 AGPRs next to the kernel's own registers: the DM nets (3 chunks =
+// 240 registers); RNNProp (4 chunks) and the kernels that hold a problem slice in registers as well (k_unroll_cu with
+// two column blocks, k_mlp_unroll) keep the 6-product form -- spills cost them more than the MFMAs (config 3 with
+// spilling packed fragments: 4.8 -> 2.8 G coordinate-steps/s).
+constexpr int kPack = 4;            // packed: MFMAs per (chunk, M-tile): 32 K-slots per lane group, 30 products + bias
+constexpr int kProducts = 6;        // 6-product form: (x level, w level) pairs below
+__host__ __device__ constexpr bool packed_default(int pre) { return pre != L2O_PRE_FC_ELU; }
+__host__ __device__ constexpr int frags(bool pk) { return pk ? kPack : 3; }                 // fragments per (chunk, M-tile)
+__host__ __device__ constexpr int chunk_mfmas(bool pk) { return (pk ? kPack : kProducts) * kNT; }   // 20 | 30
 
 __host__ __device__ constexpr int nchunks(int pre) { return pre == L2O_PRE_FC_ELU ? 4 : 3; }
-// word offsets inside wpack (the bf16 section follows the fp32 rows of l2o_common.h)
+// word offsets inside wpack (the bf16 section follows the fp32 rows of l2o_common.h): packed fragments (DM nets
+// only), 6-product fragments, then the input rows
 __host__ __device__ constexpr int base(int pre) { return wp_rows(pre) * 64; }
-__host__ __device__ constexpr int frag_off(int pre, int ch, int t, int s) {
-  return base(pre) + ((ch * kNT + t) * 3 + s) * kFragWords;
+__host__ __device__ constexpr int packed_words(int pre) { return packed_default(pre) ? nchunks(pre) * kNT * kPack * kFragWords : 0; }
+__host__ __device__ constexpr int level_words(int pre) { return nchunks(pre) * kNT * 3 * kFragWords; }
+__host__ __device__ constexpr int frag_off(int pre, bool pk, int ch, int t, int j) {
+  return base(pre) + (pk ? 0 : packed_words(pre)) + ((ch * kNT + t) * frags(pk) + j) * kFragWords;
 }
-__host__ __device__ constexpr int win_off(int pre) { return base(pre) + nchunks(pre) * kNT * 3 * kFragWords; }
+__host__ __device__ constexpr int win_off(int pre) { return base(pre) + packed_words(pre) + level_words(pre); }
 // DM nets: 2 inputs x 5 tiles rows of 64 lanes x 4 floats (the lane's four gate rows)
 __host__ __device__ constexpr int words(int pre) {
-  return nchunks(pre) * kNT * 3 * kFragWords + (pre == L2O_PRE_FC_ELU ? 0 : 2 * kNT * 256);
+  return packed_words(pre) + level_words(pre) + (pre == L2O_PRE_FC_ELU ? 0 : 2 * kNT * 256);
 }
 __host__ __device__ constexpr int prod_x(int p) { return p < 3 ? 0 : (p < 5 ? 1 : 2); }
 __host__ __device__ constexpr int prod_w(int p) { return p < 3 ? p : (p < 5 ? p - 3 : 0); }
+// K-slot table: slot h (0 = low, 1 = high half) of register r of MFMA j carries unit slot_unit (0..4 of the lane
+// group, 5 = the bias slot) at activation split level slot_x times weight split level slot_w
+struct SlotDesc { int unit, x, w; };
+__host__ __device__ constexpr SlotDesc slot_desc(int j, int r, int h) {
+  // pairs: {first unit, x level, w level}; unit-4 registers: {x, w} of the low and of the high slot
+  switch (j * 4 + r) {
+    case 0: return {0 + h, 0, 0};
+    case 1: return {2 + h, 0, 0};
+    case 2: return {4, 0, h};               // x1w1, x1w2
+    case 3: return {5, 0, h};               // bias (w = slot index; the level depends on the lane group)
+    case 4: return {0 + h, 0, 1};
+    case 5: return {2 + h, 0, 1};
+    case 6: return {0 + h, 0, 2};
+    case 7: return {2 + h, 0, 2};
+    case 8: return {0 + h, 1, 0};
+    case 9: return {2 + h, 1, 0};
+    case 10: return {4, h, h ? 0 : 2};      // x1w3, x2w1
+    case 11: return {0 + h, 1, 1};
+    case 12: return {2 + h, 1, 1};
+    case 13: return {0 + h, 2, 0};
+    case 14: return {2 + h, 2, 0};
+    default: return {4, 1 + h, h ? 0 : 1};  // x2w2, x3w1
+  }
+}
+// bias level carried by slot h of the bias register on lane group kq (-1: none)
+__host__ __device__ constexpr int bias_level(int kq, int h) { return kq == 0 ? h : (kq == 1 && h == 0 ? 2 : -1); }
 
 // a 5-value activation vector split into the B operands of its chunk
+template <bool PK>
 struct BOp {
-  u32x4 l[3];
+  u32x4 m[frags(PK)];              // packed: per MFMA; 6-product form: per split level
 };
 
 __device__ __forceinline__ unsigned cvt_pk(f32x2 v) {
@@ -77,28 +125,56 @@ __device__ __forceinline__ f32x2 mk2(float a, float b) {
   return r;
 }
 
-// one = 0x3f800000 on the q == 0 lanes (slot 7 = 1.0: the bias row), 0 elsewhere
-__device__ __forceinline__ void split5(const float (&v)[kNT], unsigned one, BOp& o) {
-#ifdef L2O_ABLATE_SPLIT
-  o.l[0][0] = __float_as_uint(v[0]); o.l[0][1] = __float_as_uint(v[1]); o.l[0][2] = __float_as_uint(v[2]); o.l[0][3] = one;
-  o.l[1][0] = __float_as_uint(v[3]); o.l[1][1] = __float_as_uint(v[4]); o.l[1][2] = 0u; o.l[1][3] = 0u;
-  o.l[2] = o.l[1];
-  return;
-#endif
-  f32x2 a = mk2(v[0], v[1]), b = mk2(v[2], v[3]), c = mk2(v[4], 0.0f);
-  unsigned pa = cvt_pk(a), pb = cvt_pk(b), pc = cvt_pk(c);
-  o.l[0][0] = pa; o.l[0][1] = pb; o.l[0][2] = pc; o.l[0][3] = one;
-  a -= widen(pa); b -= widen(pb); c -= widen(pc);
-  pa = cvt_pk(a); pb = cvt_pk(b); pc = cvt_pk(c);
-  o.l[1][0] = pa; o.l[1][1] = pb; o.l[1][2] = pc; o.l[1][3] = 0u;
-  a -= widen(pa); b -= widen(pb); c -= widen(pc);
-  o.l[2][0] = cvt_pk(a); o.l[2][1] = cvt_pk(b); o.l[2][2] = cvt_pk(c); o.l[2][3] = 0u;
+// the B = 1.0 slots of the bias row.  Packed: both slots of the bias register on q == 0, its low slot on q == 1;
+// 6-product form: slot 7 (the high half of register 3 of the first level) on q == 0
+template <bool PK>
+__device__ __forceinline__ unsigned bias_one(int q) {
+  if (PK) return q == 0 ? 0x3f803f80u : (q == 1 ? 0x00003f80u : 0u);
+  return q == 0 ? 0x3f800000u : 0u;
 }
 
-template <int PRE>
+// one = bias_one<PK>(q) for the chunks that carry a bias row, 0 otherwise
+template <bool PK>
+__device__ __forceinline__ void split5(const float (&v)[kNT], unsigned one, BOp<PK>& o) {
+  if constexpr (PK) {
+#ifdef L2O_ABLATE_SPLIT
+#pragma unroll
+    for (int j = 0; j < kPack; ++j) {
+      o.m[j][0] = __float_as_uint(v[0]) ^ j; o.m[j][1] = __float_as_uint(v[1]); o.m[j][2] = __float_as_uint(v[2 + (j & 1)]);
+      o.m[j][3] = j ? __float_as_uint(v[4]) : one;
+    }
+    return;
+#endif
+    f32x2 a = mk2(v[0], v[1]), b = mk2(v[2], v[3]);
+    const unsigned pa0 = cvt_pk(a), pb0 = cvt_pk(b), ca = cvt_pk(mk2(v[4], v[4]));
+    o.m[0][0] = pa0; o.m[0][1] = pb0; o.m[0][2] = ca; o.m[0][3] = one;
+    o.m[1][0] = pa0; o.m[1][1] = pb0; o.m[1][2] = pa0; o.m[1][3] = pb0;
+    a -= widen(pa0); b -= widen(pb0);
+    const float r1 = v[4] - __uint_as_float(ca << 16);
+    const unsigned pa1 = cvt_pk(a), pb1 = cvt_pk(b), cb = cvt_pk(mk2(v[4], r1));
+    o.m[2][0] = pa1; o.m[2][1] = pb1; o.m[2][2] = cb; o.m[2][3] = pa1;
+    a -= widen(pa1); b -= widen(pb1);
+    const float r2 = r1 - __uint_as_float(cb & 0xffff0000u);
+    o.m[3][0] = pb1; o.m[3][1] = cvt_pk(a); o.m[3][2] = cvt_pk(b); o.m[3][3] = cvt_pk(mk2(r1, r2));
+  } else {
+    // K-slots 0..4 of the lane group = its five units, 5, 6 zero, 7 = the bias slot; one register set per level
+    f32x2 a = mk2(v[0], v[1]), b = mk2(v[2], v[3]), c = mk2(v[4], 0.0f);
+    unsigned pa = cvt_pk(a), pb = cvt_pk(b), pc = cvt_pk(c);
+    o.m[0][0] = pa; o.m[0][1] = pb; o.m[0][2] = pc; o.m[0][3] = one;
+    a -= widen(pa); b -= widen(pb); c -= widen(pc);
+    pa = cvt_pk(a); pb = cvt_pk(b); pc = cvt_pk(c);
+    o.m[1][0] = pa; o.m[1][1] = pb; o.m[1][2] = pc; o.m[1][3] = 0u;
+    a -= widen(pa); b -= widen(pb); c -= widen(pc);
+    o.m[2][0] = cvt_pk(a); o.m[2][1] = cvt_pk(b); o.m[2][2] = cvt_pk(c); o.m[2][3] = 0u;
+  }
+}
+
+template <int PRE, bool PK = packed_default(PRE)>
 struct NetWB {
   static constexpr int NCH = nchunks(PRE);
-  u32x4 a[NCH][kNT][3];            // weight fragments (A operands), 3 split levels
+  static constexpr bool kPacked = PK;
+  static constexpr int NF = frags(PK);
+  u32x4 a[NCH][kNT][NF];           // weight fragments (A operands): per packed MFMA | per split level
   f32x4 win0[kNT], win1[kNT];      // DM: pre-scaled weights of input 0 / 1 for this lane's 4 gate rows
   float wl[kNT];                   // output Linear
   float bl;
@@ -107,17 +183,17 @@ struct NetWB {
 
 // FRAGS = false: the caller fills w.a itself (k_cwlstm_step stages the fragments through LDS once
 // per workgroup instead of 4 x 61 KB of L2 reads)
-template <int PRE, bool FRAGS = true>
-__device__ __forceinline__ void load_netw(NetWB<PRE>& w, const float* __restrict__ wp, int lane) {
+template <int PRE, bool FRAGS = true, bool PK = packed_default(PRE)>
+__device__ __forceinline__ void load_netw(NetWB<PRE, PK>& w, const float* __restrict__ wp, int lane) {
   const unsigned* wu = reinterpret_cast<const unsigned*>(wp);
   if (FRAGS) {
 #pragma unroll
-    for (int ch = 0; ch < NetWB<PRE>::NCH; ++ch)
+    for (int ch = 0; ch < NetWB<PRE, PK>::NCH; ++ch)
 #pragma unroll
       for (int t = 0; t < kNT; ++t)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-          w.a[ch][t][s] = *reinterpret_cast<const u32x4*>(wu + frag_off(PRE, ch, t, s) + lane * 4);
+        for (int j = 0; j < frags(PK); ++j)
+          w.a[ch][t][j] = *reinterpret_cast<const u32x4*>(wu + frag_off(PRE, PK, ch, t, j) + lane * 4);
   }
   const float* p = wp + lane;
 #pragma unroll
@@ -146,15 +222,16 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
                                                   0, 0);
 }
 
-// MFMAs [LO, HI) of chunk CH (index n: product n / 5, M-tile n % 5 -- consecutive MFMAs hit
-// different accumulators).  ZERO: the first product starts the accumulator (C = inline 0).
-template <int PRE, int CH, int LO, int HI, bool ZERO>
-__device__ __forceinline__ void issue(const NetWB<PRE>& w, const BOp& b, f32x4 (&acc)[kNT]) {
+// MFMAs [LO, HI) of chunk CH (index n: packed MFMA | product n / 5, M-tile n % 5 -- consecutive MFMAs hit
+// different accumulators).  ZERO: the first one starts the accumulator (C = inline 0).
+template <int PRE, int CH, int LO, int HI, bool ZERO, bool PK>
+__device__ __forceinline__ void issue(const NetWB<PRE, PK>& w, const BOp<PK>& b, f32x4 (&acc)[kNT]) {
   static_for<LO, HI>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
     constexpr int p = n / kNT, t = n % kNT;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.l[prod_x(p)], (ZERO && p == 0) ? zero : acc[t]);
+    if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], (ZERO && p == 0) ? zero : acc[t]);
+    else acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.m[prod_x(p)], (ZERO && p == 0) ? zero : acc[t]);
   });
 }
 
@@ -250,18 +327,19 @@ __device__ __forceinline__ void gates5_scalar(const f32x4 (&acc)[kNT], float (&c
 // acc1 must hold chunk L1H (h1(t-1), bias), acc2 chunk L2B (h2(t-1)).  On return s holds the
 // new state, b1 / b2 the split h1(t) / h2(t) (the next step's L1H / L2B operands) and, with
 // NEXT, acc1 the next step's chunk L1H.  Returns the Linear output (before tanh / scale).
-template <int PRE, bool NEXT>
-__device__ __forceinline__ float finish(const NetWB<PRE>& w, TileState& s, BOp& b1, BOp& b2, f32x4 (&acc1)[kNT],
-                                        f32x4 (&acc2)[kNT], float in0, float in1, unsigned one, int q,
-                                        PhaseClock& pc) {
+template <int PRE, bool NEXT, bool PK>
+__device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, BOp<PK>& b1, BOp<PK>& b2,
+                                        f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1, unsigned one,
+                                        int q, PhaseClock& pc) {
+  constexpr int kN = chunk_mfmas(PK);
   if (PRE == L2O_PRE_FC_ELU) {
     float fc[kNT];
 #pragma unroll
     for (int t = 0; t < kNT; ++t)
       fc[t] = eluf_(__builtin_fmaf(w.fcw1[t], in1, __builtin_fmaf(w.fcw0[t], in0, w.fcb[t])));
-    BOp bf;
-    split5(fc, 0u, bf);
-    issue<PRE, kChL1X, 0, kChunkMfmas, false>(w, bf, acc1);
+    BOp<PK> bf;
+    split5<PK>(fc, 0u, bf);
+    issue<PRE, kChL1X, 0, kN, false>(w, bf, acc1);
   } else {
 #pragma unroll
     for (int t = 0; t < kNT; ++t) {
@@ -273,23 +351,23 @@ __device__ __forceinline__ float finish(const NetWB<PRE>& w, TileState& s, BOp& 
   pc.mark(5);
   gates5(acc1, s.c1, s.h1);
   pc.mark(6);
-  split5(s.h1, one, b1);
-  issue<PRE, kChL2A, 0, kChunkMfmas, false>(w, b1, acc2);
+  split5<PK>(s.h1, one, b1);
+  issue<PRE, kChL2A, 0, kN, false>(w, b1, acc2);
   pc.mark(7);
   pc.drain(acc2);
   pc.mark(10);
   // the next step's chunk L1H rides on the matrix pipe underneath the layer-2 nonlinearities:
   // a single wave issues in order, so the MFMAs must be interleaved with the VALU stream in
-  // program order (30 back-to-back MFMAs stall the wave for 30 x 17 cycles)
+  // program order (20 back-to-back MFMAs stall the wave for 20 x 17 cycles)
   __builtin_amdgcn_sched_barrier(0);
   if (NEXT) {
 #ifndef L2O_NEXT_VALU_PER_MFMA
 #define L2O_NEXT_VALU_PER_MFMA 3
 #endif
-    issue<PRE, kChL1H, 0, kChunkMfmas, true>(w, b1, acc1);
+    issue<PRE, kChL1H, 0, kN, true>(w, b1, acc1);
     gates5_scalar(acc2, s.c2, s.h2);
 #pragma unroll
-    for (int i = 0; i < kChunkMfmas; ++i) {
+    for (int i = 0; i < kN; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
       __builtin_amdgcn_sched_group_barrier(0x402, L2O_NEXT_VALU_PER_MFMA, 0);    // VALU | transcendental
     }
@@ -298,7 +376,7 @@ __device__ __forceinline__ float finish(const NetWB<PRE>& w, TileState& s, BOp& 
   }
   __builtin_amdgcn_sched_barrier(0);
   pc.mark(8);
-  if (NEXT) split5(s.h2, one, b2);
+  if (NEXT) split5<PK>(s.h2, one, b2);
   float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];
   d0 = __builtin_fmaf(s.h2[2], w.wl[2], d0);
   d1 = __builtin_fmaf(s.h2[3], w.wl[3], d1);
@@ -308,15 +386,16 @@ __device__ __forceinline__ float finish(const NetWB<PRE>& w, TileState& s, BOp& 
 }
 
 // One optimizer-network evaluation for a 16-coordinate tile (step-granular kernel).
-template <int PRE>
-__device__ __forceinline__ float tile_step(const NetWB<PRE>& w, TileState& s, float in0, float in1, int q) {
-  const unsigned one = q == 0 ? 0x3f800000u : 0u;
-  BOp b1, b2;
+template <int PRE, bool PK>
+__device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s, float in0, float in1, int q) {
+  const unsigned one = bias_one<PK>(q);
+  constexpr int kN = chunk_mfmas(PK);
+  BOp<PK> b1, b2;
   f32x4 acc1[kNT], acc2[kNT];
-  split5(s.h2, one, b2);
-  issue<PRE, kChL2B, 0, kChunkMfmas, true>(w, b2, acc2);
-  split5(s.h1, one, b1);
-  issue<PRE, kChL1H, 0, kChunkMfmas, true>(w, b1, acc1);
+  split5<PK>(s.h2, one, b2);
+  issue<PRE, kChL2B, 0, kN, true>(w, b2, acc2);
+  split5<PK>(s.h1, one, b1);
+  issue<PRE, kChL1H, 0, kN, true>(w, b1, acc1);
   PhaseClock pc;
   return finish<PRE, false>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
 }
@@ -329,11 +408,12 @@ __device__ __forceinline__ float tile_step(const NetWB<PRE>& w, TileState& s, fl
 // BX = false: the fp32 MFMA form of l2o_common.h (<= 256 registers, two waves per SIMD)
 // kTotal = MFMAs of one recurrent chunk (h(t-1) part of a layer), kHalf = where the fused
 // kernels split them between their two GEMV passes.
-template <int PRE, bool BX>
+// PK (BX only): packed | 6-product form of the gate GEMM (l2o_lstm_bx3.h)
+template <int PRE, bool BX, bool PK = bx::packed_default(PRE)>
 struct LstmCore;
 
-template <int PRE>
-struct LstmCore<PRE, false> {
+template <int PRE, bool PK>
+struct LstmCore<PRE, false, PK> {
   static constexpr int kTotal = 25, kHalf = 12;
   NetW<PRE> w;
   __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { load_netw<PRE>(w, wpack, lane); }
@@ -356,30 +436,30 @@ struct LstmCore<PRE, false> {
   __device__ __forceinline__ void refresh(const TileState&) {}
 };
 
-template <int PRE>
-struct LstmCore<PRE, true> {
-  static constexpr int kTotal = bx::kChunkMfmas, kHalf = bx::kChunkMfmas / 2;
-  bx::NetWB<PRE> w;
-  bx::BOp b1, b2;          // split h1(t-1), h2(t-1): the recurrent chunks' B operands
+template <int PRE, bool PK>
+struct LstmCore<PRE, true, PK> {
+  static constexpr int kTotal = bx::chunk_mfmas(PK), kHalf = kTotal / 2;
+  bx::NetWB<PRE, PK> w;
+  bx::BOp<PK> b1, b2;      // split h1(t-1), h2(t-1): the recurrent chunks' B operands
   unsigned one;
-  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE>(w, wpack, lane); }
+  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, true, PK>(w, wpack, lane); }
   // Pin the 180-240 fragment registers to the accumulation half of the register file.  MFMA reads its A operand
   // from AGPRs directly; left to itself the allocator parks whatever does not fit the 256 VGPRs (fragments AND
   // VALU operands) there and pays a v_accvgpr_read per use (126 of the 618 VALU instructions of a config-2 step).
   __device__ __forceinline__ void pin() {
 #ifndef L2O_NO_AGPR_PIN
 #pragma unroll
-    for (int ch = 0; ch < bx::NetWB<PRE>::NCH; ++ch)
+    for (int ch = 0; ch < bx::NetWB<PRE, PK>::NCH; ++ch)
 #pragma unroll
       for (int t = 0; t < kNT; ++t)
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) asm volatile("" : "+a"(w.a[ch][t][s3]));
+        for (int j = 0; j < bx::frags(PK); ++j) asm volatile("" : "+a"(w.a[ch][t][j]));
 #endif
   }
   __device__ __forceinline__ void init(const TileState& s, int q) {
-    one = q == 0 ? 0x3f800000u : 0u;
-    bx::split5(s.h1, one, b1);
-    bx::split5(s.h2, one, b2);
+    one = bx::bias_one<PK>(q);
+    bx::split5<PK>(s.h1, one, b1);
+    bx::split5<PK>(s.h2, one, b2);
   }
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {
@@ -395,7 +475,7 @@ struct LstmCore<PRE, true> {
     return bx::finish<PRE, NEXT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
   }
   // after finish<false>: b1 already holds split h1(t) (finish builds it for chunk L2A); split h2(t) for chunk L2B
-  __device__ __forceinline__ void refresh(const TileState& s) { bx::split5(s.h2, one, b2); }
+  __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<PK>(s.h2, one, b2); }
 };
 
 }  // namespace l2o

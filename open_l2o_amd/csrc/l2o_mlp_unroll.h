@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int k_end = (min(j0 + 64, a.n[0]) - 1) / H;   // inclusive
   const int KR = owns_w1 ? k_end - k0 + 1 : 0;
 
-  using Core = LstmCore<PRE, true>;                    // bf16x3 gate GEMM, fragments pinned to AGPRs
+  using Core = LstmCore<PRE, true, false>;             // bf16x3 gate GEMM (6-product form: the packed fragments spill here), pinned to AGPRs
   Core core;
   core.load(a.np.wpack, lane);
   core.pin();

@@ -138,17 +138,20 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   for (int t5 = 0; t5 < kNT; ++t5) { s7.h1[t5] = 0.f; s7.c1[t5] = 0.f; s7.h2[t5] = 0.f; s7.c2[t5] = 0.f; }
   if (has7 && !a.zero_state) load_tile_state(s7, st_b + (size_t)tile7 * kStateFloatsPerTile, lane);
 
-  bx::NetWB<PRE> w;
-  bx::load_netw<PRE>(w, a.np.wpack, lane);
+  // packed gate GEMM (80 fragment registers per chunk) only beside ONE column block of the problem: with two, or with
+  // RNNProp's four chunks, the fragments spill (config 3: 4.8 -> 2.8 G coordinate-steps/s)
+  constexpr bool PK = NV == 1 && bx::packed_default(PRE);
+  bx::NetWB<PRE, PK> w;
+  bx::load_netw<PRE, true, PK>(w, a.np.wpack, lane);
   // pin the 180-240 fragment registers to the accumulation half of the register file (MFMA reads its A
   // operand from there directly): the architectural VGPRs stay free for the row ring and the gate math.
   // Left to itself the allocator spreads the fragments over both halves and spills the ring.
 #pragma unroll
-  for (int ch = 0; ch < bx::NetWB<PRE>::NCH; ++ch)
+  for (int ch = 0; ch < bx::NetWB<PRE, PK>::NCH; ++ch)
 #pragma unroll
     for (int t5 = 0; t5 < kNT; ++t5)
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) asm volatile("" : "+a"(w.a[ch][t5][s3]));
+      for (int s3 = 0; s3 < bx::frags(PK); ++s3) asm volatile("" : "+a"(w.a[ch][t5][s3]));
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   float om1 = 1.0f, om2 = 1.0f;
   __syncthreads();

@@ -147,8 +147,37 @@ def bx_nchunks(pre):
     return 4 if pre == 2 else 3
 
 
+def bx_packed_default(pre):
+    return pre != 2
+
+
+def bx_packed_words(pre):
+    return bx_nchunks(pre) * KNT * 4 * 256 if bx_packed_default(pre) else 0
+
+
+def bx_level_words(pre):
+    return bx_nchunks(pre) * KNT * 3 * 256
+
+
 def bx_words(pre):
-    return bx_nchunks(pre) * KNT * 3 * 256 + (0 if pre == 2 else 2 * KNT * 256)
+    return bx_packed_words(pre) + bx_level_words(pre) + (0 if pre == 2 else 2 * KNT * 256)
+
+
+def slot_desc(j, r, h):
+    """(unit 0..4 | 5 = bias, activation split level, weight split level) of K-slot h of register r of packed
+    MFMA j -- the table of l2o::bx::slot_desc (csrc/l2o_lstm_bx3.h), restated."""
+    pair = lambda first, x, w: (first + h, x, w)
+    table = {
+        0: pair(0, 0, 0), 1: pair(2, 0, 0), 2: (4, 0, h), 3: (5, 0, h),
+        4: pair(0, 0, 1), 5: pair(2, 0, 1), 6: pair(0, 0, 2), 7: pair(2, 0, 2),
+        8: pair(0, 1, 0), 9: pair(2, 1, 0), 10: (4, h, 0 if h else 2), 11: pair(0, 1, 1),
+        12: pair(2, 1, 1), 13: pair(0, 2, 0), 14: pair(2, 2, 0), 15: (4, 1 + h, 0 if h else 1),
+    }
+    return table[j * 4 + r]
+
+
+def bias_level(kq, h):
+    return h if kq == 0 else (2 if (kq == 1 and h == 0) else -1)
 
 
 def bf16_rne(x):
@@ -206,6 +235,24 @@ def _bop(v5, with_one):
     return out
 
 
+def _bop_packed(v5, with_one):
+    """the B operand slots of the four packed MFMAs of a chunk."""
+    q = np.arange(64) >> 4
+    levels = split3(v5)
+    out = []
+    for j in range(4):
+        s = np.zeros((64, 8))
+        for r in range(4):
+            for h in range(2):
+                unit, xl, _ = slot_desc(j, r, h)
+                if unit < 5:
+                    s[:, 2 * r + h] = levels[xl][:, unit]
+                elif with_one:
+                    s[:, 2 * r + h] = [1.0 if bias_level(int(k), h) >= 0 else 0.0 for k in q]
+        out.append(s)
+    return out
+
+
 PRODUCTS = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (2, 0)]     # (x level, w level)
 
 
@@ -221,17 +268,28 @@ def gates_scaled(acc, c):
     return cn, hn
 
 
-def tile_step_bx3(wpack, pre, h1, c1, h2, c2, in0, in1):
-    """The data flow of l2o::bx::tile_step on the packed weights (float64 accumulation)."""
+def tile_step_bx3(wpack, pre, h1, c1, h2, c2, in0, in1, packed=None):
+    """The data flow of l2o::bx::tile_step on the packed weights (float64 accumulation); packed: the 4-MFMA form
+    (default for the DM nets) or the one-MFMA-per-product form."""
+    if packed is None:
+        packed = bx_packed_default(pre)
     R = wp_rows(pre)
     wp32 = np.ascontiguousarray(wpack, np.float32)
     W = wp32.astype(np.float64).reshape(-1)[: R["total"] * 64].reshape(-1, 64)
     U = wp32.view(np.uint32)
     base = R["total"] * 64
-    frag = lambda ch, t, s: _unpack_frag(U[base + ((ch * KNT + t) * 3 + s) * 256:][:256].reshape(64, 4))
-    win_off = base + bx_nchunks(pre) * KNT * 3 * 256
+    nf = 4 if packed else 3
+    fbase = base + (0 if packed else bx_packed_words(pre))
+    frag = lambda ch, t, s: _unpack_frag(U[fbase + ((ch * KNT + t) * nf + s) * 256:][:256].reshape(64, 4))
+    win_off = base + bx_packed_words(pre) + bx_level_words(pre)
 
     def chunk(ch, vec, with_one, acc):
+        if packed:
+            b = _bop_packed(vec, with_one)
+            for j in range(4):
+                for t in range(KNT):
+                    acc[t] = mfma_bf16(frag(ch, t, j), b[j], acc[t])
+            return acc
         b = _bop(vec, with_one)
         for (xl, wl) in PRODUCTS:
             for t in range(KNT):
