@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 6
+#define L2O_ABI_VERSION 7
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -115,7 +115,10 @@ const char* l2o_last_error(void);
 #define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups                 */
 #define L2O_OPT_BWD_KERNEL 6         /* 0*: matrix-core BPTT step (needs wpack); 1: fp32 tile kernel; 2: generic kernel     */
 #define L2O_OPT_MLP_UNROLL 7         /* 1*: l2o_mlp_unroll available to the host layer (0: it reports "unsupported")       */
-#define L2O_OPT_COUNT_ 8             /* (* = default) */
+#define L2O_OPT_PAIR_NORMAL 8        /* 1*: the two-CU unroll takes W^T (W x - y) from the prepared normal matrix H = W^T W
+                                        (one GEMV and an exchange of the iterate per step; l2o_unroll_prepare);
+                                        0: the two-pass form (W x, then W^T r, exchange of the partial residuals)        */
+#define L2O_OPT_COUNT_ 9             /* (* = default) */
 int l2o_set_option(int32_t option, int64_t value);
 int64_t l2o_get_option(int32_t option);   /* -1 for an unknown option */
 
@@ -421,8 +424,11 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device */,
  *          iterate (DM/meta.py:379-383 re-runs the x initializer; a driver that restarts the SAME instance keeps x0);
  *   flags  L2O_UNROLL_ZERO_STATE: start from the zero LSTM state and zero RNNProp moments (what `reset` leaves,
  *          DM/meta.py:381, DM/meta_rnnprop_train.py:559-566) instead of reading st, m, v; they are still written.
+ *          L2O_UNROLL_PREPARED (ABI v7): the workspace holds what l2o_unroll_prepare left for THIS prob (same W, y
+ *          contents, same layout) -- the launch skips its own preparation pass.
  * i.e. `reset` + the first unroll of an epoch + fx_array.stack() in one call, without memset / copy passes. */
 #define L2O_UNROLL_ZERO_STATE 1
+#define L2O_UNROLL_PREPARED 2
 int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_problem* prob,
                       const float* x0 /* device or NULL */, float* x, float* st, float* m, float* v, int32_t T,
                       int32_t step0, int32_t flags, float* fx_part, float* fx /* device [T+1] */, void* workspace,
@@ -433,6 +439,15 @@ int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack /* device */, c
  * Between launches of one layout the library keeps the granule area clean itself (the epilogue kernel of a launch
  * re-zeroes it), so there is no memset per unroll.  layout == 0: the pair has no workspace-using kernel. */
 int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream);
+/* Problem preparation of the two-CU form (ABI v7).  The optimizees of the fused forms are  coef |W x - y|^2 + separable
+ * terms (DM/problems.py:73-213, 959-994); the two-CU kernel takes the gradient of the first term as  H x - q  with
+ * H = W^T W, q = W^T y (float64 accumulation, rounded once) kept in the workspace -- the problem is constant over an
+ * unroll and over every unroll until the caller re-samples it (MetaLoss.reset).  l2o_unroll / l2o_unroll_record and
+ * l2o_unroll_reduce without L2O_UNROLL_PREPARED run this pass themselves ahead of the unroll (two small kernels);
+ * a caller that launches many unrolls on one problem calls it once after (re)sampling W, y -- and after every
+ * l2o_unroll_workspace_init -- and passes L2O_UNROLL_PREPARED.  The loss itself is still |W x - y|^2 from W.
+ * A no-op (L2O_OK) for pairs whose unroll has no workspace-using kernel. */
+int l2o_unroll_prepare(const l2o_net_cfg* cfg, const l2o_problem* prob, void* workspace, void* stream);
 int64_t l2o_unroll_workspace_layout(const l2o_net_cfg* cfg, const l2o_problem* prob);
 int l2o_unroll_status(const void* workspace_header_host /* host copy of the first 4 bytes */);
 /* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0: the LDS-resident forms

@@ -444,12 +444,25 @@ class HipEngine(object):
             layout = int(self.lib.l2o_unroll_workspace_layout(C.byref(cc), C.byref(cp)))
             if ws is None or ws.numel() < nbytes:
                 ws = self._workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+                self._ws_prepared = None
             elif layout != self.__dict__.get("_ws_layout"):
                 # the granule area moved: zero the workspace once (the library keeps it clean between launches)
                 _abi.check(self.lib.l2o_unroll_workspace_init(C.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
+                self._ws_prepared = None
             self._ws_layout = layout
         self._last_ws = ws
         wsp = None if ws is None else C.c_void_p(ws.data_ptr())
+        flags = _abi.UNROLL_ZERO_STATE if zero_state else 0
+        if ws is not None and fx is not None and p.W is not None and p.y is not None:
+            # problem preparation of the two-CU form (l2o_unroll_prepare: H = W^T W, q = W^T y in the workspace) once
+            # per problem INSTANCE: the same W / y tensors, unmodified (torch bumps ._version on every in-place write;
+            # the tensors are kept referenced here, so their addresses cannot be recycled behind the key)
+            key = (p.W._version, p.y._version, p.B_local, p.D, p.M, p.w_shared, layout)
+            prep = self.__dict__.get("_ws_prepared")
+            if prep is None or prep[0] != key or prep[1] is not p.W or prep[2] is not p.y:
+                _abi.check(self.lib.l2o_unroll_prepare(C.byref(cc), C.byref(cp), wsp, self._stream()))
+                self._ws_prepared = (key, p.W, p.y)
+            flags |= _abi.UNROLL_PREPARED
         h = None
         if hist is not None:
             h = _abi.UnrollHist()
@@ -457,8 +470,7 @@ class HipEngine(object):
                 setattr(h, k, None if hist.get(k) is None else hist[k].data_ptr())
         if fx is not None:
             _abi.check(self.lib.l2o_unroll_reduce(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x0), _ptr(x), _ptr(st), _ptr(m),
-                                                  _ptr(v), int(T), int(step0),
-                                                  _abi.UNROLL_ZERO_STATE if zero_state else 0, _ptr(fx_part), _ptr(fx),
+                                                  _ptr(v), int(T), int(step0), flags, _ptr(fx_part), _ptr(fx),
                                                   wsp, None if h is None else C.byref(h), self._stream()))
         elif hist is None:
             _abi.check(self.lib.l2o_unroll(C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x), _ptr(st), _ptr(m),

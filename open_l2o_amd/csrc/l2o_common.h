@@ -229,7 +229,13 @@ struct PhaseClock {
   // outstanding memory operations are drained, so that each phase pays for its own work
   __device__ __forceinline__ void mark(int i) {
     __builtin_amdgcn_sched_barrier(0);
+#ifdef L2O_PROFILE_LIGHT
+    // (light marks: outstanding vector-memory operations -- the fire-and-forget publish stores, polls in flight --
+    //  are NOT drained, so a phase shows what the wave actually waits for)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     const long long n = __builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
     acc[i] += n - prev;

@@ -647,6 +647,7 @@ struct UnrollArgs {
   // zero moments instead of reading st, m, v -- `reset` + the first unroll in one launch, no memset / copy pass
   const float* x_in;
   int zero_state;
+  int prepared;      // host side only: the workspace already holds this problem's H / q (l2o_unroll_prepare)
 };
 
 #ifdef L2O_ABLATE_BARRIER
@@ -832,6 +833,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 }
 
 #include "l2o_unroll_pair.h"
+#include "l2o_unroll_pairh.h"
 
 #include "l2o_unroll_cu.h"
 
@@ -977,7 +979,7 @@ static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
 static std::atomic<int64_t> g_opt[L2O_OPT_COUNT_] = {
     /* L2O_OPT_PAIR */ {1}, /* L2O_OPT_PAIR_PLAIN_STORES */ {1}, /* L2O_OPT_UNROLL_CU */ {1},
     /* L2O_OPT_FG_TWO_PASS */ {0}, /* L2O_OPT_MLP_GENERIC */ {0}, /* L2O_OPT_BWD_BLOCKS */ {0},
-    /* L2O_OPT_BWD_KERNEL */ {0}, /* L2O_OPT_MLP_UNROLL */ {1}};
+    /* L2O_OPT_BWD_KERNEL */ {0}, /* L2O_OPT_MLP_UNROLL */ {1}, /* L2O_OPT_PAIR_NORMAL */ {1}};
 static inline int64_t opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
 
 // CUs of the device the call runs on (the stream's device; the current device for the null stream).
@@ -1005,17 +1007,40 @@ static bool pair_eligible(const l2o_problem* p, const UnrollGeom& g, hipStream_t
   if (g.CH < 2) return false;
   return 2 * p->B_local <= device_cu_count(s);
 }
-struct PairLayout { size_t xbuf_off, xbuf_bytes, fxh_off, total; int npg; size_t lds; };
+struct PairLayout { size_t xbuf_off, xbuf_bytes, h_off, q_off, fxh_off, total; int npg, nW; size_t lds; };
 static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) {
   PairLayout L;
   const int SQ = 16 * g.CH;
   L.npg = SQ;                         // granules per (half, parity): one per residual row
   L.xbuf_off = sizeof(PairWs);
   L.xbuf_bytes = (size_t)p->B_local * 2 * 2 * L.npg * sizeof(unsigned long long);
-  L.fxh_off = L.xbuf_off + L.xbuf_bytes;
+  // the prepared normal matrices H = W^T W [nW][SQ][SQ] and q = W^T y [B][SQ] (l2o_unroll_pairh.h); T-independent
+  L.nW = (p->flags & L2O_PROB_W_SHARED) ? 1 : p->B_local;
+  L.h_off = L.xbuf_off + L.xbuf_bytes;
+  L.q_off = L.h_off + sizeof(float) * (size_t)L.nW * SQ * SQ;
+  L.fxh_off = L.q_off + sizeof(float) * (size_t)p->B_local * SQ;
   L.total = L.fxh_off + sizeof(float) * (size_t)(T + 1) * g.CH * p->B_local;   // one partial per (step, problem, wave)
   L.lds = 0;                          // static LDS only (xs, rs, fpart)
   return L;
+}
+
+// H = W^T W and q = W^T y of every problem into the workspace (l2o_unroll_pairh.h)
+static int launch_pair_prepare(const l2o_problem* prob, const UnrollGeom& g, void* workspace, hipStream_t s) {
+  const PairLayout L = pair_layout(prob, g, 0);
+  float* H = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.h_off);
+  float* qv = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.q_off);
+  const int SQ = 16 * g.CH;
+  const dim3 grid(L.nW, SQ / 16);
+  switch (g.CH) {
+    case 2: hipLaunchKernelGGL(k_pair_prepare_h<2>, grid, dim3(256), 0, s, prob->W, prob->M, prob->D, H); break;
+    case 4: hipLaunchKernelGGL(k_pair_prepare_h<4>, grid, dim3(256), 0, s, prob->W, prob->M, prob->D, H); break;
+    default: hipLaunchKernelGGL(k_pair_prepare_h<8>, grid, dim3(256), 0, s, prob->W, prob->M, prob->D, H); break;
+  }
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_pair_prepare_q, dim3(prob->B_local), dim3(SQ), 0, s, prob->W, prob->y, prob->M, prob->D,
+                     (prob->flags & L2O_PROB_W_SHARED) ? 1 : 0, SQ, qv);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
 }
 
 template <int PRE, int KIND>
@@ -1033,17 +1058,36 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     //  k_combine_halves advances after every launch: no host-side launch state)
     pa.use_salt = a.T + 1 < 0xffff ? 1u : 0u;
     pa.plain_stores = opt(L2O_OPT_PAIR_PLAIN_STORES) ? 1u : 0u;
-    void (*fn)(UnrollPairArgs) = nullptr;
-    switch (g.CH) {
-      case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : k_unroll_pair<PRE, KIND, 2, false>; break;
-      case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
-      default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
-    }
     // (no memset here: the workspace starts zeroed -- l2o_unroll_workspace_init -- and the epilogue kernel of every
     //  launch leaves the granule area zeroed for the next one)
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
     const int groups = (a.pp.B_local + 7) / 8;
-    hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
+    if (opt(L2O_OPT_PAIR_NORMAL)) {
+      // the gradient from the prepared normal matrix (l2o_unroll_pairh.h); prepared here unless the caller did
+      if (!a.prepared) {
+        const int rc = launch_pair_prepare(prob, g, workspace, s);
+        if (rc) return rc;
+      }
+      UnrollPairHArgs ha;
+      ha.p = pa;
+      ha.H = reinterpret_cast<const float*>(static_cast<char*>(workspace) + L.h_off);
+      ha.qv = reinterpret_cast<const float*>(static_cast<char*>(workspace) + L.q_off);
+      void (*fh)(UnrollPairHArgs) = nullptr;
+      switch (g.CH) {
+        case 2: fh = hist ? k_unroll_pairh<PRE, KIND, 2, true> : k_unroll_pairh<PRE, KIND, 2, false>; break;
+        case 4: fh = hist ? k_unroll_pairh<PRE, KIND, 4, true> : k_unroll_pairh<PRE, KIND, 4, false>; break;
+        default: fh = hist ? k_unroll_pairh<PRE, KIND, 8, true> : k_unroll_pairh<PRE, KIND, 8, false>; break;
+      }
+      hipLaunchKernelGGL(fh, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, ha);
+    } else {
+      void (*fn)(UnrollPairArgs) = nullptr;
+      switch (g.CH) {
+        case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : k_unroll_pair<PRE, KIND, 2, false>; break;
+        case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
+        default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
+      }
+      hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
+    }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(64), 0, s, pa.fx_half, a.fx_part, a.pp.B_local, g.CH,
                        a.pp.inv_bg, fx, pa.xbuf, (long)(L.xbuf_bytes / sizeof(unsigned long long)), pa.ws);
@@ -1948,8 +1992,18 @@ int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
                       float* st, float* m, float* v, int32_t T, int32_t step0, int32_t flags, float* fx_part, float* fx,
                       void* workspace, const l2o_unroll_hist* hist, void* stream) {
   if (!fx) return fail(L2O_ERR_ARG, "l2o_unroll_reduce: NULL fx");
-  if (flags & ~L2O_UNROLL_ZERO_STATE) return fail(L2O_ERR_ARG, "l2o_unroll_reduce: unknown flags %d", flags);
+  if (flags & ~(L2O_UNROLL_ZERO_STATE | L2O_UNROLL_PREPARED))
+    return fail(L2O_ERR_ARG, "l2o_unroll_reduce: unknown flags %d", flags);
   return unroll_impl(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, hist, fx, stream, x0, flags);
+}
+
+int l2o_unroll_prepare(const l2o_net_cfg* cfg, const l2o_problem* prob, void* workspace, void* stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  UnrollGeom g;
+  if (!cfg || !l2o_unroll_supported(cfg, prob) || !unroll_geom(prob, &g) || g.CH < 2) return L2O_OK;   // nothing to prepare
+  if (!workspace) return fail(L2O_ERR_ARG, "l2o_unroll_prepare: NULL workspace");
+  return launch_pair_prepare(prob, g, workspace, (hipStream_t)stream);
 }
 
 int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream) {
@@ -1983,6 +2037,7 @@ static int unroll_impl(const l2o_net_cfg* cfg, const float* wpack, const l2o_pro
   a.pp = make_prob_params(prob);
   a.x = x; a.st = st; a.m = m; a.v = v; a.fx_part = fx_part;
   a.x_in = x0; a.zero_state = (flags & L2O_UNROLL_ZERO_STATE) ? 1 : 0;
+  a.prepared = (flags & L2O_UNROLL_PREPARED) ? 1 : 0;
   a.T = T;
   a.hist_st = hist ? hist->st : nullptr;
   a.hist_g = hist ? hist->g : nullptr;

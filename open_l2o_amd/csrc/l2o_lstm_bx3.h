@@ -37,6 +37,7 @@
 // the nonlinearity block works on unit pairs with v_pk_{add,mul,fma}_f32 (9 instead of 19
 // VALU instructions per unit; scripts/microbench/gates_variants.hip: 317 -> 215 ns).
 #pragma once
+#include <type_traits>
 #include "l2o_common.h"
 
 namespace l2o {
@@ -327,10 +328,13 @@ __device__ __forceinline__ void gates5_scalar(const f32x4 (&acc)[kNT], float (&c
 // acc1 must hold chunk L1H (h1(t-1), bias), acc2 chunk L2B (h2(t-1)).  On return s holds the
 // new state, b1 / b2 the split h1(t) / h2(t) (the next step's L1H / L2B operands) and, with
 // NEXT, acc1 the next step's chunk L1H.  Returns the Linear output (before tanh / scale).
-template <int PRE, bool NEXT, bool PK>
+// shadow(): caller work that does not feed the network (loss reductions, stores), placed behind the issue of chunk
+// L2A -- the one stretch of the step where the wave only waits for the matrix pipe.
+struct NoShadow { __device__ __forceinline__ void operator()() const {} };
+template <int PRE, bool NEXT, bool PK, class Shadow = NoShadow>
 __device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, BOp<PK>& b1, BOp<PK>& b2,
                                         f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1, unsigned one,
-                                        int q, PhaseClock& pc) {
+                                        int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
   constexpr int kN = chunk_mfmas(PK);
   if (PRE == L2O_PRE_FC_ELU) {
     float fc[kNT];
@@ -353,6 +357,19 @@ __device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, B
   pc.mark(6);
   split5<PK>(s.h1, one, b1);
   issue<PRE, kChL2A, 0, kN, false>(w, b1, acc2);
+  if constexpr (!std::is_same<typename std::decay<Shadow>::type, NoShadow>::value) {
+    // the caller's work between the MFMAs: in program order the wave would issue the kN MFMAs back to back
+    // (16 cycles each, 4 needed) and only then the shadow
+    shadow();
+#ifndef L2O_SHADOW_VALU_PER_MFMA
+#define L2O_SHADOW_VALU_PER_MFMA 3
+#endif
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, L2O_SHADOW_VALU_PER_MFMA, 0);     // VALU
+    }
+  }
   pc.mark(7);
   pc.drain(acc2);
   pc.mark(10);
@@ -427,9 +444,10 @@ struct LstmCore<PRE, false, PK> {
   __device__ __forceinline__ void issue_l2_prev(const TileState& s, f32x4 (&acc2)[kNT]) {
     lstm_issue_l2_prev<PRE, LO, HI>(w, s, acc2);
   }
-  template <bool NEXT>
+  template <bool NEXT, class Shadow = bx::NoShadow>
   __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
-                                          int q, PhaseClock& pc) {
+                                          int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
+    shadow();
     return lstm_finish<PRE, NEXT>(w, s, acc1, acc2, in0, in1, q, pc);
   }
   // after finish<false>: make the recurrent operands of the NEXT step current (nothing to do here)
@@ -469,10 +487,10 @@ struct LstmCore<PRE, true, PK> {
   __device__ __forceinline__ void issue_l2_prev(const TileState&, f32x4 (&acc2)[kNT]) {
     bx::issue<PRE, bx::kChL2B, LO, HI, true>(w, b2, acc2);
   }
-  template <bool NEXT>
+  template <bool NEXT, class Shadow = bx::NoShadow>
   __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
-                                          int q, PhaseClock& pc) {
-    return bx::finish<PRE, NEXT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
+                                          int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
+    return bx::finish<PRE, NEXT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, shadow);
   }
   // after finish<false>: b1 already holds split h1(t) (finish builds it for chunk L2A); split h2(t) for chunk L2B
   __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<PK>(s.h2, one, b2); }

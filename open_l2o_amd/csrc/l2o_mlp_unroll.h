@@ -555,6 +555,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pc.mark(8);
   }
 #ifdef L2O_PROFILE_PHASES
+#ifndef L2O_PROFILE_WG
+#define L2O_PROFILE_WG 0
+#endif
   if (wg == L2O_PROFILE_WG && tid == 0) pc.dump(a.ws->phases);
 #endif
 

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     // 30 MFMAs (L2B) give the partner time to publish; the first poll load goes out THEN and its L2 round trip
     // is covered by the other 30 MFMAs (L1H) -- in program order, a single wave issues in order
 #ifndef L2O_PAIR_POLL_AT
-#define L2O_PAIR_POLL_AT 15   // measured: 0 -> 5.94, 5/10 -> 6.05, 15 -> 6.22, 30 -> 6.15, 45 -> 6.09 G (config 2)
+#define L2O_PAIR_POLL_AT 20   // = after chunk L2B.  Packed chunks (20 MFMAs): 5 -> 7.72, 10 -> 7.86, 15 -> 7.95, 20 -> 8.02, 30 -> 7.98 G (config 2)
 #endif
     constexpr int kPollAt = L2O_PAIR_POLL_AT < Core::kTotal ? L2O_PAIR_POLL_AT : Core::kTotal;   // MFMAs before the first poll load
     constexpr int kPollAt1 = L2O_PAIR_POLL_AT > Core::kTotal ? L2O_PAIR_POLL_AT - Core::kTotal : 0;

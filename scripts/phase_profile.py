@@ -29,9 +29,9 @@ for it in range(3):
 ws = eng._last_ws
 # workspace header: 64 B status block, then long long phases[16]
 raw = ws[64:64 + 12 * 8].cpu().numpy().view(np.int64)
-names = ["xs -> LDS", "30 MFMA (L2B) + partner poll + r", "barrier B1", "partial r + publish", "wave_sum + barrier B2",
-         "g pass + preprocess + input FMAs + L1 MFMA drain", "layer-1 gates", "split h1 + issue 30 MFMA (L2A)",
-         "layer-2 gates + 30 MFMA (next L1H)", "split h2 + linear + x update", "L2 MFMA drain", "-"]
+names = ["xs -> LDS", "MFMA (L2B + L1H) + partner poll + r", "barrier B1", "partial r + publish", "wave_sum + barrier B2",
+         "g pass + preprocess + input FMAs + L1 MFMA drain", "layer-1 gates", "split h1 + issue MFMA (L2A)",
+         "layer-2 gates", "split h2 + linear + x update", "L2 MFMA drain", "-"]
 tot = raw.sum()
 print("k_unroll_pair phase clock (s_memtime ticks, wave 0 of workgroup 0, %d steps; 100 MHz-independent ratios)" % T)
 for n, v in zip(names, raw):
