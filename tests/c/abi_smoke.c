@@ -123,6 +123,16 @@ int main(int argc, char** argv) {
     HIP(hipMemcpy(&status, dws, 4, hipMemcpyDeviceToHost));
     L2O(l2o_unroll_status(&status));
   }
+  /* (a') the same launch after an explicit l2o_unroll_prepare, with L2O_UNROLL_PREPARED: bit-identical */
+  {
+    float fx_prep[T + 1];
+    HIP(hipMemcpy(dx, x0, sizeof x0, hipMemcpyHostToDevice)); HIP(hipMemset(dst, 0, nst * 4));
+    L2O(l2o_unroll_prepare(&cfg, &prob, dws, s));
+    L2O(l2o_unroll_reduce(&cfg, dwp, &prob, NULL, dx, dst, NULL, NULL, T, 1, dws ? L2O_UNROLL_PREPARED : 0, dfxp, dfx, dws, NULL, s));
+    HIP(hipStreamSynchronize(s));
+    HIP(hipMemcpy(fx_prep, dfx, sizeof fx_prep, hipMemcpyDeviceToHost));
+    CHECK(memcmp(fx_prep, fx_fused, sizeof fx_prep) == 0, "L2O_UNROLL_PREPARED launch differs from the self-preparing one");
+  }
   /* (b) the same unroll through the step-granular entry points */
   HIP(hipMemcpy(dx, x0, sizeof x0, hipMemcpyHostToDevice)); HIP(hipMemset(dst, 0, nst * 4));
   for (int t = 0; t <= T; ++t) {

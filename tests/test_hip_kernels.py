@@ -471,6 +471,35 @@ def test_fused_edge_cases(eng, kind, B, D, M, T, pair):
     assert max_abs(x, res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max()))
 
 
+def test_unroll_preparation_follows_the_problem(eng):
+    """The two-CU unroll takes W^T (W x - y) from H = W^T W, q = W^T y prepared ONCE per problem instance
+    (l2o_unroll_prepare; the engine re-prepares when the W / y tensors are replaced or written in place).
+    A problem changed in place between two launches must give the NEW problem's trajectory."""
+    cfg = O.DM_IDENTITY
+    params = make_params(cfg, seed=21, trained_like=True)
+    B, D, T = 6, 40, 8
+    prob, x0, arrays = make_problem("quadratic", B, D, seed=22)
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D)
+    fx = eng.zeros(T + 1)
+
+    def launch():
+        x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
+        eng.unroll(spec, wpack, pd, x, st, None, None, T, 1, eng.zeros((T + 1) * B), fx=fx)
+        return eng.to_numpy(fx)
+
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    assert rel_err(launch(), res.fx) < 1e-5
+    first = eng._ws_prepared
+    assert rel_err(launch(), res.fx) < 1e-5 and eng._ws_prepared is first      # same instance: prepared once
+    pd.W.mul_(1.25); pd.y.add_(0.5)                                                # the problem changes IN PLACE
+    prob2 = O.Quadratic(prob.w * np.float32(1.25), prob.y + np.float32(0.5))
+    res2 = O.unroll(prob2, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    assert rel_err(res2.fx, res.fx) > 1e-2
+    assert rel_err(launch(), res2.fx) < 1e-5 and eng._ws_prepared is not first
+
+
 def test_fused_rejects_what_it_cannot_do(eng):
     from open_l2o_amd import _abi
     cfg = O.DM_IDENTITY
@@ -619,16 +648,17 @@ def test_streaming_unroll_records_history(eng, name, kind, B, D, M):
     assert max_abs(eng.to_numpy(hist["g_final"]), eng.to_numpy(g).reshape(-1)) < 2e-5 * float(np.abs(eng.to_numpy(g)).max())
 
 
-def test_long_horizon_T1000(eng):
+@pytest.mark.parametrize("B,T", [(16, 1000), (4, 10000)])
+def test_long_horizon(eng, B, T):
     """The curriculum's longest training horizon (DM/train_dm.py:66: num_unrolls up to 50 x unroll_length 20 =
-    1000 steps) and a tenth of the evaluation drivers' 10 000 (DM/evaluate_dm.py:43) in ONE launch of the
-    fused kernel: L2O-DM on Quadratic d = 128 (config-2 shape, 16 problems), T = 1000.  fp32 trajectories
-    drift from the exact one; the bound is the drift of the fp32 ORACLE from its own float64 evaluation
-    (x 3), and never looser than 1e-4: measured 6e-7 for the oracle."""
+    1000 steps) and the evaluation drivers' 10 000 (DM/evaluate_dm.py:43), each in ONE launch of the fused
+    kernels: L2O-DM on Quadratic d = 128 (config-2 shape).  fp32 trajectories drift from the exact one; the
+    bound is the drift of the fp32 ORACLE from its own float64 evaluation (x 3), never looser than 1e-4
+    (measured 6e-7 for the oracle at T = 1000); the first 101 steps hold the 1e-5 of the short tests."""
     from oracle.c_oracle import c_unroll
     cfg = O.DM_IDENTITY
     params = make_params(cfg, seed=3, trained_like=True)
-    B, D, T = 16, 128, 1000
+    D = 128
     prob, x0, arrays = make_problem("quadratic", B, D, seed=4)
     fx32 = c_unroll("quadratic", cfg, params, arrays, x0, T)[0]
     p64 = {k: {v: a.astype(np.float64) for v, a in d.items()} for k, d in params.items()}
@@ -639,8 +669,8 @@ def test_long_horizon_T1000(eng):
         with lib_option(_abi.OPT_PAIR, pair):
             fx = _run_fused(eng, cfg, params, arrays, x0, B, D, T)[0]
         e64, e32 = rel_err(fx, r64.fx), rel_err(fx, fx32)
-        print("T=1000 (pair=%d): rel fx vs float64 oracle %.3g, vs fp32 C oracle %.3g (fp32 oracle's own drift %.3g)"
-              % (pair, e64, e32, envelope))
+        print("T=%d (pair=%d): rel fx vs float64 oracle %.3g, vs fp32 C oracle %.3g (fp32 oracle's own drift %.3g)"
+              % (T, pair, e64, e32, envelope))
         assert e64 < min(1e-4, max(1e-5, 3 * envelope))
         assert rel_err(fx[:101], r64.fx[:101]) < 1e-5
 
