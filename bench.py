@@ -373,7 +373,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
     elif streaming:
         kernel = "k_unroll_cu"
     elif fused:
-        kernel = "k_unroll_pair" if 2 * B <= 256 and D > 16 else "k_unroll"
+        kernel = "k_unroll_pairh" if 2 * B <= 256 and D > 16 else "k_unroll"
     else:
         kernel = "k_problem_fg1 + k_cwlstm_step per step"
     # HBM bytes per launch that a kernel of this form MUST move (used only when no PMC pass is committed):

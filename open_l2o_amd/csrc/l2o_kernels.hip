@@ -1030,16 +1030,19 @@ static int launch_pair_prepare(const l2o_problem* prob, const UnrollGeom& g, voi
   float* H = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.h_off);
   float* qv = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.q_off);
   const int SQ = 16 * g.CH;
-  const dim3 grid(L.nW, SQ / 16);
-  switch (g.CH) {
-    case 2: hipLaunchKernelGGL(k_pair_prepare_h<2>, grid, dim3(256), 0, s, prob->W, prob->M, prob->D, H); break;
-    case 4: hipLaunchKernelGGL(k_pair_prepare_h<4>, grid, dim3(256), 0, s, prob->W, prob->M, prob->D, H); break;
-    default: hipLaunchKernelGGL(k_pair_prepare_h<8>, grid, dim3(256), 0, s, prob->W, prob->M, prob->D, H); break;
+  const bool shared = (prob->flags & L2O_PROB_W_SHARED) != 0;
+  const dim3 grid(L.nW, 2);
+  const size_t lds = sizeof(float) * (size_t)prob->M * SQ;
+  float* qh = shared ? nullptr : qv;                       // a per-problem W: q comes out of the same blocks
+  void (*fn)(const float*, const float*, int, int, float*, float*) =
+      g.CH == 2 ? k_pair_prepare_h<2> : (g.CH == 4 ? k_pair_prepare_h<4> : k_pair_prepare_h<8>);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, prob->W, prob->y, prob->M, prob->D, H, qh);
+  HIP_TRY(hipGetLastError());
+  if (shared) {
+    hipLaunchKernelGGL(k_pair_prepare_q, dim3(prob->B_local), dim3(SQ), 0, s, prob->W, prob->y, prob->M, prob->D, SQ, qv);
+    HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_pair_prepare_q, dim3(prob->B_local), dim3(SQ), 0, s, prob->W, prob->y, prob->M, prob->D,
-                     (prob->flags & L2O_PROB_W_SHARED) ? 1 : 0, SQ, qv);
-  HIP_TRY(hipGetLastError());
   return L2O_OK;
 }
 

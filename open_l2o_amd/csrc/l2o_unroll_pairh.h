@@ -29,39 +29,100 @@ struct UnrollPairHArgs {
   const float* qv;    // [B][SQ] = W^T y
 };
 
-// ---- prepare: H = W^T W and q = W^T y, float64 accumulation ---------------------------------
-// grid (nW, SQ / 16): block (problem, 16 rows of H); thread (row i0 + tid / 16, columns tid % 16 + 16 k)
+// ---- prepare: H = W^T W and q = W^T y, float64 accumulation, rounded once ---------------------
+// grid (nW, 2): block (matrix, upper / lower half of the rows of H).  W (M x D, columns zero-padded to SQ) is staged
+// in LDS once; the 16 x 16 threads own (SQ / 32) x (SQ / 16) tiles of the half: per row of W a thread reads its
+// SQ / 32 + SQ / 16 values and issues their outer product as float64 FMAs (the DFMA rate bounds the block:
+// 4 096 per thread at SQ = 128 plus 12 v_cvt_f64_f32 per 32 of them: 30 us; all blocks run concurrently).  With a per-problem W the block also forms its
+// half of q (a shared W: k_pair_prepare_q, one block per problem).
 template <int CH>
-__global__ __launch_bounds__(256) void k_pair_prepare_h(const float* __restrict__ W, int M, int D, float* __restrict__ H) {
-  constexpr int SQ = 16 * CH;
+__global__ __launch_bounds__(256) void k_pair_prepare_h(const float* __restrict__ W, const float* __restrict__ y, int M,
+                                                        int D, float* __restrict__ H, float* __restrict__ qv) {
+  constexpr int SQ = 16 * CH, HR = SQ / 2, RT = HR / 16, CT = SQ / 16;
+  extern __shared__ float wl[];                            // [M][SQ] (as doubles, converted once: 77 us instead of 30 --
+                                                           // the 96 B per thread and row of W make the loop LDS-bound)
+  __shared__ float ys[SQ];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, half = blockIdx.y;
+  if (qv && tid < SQ) ys[tid] = tid < M ? y[(size_t)blockIdx.x * M + tid] : 0.0f;
   const float* Wb = W + (size_t)blockIdx.x * M * D;
   float* Hb = H + (size_t)blockIdx.x * SQ * SQ;
-  const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j0 = threadIdx.x & 15;
-  double acc[CH];
+  {
+    // all of the thread's loads in flight before the first LDS write (a plain loop issues them one latency at a time)
+    constexpr int NQ = (SQ * SQ / 4 + 255) / 256;          // float4 groups per thread for M == SQ
+    float4 v[NQ];
+    const bool vec = D == SQ && (((size_t)Wb) & 15) == 0;
 #pragma unroll
-  for (int k = 0; k < CH; ++k) acc[k] = 0.0;
-  if (i < D) {
-    for (int r = 0; r < M; ++r) {
-      const double wi = (double)Wb[(size_t)r * D + i];
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int j = j0 + 16 * k;
-        if (j < D) acc[k] = __builtin_fma(wi, (double)Wb[(size_t)r * D + j], acc[k]);
+    for (int k = 0; k < NQ; ++k) {
+      const int e4 = tid + 256 * k, r = e4 / (SQ / 4), c = 4 * (e4 - r * (SQ / 4));
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < M) {
+        if (vec) v[k] = *reinterpret_cast<const float4*>(Wb + (size_t)r * D + c);
+        else {
+          const float* p = Wb + (size_t)r * D + c;
+          v[k].x = c < D ? p[0] : 0.0f; v[k].y = c + 1 < D ? p[1] : 0.0f;
+          v[k].z = c + 2 < D ? p[2] : 0.0f; v[k].w = c + 3 < D ? p[3] : 0.0f;
+        }
       }
     }
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int e4 = tid + 256 * k;
+      if (e4 < M * (SQ / 4)) *reinterpret_cast<float4*>(wl + 4 * e4) = v[k];
+    }
+  }
+  __syncthreads();
+  double acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = 0.0;
+  const float* pa = wl + half * HR + ty * RT;
+  const float* pb = wl + tx * CT;
+#pragma unroll 4
+  for (int r = 0; r < M; ++r) {
+    double a[RT], bb[CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) a[i] = (double)pa[r * SQ + i];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) bb[j] = (double)pb[r * SQ + j];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_fma(a[i], bb[j], acc[i][j]);
   }
 #pragma unroll
-  for (int k = 0; k < CH; ++k) Hb[(size_t)i * SQ + j0 + 16 * k] = (float)acc[k];
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) Hb[(size_t)(half * HR + ty * RT + i) * SQ + tx * CT + j] = (float)acc[i][j];
+  if (qv && tid < HR) {                                    // per-problem W: q_i for the rows of this half
+    const int i = half * HR + tid;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = 0;
+#pragma unroll 2
+    for (; r + 3 < M; r += 4) {
+      s0 = __builtin_fma((double)wl[r * SQ + i], (double)ys[r], s0);
+      s1 = __builtin_fma((double)wl[(r + 1) * SQ + i], (double)ys[r + 1], s1);
+      s2 = __builtin_fma((double)wl[(r + 2) * SQ + i], (double)ys[r + 2], s2);
+      s3 = __builtin_fma((double)wl[(r + 3) * SQ + i], (double)ys[r + 3], s3);
+    }
+    for (; r < M; ++r) s0 = __builtin_fma((double)wl[r * SQ + i], (double)ys[r], s0);
+    qv[(size_t)blockIdx.x * SQ + i] = (float)((s0 + s1) + (s2 + s3));
+  }
 }
-// grid B, block SQ threads: q[b][i] = sum_r W[r][i] y[b][r]
-__global__ void k_pair_prepare_q(const float* __restrict__ W, const float* __restrict__ y, int M, int D, int w_shared,
-                                 int SQ, float* __restrict__ qv) {
+// shared W: grid B, block SQ threads: q[b][i] = sum_r W[r][i] y[b][r]
+__global__ void k_pair_prepare_q(const float* __restrict__ W, const float* __restrict__ y, int M, int D, int SQ,
+                                 float* __restrict__ qv) {
   const int b = blockIdx.x, i = threadIdx.x;
-  const float* Wb = W + (w_shared ? (size_t)0 : (size_t)b * M * D);
-  double acc = 0.0;
-  if (i < D)
-    for (int r = 0; r < M; ++r) acc = __builtin_fma((double)Wb[(size_t)r * D + i], (double)y[(size_t)b * M + r], acc);
-  qv[(size_t)b * SQ + i] = (float)acc;
+  double s0 = 0.0, s1 = 0.0;
+  if (i < D) {
+    int r = 0;
+    for (; r + 1 < M; r += 2) {
+      s0 = __builtin_fma((double)W[(size_t)r * D + i], (double)y[(size_t)b * M + r], s0);
+      s1 = __builtin_fma((double)W[(size_t)(r + 1) * D + i], (double)y[(size_t)b * M + r + 1], s1);
+    }
+    if (r < M) s0 = __builtin_fma((double)W[(size_t)r * D + i], (double)y[(size_t)b * M + r], s0);
+  }
+  qv[(size_t)b * SQ + i] = (float)(s0 + s1);
 }
 
 template <int PRE, int KIND, int CH, bool HIST>

@@ -4,7 +4,7 @@ TAG=${1:-r02_final}
 O=gpurun_out/$TAG; mkdir -p $O
 (timeout 1200 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -16) | tee $O/pytest.log
 (timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1) | tee $O/smoke.log
-bash scripts/gpu_counters.sh $PWD/$O c2 k_unroll_pair '["quadratic","dm",128,128,100]' --steps 20 --warmup 3
+bash scripts/gpu_counters.sh $PWD/$O c2 k_unroll_pairh '["quadratic","dm",128,128,100]' --steps 20 --warmup 3
 bash scripts/gpu_counters.sh $PWD/$O c3 k_unroll_cu '["lasso","rnnprop",512,256,200,256]' --config 3 --steps 5 --warmup 2
 cp $O/counters_c2.json profiles/${TAG}_counters_c2.json; cp $O/counters_c3.json profiles/${TAG}_counters_c3.json   # (so that the bench runs below see them)
 timeout 300 python bench.py 2>$O/bench.err | tee $O/bench_c2.json | cut -c1-300
