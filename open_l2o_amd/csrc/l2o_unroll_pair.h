@@ -349,7 +349,10 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 #ifndef L2O_PAIR_L1H_UNDER_GATES
     core.refresh(s);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
 #endif
-    if (a.np.tanh_output) d = tanhf_(d);
+    if (a.np.tanh_output) {                                 // a real (uniform) branch: as a select hipcc computes the
+      asm volatile("");                                      // exp + rcp of tanh on every step of the nets without it
+      d = tanhf_(d);
+    }
     xv = __builtin_fmaf(d, a.np.scale, xv);
     pc.mark(9);
   }

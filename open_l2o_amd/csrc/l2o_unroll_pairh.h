@@ -378,7 +378,10 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
     float d = core.template finish<false>(s, acc1, acc2, in0, in1, q, pc, loss);
     if (lane == 0) fx_wave[(size_t)t * fx_stride] = fw;
     core.refresh(s);   // marks 5 (other-half GEMV .. inputs), 6, 7, 10, 8
-    if (a.np.tanh_output) d = tanhf_(d);
+    if (a.np.tanh_output) {                                 // a real (uniform) branch: as a select hipcc computes the
+      asm volatile("");                                      // exp + rcp of tanh on every step of the nets without it
+      d = tanhf_(d);
+    }
     xv = __builtin_fmaf(d, a.np.scale, xv);
     pc.mark(9);
   }
