@@ -1002,10 +1002,18 @@ static int device_cu_count(hipStream_t s) {
 }
 
 // Split every problem over two workgroups when that still leaves all of them co-resident.
-static bool pair_eligible(const l2o_problem* p, const UnrollGeom& g, hipStream_t s) {
-  if (!opt(L2O_OPT_PAIR)) return false;
-  if (g.CH < 2) return false;
-  return 2 * p->B_local <= device_cu_count(s);
+// Problems per launch of the two-CU form, 0 = not this form.  Every problem of a launch must be co-resident with its
+// partner: at most #CU / 2 per launch.  A larger batch shard runs as consecutive launches of equal chunks (a multiple
+// of the 8-problem launch groups) -- normal-matrix kernel only; a chunk launch with every tile on its own SIMD beats
+// one round of the one-CU form (config 4, 1024 problems on one GPU: 5.3 -> 6.0 G coordinate-steps/s).
+static int pair_chunk(const l2o_problem* p, const UnrollGeom& g, hipStream_t s) {
+  if (!opt(L2O_OPT_PAIR) || g.CH < 2) return 0;
+  const int cap = device_cu_count(s) / 2;
+  if (p->B_local <= cap) return p->B_local;
+  if (!opt(L2O_OPT_PAIR_NORMAL) || cap < 8) return 0;
+  const int n = (p->B_local + cap - 1) / cap;               // launches
+  const int chunk = (((p->B_local + n - 1) / n) + 7) & ~7;  // balanced, whole launch groups
+  return chunk <= cap ? chunk : (cap & ~7);
 }
 struct PairLayout { size_t xbuf_off, xbuf_bytes, h_off, q_off, fxh_off, total; int npg, nW; size_t lds; };
 static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) {
@@ -1050,7 +1058,8 @@ template <int PRE, int KIND>
 static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s, const l2o_problem* prob,
                             void* workspace, float* fx, bool* fx_done) {
   const bool hist = a.hist_st != nullptr;
-  if (workspace && pair_eligible(prob, g, s)) {
+  const int chunk = workspace ? pair_chunk(prob, g, s) : 0;
+  if (chunk > 0) {
     const PairLayout L = pair_layout(prob, g, a.T);
     UnrollPairArgs pa;
     pa.u = a;
@@ -1064,7 +1073,8 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     // (no memset here: the workspace starts zeroed -- l2o_unroll_workspace_init -- and the epilogue kernel of every
     //  launch leaves the granule area zeroed for the next one)
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
-    const int groups = (a.pp.B_local + 7) / 8;
+    const int B = a.pp.B_local;
+    const bool one_launch = chunk >= B;
     if (opt(L2O_OPT_PAIR_NORMAL)) {
       // the gradient from the prepared normal matrix (l2o_unroll_pairh.h); prepared here unless the caller did
       if (!a.prepared) {
@@ -1081,7 +1091,17 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
         case 4: fh = hist ? k_unroll_pairh<PRE, KIND, 4, true> : k_unroll_pairh<PRE, KIND, 4, false>; break;
         default: fh = hist ? k_unroll_pairh<PRE, KIND, 8, true> : k_unroll_pairh<PRE, KIND, 8, false>; break;
       }
-      hipLaunchKernelGGL(fh, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, ha);
+      for (int b0 = 0; b0 < B; b0 += chunk) {
+        ha.b0 = b0;
+        ha.nb = B - b0 < chunk ? B - b0 : chunk;
+        hipLaunchKernelGGL(fh, dim3((ha.nb + 7) / 8 * 16), dim3(64 * (g.CH / 2)), L.lds, s, ha);
+        HIP_TRY(hipGetLastError());
+        // (the epilogue of a chunk: its loss partials -> fx_part columns [b0, b0 + nb), its granules zeroed, the launch
+        //  sequence advanced -- the next chunk salts its tags with the new value)
+        hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(64), 0, s, pa.fx_half, a.fx_part, ha.nb, g.CH,
+                           a.pp.inv_bg, one_launch ? fx : nullptr, pa.xbuf, (long)ha.nb * 2 * 2 * L.npg, pa.ws, b0, B);
+        HIP_TRY(hipGetLastError());
+      }
     } else {
       void (*fn)(UnrollPairArgs) = nullptr;
       switch (g.CH) {
@@ -1089,13 +1109,13 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
         case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
         default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
       }
-      hipLaunchKernelGGL(fn, dim3(groups * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
+      hipLaunchKernelGGL(fn, dim3((B + 7) / 8 * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
+      HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(64), 0, s, pa.fx_half, a.fx_part, B, g.CH, a.pp.inv_bg,
+                         fx, pa.xbuf, (long)(L.xbuf_bytes / sizeof(unsigned long long)), pa.ws, 0, B);
+      HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(64), 0, s, pa.fx_half, a.fx_part, a.pp.B_local, g.CH,
-                       a.pp.inv_bg, fx, pa.xbuf, (long)(L.xbuf_bytes / sizeof(unsigned long long)), pa.ws);
-    HIP_TRY(hipGetLastError());
-    if (fx_done) *fx_done = fx != nullptr;
+    if (fx_done) *fx_done = fx != nullptr && (one_launch || !opt(L2O_OPT_PAIR_NORMAL));
     return L2O_OK;
   }
   void (*fn)(UnrollArgs) = nullptr;

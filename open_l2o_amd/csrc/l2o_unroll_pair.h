@@ -374,18 +374,20 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 //   the exchange granules are zeroed for the NEXT launch (tag 0 is never valid; no memset launch per unroll)
 //   the launch sequence word the next launch salts its tags with advances
 __global__ __launch_bounds__(64) void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part,
-                                                       int B_local, int nparts, float inv_bg, float* __restrict__ fx,
-                                                       unsigned long long* __restrict__ xbuf, long xwords, PairWs* ws) {
+                                                       int nb, int nparts, float inv_bg, float* __restrict__ fx,
+                                                       unsigned long long* __restrict__ xbuf, long xwords, PairWs* ws,
+                                                       int b0, int B_local) {
+  // nb problems of this launch = problems [b0, b0 + nb) of the shard (fx_part rows have B_local entries)
   const int t = blockIdx.x, lane = threadIdx.x;
   float acc = 0.0f;
-  for (int b = lane; b < B_local; b += 64) {
-    const float* p = fx_half + ((size_t)t * B_local + b) * nparts;
+  for (int b = lane; b < nb; b += 64) {
+    const float* p = fx_half + ((size_t)t * nb + b) * nparts;
     float f = p[0];
     for (int k = 1; k < nparts; ++k) f += p[k];
-    fx_part[(size_t)t * B_local + b] = f;
+    fx_part[(size_t)t * B_local + b0 + b] = f;
     acc += f;
   }
-  if (fx) {
+  if (fx) {                                               // (single-launch batches only: nb == B_local)
     acc = l2o::wave_sum64(acc);
     if (lane == 0) fx[t] = acc * inv_bg;
   }

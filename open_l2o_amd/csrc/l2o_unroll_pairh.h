@@ -27,6 +27,8 @@ struct UnrollPairHArgs {
   UnrollPairArgs p;
   const float* H;     // [nW][SQ][SQ], zero beyond D (nW = 1 for a shared W)
   const float* qv;    // [B][SQ] = W^T y
+  int b0, nb;         // this launch steps problems [b0, b0 + nb) of the shard: a batch of more than #CU / 2 problems
+                      // runs as consecutive launches of <= #CU / 2 (exchange granules and loss partials are per launch)
 };
 
 // ---- prepare: H = W^T W and q = W^T y, float64 accumulation, rounded once ---------------------
@@ -143,8 +145,9 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
   const int bid = blockIdx.x;
   const unsigned salt = pa.use_salt ? ((pa.ws->seq + 1u) & 0x7fffu) << 16 : 0u;
   const int half = (bid >> 3) & 1;
-  const int b = ((bid >> 4) << 3) | (bid & 7);          // problem index
-  if (b >= pp.B_local) return;                          // padding blocks of the last group of 16 (both halves)
+  const int bl = ((bid >> 4) << 3) | (bid & 7);         // problem index inside this launch's chunk
+  if (bl >= ha.nb) return;                              // padding blocks of the last group of 16 (both halves)
+  const int b = ha.b0 + bl;                             // problem index inside the batch shard
   const int tile_in_prob = half * NWH + wv;             // this wave's coordinate tile
   const int j = tile_in_prob * kTile + c;               // the lane's coordinate AND its residual row
   const bool live = j < D;
@@ -200,8 +203,8 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
   const float kTwoPi = pp.twopi;
   const float* xsq = xs + 4 * q;
   const float* xoq = xo + 4 * q;
-  unsigned long long* mine = pa.xbuf + ((size_t)b * 2 + half) * 2 * SQ;
-  const unsigned long long* theirs = pa.xbuf + ((size_t)b * 2 + (half ^ 1)) * 2 * SQ;
+  unsigned long long* mine = pa.xbuf + ((size_t)bl * 2 + half) * 2 * SQ;
+  const unsigned long long* theirs = pa.xbuf + ((size_t)bl * 2 + (half ^ 1)) * 2 * SQ;
   const int slot = wv * kTile + c;                                // this lane's granule inside a (half, parity) block
   bool dead = false;                                             // partner timed out
   // ---- handshake (l2o_unroll_pair.h): same XCD?  Through the coherent path, in the slot of parity 1 that the
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
     if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
     return live ? gv * cg * sc : 0.0f;
   };
-  float* const fx_wave = pa.fx_half + (size_t)b * (2 * NWH) + half * NWH + wv;   // + t * B_local * 2 NWH
-  const size_t fx_stride = (size_t)pp.B_local * (2 * NWH);
+  float* const fx_wave = pa.fx_half + (size_t)bl * (2 * NWH) + half * NWH + wv;  // + t * nb * 2 NWH
+  const size_t fx_stride = (size_t)ha.nb * (2 * NWH);
 
   for (int t = 0; t < a.T; ++t) {
     const float xsv = live ? xv * sc : 0.0f;
