@@ -384,9 +384,10 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
  * Returns L2O_ERR_UNSUPPORTED when (problem size, net) has no fused kernel.
  *
  * workspace: caller-owned device scratch of l2o_unroll_workspace_bytes() bytes, or NULL.
- * With a workspace, and when 2*B_local workgroups are all co-resident on the device, every
- * problem is split over TWO workgroups (two CUs) that exchange the iterate once per step
- * through tagged 8-byte granules in the workspace; otherwise one workgroup per problem.
+ * With a workspace every problem is split over TWO workgroups (two CUs) that exchange the
+ * iterate once per step through tagged 8-byte granules in the workspace; a launch holds at most
+ * #CU / 2 problems (both halves of each co-resident), a larger shard runs as consecutive launches
+ * of equal chunks.  Without a workspace: one workgroup per problem.
  * The first 4 bytes of the workspace are a STICKY status word the kernel raises if a partner
  * never showed up (bounded spin, no hang; the results of that launch are then invalid): after
  * synchronising, copy them to the host and pass them to l2o_unroll_status(); the caller clears
