@@ -606,9 +606,12 @@ def test_c3_streaming_full_size(eng):
 
 
 @pytest.mark.parametrize("name,kind,B,D,M", [("dm", "quadratic", 2, 256, None), ("rnnprop", "lasso", 3, 512, 40),
-                                             ("dm_logsign", "lasso", 2, 200, 24)])
+                                             ("dm_logsign", "lasso", 2, 200, 24),
+                                             ("rnnprop", "quadratic", 150, 40, None),   # two-CU form, 2 chunk launches
+                                             ("dm", "quadratic", 131, 20, None)])
 def test_streaming_unroll_records_history(eng, name, kind, B, D, M):
-    """l2o_unroll_record on the streaming form (D > 128): the recorded history -- packed state BEFORE each step,
+    """l2o_unroll_record on the streaming form (D > 128) and on the two-CU form with more problems than one launch
+    holds (consecutive chunk launches): the recorded history -- packed state BEFORE each step,
     the gradient fed to the network, RNNProp moments AFTER the step, the gradient at x_T -- equals what the
     step-granular kernels see along the same trajectory, and the recording launch leaves the same x / fx as
     the plain one."""
