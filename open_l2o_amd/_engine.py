@@ -462,6 +462,9 @@ class HipEngine(object):
             if prep is None or prep[0] != key or prep[1] is not p.W or prep[2] is not p.y:
                 _abi.check(self.lib.l2o_unroll_prepare(C.byref(cc), C.byref(cp), wsp, self._stream()))
                 self._ws_prepared = (key, p.W, p.y)
+                # (bench.py times this pass on its own: it is outside the timed unrolls, once per problem instance)
+                self._prepare_again = lambda: _abi.check(self.lib.l2o_unroll_prepare(C.byref(cc), C.byref(cp), wsp,
+                                                                                    self._stream()))
             flags |= _abi.UNROLL_PREPARED
         h = None
         if hist is not None:
