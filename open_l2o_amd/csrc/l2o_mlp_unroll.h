@@ -507,7 +507,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pc.mark(5);                                        // dH
     // ---- the gradient of this lane's coordinate: a sum over the samples, split over the four q lanes
     float gv = 0.0f;
-    if (live) {
+    if (FAST && live && var == 0) {
+      // static trip count (minibatch 64: 16 samples per q lane): all 32 LDS reads in flight, four partial sums --
+      // the dynamic-bound loop below waited out one LDS round trip per sample (1.385 -> 1.41 G).  The same cure for
+      // the forward tail and dH (79 s_waitcnt lgkmcnt: one per w2 row) does NOT pay: batched reads need 48-60 more
+      // registers in a kernel that already spills 20 (1.41 -> 1.22 G; profiles/r02u_mlp_variants.txt)
+      const int k = jl / 20, h = jl - k * 20;
+      float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g4[i & 3] = __builtin_fmaf(imgs[par][q + 4 * i][k - k0], dHs[q + 4 * i][h], g4[i & 3]);
+      gv = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+    } else if (live) {
       if (var == 0) {
         const int k = jl / H, h = jl - k * H;
         for (int sidx = q; sidx < Bn; sidx += 4) gv = __builtin_fmaf(imgs[par][sidx][k - k0], dHs[sidx][h], gv);
