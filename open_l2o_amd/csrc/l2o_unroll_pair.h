@@ -49,7 +49,12 @@ __device__ __forceinline__ unsigned long long pack_granule(float v, unsigned tag
   return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
 
-// N ds_read_b128 at p, p + 64 B, ... issued together, then one s_waitcnt lgkmcnt(0)
+// N ds_read_b128 at p, p + 64 B, ... issued together, then one s_waitcnt lgkmcnt(0).
+// NOT directly behind MFMAs: the hazard recognizer does not see loads inside inline asm, so nothing would keep
+// their data from landing in a register an in-flight MFMA still reads as SrcC (the allocator hands dead chain
+// registers out at once).  Every use below sits behind an LDS barrier (>= the 18 wait states of the longest
+// MFMA WAR hazard); an experiment in k_mlp_unroll that issued such reads right after 60 MFMAs produced NaNs
+// (profiles/r02u_mlp_variants.txt).
 template <int N>
 __device__ __forceinline__ void lds_read_f4(float4 (&v)[N], const float* p) {
   const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
