@@ -270,6 +270,37 @@ def test_fused_unroll_random_shapes(eng):
     print("random-shape sweep: worst rel fx err %.3g over %d cases x 2 kernels" % (worst, len(cases)))
 
 
+def test_two_cu_form_big_batches_random(eng):
+    """Seeded sweep of the two-CU form where it runs as SEVERAL launches (more than #CU / 2 problems: equal chunks
+    of whole launch groups), with x scaling, B_global > B_local and a non-unit step0, against the oracle; the
+    chunked launches also agree bit for bit with the same problems run in two separate smaller batches."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for case in range(6):
+        kind = ["quadratic", "lasso", "square_cos"][case % 3]
+        name = ["dm", "dm_logsign", "rnnprop"][int(rng.integers(3))]
+        D = int(rng.integers(17, 129))
+        B = int(rng.integers(129, 300))
+        M = int(rng.integers(4, 16 * ((D + 15) // 16) + 1)) if kind == "lasso" else None
+        cfg = ORACLE_CFGS[name]
+        params = make_params(cfg, seed=case + 5, trained_like=True)
+        prob, x0, arrays = make_problem(kind, B, D, seed=300 + case, M=M)
+        prob.batch_global = 2 * B
+        xs = np.exp(rng.uniform(-0.3, 0.3, (B, D))).astype(np.float32)
+        T = 4
+        res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, x_scale=xs, step0=2)
+        fx, x, st, m, v = _run_fused(eng, cfg, params, arrays, x0, B, D, T, step0=2, Bg=2 * B, x_scale=xs)
+        e = rel_err(fx, res.fx)
+        worst = max(worst, e)
+        assert e < 1e-5, (kind, name, B, D, M, e)
+        assert max_abs(x, res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max())), (kind, name, B, D, M)
+        # the first 64 problems alone (ONE launch; same B_global, hence the same scaling): bit-identical iterates
+        sub = {k_: (a[:64] if isinstance(a, np.ndarray) and a.shape[:1] == (B,) else a) for k_, a in arrays.items()}
+        x_sub = _run_fused(eng, cfg, params, sub, x0.reshape(B, D)[:64], 64, D, T, step0=2, Bg=2 * B, x_scale=xs[:64])[1]
+        assert np.array_equal(x_sub, x[:64]), (kind, name, B, D, M)
+    print("two-CU form, 129..299 problems (2-3 chunk launches): worst rel fx err %.3g" % worst)
+
+
 def test_fused_unroll_continuation_and_scale(eng):
     """Two T=10 launches carrying x/state/m/v (the harness' `update`) == one T=20 launch;
     x_scale placeholder chain rule; B_global > B_local."""
