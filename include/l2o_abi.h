@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 7
+#define L2O_ABI_VERSION 8
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -361,6 +361,14 @@ int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, cons
  * workspace: l2o_atb_workspace_bytes() bytes of device scratch. */
 size_t l2o_atb_workspace_bytes(int64_t R, int32_t KA, int32_t KB);
 int l2o_atb(const float* A, const float* B, int64_t R, int32_t KA, int32_t KB, float* out, void* workspace, void* stream);
+/* The same contraction restricted to what IS a weight gradient (ABI v8): G [KA][KB] = A^T Bm for the rows written by
+ * l2o_cwlstm_bwd_unroll / _multi / _step of a layers=(20,20) net (KA, KB from l2o_cwlstm_wgrad_dims), computing only
+ * the blocks  [in | h1_prev]^T dz1,  [h1 | h2_prev]^T dz2,  h2^T dd,  (RNNProp) feats^T du  and the bias row
+ * 1^T [dz1 | dz2 | dd | du]  -- 38 of the 66 (43 of 84) 16 x 16 tiles; every other entry of G is written as 0.
+ * Same arithmetic per tile as l2o_atb (bit-equal there), same workspace (l2o_atb_workspace_bytes(R, KA, KB)). */
+int32_t l2o_cwlstm_wgrad_dims(const l2o_net_cfg* cfg, int32_t* KA, int32_t* KB);
+int l2o_cwlstm_wgrad(const l2o_net_cfg* cfg, const float* A, const float* Bm, int64_t R, float* G /* device [KA][KB] */,
+                     void* workspace, void* stream);
 
 /* ---- the meta-step on the device (ABI v5): tf.train.AdamOptimizer(learning_rate).minimize(loss)
  * (DM/meta.py:410-414) without a host round trip of the weights.

@@ -505,6 +505,23 @@ class HipEngine(object):
         _abi.check(self.lib.l2o_atb(_ptr(A), _ptr(B), int(R), int(KA), int(KB), _ptr(out), _ptr(ws), self._stream()))
         return out
 
+    def wgrad(self, spec: NetSpec, A, B):
+        """The weight-gradient blocks of A^T B for the BPTT rows of a layers=(20,20) net (l2o_cwlstm_wgrad: only the
+        tiles that are somebody's gradient; zeros elsewhere) -> new [KA, KB] device tensor."""
+        R, KA = A.shape
+        KB = B.shape[1]
+        cc = spec.to_c()
+        ka, kb = C.c_int32(0), C.c_int32(0)
+        _abi.check(self.lib.l2o_cwlstm_wgrad_dims(C.byref(cc), C.byref(ka), C.byref(kb)))
+        assert (ka.value, kb.value) == (KA, KB), ((ka.value, kb.value), (KA, KB))
+        n = int(self.lib.l2o_atb_workspace_bytes(int(R), int(KA), int(KB)))
+        ws = self.__dict__.get("_atb_ws")
+        if ws is None or ws.numel() * 4 < n:
+            ws = self._atb_ws = self.empty((n + 3) // 4)
+        out = self.empty(KA, KB)
+        _abi.check(self.lib.l2o_cwlstm_wgrad(C.byref(cc), _ptr(A), _ptr(B), int(R), _ptr(out), _ptr(ws), self._stream()))
+        return out
+
     def reduce_fx(self, fx_part, T1, B_local, B_global, fx):
         _abi.check(self.lib.l2o_reduce_fx(_ptr(fx_part), int(T1), int(B_local), int(B_global), _ptr(fx),
                                           self._stream()))

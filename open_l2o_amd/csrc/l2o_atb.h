@@ -14,17 +14,49 @@
 #pragma once
 
 constexpr int kAtbRows = 32;               // rows per block (8 k-steps of the 16x16x4 MFMA)
-constexpr int kAtbMaxGroups = 512;         // split-K partials (persistent workgroups)
+#ifndef L2O_ATB_NBUF
+#define L2O_ATB_NBUF 2                      // LDS buffers per operand (1: single-buffered with 3 / 4 workgroups per CU:
+                                           // measured slower, train step T = 100 1.62 -> 1.74 / 1.70 ms)
+#endif
+#ifndef L2O_ATB_WGS_PER_CU
+#define L2O_ATB_WGS_PER_CU 2
+#endif
+constexpr int kAtbMaxGroups = 256 * L2O_ATB_WGS_PER_CU;   // split-K partials (persistent workgroups)
 
 __host__ __device__ constexpr int atb_ld(int tiles) { return (16 * tiles) % 32 == 16 ? 16 * tiles : 16 * tiles + 16; }
 
-template <int MT, int NT>
+// Which 16 x 16 tiles of the product a caller reads.  MASK 0: all of them (l2o_atb).  MASK 1 / 2 (l2o_cwlstm_wgrad):
+// only the weight-gradient BLOCKS of A^T Bm for the DM nets (KA = 82 | 83, KB = 161) / RNNProp (103 x 181) --
+//   [in | h1_prev]^T dz1,  [h1 | h2_prev]^T dz2,  h2^T dd,  (RNNProp) feats^T du,  and the bias row 1^T [dz1 | dz2 | dd | du]
+// (DM/meta.py:398-414 differentiates w.r.t. exactly these; the cross blocks act1^T dz2, ... are nobody's gradient):
+// 38 of 66 / 43 of 84 tiles.
+__host__ __device__ constexpr bool atb_needed(int mask, int mt, int nt) {
+  return mask == 0 ? true
+       : mask == 1 ? ((mt <= 1 && nt <= 4) || (mt >= 1 && mt <= 3 && nt >= 5 && nt <= 9) || (mt >= 3 && nt == 10) || mt == 5)
+                   : ((mt <= 2 && nt <= 4) || (mt >= 2 && mt <= 4 && nt >= 5 && nt <= 9) || (mt >= 5 && nt == 10) || mt == 6);
+}
+__host__ __device__ constexpr int atb_count(int mask, int MT, int NT) {
+  int n = 0;
+  for (int t = 0; t < MT * NT; ++t) n += atb_needed(mask, t / NT, t % NT) ? 1 : 0;
+  return n;
+}
+// the k-th needed tile (row-major order), -1 past the end
+__host__ __device__ constexpr int atb_nth(int mask, int MT, int NT, int k) {
+  for (int t = 0; t < MT * NT; ++t)
+    if (atb_needed(mask, t / NT, t % NT)) {
+      if (k == 0) return t;
+      --k;
+    }
+  return -1;
+}
+
+template <int MT, int NT, int MASK = 0>
 __global__ __launch_bounds__(256) void k_atb(const float* __restrict__ A, const float* __restrict__ B, long R, int KA,
                                              int KB, float* __restrict__ part) {
   constexpr int LDA = atb_ld(MT), LDB = atb_ld(NT);
-  constexpr int NTILES = MT * NT, TPW = (NTILES + 3) / 4;          // tiles per wave
-  __shared__ float sA[2][kAtbRows * LDA];
-  __shared__ float sB[2][kAtbRows * LDB];
+  constexpr int NTILES = atb_count(MASK, MT, NT), TPW = (NTILES + 3) / 4;   // (needed) tiles, per wave
+  __shared__ float sA[L2O_ATB_NBUF][kAtbRows * LDA];
+  __shared__ float sB[L2O_ATB_NBUF][kAtbRows * LDB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ml = lane & 15, kq = lane >> 4;
@@ -32,8 +64,8 @@ __global__ __launch_bounds__(256) void k_atb(const float* __restrict__ A, const 
 #pragma unroll
   for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // zero the padding columns once (never overwritten)
-  for (int e = tid; e < 2 * kAtbRows * LDA; e += 256) (&sA[0][0])[e] = 0.0f;
-  for (int e = tid; e < 2 * kAtbRows * LDB; e += 256) (&sB[0][0])[e] = 0.0f;
+  for (int e = tid; e < L2O_ATB_NBUF * kAtbRows * LDA; e += 256) (&sA[0][0])[e] = 0.0f;
+  for (int e = tid; e < L2O_ATB_NBUF * kAtbRows * LDB; e += 256) (&sB[0][0])[e] = 0.0f;
   __syncthreads();
   const long nblk = (R + kAtbRows - 1) / kAtbRows;
   // global -> registers -> LDS: wave w fetches rows w * 8 .. w * 8 + 7 of the block, one dword per (row, column)
@@ -90,17 +122,16 @@ __global__ __launch_bounds__(256) void k_atb(const float* __restrict__ A, const 
       constexpr int W = decltype(wc)::value;
 #pragma unroll
       for (int ks = 0; ks < kAtbRows / 4; ++ks) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-          constexpr int dummy = 0; (void)dummy;
-          const int ti = W + 4 * i;
-          if (ti < NTILES) {
-            const int mt = ti / NT, nt = ti - mt * NT;
+        l2o::static_for<0, TPW>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int ti = atb_nth(MASK, MT, NT, W + 4 * i);      // the wave's i-th tile: a compile-time constant
+          if constexpr (ti >= 0) {
+            constexpr int mt = ti / NT, nt = ti - mt * NT;
             const float av = pa[(4 * ks) * LDA + 16 * mt];
             const float bv = pb[(4 * ks) * LDB + 16 * nt];
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
           }
-        }
+        });
       }
     };
     switch (wv) {
@@ -109,31 +140,52 @@ __global__ __launch_bounds__(256) void k_atb(const float* __restrict__ A, const 
       case 2: compute(std::integral_constant<int, 2>{}); break;
       default: compute(std::integral_constant<int, 3>{});
     }
+#if L2O_ATB_NBUF == 2
     if (nxt < nblk) stage(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+#else
+    __syncthreads();                                               // every wave is done with the block in LDS
+    if (nxt < nblk) stage(0);
+    __syncthreads();
+#endif
   }
-  // ---- this workgroup's partial: D[16 mt + 4 kq + r][16 nt + ml]
+  // ---- this workgroup's partial: D[16 mt + 4 kq + r][16 nt + ml] (needed tiles only: the reduction never reads the rest)
   float* out = part + (size_t)blockIdx.x * KA * KB;
+  auto store = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    l2o::static_for<0, TPW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int ti = atb_nth(MASK, MT, NT, W + 4 * i);
+      if constexpr (ti >= 0) {
+        constexpr int mt = ti / NT, nt = ti - mt * NT;
+        const int col = 16 * nt + ml;
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int ti = wv + 4 * i;
-    if (ti < NTILES) {
-      const int mt = ti / NT, nt = ti - mt * NT;
-      const int col = 16 * nt + ml;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mt + 4 * kq + r;
-        if (row < KA && col < KB) out[(size_t)row * KB + col] = acc[i][r];
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + 4 * kq + r;
+          if (row < KA && col < KB) out[(size_t)row * KB + col] = acc[i][r];
+        }
       }
-    }
+    });
+  };
+  switch (wv) {
+    case 0: store(std::integral_constant<int, 0>{}); break;
+    case 1: store(std::integral_constant<int, 1>{}); break;
+    case 2: store(std::integral_constant<int, 2>{}); break;
+    default: store(std::integral_constant<int, 3>{});
   }
 }
 
 // out[e] = sum_g part[g][e], ascending g (bit-reproducible)
-__global__ void k_atb_reduce(const float* __restrict__ part, int groups, int n, float* __restrict__ out) {
+// mask / NT / KB: entries outside the needed tiles are written as zeros without reading the partials
+__global__ void k_atb_reduce(const float* __restrict__ part, int groups, int n, float* __restrict__ out, int mask,
+                             int NT, int KB) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
+  if (mask) {
+    const int row = e / KB, col = e - row * KB;
+    if (!atb_needed(mask, row >> 4, col >> 4)) { out[e] = 0.0f; return; }
+  }
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
   int g = 0;
   for (; g + 3 < groups; g += 4) {

@@ -1543,7 +1543,7 @@ size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp) {
 // ---- G = A^T B, the weight-gradient contraction of the meta-gradient (csrc/l2o_atb.h) ----------------------
 static int atb_groups(int64_t R, hipStream_t s) {
   const int64_t nblk = (R + kAtbRows - 1) / kAtbRows;
-  int g = 2 * device_cu_count(s);                         // two workgroups per CU (72 KB of LDS each)
+  int g = L2O_ATB_WGS_PER_CU * device_cu_count(s);        // workgroups per CU (72 KB of LDS each when double-buffered)
   if (g <= 0 || g > kAtbMaxGroups) g = kAtbMaxGroups;
   return (int)(nblk < g ? nblk : g);
 }
@@ -1551,23 +1551,48 @@ size_t l2o_atb_workspace_bytes(int64_t R, int32_t KA, int32_t KB) {
   if (R <= 0 || KA <= 0 || KB <= 0) return 0;
   return sizeof(float) * (size_t)kAtbMaxGroups * KA * KB;
 }
-int l2o_atb(const float* A, const float* B, int64_t R, int32_t KA, int32_t KB, float* out, void* workspace, void* stream) {
-  if (!A || !B || !out || !workspace || R <= 0 || KA <= 0 || KB <= 0) return fail(L2O_ERR_ARG, "l2o_atb: bad argument");
-  if (KA > 112 || KB > 192) return fail(L2O_ERR_UNSUPPORTED, "l2o_atb: KA <= 112 and KB <= 192 (got %d x %d)", KA, KB);
-  hipStream_t s = (hipStream_t)stream;
+static int atb_launch(const float* A, const float* B, int64_t R, int KA, int KB, int mask, float* out, void* workspace,
+                      hipStream_t s) {
   const int groups = atb_groups(R, s);
   float* part = static_cast<float*>(workspace);
   const int MT = (KA + 15) / 16, NT = (KB + 15) / 16;
   void (*fn)(const float*, const float*, long, int, int, float*) = nullptr;
-  if (MT <= 1 && NT <= 1) fn = k_atb<1, 1>;
+  if (mask == 1) fn = k_atb<6, 11, 1>;
+  else if (mask == 2) fn = k_atb<7, 12, 2>;
+  else if (MT <= 1 && NT <= 1) fn = k_atb<1, 1>;
   else if (MT <= 6 && NT <= 11) fn = k_atb<6, 11>;
   else fn = k_atb<7, 12>;
-  hipLaunchKernelGGL(fn, dim3(groups), dim3(256), 0, s, A, B, (long)R, (int)KA, (int)KB, part);
+  hipLaunchKernelGGL(fn, dim3(groups), dim3(256), 0, s, A, B, (long)R, KA, KB, part);
   HIP_TRY(hipGetLastError());
   const int n = KA * KB;
-  hipLaunchKernelGGL(k_atb_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, groups, n, out);
+  hipLaunchKernelGGL(k_atb_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, groups, n, out, mask,
+                     mask == 2 ? 12 : 11, KB);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
+}
+
+int l2o_atb(const float* A, const float* B, int64_t R, int32_t KA, int32_t KB, float* out, void* workspace, void* stream) {
+  if (!A || !B || !out || !workspace || R <= 0 || KA <= 0 || KB <= 0) return fail(L2O_ERR_ARG, "l2o_atb: bad argument");
+  if (KA > 112 || KB > 192) return fail(L2O_ERR_UNSUPPORTED, "l2o_atb: KA <= 112 and KB <= 192 (got %d x %d)", KA, KB);
+  return atb_launch(A, B, R, KA, KB, 0, out, workspace, (hipStream_t)stream);
+}
+
+int32_t l2o_cwlstm_wgrad_dims(const l2o_net_cfg* cfg, int32_t* KA, int32_t* KB) {
+  if (!cfg || !net_ok_for_mfma(cfg) || cfg->n_layers == 0) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_wgrad: layers=(20,20) nets only");
+  const bool fc = cfg->preprocess == L2O_PRE_FC_ELU;
+  const int P = fc ? kH : (cfg->preprocess == L2O_PRE_LOGSIGN ? 2 : 1);
+  if (KA) *KA = P + kH + 3 * kH + (fc ? 2 : 0) + 1;         // act1 | act2 | h2 | feats | 1   (BwdTileGeom::KA)
+  if (KB) *KB = 8 * kH + 1 + (fc ? kH : 0);                 // dz1 | dz2 | dd | du             (BwdTileGeom::KB)
+  return L2O_OK;
+}
+
+int l2o_cwlstm_wgrad(const l2o_net_cfg* cfg, const float* A, const float* Bm, int64_t R, float* G, void* workspace,
+                     void* stream) {
+  int32_t KA = 0, KB = 0;
+  const int rc = l2o_cwlstm_wgrad_dims(cfg, &KA, &KB);
+  if (rc) return rc;
+  if (!A || !Bm || !G || !workspace || R <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_wgrad: bad argument");
+  return atb_launch(A, Bm, R, KA, KB, cfg->preprocess == L2O_PRE_FC_ELU ? 2 : 1, G, workspace, (hipStream_t)stream);
 }
 
 // ---- generic-`layers` optimizer step (csrc/l2o_generic.h) --------------------------------------------------

@@ -925,7 +925,8 @@ class UnrollGraph(object):
                     if second:
                         hess_update(pn, t, N)
                 carry_in, carry_out = carry_out, carry_in
-            Gm = eng.atb(A.view(T * R, KA), Bm.view(T * R, KB))      # l2o_atb: every weight gradient is a block of A^T Bm
+            # l2o_cwlstm_wgrad: every weight gradient is a block of A^T Bm (only those blocks are computed)
+            Gm = eng.wgrad(spec, A.view(T * R, KA), Bm.view(T * R, KB))
             add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
             add("lstm_1", "b_gates", Gm[KA - 1, 0:4 * H])
             add("lstm_2", "w_gates", Gm[K1:K1 + 2 * H, 4 * H:8 * H])

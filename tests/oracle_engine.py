@@ -53,6 +53,10 @@ class OracleEngine(object):
         """A^T B (the HIP engine's l2o_atb), CPU torch."""
         return A.t().contiguous() @ B
 
+    def wgrad(self, spec, A, B):
+        """The HIP engine's l2o_cwlstm_wgrad: the callers read the weight-gradient blocks of A^T B only."""
+        return self.atb(A, B)
+
     def tensor(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).copy())
 

@@ -270,6 +270,40 @@ def test_fused_unroll_random_shapes(eng):
     print("random-shape sweep: worst rel fx err %.3g over %d cases x 2 kernels" % (worst, len(cases)))
 
 
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_wgrad_blocks_equal_the_dense_product(eng, name):
+    """l2o_cwlstm_wgrad computes only the tiles of A^T Bm that hold a weight gradient: on those BLOCKS it is bit-equal
+    to the dense l2o_atb (same arithmetic per tile), the rest of G is zero."""
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    fc = cfg.kind == "rnnprop"
+    P = 20 if fc else (2 if name == "dm_logsign" else 1)
+    H = 20
+    K1 = P + H
+    KA, KB = K1 + 3 * H + (2 if fc else 0) + 1, 8 * H + 1 + (H if fc else 0)
+    rng = np.random.default_rng(5)
+    R = 16384 * 3 + 5
+    A = eng.tensor(rng.standard_normal((R, KA)).astype(np.float32))
+    B = eng.tensor(rng.standard_normal((R, KB)).astype(np.float32))
+    dense = eng.to_numpy(eng.atb(A, B))
+    got = eng.to_numpy(eng.wgrad(spec, A, B))
+    blocks = [(slice(0, K1), slice(0, 4 * H)), (slice(K1, K1 + 2 * H), slice(4 * H, 8 * H)),
+              (slice(K1 + 2 * H, K1 + 3 * H), slice(8 * H, 8 * H + 1)), (slice(KA - 1, KA), slice(0, KB))]
+    if fc:
+        blocks.append((slice(K1 + 3 * H, K1 + 3 * H + 2), slice(8 * H + 1, 8 * H + 1 + H)))
+    used = np.zeros((KA, KB), bool)
+    for r, c in blocks:
+        assert np.array_equal(got[r, c], dense[r, c]), (name, r, c)
+        used[r, c] = True
+    tiles = np.zeros((KA, KB), bool)                      # whole 16 x 16 tiles that touch a block are computed
+    for i in range(0, KA, 16):
+        for j in range(0, KB, 16):
+            if used[i:i + 16, j:j + 16].any():
+                tiles[i:i + 16, j:j + 16] = True
+    assert np.all(got[~tiles] == 0.0)
+    assert tiles.sum() < 0.75 * KA * KB
+
+
 def test_two_cu_form_big_batches_random(eng):
     """Seeded sweep of the two-CU form where it runs as SEVERAL launches (more than #CU / 2 problems: equal chunks
     of whole launch groups), with x scaling, B_global > B_local and a non-unit step0, against the oracle; the
