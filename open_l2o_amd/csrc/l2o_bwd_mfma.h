@@ -163,6 +163,16 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
   constexpr int kN = bx::chunk_mfmas(PK);
   bx::NetWB<PRE, PK> w;
   bx::load_netw<PRE, true, PK>(w, p.wpack, lane);
+#ifndef L2O_BWD_NO_AGPR_PIN
+  // the forward fragments (MFMA A operands) pinned to the AGPR half of the register file, like LstmCore::pin():
+  // left to itself the allocator parked VALU operands there (212 v_accvgpr_read of the 1 678 instructions of a step)
+#pragma unroll
+  for (int ch = 0; ch < bx::NetWB<PRE, PK>::NCH; ++ch)
+#pragma unroll
+    for (int t5 = 0; t5 < kNT; ++t5)
+#pragma unroll
+      for (int j = 0; j < bx::frags(PK); ++j) asm volatile("" : "+a"(w.a[ch][t5][j]));
+#endif
   const unsigned one = bx::bias_one<PK>(q);
   const size_t ntiles = (size_t)p.tile_end[p.nseg - 1];
   const size_t ngrp4 = (ntiles + 3) / 4;
