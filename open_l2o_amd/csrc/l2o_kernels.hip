@@ -151,6 +151,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           w.a[ch][t][s3] = __builtin_bit_cast(bx::u32x4, v4);
         }
     __syncthreads();                                               // everyone holds its copy: the ring may be used
+#pragma unroll
+    for (int ch = 0; ch < bx::NetWB<PRE, PK>::NCH; ++ch)           // fragments -> AGPRs (MFMA reads them there)
+#pragma unroll
+      for (int t = 0; t < kNT; ++t)
+#pragma unroll
+        for (int s3 = 0; s3 < bx::frags(PK); ++s3) asm volatile("" : "+a"(w.a[ch][t][s3]));
   }
   if (wave >= ntiles) return;
   const int ntl = (ntiles - wave + nwaves - 1) / nwaves;         // tiles of this wave
@@ -706,6 +712,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   // ---- per-lane persistent registers -------------------------------------
   Core core;
   core.load(a.np.wpack, lane);
+  core.pin();   // (bf16x3 forms: fragments -> AGPRs; without it 125-133 v_accvgpr_read per step)
   const int j = wv * kTile + c;             // this lane's coordinate (LSTM role)
   const bool live = j < D;
   const size_t idx = (size_t)b * D + j;
