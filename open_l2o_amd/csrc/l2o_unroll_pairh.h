@@ -283,10 +283,13 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
       for (int m = 0; m < NWH; ++m) dot4(wown[m], x4[m], racc);
       if (!LAST) {
         core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
+#ifndef L2O_PAIRH_OWN_VPM
+#define L2O_PAIRH_OWN_VPM 2     // VALU per MFMA gap: 1 .. 4 all 8.5-8.6 G (profiles/r02w_variants_own_vpm.txt)
+#endif
 #pragma unroll
-        for (int i = 0; i < 4 * NWH; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    // two VALU
+        for (int i = 0; i < (8 * NWH + L2O_PAIRH_OWN_VPM - 1) / L2O_PAIRH_OWN_VPM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, L2O_PAIRH_OWN_VPM, 0);     // VALU
         }
       }
       // (the sums are pinned HERE: the IR-level sinking pass otherwise moves the FMAs to their use behind B2)
