@@ -6,8 +6,11 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from open_l2o_amd._engine import HipEngine
+from open_l2o_amd import _abi
+from open_l2o_amd._engine import HipEngine, NetSpec
 eng = HipEngine()
+SPEC = {82: NetSpec(_abi.NET_CW, _abi.PRE_IDENTITY, (20, 20), 1.0, False),
+        103: NetSpec(_abi.NET_RNNPROP, _abi.PRE_FC_ELU, (20, 20), 0.01, True)}
 
 
 def lib_atb(A, B, chunk):
@@ -38,8 +41,10 @@ for T, KA, KB in ((20, 82, 161), (100, 82, 161), (20, 103, 181), (100, 103, 181)
     B = torch.randn(R, KB, device=eng.device)
     chunk = 4096 if R < (1 << 20) else 8192
     t_new = timeit(lambda: eng.atb(A, B))
+    t_blk = timeit(lambda: eng.wgrad(SPEC[KA], A, B))            # only the weight-gradient tiles (l2o_cwlstm_wgrad)
     t_lib = timeit(lambda: lib_atb(A, B, chunk))
     err = float((eng.atb(A, B) - lib_atb(A, B, chunk)).abs().max())
     gb = 4.0 * R * (KA + KB) / 1e9
-    print("T=%3d rows=%8d %3dx%3d  l2o_atb %7.1f us (%.2f TB/s, %.1f TFLOP/s)   library bmm %7.1f us   max |diff| %.2g"
-          % (T, R, KA, KB, t_new, gb / t_new * 1e-3 * 1e3, 2.0 * R * KA * KB / t_new / 1e6, t_lib, err))
+    print("T=%3d rows=%8d %3dx%3d  l2o_atb %7.1f us (%.2f TB/s, %.1f TFLOP/s)   l2o_cwlstm_wgrad %7.1f us (%.2f TB/s)   "
+          "library bmm %7.1f us   max |diff| %.2g"
+          % (T, R, KA, KB, t_new, gb / t_new * 1e3, 2.0 * R * KA * KB / t_new / 1e6, t_blk, gb / t_blk * 1e3, t_lib, err))
