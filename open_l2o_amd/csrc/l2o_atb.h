@@ -13,7 +13,10 @@
 // bank-conflict free.  Both operands stream from HBM exactly once: 4 (KA + KB) bytes per row.
 #pragma once
 
-constexpr int kAtbRows = 32;               // rows per block (8 k-steps of the 16x16x4 MFMA)
+#ifndef L2O_ATB_ROWS
+#define L2O_ATB_ROWS 32
+#endif
+constexpr int kAtbRows = L2O_ATB_ROWS;     // rows per block (8 k-steps of the 16x16x4 MFMA per 32)
 #ifndef L2O_ATB_NBUF
 #define L2O_ATB_NBUF 2                      // LDS buffers per operand (1: single-buffered with 3 / 4 workgroups per CU:
                                            // measured slower, train step T = 100 1.62 -> 1.74 / 1.70 ms)
