@@ -1572,7 +1572,7 @@ static int atb_launch(const float* A, const float* B, int64_t R, int KA, int KB,
   hipLaunchKernelGGL(fn, dim3(groups), dim3(256), 0, s, A, B, (long)R, KA, KB, part);
   HIP_TRY(hipGetLastError());
   const int n = KA * KB;
-  hipLaunchKernelGGL(k_atb_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, groups, n, out, mask,
+  hipLaunchKernelGGL(k_atb_reduce, dim3((n + 31) / 32), dim3(256), 0, s, part, groups, n, out, mask,
                      mask == 2 ? 12 : 11, KB);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
