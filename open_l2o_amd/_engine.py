@@ -483,11 +483,27 @@ class HipEngine(object):
                                                   _ptr(v), int(T), int(step0), _ptr(fx_part), wsp, C.byref(h),
                                                   self._stream()))
 
+    def prefetch_unroll_status(self):
+        """Queue the copy of the status word into pinned host memory on the launch stream, so that the host sync the
+        caller is about to make anyway (reading the losses back) delivers it too: check_unroll_status() then costs
+        no round trip of its own."""
+        ws = self._last_ws
+        if ws is None:
+            return
+        pin = self.__dict__.get("_status_pin")
+        if pin is None:
+            pin = self._status_pin = torch.zeros(4, dtype=torch.uint8).pin_memory()
+        pin.copy_(ws[:4], non_blocking=True)
+        self._status_pending = ws
+
     def check_unroll_status(self):
         """After a host sync: raise if the split-problem kernel reported a partner timeout."""
         ws = self._last_ws
         if ws is not None:
-            hdr = ws[:4].cpu().numpy().tobytes()
+            if self.__dict__.pop("_status_pending", None) is ws:
+                hdr = self._status_pin.numpy().tobytes()      # (prefetched ahead of the sync that just happened)
+            else:
+                hdr = ws[:4].cpu().numpy().tobytes()
             if hdr != b"\0\0\0\0":
                 ws[:4].zero_()                               # the status word is sticky: handled here, cleared here
             _abi.check(self.lib.l2o_unroll_status(hdr))

@@ -435,8 +435,11 @@ class UnrollGraph(object):
         eng = self.engine
         T = self.len_unroll
         self.wait_fx()
+        fused = self.last_path in ("fused", "mlp_unroll") and hasattr(eng, "check_unroll_status")
+        if fused and hasattr(eng, "prefetch_unroll_status"):
+            eng.prefetch_unroll_status()                 # (rides on the sync below)
         fx_host = eng.to_numpy(fx)                       # host sync
-        if self.last_path in ("fused", "mlp_unroll") and hasattr(eng, "check_unroll_status"):
+        if fused:
             eng.check_unroll_status()
         x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
@@ -795,8 +798,11 @@ class UnrollGraph(object):
         T = self.len_unroll
         grads = self._backward(T, record)                   # (launched before the host reads anything back)
         self.wait_fx()
+        fused = self.last_path == "fused" and hasattr(eng, "check_unroll_status")
+        if fused and hasattr(eng, "prefetch_unroll_status"):
+            eng.prefetch_unroll_status()                    # (rides on the sync below)
         fx_host = eng.to_numpy(fx)                          # host sync
-        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
+        if fused:
             eng.check_unroll_status()                       # a partner timeout leaves a garbage history: raise BEFORE the Adam update
         x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
         self._adam_apply(grads, learning_rate)
