@@ -385,7 +385,9 @@ def run_case(args, eng, world, rank, Bg, B, label):
     elif streaming:
         kernel = "k_unroll_cu"
     elif fused:
-        kernel = "k_unroll_pairh" if 2 * B <= 256 and D > 16 else "k_unroll"
+        # (the two-CU kernel; a shard of more than #CU / 2 = 128 problems runs it as consecutive chunk launches)
+        kernel = "k_unroll" if D <= 16 else ("k_unroll_pairh" if 2 * B <= 256 else
+                                             "k_unroll_pairh x %d chunk launches" % ((B + 127) // 128))
     else:
         kernel = "k_problem_fg1 + k_cwlstm_step per step"
     # HBM bytes per launch that a kernel of this form MUST move (used only when no PMC pass is committed):
