@@ -520,9 +520,10 @@ def main(argv=None):
             "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
                                    % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
                        "kernel": case["kernel"],
-                       "arithmetic": "fp32 state, inputs and outputs; the LSTM gate GEMM is a 6-product 3-way bf16 "
-                                     "split on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level error, "
-                                     "DESIGN.md 2); everything else fp32 VALU",
+                       "arithmetic": "fp32 state, inputs and outputs; the LSTM gate GEMM is a 3-way bf16 split (the six "
+                                     "exact products per term, packed into 4 MFMAs per tile for the DM nets) on "
+                                     "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level error, DESIGN.md 2); "
+                                     "everything else fp32 VALU",
                        "api": "open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> UnrollGraph.launch",
                        "parallelism": "problem-batch sharding x%d, one all-reduce of T+1 floats per unroll" % world,
                        "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
