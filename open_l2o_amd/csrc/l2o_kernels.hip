@@ -1105,7 +1105,7 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
         HIP_TRY(hipGetLastError());
         // (the epilogue of a chunk: its loss partials -> fx_part columns [b0, b0 + nb), its granules zeroed, the launch
         //  sequence advanced -- the next chunk salts its tags with the new value)
-        hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(64), 0, s, pa.fx_half, a.fx_part, ha.nb, g.CH,
+        hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(256), 0, s, pa.fx_half, a.fx_part, ha.nb, g.CH,
                            a.pp.inv_bg, one_launch ? fx : nullptr, pa.xbuf, (long)ha.nb * 2 * 2 * L.npg, pa.ws, b0, B);
         HIP_TRY(hipGetLastError());
       }
@@ -1118,7 +1118,7 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
       }
       hipLaunchKernelGGL(fn, dim3((B + 7) / 8 * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
       HIP_TRY(hipGetLastError());
-      hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(64), 0, s, pa.fx_half, a.fx_part, B, g.CH, a.pp.inv_bg,
+      hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(256), 0, s, pa.fx_half, a.fx_part, B, g.CH, a.pp.inv_bg,
                          fx, pa.xbuf, (long)(L.xbuf_bytes / sizeof(unsigned long long)), pa.ws, 0, B);
       HIP_TRY(hipGetLastError());
     }

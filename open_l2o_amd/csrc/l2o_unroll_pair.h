@@ -378,26 +378,40 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 //   fx[t]         = (sum_b fx_part[t][b]) / B_global, the summation order of k_reduce_fx (optional)
 //   the exchange granules are zeroed for the NEXT launch (tag 0 is never valid; no memset launch per unroll)
 //   the launch sequence word the next launch salts its tags with advances
-__global__ __launch_bounds__(64) void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part,
-                                                       int nb, int nparts, float inv_bg, float* __restrict__ fx,
-                                                       unsigned long long* __restrict__ xbuf, long xwords, PairWs* ws,
-                                                       int b0, int B_local) {
-  // nb problems of this launch = problems [b0, b0 + nb) of the shard (fx_part rows have B_local entries)
-  const int t = blockIdx.x, lane = threadIdx.x;
-  float acc = 0.0f;
-  for (int b = lane; b < nb; b += 64) {
-    const float* p = fx_half + ((size_t)t * nb + b) * nparts;
-    float f = p[0];
-    for (int k = 1; k < nparts; ++k) f += p[k];
-    fx_part[(size_t)t * B_local + b0 + b] = f;
-    acc += f;
-  }
-  if (fx) {                                               // (single-launch batches only: nb == B_local)
-    acc = l2o::wave_sum64(acc);
-    if (lane == 0) fx[t] = acc * inv_bg;
+__global__ __launch_bounds__(256) void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part,
+                                                        int nb, int nparts, float inv_bg, float* __restrict__ fx,
+                                                        unsigned long long* __restrict__ xbuf, long xwords, PairWs* ws,
+                                                        int b0, int B_local) {
+  // nb problems of this launch = problems [b0, b0 + nb) of the shard (fx_part rows have B_local entries).  256 threads:
+  // wave 0 forms the sums (one problem per lane, the partials of a problem as 16-byte loads, all in flight), every
+  // wave zeroes a share of the granules (4.8 -> 3.x us: the kernel sits between two unrolls of a bench step)
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (tid < 64) {
+    float acc = 0.0f;
+    for (int b = lane; b < nb; b += 64) {
+      const float* p = fx_half + ((size_t)t * nb + b) * nparts;
+      float f;
+      if ((nparts & 3) == 0) {                           // (2 * NWH = 4 or 8 partials: whole float4s, 16-byte aligned)
+        const float4 p0 = *reinterpret_cast<const float4*>(p);
+        f = ((p0.x + p0.y) + p0.z) + p0.w;               // (the order of the scalar loop below)
+        for (int k = 4; k < nparts; k += 4) {
+          const float4 pk = *reinterpret_cast<const float4*>(p + k);
+          f = (((f + pk.x) + pk.y) + pk.z) + pk.w;
+        }
+      } else {
+        f = p[0];
+        for (int k = 1; k < nparts; ++k) f += p[k];
+      }
+      fx_part[(size_t)t * B_local + b0 + b] = f;
+      acc += f;
+    }
+    if (fx) {                                             // (single-launch batches only: nb == B_local)
+      acc = l2o::wave_sum64(acc);
+      if (lane == 0) fx[t] = acc * inv_bg;
+    }
   }
   const long per = (xwords + gridDim.x - 1) / gridDim.x;
   const long lo = (long)t * per, hi = lo + per < xwords ? lo + per : xwords;
-  for (long e = lo + lane; e < hi; e += 64) xbuf[e] = 0ull;
-  if (t == 0 && lane == 0) ws->seq = ws->seq + 1u;
+  for (long e = lo + tid; e < hi; e += 256) xbuf[e] = 0ull;
+  if (t == 0 && tid == 0) ws->seq = ws->seq + 1u;
 }
