@@ -5,13 +5,19 @@ product API (open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> one unro
 Default workload (BASELINE.json configs[1]): L2O-DM (CoordinateWiseDeepLSTM, layers (20,20),
 identity preprocess -- what util.get_config("quadratic") builds) on Quadratic d=128,
 batch=128 per GPU, T=100 optimizer steps per unroll, fp32, synthetic data
-(W, y ~ U[0,1), x0 ~ N(0, 0.01^2) as DM/problems.py:84-96; Sonnet-default random LSTM weights,
-output Linear x0.1 so that the untrained optimizer's trajectory stays finite).
+(W, y ~ U[0,1), x0 ~ N(0, 0.01^2) as DM/problems.py:84-96).  The optimizer is the TRAINED one committed
+under tests/golden/trained/ (meta-trained on the MI355X with scripts/train_dm.py / train_rnnprop.py, command
+lines in tests/golden/trained/README.md): its loss FALLS over the unroll, the regime the reference runs in.
+Without a trained file for the workload (config 5, --net dm_logsign) the weights are Sonnet-default random
+draws with the output Linear x0.1 and the line says "untrained" (that trajectory diverges).
 
-One "step" of this benchmark = one complete unroll: rewind x / LSTM state -> T x
-{f(x), grad f, LSTM optimizer step, x += delta} -> f(x_T) -> per-step loss reduction
-(-> all-reduce of the T+1 partial losses over ranks when N > 1).  Inputs are resident in
-HBM when the timed region starts; nothing is copied to the host inside it.
+One UNROLL = what the reference does between `reset` and the last `fx`: a FRESH problem instance
+(one of a ring of --instances pre-sampled instances already resident in HBM) -> its per-problem preparation
+(l2o_unroll_prepare: H = W^T W, q = W^T y for the two-CU form) -> rewind x / LSTM state -> T x {f(x), grad f,
+LSTM optimizer step, x += delta} -> f(x_T) -> per-step loss reduction (-> all-reduce of the T+1 partial losses
+over ranks when N > 1).  One bench "step" = --unrolls-per-step consecutive unrolls (default per config, so that
+--steps 20 times >= 50 ms of GPU work); value counts every one of them.  Inputs are resident in HBM when the
+timed region starts; nothing is copied to the host inside it.
 
     python bench.py --gpus N --steps K --warmup W     (N > 1 without WORLD_SIZE: re-launches itself under
                                                        torch.distributed.run, one rank per GPU, 127.0.0.1)
@@ -140,6 +146,26 @@ def cpu_baseline_mnist(weights, batch, T, max_seconds=15.0):
                       "the 784-20-10 MLP, minibatch %d, %.1f s" % (steps, batch, dt)}
 
 
+TRAINED = {("quadratic", "dm", 128): "dm_quadratic_d128", ("rastrigin", "dm", 100): "dm_rastrigin_d100",
+           ("lasso", "rnnprop", 512): "rnnprop_lasso_256x512"}
+
+
+def trained_weights(args, key):
+    """The committed meta-trained optimizer of this workload (tests/golden/trained/<name>/<net key>.l2l-0, the
+    reference's checkpoint format, DM/networks.py:47-62), or (None, None)."""
+    name = TRAINED.get((args.problem, args.net, args.dims))
+    if name is None or args.untrained:
+        return None, None
+    path = os.path.join(ROOT, "tests", "golden", "trained", name, "%s.l2l-0" % key)
+    if not os.path.exists(path):
+        return None, None
+    import dill
+    with open(path, "rb") as f:
+        d = dill.load(f)
+    w = {m: {v: np.asarray(a, np.float32) for v, a in mv.items()} for m, mv in d.items()}
+    return w, "trained: %s" % os.path.relpath(path, ROOT)
+
+
 def build_workload(args, Bg):
     """Problem + optimizer through the product API."""
     from open_l2o_amd import meta, meta_rnnprop_eval, networks, util
@@ -164,10 +190,14 @@ def build_workload(args, Bg):
         net_config = {"cw": util.get_default_net_config(None)}
     key = next(iter(net_config))
     cfg = dict(net_config[key])
-    # Sonnet-default random init, output Linear x0.1 (see module docstring)
-    weights = networks.factory(cfg["net"], cfg["net_options"]).variables
-    weights = {m: {v: np.array(a) for v, a in d.items()} for m, d in weights.items()}
-    weights["linear"] = {k: (a * np.float32(0.1)).astype(np.float32) for k, a in weights["linear"].items()}
+    weights, wsrc = trained_weights(args, key)
+    if weights is None:
+        # Sonnet-default random init, output Linear x0.1: an UNTRAINED optimizer (its trajectory diverges)
+        weights = networks.factory(cfg["net"], cfg["net_options"]).variables
+        weights = {m: {v: np.array(a) for v, a in d.items()} for m, d in weights.items()}
+        weights["linear"] = {k: (a * np.float32(0.1)).astype(np.float32) for k, a in weights["linear"].items()}
+        wsrc = "untrained: Sonnet-default random draw, output Linear x0.1 (the loss trajectory of this optimizer DIVERGES)"
+    args.weights_source = wsrc
     cfg["net_options"] = dict(cfg["net_options"], initializer=weights)
     net_config = {key: cfg}
     feed = {}
@@ -192,6 +222,12 @@ def parse_args(argv=None):
     ap.add_argument("--unroll", type=int, default=100, help="T")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--untrained", action="store_true", help="random Sonnet-default weights even where a trained "
+                                                             "optimizer is committed (the round-1/2 bench)")
+    ap.add_argument("--unrolls-per-step", dest="reps", type=int, default=None,
+                    help="complete unrolls (each on a fresh problem instance) per bench step; default per config so "
+                         "that 20 steps are >= 50 ms of GPU work")
+    ap.add_argument("--instances", type=int, default=4, help="ring of pre-sampled problem instances resident in HBM")
     ap.add_argument("--no-also", action="store_true", help="N > 1: skip the extra strong-scaling / config-4 runs")
     ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin", "mnist"])
     ap.add_argument("--rows", type=int, default=None, help="lasso rows M (default: dims)")
@@ -209,6 +245,9 @@ def parse_args(argv=None):
         args.problem, args.net, args.dims, args.batch, args.unroll, args.scaling = "rastrigin", "dm", 100, 1024, 100, "strong"
     elif args.config == 5:
         args.problem, args.net, args.batch, args.unroll = "mnist", "rnnprop", 64, 200
+    if args.reps is None:
+        # one unroll: config 2 ~0.22 ms, config 4 (one GPU) ~1.6 ms, config 3 ~5.5 ms, config 5 ~2.3 ms
+        args.reps = {"quadratic": 16, "rastrigin": 4, "lasso": 2, "mnist": 2}[args.problem]
     return args
 
 
@@ -314,23 +353,46 @@ def run_case(args, eng, world, rank, Bg, B, label):
     graph = optimizer.graph
     graph.reset()                                           # (first call: allocator / context warm-up)
     torch.cuda.synchronize()
-    t_reset = time.perf_counter()
-    graph.reset()                                           # sample x0, W, y on the host (NumPy), upload this rank's shard
+    # ---- a ring of problem instances, sampled and uploaded BEFORE the timed region (H2D excluded):
+    # every timed unroll runs on the next instance, so whatever a new instance costs on the device (the two-CU
+    # form's l2o_unroll_prepare) is inside the timed region.  The iterate lives in its own working buffer.
+    graph.launch(feed, commit=True, use_graph=True, restart=[v.value.clone() for v in graph.x])   # which path?
     torch.cuda.synchronize()
-    t_reset = time.perf_counter() - t_reset
-    x0 = [v.value.clone() for v in graph.x]
+    # (only the single-launch fused forms take a new instance per unroll: the step-granular path replays a captured
+    #  HIP graph that holds the instance's pointers, and the MLP optimizee has no per-instance constants)
+    n_inst = max(1, args.instances) if graph.last_path == "fused" else 1
+    ring, t_reset = [], 0.0
+    for r in range(n_inst):
+        t1 = time.perf_counter()
+        graph.reset()                                       # sample x0, W, y on the host (NumPy), upload this rank's shard
+        torch.cuda.synchronize()
+        t_reset = time.perf_counter() - t1
+        ring.append(([v.value.clone() for v in graph.x], [v.value for v in graph.constants]))
+    x0 = ring[0][0]
+
+    def use_instance(r):
+        for v, t in zip(graph.constants, ring[r][1]):
+            v.value = t
+        return ring[r][0]
+
     # HIP events: ONE pair around the whole timed region (a timing event is a barrier packet + a timestamp write:
     # a pair per launch put ~10 us of idle GPU between two unrolls), plus per-launch pairs on a few EXTRA launches
     # after the timed region (kernel_ms_min / the per-launch spread; not part of `value`)
     ev_all = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev_rep = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     n_extra = min(5, args.steps)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_extra)]
+    reps = max(1, args.reps)
+    cursor = [0]
 
-    def one_unroll(i=None):
-        # x <- x0, LSTM state (m, v) <- 0, then the unroll: restart= folds the rewind into the fused kernels' prologue
-        # (they read x0 and start from zero registers); every other path runs graph.rewind(x0) first
-        # (the step-granular path replays its 2..6 x T small launches from a HIP graph)
-        fx, _ = graph.launch(feed, commit=True, events=None if i is None else ev[i], use_graph=True, restart=x0)
+    def one_unroll(i=None, fresh=True):
+        # next problem instance; x <- its x0, LSTM state (m, v) <- 0, then the unroll: restart= folds the rewind into
+        # the fused kernels' prologue (they read x0 and start from zero registers); every other path runs
+        # graph.rewind(x0) first (the step-granular path replays its 2..6 x T small launches from a HIP graph)
+        if fresh:
+            cursor[0] = (cursor[0] + 1) % n_inst
+        xi = use_instance(cursor[0])
+        fx, _ = graph.launch(feed, commit=True, events=None if i is None else ev[i], use_graph=True, restart=xi)
         return fx
 
     def fence():
@@ -341,12 +403,14 @@ def run_case(args, eng, world, rank, Bg, B, label):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_unroll()
+        for _ in range(reps):
+            one_unroll()
     fence()
     t0 = time.perf_counter()
     ev_all[0].record()
     for i in range(args.steps):
-        fx = one_unroll()
+        for _ in range(reps):
+            fx = one_unroll()
     ev_all[1].record()
     fence()
     dt = time.perf_counter() - t0
@@ -355,14 +419,24 @@ def run_case(args, eng, world, rank, Bg, B, label):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fx_host = eng.to_numpy(fx)
+    fx_instance = cursor[0]
     eng.check_unroll_status()
-    for i in range(n_extra):                                # (outside the timed region)
-        one_unroll(i)
+    n_unrolls = args.steps * reps
+    unroll_all_ms = ev_all[0].elapsed_time(ev_all[1]) / n_unrolls
+    # ---- (outside the timed region) the dominant kernel on its own: the SAME instance replayed, so no preparation
+    # runs between the launches -- the time base of the roofline block
+    one_unroll(None, fresh=False)
+    ev_rep[0].record()
+    for _ in range(max(10, reps)):
+        one_unroll(None, fresh=False)
+    ev_rep[1].record()
+    for i in range(n_extra):
+        one_unroll(i, fresh=False)
     torch.cuda.synchronize()
     kt = [a.elapsed_time(b) for a, b in ev]
-    kern_all = ev_all[0].elapsed_time(ev_all[1]) / args.steps
+    kern_all = ev_rep[0].elapsed_time(ev_rep[1]) / max(10, reps)
     # the per-problem preparation of the two-CU form (H = W^T W, q = W^T y; l2o_unroll_prepare): runs once per problem
-    # instance (here: inside the first warm-up launch), NOT inside the timed unrolls -- reported on its own
+    # instance -- INSIDE every timed unroll above; timed on its own here for the breakdown
     prepare_ms = None
     again = getattr(eng, "_prepare_again", None)
     if again is not None and graph.last_path == "fused":
@@ -394,8 +468,11 @@ def run_case(args, eng, world, rank, Bg, B, label):
     # the per-problem matrices once per evaluation (T + 1) + x / state once each way
     mat_bytes = 0 if args.problem == "mnist" else 4.0 * (1 if shared else B) * Mrows * D
     hbm_model = mat_bytes * ((T + 1) if (streaming or not fused) else 2) + 2 * 4.0 * B * D * 81
-    return {"label": label, "graph": graph, "weights": weights, "x0": x0, "fx_host": fx_host, "dt": dt,
-            "value": world * coord_steps * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+    return {"label": label, "graph": graph, "weights": weights, "x0": ring[fx_instance][0], "fx_host": fx_host, "dt": dt,
+            "value": world * coord_steps * n_unrolls / dt, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_unroll": dt / n_unrolls * 1e3, "unroll_ms_events": float(unroll_all_ms), "reps": reps,
+            "n_inst": n_inst, "fx_instance": fx_instance,
+            "value_replayed": world * coord_steps / (float(kern_all) * 1e-3),
             "kern_ms": float(kern_all), "kern_ms_min": float(np.min(kt)), "coord_steps": coord_steps,
             "bpc": bpc, "alg_bytes": bpc * coord_steps,
             "flops": alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps,
@@ -501,11 +578,14 @@ def main(argv=None):
                                     case["kernel"] if case["fused"] else "")
         roof = roofline_block(case, args, counters)
         roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms_host_sampling_plus_h2d=case["t_reset"] * 1e3)
+        roof.update(time_base="kernel_ms_avg: HIP events on the launch stream of THIS run around replays of one problem "
+                              "instance (the unroll kernel + its epilogue, no preparation); counters (traffic, issue): the "
+                              "committed rocprofv3 --pmc passes named in counters_source, collected on an earlier lease "
+                              "of the same bench command")
         if case.get("prepare_ms") is not None:
-            roof.update(problem_prepare_ms_once_per_reset=case["prepare_ms"],
-                        problem_prepare_note="l2o_unroll_prepare (H = W^T W, q = W^T y of the sampled problems) runs once "
-                                             "per problem instance, outside the timed unrolls; a launch without "
-                                             "L2O_UNROLL_PREPARED pays it every time")
+            roof.update(problem_prepare_ms=case["prepare_ms"],
+                        problem_prepare_note="l2o_unroll_prepare (H = W^T W, q = W^T y of the sampled problems): once per "
+                                             "problem instance, INSIDE every timed unroll (each runs on a fresh instance)")
         scaling_note = None
         if world > 1 or args.scaling == "strong":
             scaling_note = ("weak: %d problems per GPU, global batch %d (config 2 cannot strong-scale: a T-step unroll "
@@ -515,11 +595,16 @@ def main(argv=None):
         out = {
             "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
             "value": case["value"], "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": case["ms_per_step"], "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": case["ms_per_step"], "unrolls_per_step": case["reps"],
+            "ms_per_unroll": case["ms_per_unroll"], "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
                                    % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
                        "kernel": case["kernel"],
+                       "optimizer_weights": getattr(args, "weights_source", None),
+                       "step_definition": "one bench step = %d complete unrolls, each on the next of %d pre-uploaded problem "
+                                          "instances: per-problem preparation + rewind + T optimizer steps + f(x_T) + loss "
+                                          "reduction; value counts all steps x unrolls" % (case["reps"], case["n_inst"]),
                        "arithmetic": "fp32 state, inputs and outputs; the LSTM gate GEMM is a 3-way bf16 split (the six "
                                      "exact products per term, packed into 4 MFMAs per tile for the DM nets) on "
                                      "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level error, DESIGN.md 2); "
@@ -530,6 +615,9 @@ def main(argv=None):
                        "backend": (dist.get_backend() if world > 1 else None),
                        "scaling_note": scaling_note},
             "final_loss_fx_T": float(case["fx_host"][-1]), "fx_0": float(case["fx_host"][0]),
+            "value_replayed_problem": case["value_replayed"],
+            "value_replayed_note": "the round-1/2 figure: the same instance replayed (no per-problem preparation in the "
+                                   "timed launches); not the headline",
             "parity_pin": PARITY_PIN,
             "roofline": roof,
         }
@@ -549,6 +637,9 @@ def main(argv=None):
                 out["cpu_baseline"] = cpu_baseline(args.problem, args.net, arrays, case["weights"],
                                                    eng.to_numpy(case["x0"][0]).reshape(B, D), T)
             out["speedup_vs_cpu_baseline"] = case["value"] / out["cpu_baseline"]["value"]
+            if "fx_T" in out["cpu_baseline"]:
+                ref = out["cpu_baseline"]["fx_T"]
+                out["final_loss_rel_diff_vs_cpu_port"] = abs(out["final_loss_fx_T"] - ref) / max(abs(ref), 1e-30)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -466,6 +466,10 @@ class HipEngine(object):
                 self._prepare_again = lambda: _abi.check(self.lib.l2o_unroll_prepare(C.byref(cc), C.byref(cp), wsp,
                                                                                     self._stream()))
             flags |= _abi.UNROLL_PREPARED
+        elif ws is not None:
+            # a launch WITHOUT the PREPARED flag re-prepares H / q of THIS problem in the shared workspace: whatever
+            # the fx= path cached there for another problem is gone (stale H / q -> silently wrong iterates)
+            self._ws_prepared = None
         h = None
         if hist is not None:
             h = _abi.UnrollHist()

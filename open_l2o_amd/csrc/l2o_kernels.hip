@@ -1017,7 +1017,7 @@ static int pair_chunk(const l2o_problem* p, const UnrollGeom& g, hipStream_t s) 
   if (!opt(L2O_OPT_PAIR) || g.CH < 2) return 0;
   const int cap = device_cu_count(s) / 2;
   if (p->B_local <= cap) return p->B_local;
-  if (!opt(L2O_OPT_PAIR_NORMAL) || cap < 8) return 0;
+  if (cap < 8) return 0;
   const int n = (p->B_local + cap - 1) / cap;               // launches
   const int chunk = (((p->B_local + n - 1) / n) + 7) & ~7;  // balanced, whole launch groups
   return chunk <= cap ? chunk : (cap & ~7);
@@ -1077,6 +1077,8 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     //  k_combine_halves advances after every launch: no host-side launch state)
     pa.use_salt = a.T + 1 < 0xffff ? 1u : 0u;
     pa.plain_stores = opt(L2O_OPT_PAIR_PLAIN_STORES) ? 1u : 0u;
+    pa.b0 = 0;
+    pa.nb = a.pp.B_local;
     // (no memset here: the workspace starts zeroed -- l2o_unroll_workspace_init -- and the epilogue kernel of every
     //  launch leaves the granule area zeroed for the next one)
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
@@ -1116,13 +1118,17 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
         case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
         default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
       }
-      hipLaunchKernelGGL(fn, dim3((B + 7) / 8 * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
-      HIP_TRY(hipGetLastError());
-      hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(256), 0, s, pa.fx_half, a.fx_part, B, g.CH, a.pp.inv_bg,
-                         fx, pa.xbuf, (long)(L.xbuf_bytes / sizeof(unsigned long long)), pa.ws, 0, B);
-      HIP_TRY(hipGetLastError());
+      for (int b0 = 0; b0 < B; b0 += chunk) {
+        pa.b0 = b0;
+        pa.nb = B - b0 < chunk ? B - b0 : chunk;
+        hipLaunchKernelGGL(fn, dim3((pa.nb + 7) / 8 * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(256), 0, s, pa.fx_half, a.fx_part, pa.nb, g.CH,
+                           a.pp.inv_bg, one_launch ? fx : nullptr, pa.xbuf, (long)pa.nb * 2 * 2 * L.npg, pa.ws, b0, B);
+        HIP_TRY(hipGetLastError());
+      }
     }
-    if (fx_done) *fx_done = fx != nullptr && (one_launch || !opt(L2O_OPT_PAIR_NORMAL));
+    if (fx_done) *fx_done = fx != nullptr && one_launch;
     return L2O_OK;
   }
   void (*fn)(UnrollArgs) = nullptr;

@@ -43,6 +43,8 @@ struct UnrollPairArgs {
   unsigned use_salt;          // tags carry the launch sequence in their upper bits (T + 1 < 65 535): a granule left by an
                               // earlier launch never matches, on top of the memset of the granule area ahead of every launch
   unsigned plain_stores;      // L2O_OPT_PAIR_PLAIN_STORES: a confirmed same-XCD pair publishes with plain stores
+  int b0, nb;                 // this launch steps problems [b0, b0 + nb) of the shard: a batch of more than #CU / 2 problems
+                              // runs as consecutive launches of <= #CU / 2 (exchange granules and loss partials are per launch)
 };
 
 __device__ __forceinline__ unsigned long long pack_granule(float v, unsigned tag) {
@@ -95,8 +97,9 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const int bid = blockIdx.x;
   const unsigned salt = pa.use_salt ? ((pa.ws->seq + 1u) & 0x7fffu) << 16 : 0u;
   const int half = (bid >> 3) & 1;
-  const int b = ((bid >> 4) << 3) | (bid & 7);          // problem index
-  if (b >= pp.B_local) return;                          // padding blocks of the last group of 16 (both halves)
+  const int bl = ((bid >> 4) << 3) | (bid & 7);         // problem index inside this launch's chunk
+  if (bl >= pa.nb) return;                              // padding blocks of the last group of 16 (both halves)
+  const int b = pa.b0 + bl;                             // problem index inside the batch shard
   const int tile_in_prob = half * NWH + wv;             // this wave's coordinate tile
   // GEMV role of a lane = its LSTM role: row / column gr = c, 16-byte chunk gq = q.  The four chunk partial sums
   // of a row / column then sit on the lanes (c, 0..3) and two permlane swaps add them INTO the lanes that feed
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const float kTwoPi = pp.twopi;
   const float* xsq = xs + 4 * gq;
   const float* rsq = rs + 4 * gq;
-  unsigned long long* mine = pa.xbuf + ((size_t)b * 2 + half) * 2 * SQ;
-  const unsigned long long* theirs = pa.xbuf + ((size_t)b * 2 + (half ^ 1)) * 2 * SQ;
+  unsigned long long* mine = pa.xbuf + ((size_t)bl * 2 + half) * 2 * SQ;
+  const unsigned long long* theirs = pa.xbuf + ((size_t)bl * 2 + (half ^ 1)) * 2 * SQ;
   bool dead = false;                                             // partner timed out
   // ---- handshake: do the two halves of this problem run on the same XCD?  HIP promises nothing about
   // placement (observed: block b on XCD b % 8, hence the b / b + 8 pairing above), so the halves tell each
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     // thread-0 sum on the step's critical path; k_combine_halves adds the 2 x NWH partials per (step, problem)
     {
       const float fw = wave_sum64(contrib);
-      if (lane == 0) pa.fx_half[((size_t)t * pp.B_local + b) * (2 * NWH) + half * NWH + wv] = fw;
+      if (lane == 0) pa.fx_half[((size_t)t * pa.nb + bl) * (2 * NWH) + half * NWH + wv] = fw;
     }
     if (t == a.T && !HIST) break;
 

@@ -196,6 +196,7 @@ class StandardDeepLSTM(Network):
     def variables(self, value):
         self._variables = value
         self._host_stale = False
+        self._wversion = getattr(self, "_wversion", 0) + 1
 
     def _pull_from_device(self):
         flat = self._wdev_engine.to_numpy(self._wdev_buf)
@@ -207,6 +208,7 @@ class StandardDeepLSTM(Network):
     def mark_device_updated(self):
         """The flat device buffer (and the packed copy) were updated in place: the host dict is stale."""
         self._host_stale = True
+        self._wversion = getattr(self, "_wversion", 0) + 1     # (every cache derived from the weights keys on this)
 
     # -- device weights ----------------------------------------------------
     def wpack(self, engine):
@@ -230,6 +232,7 @@ class StandardDeepLSTM(Network):
         self._variables[module_name][variable_name] = np.asarray(value, np.float32).reshape(cur.shape).copy()
         self._wpack = None
         self._wdev = None
+        self._wversion = getattr(self, "_wversion", 0) + 1
 
     def device_weights(self, engine):
         """Device copies of the weights in their Sonnet layouts, keyed like struct
@@ -308,8 +311,10 @@ class RNNprop(StandardDeepLSTM):
         engine = prev_state.engine
         n = self._panel(g)
         gen = self.__dict__.get("_gen_direct")
-        if gen is None or gen[0] is not engine or gen[2] is not self._variables:
-            gen = self._gen_direct = (engine, engine.gen_net(self.spec, self.variables, direct=True), self._variables)
+        # keyed on the weights VERSION: assign() / the device meta-step mutate the dict in place (its identity never
+        # changes), and an eager call after restore() or a training step must see the new weights
+        if gen is None or gen[0] is not engine or gen[2] != self._wversion:
+            gen = self._gen_direct = (engine, engine.gen_net(self.spec, self.variables, direct=True), self._wversion)
         if prev_state.generic:
             st = prev_state.packed.clone()
         else:                                              # (20, 20): tile-major packed -> per-layer [N, H] -> back

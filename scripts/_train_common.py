@@ -53,6 +53,10 @@ def parse_flags(rnnprop):
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--batch_size", type=int, default=None)
     p.add_argument("--num_dims", type=int, default=None)
+    p.add_argument("--num_rows", type=int, default=None, help="lasso: rows of the sensing matrix (default: num_dims)")
+    p.add_argument("--l", type=float, default=None, help="lasso: l1 weight (DM/problems.py:103 default 0.005)")
+    p.add_argument("--max_seconds", type=float, default=None,
+                   help="stop after the first evaluation past this wall time (bounded GPU leases)")
     p.add_argument("--synthetic_mnist", type=int, default=0,
                    help="problems.mnist on N synthetic MNIST-shaped examples (no dataset ships offline)")
     if rnnprop:
@@ -73,7 +77,9 @@ class Trainer(object):
             np.random.seed(flags.seed)
         if flags.save_path and not os.path.exists(flags.save_path):
             os.mkdir(flags.save_path)
-        opts = {k: v for k, v in (("batch_size", flags.batch_size), ("num_dims", flags.num_dims)) if v is not None}
+        opts = {k: v for k, v in (("batch_size", flags.batch_size), ("num_dims", flags.num_dims),
+                                  ("num_rows", getattr(flags, "num_rows", None)), ("l", getattr(flags, "l", None)))
+                if v is not None}
         if getattr(flags, "synthetic_mnist", 0):
             from open_l2o_amd import problems
             opts["data"] = problems.synthetic_mnist(flags.synthetic_mnist)
@@ -137,6 +143,7 @@ class Trainer(object):
         t0 = timer()
         mt_ratios = [float(r) for r in getattr(f, "mt_ratios", "0.3").split()]
         mti = -1
+        stop = False
         with MonitoredSession() as sess:
             for rst in [self.minimize.reset] + self.reset_mt:
                 sess.run(rst)
@@ -160,6 +167,8 @@ class Trainer(object):
                 eval_cost = self._evaluate(sess, stages[1:][stage] if f.if_cl else n_train)
                 print("epoch={}, num_steps={}, eval_loss={}".format(e, horizon, eval_cost / f.evaluation_epochs),
                       flush=True)
+                if getattr(f, "max_seconds", None) and timer() - t0 > f.max_seconds:
+                    stop = True
                 if not f.if_cl:
                     if eval_cost < best:
                         best = eval_cost
@@ -167,6 +176,8 @@ class Trainer(object):
                             self.optimizer.save(sess, f.save_path, e + 1)
                             self.optimizer.save(sess, f.save_path, 0)
                             print("Saving optimizer of epoch {}...".format(e + 1))
+                    if stop:
+                        break
                     continue
                 # curriculum: advance when a stage stopped improving (DM/train_dm.py:198-226)
                 if eval_cost < best:
@@ -184,6 +195,8 @@ class Trainer(object):
                                                                        best / f.evaluation_epochs), flush=True)
                 elif n_eval >= f.min_num_eval and not improved:
                     print("no improve during curriculum {} --> stop".format(stage))
+                    break
+                if stop:
                     break
         print("total time = {}s...".format(timer() - t0))
 

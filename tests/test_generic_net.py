@@ -84,6 +84,32 @@ def test_rnnprop_eager_call(hip, layers):
             assert max_abs(h, hr) < 2e-6 and max_abs(c, cr) < 4e-6
 
 
+def test_rnnprop_eager_call_follows_assign(hip):
+    """the eager net(m, g, state) caches a device copy of the weights; assign() (MetaOptimizer.restore,
+    the host Adam step) mutates the weight dict IN PLACE -- the next call must run the new weights."""
+    layers = (20, 20)
+    cfg = O.NetConfig("rnnprop", layers, "fc", {"dim": 20}, 0.01, True)
+    params = make_params(cfg, seed=38)
+    net = networks.RNNprop(layers=layers, preprocess_name="fc", preprocess_options={"dim": 20}, scale=0.01,
+                           tanh_output=True, initializer=params)
+    rng = np.random.default_rng(39)
+    shape = (5, 16)
+    m = rng.standard_normal(shape).astype(np.float32)
+    g = rng.standard_normal(shape).astype(np.float32)
+    state = net.initial_state_for_inputs(hip.tensor(np.zeros(shape)), engine=hip)
+    upd0, _ = net(hip.tensor(m), hip.tensor(g), state)
+    new = {k: {v: a.copy() for v, a in d.items()} for k, d in params.items()}
+    new["linear"]["w"] = (new["linear"]["w"] * 3.0 + 0.05).astype(np.float32)
+    new["lstm_1"]["b_gates"] = (new["lstm_1"]["b_gates"] + 0.2).astype(np.float32)
+    for mod in ("linear", "lstm_1"):
+        for var, val in new[mod].items():
+            net.assign(mod, var, val)
+    upd1, _ = net(hip.tensor(m), hip.tensor(g), state)
+    want, _ = O.net_apply(cfg, new, (m, g), O.net_initial_state(cfg, 80))
+    assert max_abs(hip.to_numpy(upd0), hip.to_numpy(upd1)) > 1e-4          # the weights did change the update
+    assert max_abs(hip.to_numpy(upd1), want) < 2e-7 + 2e-5 * float(np.abs(want).max())
+
+
 def test_generic_net_drives_an_unroll(hip):
     """MetaOptimizer.meta_loss with CoordinateWiseDeepLSTM(layers=(4, 3)) on Quadratic: the step-granular path with the
     generic optimizer step, against the oracle's unroll."""

@@ -565,6 +565,33 @@ def test_unroll_preparation_follows_the_problem(eng):
     assert rel_err(launch(), res2.fx) < 1e-5 and eng._ws_prepared is not first
 
 
+def test_unroll_preparation_survives_an_unprepared_launch_of_another_problem(eng):
+    """a launch WITHOUT fx= (l2o_unroll / l2o_unroll_record) prepares H, q of ITS problem in the shared
+    workspace; the engine must forget what the fx= path had cached there, or the next fx= launch of the first
+    problem runs on the other problem's H / q (silently wrong iterates)."""
+    cfg = O.DM_IDENTITY
+    params = make_params(cfg, seed=23, trained_like=True)
+    B, D, T = 6, 40, 8
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    probA, x0, arrA = make_problem("quadratic", B, D, seed=24)
+    probB, _, arrB = make_problem("quadratic", B, D, seed=25)
+    pdA, pdB = device_problem(eng, arrA, B, D), device_problem(eng, arrB, B, D)
+    fx = eng.zeros(T + 1)
+    with lib_option(_abi.OPT_PAIR_NORMAL, 1):
+        def launch_a():
+            x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
+            eng.unroll(spec, wpack, pdA, x, st, None, None, T, 1, eng.zeros((T + 1) * B), fx=fx)
+            return eng.to_numpy(fx).copy()
+        first = launch_a()
+        x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
+        eng.unroll(spec, wpack, pdB, x, st, None, None, T, 1, eng.zeros((T + 1) * B))      # no fx=: unprepared launch of B
+        again = launch_a()
+    res = O.unroll(probA, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    assert rel_err(first, res.fx) < 1e-5
+    assert np.array_equal(first, again)
+
+
 def test_fused_rejects_what_it_cannot_do(eng):
     from open_l2o_amd import _abi
     cfg = O.DM_IDENTITY

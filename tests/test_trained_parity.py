@@ -1,0 +1,243 @@
+"""Parity in the regime the reference actually runs in: a TRAINED optimizer whose loss FALLS.
+
+The weights are the committed `.l2l` files of tests/golden/trained/ (meta-trained on the MI355X with the repo's own
+drivers; command lines in the README there).  Every test runs the full-size BASELINE configuration through the C ABI
+and compares with the fp32 C oracle (and, for the long horizons, the float64 NumPy oracle) on the same inputs:
+
+  * configs 2 / 4-shard, T = 100: the whole fx[0..T] at 1e-5 relative (the north_star bar), x_T and the LSTM state, on
+    ALL three fused forms -- the two-CU kernel in its reference-arithmetic form (r = Wx - y, g = W^T r), its
+    normal-matrix form (H x - q) and the one-CU kernel;
+  * the per-step GRADIENT of both two-CU forms against the float64 gradient at the kernel's own iterates, bounded by
+    the error of the reference's own fp32 arithmetic (NumPy two-pass) -- the probe that shows what H x - q costs once
+    |g| has fallen (profiles/r03a_trained_parity_probe.txt);
+  * T = 1000 and T = 10 000 (DM/train_dm.py:66, DM/evaluate_dm.py:43) against the float64 oracle, bounded by 3 x the
+    drift of the fp32 oracle itself;
+  * config 3 (RNNProp on Lasso, T = 200): the l1 term's sign(x) makes the CONVERGED trajectory chaotic -- the fp32
+    oracle started one ulp away from x_0 drifts by 2e-3 in fx after ~100 steps -- so the trajectory is held to 1e-5 on
+    the prefix where that sensitivity is below 1e-6, to 3 x the oracle's own one-ulp sensitivity beyond, and the
+    converged regime is checked by RE-SYNCHRONISED segments (20 steps from the oracle's x / state / moments at
+    t = 100 and 160) at 1e-5.
+"""
+import contextlib
+import os
+
+import dill
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import device_problem, lib_option, make_problem, max_abs, rel_err, spec_of
+from open_l2o_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRAINED = os.path.join(ROOT, "tests", "golden", "trained")
+
+FORMS = {"two_pass": {_abi.OPT_PAIR_NORMAL: 0}, "normal": {_abi.OPT_PAIR_NORMAL: 1}, "one_cu": {_abi.OPT_PAIR: 0}}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from open_l2o_amd._engine import HipEngine
+    return HipEngine()
+
+
+def load_l2l(name, key):
+    with open(os.path.join(TRAINED, name, "%s.l2l-0" % key), "rb") as f:
+        d = dill.load(f)
+    return {k: {v: np.asarray(a, np.float32) for v, a in m.items()} for k, m in d.items()}
+
+
+@contextlib.contextmanager
+def form(name):
+    with contextlib.ExitStack() as es:
+        for o, v in FORMS[name].items():
+            es.enter_context(lib_option(o, v))
+        yield
+
+
+def fused(eng, cfg, params, arrays, x0, B, D, T, Bg=None, state0=None, m0=None, v0=None, step0=1, hist=False):
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D, B_global=Bg)
+    x = eng.tensor(np.asarray(x0, np.float32).reshape(B, D))
+    st = eng.state_alloc(B, D) if state0 is None else eng.state_pack(*[eng.tensor(a) for hc in state0 for a in hc], B, D)
+    m = eng.zeros(B, D) if m0 is None else eng.tensor(m0.reshape(B, D))
+    v = eng.zeros(B, D) if v0 is None else eng.tensor(v0.reshape(B, D))
+    fx_part, fx = eng.zeros((T + 1) * B), eng.zeros(T + 1)
+    h = None
+    if hist:
+        h = dict(st=eng.zeros(T, eng.state_floats(B, D)), g=eng.zeros(T, B * D), g_final=eng.zeros(B * D))
+    eng.unroll(spec, wpack, pd, x, st, m, v, T, step0, fx_part, hist=h)
+    eng.reduce_fx(fx_part, T + 1, B, Bg or B, fx)
+    eng.synchronize()
+    eng.check_unroll_status()
+    state = [eng.to_numpy(t).reshape(-1, 20) for t in eng.state_unpack(st, B, D)]
+    return eng.to_numpy(fx), eng.to_numpy(x), state, eng.to_numpy(m), eng.to_numpy(v), h
+
+
+def one_ulp(x0):
+    return np.nextafter(x0, np.float32(np.inf)).astype(np.float32)
+
+
+CASES = {"c2": ("quadratic", "dm_quadratic_d128", 128, 128, None, 14),
+         "c4shard": ("rastrigin", "dm_rastrigin_d100", 128, 100, 1024, 16)}
+
+
+@pytest.mark.parametrize("which", ["two_pass", "normal", "one_cu"])
+@pytest.mark.parametrize("case", ["c2", "c4shard"])
+def test_trained_full_size_trajectory(eng, case, which):
+    """Configs 2 and 4 (this GPU's shard of the 1024 problems), T = 100, the trained L2O-DM optimizer: the loss FALLS
+    by more than 5x and the whole trajectory matches the C oracle at 1e-5; x_T and the LSTM state within the oracle's
+    own sensitivity to a one-ulp change of x_0 (x 3; never tighter than 1e-5 of the largest entry)."""
+    from oracle.c_oracle import c_unroll
+    kind, wname, B, D, Bg, seed = CASES[case]
+    cfg = O.DM_IDENTITY
+    params = load_l2l(wname, "cw")
+    prob, x0, arrays = make_problem(kind, B, D, seed=seed)
+    T = 100
+    fx_ref, x_ref, st_ref = c_unroll(kind, cfg, params, arrays, x0, T, B_global=Bg)[:3]
+    fx_p, x_p, st_p = c_unroll(kind, cfg, params, arrays, one_ulp(x0), T, B_global=Bg)[:3]
+    assert fx_ref[-1] < fx_ref[0] / 5 and np.all(np.diff(fx_ref[::10]) < 0), (fx_ref[0], fx_ref[-1])
+    with form(which):
+        fx, x, st, _, _, _ = fused(eng, cfg, params, arrays, x0, B, D, T, Bg=Bg)
+    e = rel_err(fx, fx_ref)
+    xs = max(1.0, float(np.abs(x_ref).max()))
+    ex, env_x = max_abs(x, x_ref) / xs, max_abs(x_p, x_ref) / xs
+    st_ref = [st_ref[0][0], st_ref[0][1], st_ref[1][0], st_ref[1][1]]
+    st_p = [st_p[0][0], st_p[0][1], st_p[1][0], st_p[1][1]]
+    es = max(max_abs(a, b) for a, b in zip(st, st_ref))
+    env_s = max(max_abs(a, b) for a, b in zip(st_p, st_ref))
+    print("%s %s: fx %.5g -> %.5g, rel fx %.3g, x_T %.3g (oracle one-ulp sensitivity %.3g), state %.3g (%.3g)"
+          % (case, which, fx_ref[0], fx_ref[-1], e, ex, env_x, es, env_s))
+    assert np.all(np.isfinite(fx)) and e < 1e-5
+    assert fx[-1] < fx[0] / 5
+    assert ex < max(1e-5, 3 * env_x)
+    assert es < max(1e-5, 3 * env_s)
+
+
+def grad64(kind, prob, x, Bg):
+    x = x.astype(np.float64)
+    if kind == "quadratic":
+        W, y = prob.w.astype(np.float64), prob.y.astype(np.float64)
+        r = np.einsum("bmd,bd->bm", W, x) - y
+        return 2.0 / Bg * np.einsum("bmd,bm->bd", W, r)
+    A, Bv, Cv = prob.A.astype(np.float64), prob.B.astype(np.float64)[..., 0], prob.C.astype(np.float64)[..., 0]
+    r = np.einsum("bmd,bd->bm", A, x) - Bv
+    return (np.einsum("bmd,bm->bd", A, r) + 2 * np.pi * prob.alpha * Cv * np.sin(2 * np.pi * x)) / Bg
+
+
+def grad32_reference_form(kind, prob, x, Bg):
+    """The reference's own fp32 arithmetic (DM/problems.py:98-99 + autodiff): r = Wx - y, then W^T r."""
+    f = np.float32
+    if kind == "quadratic":
+        r = np.einsum("bmd,bd->bm", prob.w, x).astype(f) - prob.y
+        return (f(2.0) / f(Bg) * np.einsum("bmd,bm->bd", prob.w, r)).astype(f)
+    A, Bv, Cv = prob.A, prob.B[..., 0], prob.C[..., 0]
+    r = np.einsum("bmd,bd->bm", A, x).astype(f) - Bv
+    return ((np.einsum("bmd,bm->bd", A, r) + f(2 * np.pi * prob.alpha) * Cv * np.sin(f(2 * np.pi) * x)) / f(Bg)).astype(f)
+
+
+@pytest.mark.parametrize("case", ["c2", "c4shard"])
+def test_gradient_error_in_the_converged_regime(eng, case):
+    """The recorded per-step gradient (hist["g"][t] of l2o_unroll_record) of both two-CU forms against the float64
+    gradient at the kernel's OWN iterate x_t, t = 0 .. 99.  The reference-arithmetic form (two-pass) must stay within
+    2 x the error of a NumPy fp32 evaluation of the same formula; the normal-matrix form is measured next to it and
+    bounded only by what the probe found (its error no longer scales with the residual: DESIGN.md 4)."""
+    kind, wname, B, D, Bg, seed = CASES[case]
+    cfg = O.DM_IDENTITY
+    params = load_l2l(wname, "cw")
+    prob, x0, arrays = make_problem(kind, B, D, seed=seed)
+    x0 = x0.reshape(B, D)
+    T = 100
+    out = {}
+    for which in ("two_pass", "normal"):
+        with form(which):
+            h = fused(eng, cfg, params, arrays, x0, B, D, T, Bg=Bg, hist=True)[5]
+            hg = eng.to_numpy(h["g"]).reshape(T, B, D)
+            rows = []
+            for t in (0, 5, 20, 50, 99):
+                xt = fused(eng, cfg, params, arrays, x0, B, D, t, Bg=Bg)[1] if t else x0
+                g64 = grad64(kind, prob, xt, Bg or B)
+                g32 = grad32_reference_form(kind, prob, xt.astype(np.float32), Bg or B)
+                n = float(np.linalg.norm(g64))
+                rows.append((t, n, float(np.linalg.norm(hg[t] - g64)) / n, float(np.linalg.norm(g32 - g64)) / n))
+        out[which] = rows
+        for r in rows:
+            print("%s %-8s t=%3d |g|=%9.4g  rel err HIP %.3g   NumPy fp32 (reference form) %.3g" % ((case, which) + r))
+    assert out["two_pass"][-1][1] < out["two_pass"][0][1] / 20          # the gradient did shrink
+    for t, n, e_hip, e_np in out["two_pass"]:
+        assert e_hip < 2 * e_np + 1e-7, (t, e_hip, e_np)
+    for (t, n, e_hip, e_np), (_, _, e2, _) in zip(out["normal"], out["two_pass"]):
+        assert e_hip < 20 * max(e2, e_np) + 1e-7, (t, e_hip, e2)
+
+
+@pytest.mark.parametrize("which", ["two_pass", "normal", "one_cu"])
+@pytest.mark.parametrize("case,T,Bt", [("c2", 1000, 16), ("c2", 10000, 4), ("c4shard", 1000, 16), ("c4shard", 10000, 4)])
+def test_trained_long_horizon(eng, case, T, Bt, which):
+    """T = 1000 (the curriculum's horizon, DM/train_dm.py:66) and T = 10 000 (DM/evaluate_dm.py:43) in ONE launch, the
+    trained optimizer, a slice of the batch with the 1/B of the full batch: the loss keeps falling; HIP vs the float64
+    oracle within 3 x the worst drift of three fp32 evaluations of the same unroll from their float64 twin (the C
+    oracle, the C oracle started one ulp away, the NumPy oracle's first 101 steps hold 1e-5)."""
+    from oracle.c_oracle import c_unroll
+    kind, wname, B, D, Bg, seed = CASES[case]
+    Bg = Bg or B
+    cfg = O.DM_IDENTITY
+    params = load_l2l(wname, "cw")
+    prob, x0, arrays = make_problem(kind, B, D, seed=seed)
+    arr = {k: (v[:Bt] if isinstance(v, np.ndarray) else v) for k, v in arrays.items()}
+    x0 = x0.reshape(B, -1)[:Bt]
+    p64 = {k: {v: a.astype(np.float64) for v, a in d.items()} for k, d in params.items()}
+    if kind == "quadratic":
+        pr = O.Quadratic(prob.w[:Bt].astype(np.float64), prob.y[:Bt].astype(np.float64), batch_global=Bg)
+        x64 = x0.astype(np.float64)
+    else:
+        pr = O.Rastrigin(prob.A[:Bt].astype(np.float64), prob.B[:Bt].astype(np.float64), prob.C[:Bt].astype(np.float64),
+                         alpha=prob.alpha, batch_global=Bg)
+        x64 = x0.astype(np.float64).reshape(Bt, D, 1)
+    r64 = O.unroll(pr, cfg, p64, x64, O.net_initial_state(cfg, Bt * D, np.float64), T)
+    fx32 = c_unroll(kind, cfg, params, arr, x0, T, B_global=Bg)[0]
+    fx32p = c_unroll(kind, cfg, params, arr, one_ulp(x0), T, B_global=Bg)[0]
+    env = max(rel_err(fx32, r64.fx), rel_err(fx32p, r64.fx))
+    with form(which):
+        fx = fused(eng, cfg, params, arr, x0, Bt, D, T, Bg=Bg)[0]
+    e64 = rel_err(fx, r64.fx)
+    print("%s T=%d %s: fx %.4g -> %.4g; HIP vs float64 %.3g (fp32 oracles' drift %.3g), first 101 steps %.3g"
+          % (case, T, which, r64.fx[0], r64.fx[-1], e64, env, rel_err(fx[:101], r64.fx[:101])))
+    assert r64.fx[-1] < r64.fx[100] < r64.fx[0]
+    assert rel_err(fx[:101], r64.fx[:101]) < 1e-5
+    assert e64 < 3 * env
+
+
+def test_c3_trained_lasso_rnnprop(eng):
+    """Config 3 with the trained RNNProp optimizer (f: 44.7 -> 1.6 in 200 steps).  See the module docstring: the
+    converged trajectory is chaotic (sign(x) of the l1 term + a +-0.01 tanh step), so parity is (a) 1e-5 on the prefix
+    where the oracle's own one-ulp sensitivity is below 1e-6, (b) within 3 x that sensitivity beyond, (c) 1e-5 on
+    re-synchronised 20-step segments started from the oracle's x / LSTM state / moments at t = 100 and t = 160."""
+    from oracle.c_oracle import c_unroll
+    cfg = O.RNNPROP
+    params = load_l2l("rnnprop_lasso_256x512", "rp")
+    B, D, M, T = 256, 512, 256, 200
+    prob, x0, arrays = make_problem("lasso", B, D, seed=18, M=M)
+    fx_ref = c_unroll("lasso", cfg, params, arrays, x0, T)[0]
+    fx_p = c_unroll("lasso", cfg, params, arrays, one_ulp(x0), T)[0]
+    assert fx_ref[-1] < fx_ref[0] / 5
+    sens = np.abs(fx_p.astype(np.float64) - fx_ref) / np.abs(fx_ref)
+    fx = fused(eng, cfg, params, arrays, x0, B, D, T)[0]
+    err = np.abs(fx.astype(np.float64) - fx_ref) / np.abs(fx_ref)
+    stable = int(np.argmax(np.maximum.accumulate(sens) > 1e-6)) if np.any(sens > 1e-6) else T + 1
+    print("C3 trained: fx %.4g -> %.4g; one-ulp sensitivity of the oracle exceeds 1e-6 from step %d (max %.3g); HIP: "
+          "prefix %.3g, whole trajectory %.3g" % (fx_ref[0], fx_ref[-1], stable, sens.max(), err[:stable].max(), err.max()))
+    assert stable >= 40
+    assert err[:stable].max() < 1e-5
+    assert err.max() < max(1e-5, 3 * sens.max())
+    assert fx[-1] < fx[0] / 5
+    # (c) re-synchronised segments in the converged regime
+    for t0 in (100, 160):
+        _, x_t, st_t, m_t, v_t, _ = c_unroll("lasso", cfg, params, arrays, x0, t0)
+        seg_ref, xs_ref = c_unroll("lasso", cfg, params, arrays, x_t, 20, state0=st_t, m0=m_t, v0=v_t, step0=1 + t0)[:2]
+        seg, xs, _, _, _, _ = fused(eng, cfg, params, arrays, x_t, B, D, 20, state0=st_t, m0=m_t, v0=v_t, step0=1 + t0)
+        e, ex = rel_err(seg, seg_ref), max_abs(xs, xs_ref) / max(1.0, float(np.abs(xs_ref).max()))
+        print("   segment from the oracle's state at t=%d: rel fx %.3g, x %.3g (f %.4g -> %.4g)" % (t0, e, ex, seg_ref[0], seg_ref[-1]))
+        assert e < 1e-5
