@@ -419,6 +419,12 @@ def run_case(args, eng, world, rank, Bg, B, label):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fx_host = eng.to_numpy(fx)
+    fx_ranks = None
+    if world > 1:                                   # every rank's copy of the all-reduced final loss (must be identical)
+        mine = torch.tensor([float(fx_host[-1])], device=eng.device, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        fx_ranks = [float(g.item()) for g in gathered]
     fx_instance = cursor[0]
     eng.check_unroll_status()
     n_unrolls = args.steps * reps
@@ -460,8 +466,14 @@ def run_case(args, eng, world, rank, Bg, B, label):
         kernel = "k_unroll_cu"
     elif fused:
         # (the two-CU kernel; a shard of more than #CU / 2 = 128 problems runs it as consecutive chunk launches)
-        kernel = "k_unroll" if D <= 16 else ("k_unroll_pairh" if 2 * B <= 256 else
-                                             "k_unroll_pairh x %d chunk launches" % ((B + 127) // 128))
+        from open_l2o_amd import _abi
+        two_cu = "k_unroll_pairh" if _abi.get_option(_abi.OPT_PAIR_NORMAL) and not _abi.get_option(_abi.OPT_EXACT_GATES) \
+            else "k_unroll_pair"
+        if _abi.get_option(_abi.OPT_EXACT_GATES):
+            two_cu += " (exact gates)"
+        cap = max(8, eng.coresident_cus // 2)
+        kernel = "k_unroll" if (D <= 16 or not _abi.get_option(_abi.OPT_PAIR)) else (
+            two_cu if B <= cap else "%s x %d chunk launches" % (two_cu, (B + cap - 1) // cap))
     else:
         kernel = "k_problem_fg1 + k_cwlstm_step per step"
     # HBM bytes per launch that a kernel of this form MUST move (used only when no PMC pass is committed):
@@ -471,7 +483,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
     return {"label": label, "graph": graph, "weights": weights, "x0": ring[fx_instance][0], "fx_host": fx_host, "dt": dt,
             "value": world * coord_steps * n_unrolls / dt, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_unroll": dt / n_unrolls * 1e3, "unroll_ms_events": float(unroll_all_ms), "reps": reps,
-            "n_inst": n_inst, "fx_instance": fx_instance,
+            "n_inst": n_inst, "fx_instance": fx_instance, "fx_ranks": fx_ranks,
             "value_replayed": world * coord_steps / (float(kern_all) * 1e-3),
             "kern_ms": float(kern_all), "kern_ms_min": float(np.min(kt)), "coord_steps": coord_steps,
             "bpc": bpc, "alg_bytes": bpc * coord_steps,
@@ -605,16 +617,19 @@ def main(argv=None):
                        "step_definition": "one bench step = %d complete unrolls, each on the next of %d pre-uploaded problem "
                                           "instances: per-problem preparation + rewind + T optimizer steps + f(x_T) + loss "
                                           "reduction; value counts all steps x unrolls" % (case["reps"], case["n_inst"]),
-                       "arithmetic": "fp32 state, inputs and outputs; the LSTM gate GEMM is a 3-way bf16 split (the six "
-                                     "exact products per term, packed into 4 MFMAs per tile for the DM nets) on "
-                                     "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level error, DESIGN.md 2); "
-                                     "everything else fp32 VALU",
+                       "arithmetic": "fp32 state, inputs and outputs; optimizee gradient in the reference's form (r = Wx - y, "
+                                     "g = W^T r); the LSTM gate GEMM is a 3-way bf16 split (the six exact products per term, "
+                                     "packed into 4 MFMAs per tile for the DM nets) on v_mfma_f32_16x16x32_bf16 with fp32 "
+                                     "accumulation (fp32-level error per step; its in-group truncation shows as ~1e-5 "
+                                     "drift at T = 1000 -- L2O_EXACT_GATES=1 selects the fmaf-chain-equal fp32 MFMA, "
+                                     "DESIGN.md 4); everything else fp32 VALU",
                        "api": "open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> UnrollGraph.launch",
                        "parallelism": "problem-batch sharding x%d, one all-reduce of T+1 floats per unroll" % world,
                        "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() if world > 1 else None),
                        "scaling_note": scaling_note},
             "final_loss_fx_T": float(case["fx_host"][-1]), "fx_0": float(case["fx_host"][0]),
+            "final_loss_fx_T_per_rank": case["fx_ranks"],
             "value_replayed_problem": case["value_replayed"],
             "value_replayed_note": "the round-1/2 figure: the same instance replayed (no per-problem preparation in the "
                                    "timed launches); not the headline",

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 8
+#define L2O_ABI_VERSION 9
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -71,6 +71,8 @@ typedef struct l2o_net_cfg {
   double beta1;         /* RNNProp MetaOptimizer(beta1, beta2) DM/meta_rnnprop_eval.py:230 */
   double beta2;         /* (python floats in the reference: kept as doubles so that the
                            fp32 constants are rounded exactly like TF rounds them)  */
+  uint64_t options;     /* ABI v9: kernel A/B switches of THIS call, L2O_OPTW(option, value) words OR-ed together;
+                           0 = every default (see "options" below).  The library keeps no option state.        */
 } l2o_net_cfg;
 
 /* One optimizee batch: the non-trainable variables that problems.<name>().build()
@@ -78,6 +80,7 @@ typedef struct l2o_net_cfg {
  * sharded over GPUs by problem index.  The loss is a mean over the GLOBAL batch
  * (DM/problems.py:99, 131, 211), hence B_global. */
 #define L2O_PROB_W_SHARED 1
+#define L2O_PROB_FG_TWO_PASS 2   /* l2o_problem_fg / _hvp: the two-pass gradient kernel (default: one pass over the matrix) */
 
 typedef struct l2o_problem {
   int32_t kind;          /* L2O_PROB_*                                                    */
@@ -100,27 +103,46 @@ typedef struct l2o_problem {
 int l2o_abi_version(void);
 const char* l2o_last_error(void);
 
-/* ---- library options (ABI v6) -------------------------------------------
- * Process-wide A/B switches between kernels that compute the same thing (all results stay within
- * the parity tolerance).  The library never reads the environment: a host binding that wants
- * L2O_* environment variables applies them once through this call (open_l2o_amd/_abi.py does).
- * Apart from these switches the library keeps no state between calls: per-launch state (status
- * word, launch sequence) lives in the caller-owned workspace. */
+/* ---- options (ABI v9: per call, caller-owned) -------------------------------
+ * A/B switches between kernels that compute the same thing (all results stay within the parity tolerance).  The
+ * library keeps NO option state and never reads the environment: a call carries its switches in the caller's own
+ * structs -- l2o_net_cfg.options = L2O_OPTW(option, value) | ..., l2o_problem.flags (L2O_PROB_FG_TWO_PASS),
+ * l2o_mlp.flags (L2O_MLP_GENERIC) -- and a field left 0 means every default.  (ABI v6..v8 had a process-wide
+ * l2o_set_option; removed.)  Apart from immutable hardware facts cached per device (CU count, measured co-resident
+ * capacity) the library keeps no state between calls: per-launch state (status word, launch sequence) lives in the
+ * caller-owned workspace. */
 #define L2O_OPT_PAIR 0               /* 1*: l2o_unroll may split every problem over two CUs; 0: one CU per problem        */
 #define L2O_OPT_PAIR_PLAIN_STORES 1  /* 1*: partners that CONFIRMED (XCC_ID handshake) they share an XCD publish their
                                         exchange granules with plain stores (L2-resident); 0: agent-scope stores always    */
 #define L2O_OPT_UNROLL_CU 2          /* 1*: the streaming fused unroll for D > 128; 0: such sizes run step-granular         */
-#define L2O_OPT_FG_TWO_PASS 3        /* 0*: l2o_problem_fg reads a per-problem matrix once; 1: the two-pass kernel          */
-#define L2O_OPT_MLP_GENERIC 4        /* 0*: hidden width 20 uses the wave-per-sample MLP kernels; 1: the generic ones       */
-#define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups                 */
+#define L2O_OPT_FG_TWO_PASS 3        /* (l2o_problem.flags: L2O_PROB_FG_TWO_PASS)                                           */
+#define L2O_OPT_MLP_GENERIC 4        /* (l2o_mlp.flags: L2O_MLP_GENERIC)                                                    */
+#define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups (L2O_OPTW_BWD_BLOCKS) */
 #define L2O_OPT_BWD_KERNEL 6         /* 0*: matrix-core BPTT step (needs wpack); 1: fp32 tile kernel; 2: generic kernel     */
 #define L2O_OPT_MLP_UNROLL 7         /* 1*: l2o_mlp_unroll available to the host layer (0: it reports "unsupported")       */
-#define L2O_OPT_PAIR_NORMAL 8        /* 1*: the two-CU unroll takes W^T (W x - y) from the prepared normal matrix H = W^T W
-                                        (one GEMV and an exchange of the iterate per step; l2o_unroll_prepare);
-                                        0: the two-pass form (W x, then W^T r, exchange of the partial residuals)        */
-#define L2O_OPT_COUNT_ 9             /* (* = default) */
-int l2o_set_option(int32_t option, int64_t value);
-int64_t l2o_get_option(int32_t option);   /* -1 for an unknown option */
+#define L2O_OPT_PAIR_NORMAL 8        /* 0*: the two-CU unroll uses the reference's arithmetic, r = W x - y then g = W^T r
+                                        (exchange of the partial residuals); 1: g = H x - q from the PREPARED normal matrix
+                                        H = W^T W (l2o_unroll_prepare; one GEMV and an exchange of the iterate per step):
+                                        faster when ONE problem instance is unrolled many times, but its gradient error no
+                                        longer shrinks with the residual                                       */
+#define L2O_OPT_EXACT_GATES 9        /* 0*: LSTM gate GEMM as a 3-way bf16 split on v_mfma_f32_16x16x32_bf16 (fp32-level error,
+                                        but the matrix pipe TRUNCATES small products inside an 8-slot group: a deterministic
+                                        bias that shows as ~1e-5 drift at T = 1000); 1: v_mfma_f32_16x16x4_f32 (bit-equal to
+                                        an fmaf chain) in the fused unroll kernels -- slower, for long-horizon evaluation    */
+#define L2O_OPT_COUNT_ 10            /* (* = default) */
+#define L2O_OPTW(o, v) ((uint64_t)(8u | ((unsigned)(v) & 7u)) << (4 * (o)))
+#define L2O_OPTW_BWD_BLOCKS(n) (((uint64_t)(n) & 0xffffu) << 48)
+
+/* ---- co-residency (ABI v9) -------------------------------------------------
+ * The two-CU unroll and l2o_mlp_unroll exchange data between workgroups that must be resident at the same time.  Before
+ * every launch the library sizes them against the CUs this STREAM can use: the device's CU count (which already
+ * reflects ROC_GLOBAL_CU_MASK and the compute-partition mode), the stream's own CU mask (hipExtStreamGetCUMask) and --
+ * for restrictions HIP cannot see, e.g. HSA_CU_MASK -- the capacity MEASURED by this call: one probe launch of
+ * one-workgroup-per-CU blocks that count each other; returns the number found co-resident (> 0, cached per device for
+ * the life of the process) or a negative error.  Synchronizes `stream`.  scratch: >= 64 bytes of device memory.
+ * A batch that does not fit runs as several smaller launches or on the one-CU kernel -- never as a launch that waits
+ * for a partner that cannot be resident. */
+int32_t l2o_coresident_workgroups(void* scratch, void* stream);
 
 /* ---- weights: networks.factory / networks.save (DM/networks.py:34-62) ---
  * The `.l2l` dict {lstm_1:{w_gates,b_gates}, lstm_2:{...}, linear:{w,b},
@@ -171,6 +193,7 @@ int l2o_problem_hvp(const l2o_problem* prob, const float* x /* device [B_local,D
  * dataset; forward + tf.gradients w.r.t. the four variables (DM/meta.py:322, 344).
  * One hidden layer (util.get_config("mnist"): layers=(20,), DM/util.py:147-149).
  * loss[0] = the scalar loss; gradients may all be NULL (forward only). */
+#define L2O_MLP_GENERIC 1   /* l2o_mlp_fg: the generic-width kernels also for hidden width 20 */
 typedef struct l2o_mlp {
   int32_t n_in;          /* 784                                                      */
   int32_t n_hidden;      /* layers[0] (<= 32)                                        */
@@ -178,6 +201,8 @@ typedef struct l2o_mlp {
   int32_t batch;         /* minibatch size (<= 256)                                  */
   int32_t activation;    /* 0 = sigmoid, 1 = relu  (DM/problems.py:260-265)          */
   int32_t n_data;        /* rows of `images`                                         */
+  int32_t flags;         /* ABI v9: L2O_MLP_GENERIC                                  */
+  int32_t reserved;
   const float* images;   /* device [n_data, n_in]                                    */
   const int32_t* labels; /* device [n_data]                                          */
 } l2o_mlp;
@@ -392,10 +417,11 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
  * Returns L2O_ERR_UNSUPPORTED when (problem size, net) has no fused kernel.
  *
  * workspace: caller-owned device scratch of l2o_unroll_workspace_bytes() bytes, or NULL.
- * With a workspace every problem is split over TWO workgroups (two CUs) that exchange the
- * iterate once per step through tagged 8-byte granules in the workspace; a launch holds at most
- * #CU / 2 problems (both halves of each co-resident), a larger shard runs as consecutive launches
- * of equal chunks.  Without a workspace: one workgroup per problem.
+ * With a workspace every problem is split over TWO workgroups (two CUs) that exchange their partial
+ * residuals (L2O_OPT_PAIR_NORMAL: the iterate) once per step through tagged 8-byte granules in the
+ * workspace; a launch holds at most (CUs usable by the stream) / 2 problems -- both halves of each
+ * co-resident, see l2o_coresident_workgroups -- and a larger shard runs as consecutive launches of
+ * equal chunks.  Without a workspace: one workgroup per problem.
  * The first 4 bytes of the workspace are a STICKY status word the kernel raises if a partner
  * never showed up (bounded spin, no hang; the results of that launch are then invalid): after
  * synchronising, copy them to the host and pass them to l2o_unroll_status(); the caller clears
@@ -448,10 +474,11 @@ int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack /* device */, c
  * Between launches of one layout the library keeps the granule area clean itself (the epilogue kernel of a launch
  * re-zeroes it), so there is no memset per unroll.  layout == 0: the pair has no workspace-using kernel. */
 int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream);
-/* Problem preparation of the two-CU form (ABI v7).  The optimizees of the fused forms are  coef |W x - y|^2 + separable
- * terms (DM/problems.py:73-213, 959-994); the two-CU kernel takes the gradient of the first term as  H x - q  with
- * H = W^T W, q = W^T y (float64 accumulation, rounded once) kept in the workspace -- the problem is constant over an
- * unroll and over every unroll until the caller re-samples it (MetaLoss.reset).  l2o_unroll / l2o_unroll_record and
+/* Problem preparation of the NORMAL-MATRIX two-CU form (ABI v7; since ABI v9 only with L2O_OPT_PAIR_NORMAL = 1 in
+ * cfg->options -- the default two-CU form needs none and this call is then a no-op).  The optimizees of the fused forms
+ * are  coef |W x - y|^2 + separable terms (DM/problems.py:73-213, 959-994); that form takes the gradient of the first
+ * term as  H x - q  with H = W^T W, q = W^T y (float64 accumulation, rounded once) kept in the workspace -- the problem
+ * is constant over an unroll and over every unroll until the caller re-samples it (MetaLoss.reset).  l2o_unroll / l2o_unroll_record and
  * l2o_unroll_reduce without L2O_UNROLL_PREPARED run this pass themselves ahead of the unroll (two small kernels);
  * a caller that launches many unrolls on one problem calls it once after (re)sampling W, y -- and after every
  * l2o_unroll_workspace_init -- and passes L2O_UNROLL_PREPARED.  The loss itself is still |W x - y|^2 from W.

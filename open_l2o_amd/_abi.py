@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # L2O_HIP_LIB: alternative build of the SAME library (timing ablations, scripts/ablate.sh)
 LIB_PATH = os.environ.get("L2O_HIP_LIB") or os.path.join(_HERE, "libl2o_hip.so")
 
-L2O_ABI_VERSION = 8
+L2O_ABI_VERSION = 9
 L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
 
 NET_CW, NET_RNNPROP = 0, 1
@@ -23,7 +23,7 @@ PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_M
 
 # every symbol include/l2o_abi.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "l2o_abi_version", "l2o_last_error", "l2o_set_option", "l2o_get_option", "l2o_wpack_floats", "l2o_wpack_host",
+    "l2o_abi_version", "l2o_last_error", "l2o_coresident_workgroups", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_unroll_prepare", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
@@ -31,9 +31,17 @@ SYMBOLS = (
 )
 
 
-# l2o_set_option ids (include/l2o_abi.h)
+# option ids of include/l2o_abi.h ("options": per call, caller-owned -- the LIBRARY keeps no option state since ABI v9).
+# This binding keeps the caller's side of it: one process-wide dict of non-default values (applied from the L2O_*
+# environment variables once at import, changed by set_option) that NetSpec.to_c() / the problem and MLP descriptors
+# encode into every struct they hand to the library.
 OPT_PAIR, OPT_PAIR_PLAIN_STORES, OPT_UNROLL_CU, OPT_FG_TWO_PASS, OPT_MLP_GENERIC, OPT_BWD_BLOCKS, OPT_BWD_KERNEL, \
-    OPT_MLP_UNROLL, OPT_PAIR_NORMAL = range(9)
+    OPT_MLP_UNROLL, OPT_PAIR_NORMAL, OPT_EXACT_GATES = range(10)
+OPT_DEFAULTS = {OPT_PAIR: 1, OPT_PAIR_PLAIN_STORES: 1, OPT_UNROLL_CU: 1, OPT_FG_TWO_PASS: 0, OPT_MLP_GENERIC: 0,
+                OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_PAIR_NORMAL: 0, OPT_EXACT_GATES: 0}
+PROB_FG_TWO_PASS = 2      # l2o_problem.flags
+MLP_GENERIC = 1           # l2o_mlp.flags
+_options = {}
 # The library never reads the environment; this binding applies these variables ONCE, when it loads it.
 _ENV_OPTIONS = (
     ("L2O_NO_PAIR", OPT_PAIR, lambda v: 0),
@@ -46,7 +54,44 @@ _ENV_OPTIONS = (
     ("L2O_BWD_GENERIC", OPT_BWD_KERNEL, lambda v: 2),
     ("L2O_NO_MLP_UNROLL", OPT_MLP_UNROLL, lambda v: 0),
     ("L2O_PAIR_TWO_PASS", OPT_PAIR_NORMAL, lambda v: 0),
+    ("L2O_PAIR_NORMAL", OPT_PAIR_NORMAL, lambda v: 1),
+    ("L2O_EXACT_GATES", OPT_EXACT_GATES, lambda v: 1),
 )
+for _name, _opt, _conv in _ENV_OPTIONS:
+    if os.environ.get(_name):
+        _options[_opt] = int(_conv(os.environ[_name]))
+
+
+def set_option(opt, value):
+    """Change one kernel A/B switch for every later call of this process; returns the previous value."""
+    if opt not in OPT_DEFAULTS:
+        raise ValueError("unknown option %r" % (opt,))
+    old = get_option(opt)
+    value = int(value)
+    if value == OPT_DEFAULTS[opt]:
+        _options.pop(opt, None)
+    else:
+        if opt != OPT_BWD_BLOCKS and not 0 <= value <= 7:
+            raise ValueError("option %d: value %d out of range" % (opt, value))
+        _options[opt] = value
+    return old
+
+
+def get_option(opt):
+    if opt not in OPT_DEFAULTS:
+        return -1
+    return _options.get(opt, OPT_DEFAULTS[opt])
+
+
+def options_word():
+    """l2o_net_cfg.options of the current settings: L2O_OPTW(o, v) words OR-ed together (0 = every default)."""
+    w = 0
+    for o, v in _options.items():
+        if o == OPT_BWD_BLOCKS:
+            w |= (v & 0xffff) << 48
+        else:
+            w |= (8 | (v & 7)) << (4 * o)
+    return w
 
 
 class NetCfg(C.Structure):
@@ -55,7 +100,7 @@ class NetCfg(C.Structure):
         ("kind", C.c_int32), ("preprocess", C.c_int32), ("n_layers", C.c_int32),
         ("hidden", C.c_int32), ("tanh_output", C.c_int32), ("reserved", C.c_int32),
         ("scale", C.c_double), ("logsign_k", C.c_double),
-        ("beta1", C.c_double), ("beta2", C.c_double),
+        ("beta1", C.c_double), ("beta2", C.c_double), ("options", C.c_uint64),
     ]
 
 
@@ -73,7 +118,8 @@ class Mlp(C.Structure):
     """struct l2o_mlp"""
     _fields_ = [
         ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32), ("batch", C.c_int32),
-        ("activation", C.c_int32), ("n_data", C.c_int32), ("images", C.c_void_p), ("labels", C.c_void_p),
+        ("activation", C.c_int32), ("n_data", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("images", C.c_void_p), ("labels", C.c_void_p),
     ]
 
 
@@ -151,10 +197,8 @@ def lib():
     L.l2o_abi_version.argtypes = []
     L.l2o_last_error.restype = C.c_char_p
     L.l2o_last_error.argtypes = []
-    L.l2o_set_option.restype = C.c_int
-    L.l2o_set_option.argtypes = [C.c_int32, C.c_int64]
-    L.l2o_get_option.restype = C.c_int64
-    L.l2o_get_option.argtypes = [C.c_int32]
+    L.l2o_coresident_workgroups.restype = C.c_int32
+    L.l2o_coresident_workgroups.argtypes = [C.c_void_p, C.c_void_p]
     L.l2o_wpack_floats.restype = C.c_size_t
     L.l2o_wpack_floats.argtypes = [C.POINTER(NetCfg)]
     L.l2o_wpack_host.restype = C.c_int
@@ -235,23 +279,8 @@ def lib():
     if L.l2o_abi_version() != L2O_ABI_VERSION:
         raise RuntimeError("libl2o_hip.so ABI version %d != binding version %d"
                            % (L.l2o_abi_version(), L2O_ABI_VERSION))
-    for name, opt, conv in _ENV_OPTIONS:
-        if os.environ.get(name):
-            L.l2o_set_option(opt, conv(os.environ[name]))
     _lib = L
     return L
-
-
-def set_option(opt, value):
-    """l2o_set_option; returns the previous value (tests restore it)."""
-    L = lib()
-    old = int(L.l2o_get_option(opt))
-    check(L.l2o_set_option(opt, int(value)))
-    return old
-
-
-def get_option(opt):
-    return int(lib().l2o_get_option(opt))
 
 
 def check(rc):

@@ -48,6 +48,7 @@ class NetSpec:
         c.tanh_output = 1 if self.tanh_output else 0
         c.scale, c.logsign_k = float(self.scale), float(self.logsign_k)
         c.beta1, c.beta2 = float(self.beta1), float(self.beta2)
+        c.options = _abi.options_word()             # the caller-owned kernel switches travel with every call
         return c
 
 
@@ -101,6 +102,14 @@ class HipEngine(object):
         self._workspace = None
         self._last_ws = None
         self._mlp_scratch = None
+        # how many one-per-CU workgroups are really co-resident on this device (CU masks below HIP's view, shared
+        # partitions): measured ONCE per device, cached by the library; the two-CU unroll and l2o_mlp_unroll size their
+        # launches against it (l2o_coresident_workgroups)
+        with torch.cuda.device(self.device):
+            scratch = torch.zeros(16, dtype=torch.int32, device=self.device)
+            self.coresident_cus = int(self.lib.l2o_coresident_workgroups(C.c_void_p(scratch.data_ptr()), self._stream()))
+        if self.coresident_cus <= 0:
+            _abi.check(self.coresident_cus)
 
     # -- memory plumbing (torch) ------------------------------------------
     def tensor(self, a):
@@ -179,7 +188,8 @@ class HipEngine(object):
         c = _abi.Problem()
         c.kind, c.B_local, c.B_global, c.D, c.M = p.kind, p.B_local, p.B_global, p.D, p.M
         c.l1, c.alpha = float(p.l1), float(p.alpha)
-        c.flags = _abi.PROB_W_SHARED if p.w_shared else 0
+        c.flags = (_abi.PROB_W_SHARED if p.w_shared else 0) | \
+                  (_abi.PROB_FG_TWO_PASS if _abi.get_option(_abi.OPT_FG_TWO_PASS) else 0)
         c.W, c.y, c.C, c.x_scale = _ptr(p.W), _ptr(p.y), _ptr(p.C), _ptr(p.x_scale)
         return c
 
@@ -203,6 +213,7 @@ class HipEngine(object):
         c = _abi.Mlp()
         c.n_in, c.n_hidden, c.n_out, c.batch = d.n_in, d.n_hidden, d.n_out, d.batch
         c.activation, c.n_data = d.activation, int(d.images.shape[0])
+        c.flags = _abi.MLP_GENERIC if _abi.get_option(_abi.OPT_MLP_GENERIC) else 0
         c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
         g = [None] * 4 if grads is None else [_ptr(t) for t in grads]
         n = int(self.lib.l2o_mlp_scratch_floats(C.byref(c)))
@@ -215,6 +226,7 @@ class HipEngine(object):
         c = _abi.Mlp()
         c.n_in, c.n_hidden, c.n_out, c.batch = d.n_in, d.n_hidden, d.n_out, d.batch
         c.activation, c.n_data = d.activation, int(d.images.shape[0])
+        c.flags = _abi.MLP_GENERIC if _abi.get_option(_abi.OPT_MLP_GENERIC) else 0
         c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
         return c
 
@@ -250,6 +262,7 @@ class HipEngine(object):
         c = _abi.Mlp()
         c.n_in, c.n_hidden, c.n_out, c.batch = d.n_in, d.n_hidden, d.n_out, d.batch
         c.activation, c.n_data = d.activation, int(d.images.shape[0])
+        c.flags = _abi.MLP_GENERIC if _abi.get_option(_abi.OPT_MLP_GENERIC) else 0
         c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
         g = [None] * 4 if grads is None else [_ptr(t) for t in grads]
         n = int(self.lib.l2o_mlp_scratch_floats(C.byref(c)))
@@ -453,7 +466,8 @@ class HipEngine(object):
         self._last_ws = ws
         wsp = None if ws is None else C.c_void_p(ws.data_ptr())
         flags = _abi.UNROLL_ZERO_STATE if zero_state else 0
-        if ws is not None and fx is not None and p.W is not None and p.y is not None:
+        if ws is not None and fx is not None and p.W is not None and p.y is not None \
+                and _abi.get_option(_abi.OPT_PAIR_NORMAL) and not _abi.get_option(_abi.OPT_EXACT_GATES):
             # problem preparation of the two-CU form (l2o_unroll_prepare: H = W^T W, q = W^T y in the workspace) once
             # per problem INSTANCE: the same W / y tensors, unmodified (torch bumps ._version on every in-place write;
             # the tensors are kept referenced here, so their addresses cannot be recycled behind the key)

@@ -675,11 +675,11 @@ __device__ __forceinline__ void dot4(const float4 a, const float4 b, float4& acc
 }
 __device__ __forceinline__ float hsum4(const float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-template <int PRE, int KIND, int CH, bool HIST>
+template <int PRE, int KIND, int CH, bool HIST, bool EXACT = false>
 __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   // CH <= 4 <=> at most 4 waves per workgroup = one wave per SIMD: the bf16x3 gate GEMM with
-  // its weights in VGPR + AGPR; CH == 8 (5..8 waves) keeps the fp32 MFMA form
-  using Core = LstmCore<PRE, (CH <= 4)>;
+  // its weights in VGPR + AGPR; CH == 8 (5..8 waves) keeps the fp32 MFMA form (as does EXACT: L2O_OPT_EXACT_GATES)
+  using Core = LstmCore<PRE, (CH <= 4) && !EXACT>;
   constexpr int SQ = 16 * CH;      // padded square size of the LDS-resident matrix
   constexpr int S = SQ + 16;       // row stride (floats)
   extern __shared__ float sm[];
@@ -979,15 +979,27 @@ static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
 }
 
 // ---------------------------------------------------------------------------
-// library options (l2o_set_option): process-wide A/B switches, read on the launch paths as plain
-// relaxed atomics.  The library itself never calls getenv(); the Python binding applies the L2O_*
-// environment variables ONCE when it loads the library (open_l2o_amd/_abi.py).
+// options: A/B switches between kernels that compute the same thing.  The library keeps NO option state: every call
+// carries its switches in the caller's own structs -- l2o_net_cfg.options (L2O_OPTW(option, value) words OR-ed
+// together; 0 = every default), l2o_problem.flags (L2O_PROB_FG_TWO_PASS) and l2o_mlp.flags (L2O_MLP_GENERIC).  An entry
+// point copies the word into a call-scoped thread-local (OptScope) that the launch helpers below read through opt().
 // ---------------------------------------------------------------------------
-static std::atomic<int64_t> g_opt[L2O_OPT_COUNT_] = {
-    /* L2O_OPT_PAIR */ {1}, /* L2O_OPT_PAIR_PLAIN_STORES */ {1}, /* L2O_OPT_UNROLL_CU */ {1},
-    /* L2O_OPT_FG_TWO_PASS */ {0}, /* L2O_OPT_MLP_GENERIC */ {0}, /* L2O_OPT_BWD_BLOCKS */ {0},
-    /* L2O_OPT_BWD_KERNEL */ {0}, /* L2O_OPT_MLP_UNROLL */ {1}, /* L2O_OPT_PAIR_NORMAL */ {1}};
-static inline int64_t opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
+static const int64_t kOptDefault[L2O_OPT_COUNT_] = {
+    /* L2O_OPT_PAIR */ 1, /* L2O_OPT_PAIR_PLAIN_STORES */ 1, /* L2O_OPT_UNROLL_CU */ 1,
+    /* L2O_OPT_FG_TWO_PASS */ 0, /* L2O_OPT_MLP_GENERIC */ 0, /* L2O_OPT_BWD_BLOCKS */ 0,
+    /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* L2O_OPT_PAIR_NORMAL */ 0, /* L2O_OPT_EXACT_GATES */ 0};
+static thread_local uint64_t t_optw = 0;
+struct OptScope {
+  uint64_t saved;
+  explicit OptScope(uint64_t w) : saved(t_optw) { t_optw = w; }
+  ~OptScope() { t_optw = saved; }
+};
+static inline uint64_t cfg_optw(const l2o_net_cfg* cfg) { return cfg ? cfg->options : 0; }
+static inline int64_t opt(int o) {
+  if (o == L2O_OPT_BWD_BLOCKS) return (int64_t)((t_optw >> 48) & 0xffffu);     // a count: its own 16-bit field
+  const unsigned nib = (unsigned)(t_optw >> (4 * o)) & 0xfu;
+  return (nib & 8u) ? (int64_t)(nib & 7u) : kOptDefault[o];
+}
 
 // CUs of the device the call runs on (the stream's device; the current device for the null stream).
 // Immutable hardware facts cached per device ordinal -- not launch state.
@@ -1008,6 +1020,54 @@ static int device_cu_count(hipStream_t s) {
   return n;
 }
 
+static int device_ordinal(hipStream_t s) {
+  int dev = -1;
+  if (s == nullptr || hipStreamGetDevice(s, &dev) != hipSuccess || dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+  }
+  return dev;
+}
+// measured co-resident one-per-CU workgroups per device (l2o_coresident_workgroups); 0 = never probed
+static std::atomic<int> g_measured_cus[64];
+
+// CUs on which workgroups of a launch on stream `s` can be resident AT THE SAME TIME -- what the kernels with
+// inter-workgroup exchanges (two-CU unroll, l2o_mlp_unroll) size their grids against:
+//   the device's CU count (reflects ROC_GLOBAL_CU_MASK and the partition mode), the stream's own CU mask
+//   (hipExtStreamCreateWithCUMask; 0.3 us per query), and the MEASURED capacity where the caller ran the probe
+//   (restrictions below HIP, e.g. HSA_CU_MASK: the device still reports every CU).
+static int coresident_cus(hipStream_t s) {
+  int n = device_cu_count(s);
+  uint32_t mask[16] = {0};
+  if (hipExtStreamGetCUMask(s, 16, mask) == hipSuccess) {
+    int pop = 0;
+    for (uint32_t w : mask) pop += __builtin_popcount(w);
+    if (pop > 0 && pop < n) n = pop;
+  } else {
+    (void)hipGetLastError();
+  }
+  const int dev = device_ordinal(s);
+  if (dev >= 0 && dev < 64) {
+    const int m = g_measured_cus[dev].load(std::memory_order_relaxed);
+    if (m > 0 && m < n) n = m;
+  }
+  return n;
+}
+
+// The probe: one workgroup per CU (100 KB of LDS each), every workgroup counts itself, waits a FIXED ~30 us (the
+// dispatch of a grid this size takes a few) and records how many had arrived by then; the minimum over the workgroups
+// is the number that were resident together (a second wave of workgroups sees the full count, the first wave its own
+// size).  Bounded: no workgroup waits for another.
+__global__ __launch_bounds__(256) void k_coresident_probe(unsigned* ctr, unsigned* min_seen) {
+  extern __shared__ float probe_lds[];
+  if (threadIdx.x == 0) {
+    probe_lds[0] = 1.0f;
+    atomicAdd(ctr, 1u);
+    for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);        // 8 x 127 x 64 clocks ~ 28 us
+    const unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicMin(min_seen, v);
+  }
+}
+
 // Split every problem over two workgroups when that still leaves all of them co-resident.
 // Problems per launch of the two-CU form, 0 = not this form.  Every problem of a launch must be co-resident with its
 // partner: at most #CU / 2 per launch.  A larger batch shard runs as consecutive launches of equal chunks (a multiple
@@ -1015,7 +1075,7 @@ static int device_cu_count(hipStream_t s) {
 // one round of the one-CU form (config 4, 1024 problems on one GPU: 5.3 -> 6.0 G coordinate-steps/s).
 static int pair_chunk(const l2o_problem* p, const UnrollGeom& g, hipStream_t s) {
   if (!opt(L2O_OPT_PAIR) || g.CH < 2) return 0;
-  const int cap = device_cu_count(s) / 2;
+  const int cap = coresident_cus(s) / 2;
   if (p->B_local <= cap) return p->B_local;
   if (cap < 8) return 0;
   const int n = (p->B_local + cap - 1) / cap;               // launches
@@ -1084,7 +1144,8 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     // grid: groups of 16 blocks = 8 problems x 2 halves (partners are b and b + 8)
     const int B = a.pp.B_local;
     const bool one_launch = chunk >= B;
-    if (opt(L2O_OPT_PAIR_NORMAL)) {
+    const bool exact = opt(L2O_OPT_EXACT_GATES) != 0 && !hist;   // (the recording unroll keeps the bf16x3 core)
+    if (opt(L2O_OPT_PAIR_NORMAL) && !exact) {
       // the gradient from the prepared normal matrix (l2o_unroll_pairh.h); prepared here unless the caller did
       if (!a.prepared) {
         const int rc = launch_pair_prepare(prob, g, workspace, s);
@@ -1114,9 +1175,9 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     } else {
       void (*fn)(UnrollPairArgs) = nullptr;
       switch (g.CH) {
-        case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : k_unroll_pair<PRE, KIND, 2, false>; break;
-        case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : k_unroll_pair<PRE, KIND, 4, false>; break;
-        default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : k_unroll_pair<PRE, KIND, 8, false>; break;
+        case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : (exact ? k_unroll_pair<PRE, KIND, 2, false, true> : k_unroll_pair<PRE, KIND, 2, false>); break;
+        case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : (exact ? k_unroll_pair<PRE, KIND, 4, false, true> : k_unroll_pair<PRE, KIND, 4, false>); break;
+        default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : (exact ? k_unroll_pair<PRE, KIND, 8, false, true> : k_unroll_pair<PRE, KIND, 8, false>); break;
       }
       for (int b0 = 0; b0 < B; b0 += chunk) {
         pa.b0 = b0;
@@ -1132,10 +1193,11 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     return L2O_OK;
   }
   void (*fn)(UnrollArgs) = nullptr;
+  const bool exact1 = opt(L2O_OPT_EXACT_GATES) != 0 && !hist;
   switch (g.CH) {
-    case 1: fn = hist ? k_unroll<PRE, KIND, 1, true> : k_unroll<PRE, KIND, 1, false>; break;
-    case 2: fn = hist ? k_unroll<PRE, KIND, 2, true> : k_unroll<PRE, KIND, 2, false>; break;
-    case 4: fn = hist ? k_unroll<PRE, KIND, 4, true> : k_unroll<PRE, KIND, 4, false>; break;
+    case 1: fn = hist ? k_unroll<PRE, KIND, 1, true> : (exact1 ? k_unroll<PRE, KIND, 1, false, true> : k_unroll<PRE, KIND, 1, false>); break;
+    case 2: fn = hist ? k_unroll<PRE, KIND, 2, true> : (exact1 ? k_unroll<PRE, KIND, 2, false, true> : k_unroll<PRE, KIND, 2, false>); break;
+    case 4: fn = hist ? k_unroll<PRE, KIND, 4, true> : (exact1 ? k_unroll<PRE, KIND, 4, false, true> : k_unroll<PRE, KIND, 4, false>); break;
     default: fn = hist ? k_unroll<PRE, KIND, 8, true> : k_unroll<PRE, KIND, 8, false>; break;
   }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1182,16 +1244,6 @@ extern "C" {
 
 int l2o_abi_version(void) { return L2O_ABI_VERSION; }
 const char* l2o_last_error(void) { return g_err; }
-
-int l2o_set_option(int32_t option, int64_t value) {
-  if (option < 0 || option >= L2O_OPT_COUNT_) return fail(L2O_ERR_ARG, "l2o_set_option: unknown option %d", option);
-  g_opt[option].store(value, std::memory_order_relaxed);
-  return L2O_OK;
-}
-int64_t l2o_get_option(int32_t option) {
-  if (option < 0 || option >= L2O_OPT_COUNT_) return -1;
-  return opt(option);
-}
 
 size_t l2o_wpack_floats(const l2o_net_cfg* cfg) {
   if (!cfg) return 0;
@@ -1389,6 +1441,7 @@ int l2o_wpack_host(const l2o_net_cfg* cfg, const float* wg1, const float* bg1, c
 }
 
 int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wpack, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !w || !wpack) return fail(L2O_ERR_ARG, "l2o_wpack_device: NULL argument");
   if (!net_ok_for_mfma(cfg) || cfg->n_layers == 0)
     return fail(L2O_ERR_UNSUPPORTED, "l2o_wpack_device: layers=(20,20) nets only");
@@ -1463,6 +1516,7 @@ static int launch_problem_fg(const ProbParams& pp, const float* x, float* f_part
 }
 
 int l2o_problem_fg(const l2o_problem* prob, const float* x, float* f_part, float* g, void* stream) {
+  OptScope opt_scope((prob && (prob->flags & L2O_PROB_FG_TWO_PASS)) ? L2O_OPTW(L2O_OPT_FG_TWO_PASS, 1) : 0);
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!x || !f_part) return fail(L2O_ERR_ARG, "l2o_problem_fg: NULL x / f_part");
@@ -1479,6 +1533,7 @@ __global__ void k_hvp_sep(ProbParams pp, const float* __restrict__ x, const floa
 }
 
 int l2o_problem_hvp(const l2o_problem* prob, const float* x, const float* u, float* out, float* scratch, void* stream) {
+  OptScope opt_scope((prob && (prob->flags & L2O_PROB_FG_TWO_PASS)) ? L2O_OPTW(L2O_OPT_FG_TWO_PASS, 1) : 0);
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!x || !u || !out || !scratch) return fail(L2O_ERR_ARG, "l2o_problem_hvp: NULL argument");
@@ -1497,6 +1552,7 @@ int l2o_problem_hvp(const l2o_problem* prob, const float* x, const float* u, flo
 int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices, const float* w1, const float* b1, const float* w2,
                const float* b2, float* loss, float* gw1, float* gb1, float* gw2, float* gb2, float* scratch,
                void* stream) {
+  OptScope opt_scope((mlp && (mlp->flags & L2O_MLP_GENERIC)) ? L2O_OPTW(L2O_OPT_MLP_GENERIC, 1) : 0);
   if (!mlp || !indices || !w1 || !b1 || !w2 || !b2 || !loss || !mlp->images || !mlp->labels)
     return fail(L2O_ERR_ARG, "l2o_mlp_fg: NULL argument");
   const bool want_g = gw1 || gb1 || gw2 || gb2;
@@ -1601,6 +1657,7 @@ int32_t l2o_cwlstm_wgrad_dims(const l2o_net_cfg* cfg, int32_t* KA, int32_t* KB) 
 
 int l2o_cwlstm_wgrad(const l2o_net_cfg* cfg, const float* A, const float* Bm, int64_t R, float* G, void* workspace,
                      void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   int32_t KA = 0, KB = 0;
   const int rc = l2o_cwlstm_wgrad_dims(cfg, &KA, &KB);
   if (rc) return rc;
@@ -1635,6 +1692,7 @@ size_t l2o_gen_state_floats(const l2o_gen_net* net, int64_t N) {
 
 int l2o_cwlstm_step_generic(const l2o_net_cfg* cfg, const l2o_gen_net* net, const float* g, const float* m_tilde, float* m,
                             float* v, double pow1, double pow2, float* state, float* x, int64_t N, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   int rc = check_gen_net(cfg, net);
   if (rc) return rc;
   if (!g || !state || !x || N <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_step_generic: bad argument");
@@ -1692,9 +1750,10 @@ static bool mlp_unroll_layout(const l2o_mlp* mlp, MlpUnrollLayout* L) {
 }
 
 int l2o_mlp_unroll_supported(const l2o_net_cfg* cfg, const l2o_mlp* mlp, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   MlpUnrollLayout L;
   if (!cfg || !net_ok_for_mfma(cfg) || !opt(L2O_OPT_MLP_UNROLL) || !mlp_unroll_layout(mlp, &L)) return 0;
-  return L.nwg <= device_cu_count((hipStream_t)stream) ? 1 : 0;   // one workgroup per CU, all co-resident
+  return L.nwg <= coresident_cus((hipStream_t)stream) ? 1 : 0;   // one workgroup per CU, all co-resident
 }
 
 size_t l2o_mlp_unroll_workspace_bytes(const l2o_mlp* mlp) {
@@ -1705,11 +1764,12 @@ size_t l2o_mlp_unroll_workspace_bytes(const l2o_mlp* mlp) {
 int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* mlp, const int32_t* indices,
                    float* const* x, float* const* st, float* const* m, float* const* v, const float* const* x_scale,
                    int32_t T, int32_t step0, float* fx, void* workspace, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !wpack || !mlp || !indices || !x || !st || !fx || !workspace || T < 0 || !mlp->images || !mlp->labels)
     return fail(L2O_ERR_ARG, "l2o_mlp_unroll: bad argument");
   hipStream_t s = (hipStream_t)stream;
   MlpUnrollLayout L;
-  if (!net_ok_for_mfma(cfg) || !mlp_unroll_layout(mlp, &L) || L.nwg > device_cu_count(s))
+  if (!net_ok_for_mfma(cfg) || !mlp_unroll_layout(mlp, &L) || L.nwg > coresident_cus(s))
     return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_unroll: no fused kernel for n_in=%d hidden=%d out=%d batch=%d net(layers=%d)",
                 mlp->n_in, mlp->n_hidden, mlp->n_out, mlp->batch, cfg->n_layers);
   const bool rn = cfg->preprocess == L2O_PRE_FC_ELU;
@@ -1751,6 +1811,7 @@ int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* ml
 
 int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_step_seg* segs, int32_t nseg,
                           double pow1, double pow2, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !wpack || !segs || nseg < 1) return fail(L2O_ERR_ARG, "l2o_cwlstm_step: bad argument");
   if (nseg > kMaxStepSegs) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_step_multi: at most %d segments", kMaxStepSegs);
   for (int i = 0; i < nseg; ++i)
@@ -1806,6 +1867,7 @@ int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_
 
 int l2o_cwlstm_step(const l2o_net_cfg* cfg, const float* wpack, const float* g, float* m, float* v, double pow1,
                     double pow2, float* st, float* x, int64_t B, int64_t D, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   l2o_step_seg seg;
   std::memset(&seg, 0, sizeof(seg));
   seg.g = g; seg.m = m; seg.v = v; seg.st = st; seg.x = x; seg.B = B; seg.D = D;
@@ -1855,6 +1917,7 @@ static void fill_bwd_net(BwdParams& p, const l2o_net_cfg* cfg, const l2o_net_wei
 int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_seg* segs, int32_t nseg,
                          const float* carry_in, float* carry_out, float* A, float* Bm, double pow1, double pow2,
                          void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !w || !segs || nseg < 1 || !carry_in || !carry_out || !A || !Bm)
     return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_multi: bad argument");
   if (nseg > 8) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_multi: at most 8 panels");
@@ -1892,6 +1955,7 @@ int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const
 int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
                           int32_t nseg, const float* const* table, int32_t T, int64_t step0, const float* carry_in,
                           float* carry_out, float* A, float* Bm, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !w || !segs || nseg < 1 || !table || T < 1 || step0 < 0 || !A || !Bm)
     return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_unroll: bad argument");
   if (nseg > 8) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll: at most 8 panels");
@@ -1926,6 +1990,7 @@ int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, cons
 
 int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_io* io, double pow1,
                         double pow2, int64_t B, int64_t D, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !w || !io || B <= 0 || D <= 0 || !io->g || !io->dx_next || !io->act1 || !io->dd || !w->w_lin ||
       !w->b_lin)
     return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step: bad argument");
@@ -2006,6 +2071,7 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
 }
 
 int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !prob || !net_ok_for_mfma(cfg)) return 0;
   if (prob->kind != L2O_PROB_QUADRATIC && prob->kind != L2O_PROB_LASSO && prob->kind != L2O_PROB_RASTRIGIN &&
       prob->kind != L2O_PROB_SQUARE_COS)
@@ -2016,10 +2082,12 @@ int l2o_unroll_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
 }
 
 int l2o_unroll_record_supported(const l2o_net_cfg* cfg, const l2o_problem* prob) {
+  OptScope opt_scope(cfg_optw(cfg));
   return l2o_unroll_supported(cfg, prob);                   // every fused form records (ABI v6: the streaming form too)
 }
 
 size_t l2o_unroll_workspace_bytes(const l2o_net_cfg* cfg, const l2o_problem* prob, int32_t T) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!l2o_unroll_supported(cfg, prob) || T < 0) return 0;
   UnrollGeom g;
   if (!unroll_geom(prob, &g) || g.CH < 2) return 0;       // (the streaming form needs no workspace)
@@ -2030,8 +2098,16 @@ int l2o_unroll_status(const void* workspace_header_host) {
   if (!workspace_header_host) return L2O_OK;
   const unsigned st = *static_cast<const unsigned*>(workspace_header_host);
   if (st == 0) return L2O_OK;
-  return fail(L2O_ERR_HIP, "l2o_unroll: partner workgroup timed out (status %u): the two halves of a problem "
-                           "were not co-resident; rerun with L2O_NO_PAIR=1", st);
+  if (st == 2)
+    return fail(L2O_ERR_HIP, "l2o_mlp_unroll: a workgroup's all-reduce inputs never arrived (status 2): the persistent "
+                             "launch was not fully co-resident (a shared / masked device?); the iterate and LSTM state "
+                             "of that launch are invalid.  Run l2o_coresident_workgroups once so that the library "
+                             "sizes against what is really available, or switch the fused form off "
+                             "(L2O_OPT_MLP_UNROLL = 0 / L2O_NO_MLP_UNROLL=1)");
+  return fail(L2O_ERR_HIP, "l2o_unroll: partner workgroup timed out (status %u): the two halves of a problem were not "
+                           "co-resident (a shared / masked device?); the iterate and LSTM state of that launch are "
+                           "invalid.  Run l2o_coresident_workgroups once so that the library sizes against what is "
+                           "really available, or use one CU per problem (L2O_OPT_PAIR = 0 / L2O_NO_PAIR=1)", st);
 }
 
 static int unroll_impl(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st,
@@ -2040,18 +2116,21 @@ static int unroll_impl(const l2o_net_cfg* cfg, const float* wpack, const l2o_pro
 
 int l2o_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st, float* m,
                float* v, int32_t T, int32_t step0, float* fx_part, void* workspace, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   return unroll_impl(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, nullptr, nullptr, stream);
 }
 
 int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, float* x, float* st,
                       float* m, float* v, int32_t T, int32_t step0, float* fx_part, void* workspace,
                       const l2o_unroll_hist* hist, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   return unroll_impl(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, hist, nullptr, stream);
 }
 
 int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack, const l2o_problem* prob, const float* x0, float* x,
                       float* st, float* m, float* v, int32_t T, int32_t step0, int32_t flags, float* fx_part, float* fx,
                       void* workspace, const l2o_unroll_hist* hist, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   if (!fx) return fail(L2O_ERR_ARG, "l2o_unroll_reduce: NULL fx");
   if (flags & ~(L2O_UNROLL_ZERO_STATE | L2O_UNROLL_PREPARED))
     return fail(L2O_ERR_ARG, "l2o_unroll_reduce: unknown flags %d", flags);
@@ -2059,12 +2138,41 @@ int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
 }
 
 int l2o_unroll_prepare(const l2o_net_cfg* cfg, const l2o_problem* prob, void* workspace, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
   int rc = check_problem(prob);
   if (rc) return rc;
   UnrollGeom g;
-  if (!cfg || !l2o_unroll_supported(cfg, prob) || !unroll_geom(prob, &g) || g.CH < 2) return L2O_OK;   // nothing to prepare
+  if (!cfg || !l2o_unroll_supported(cfg, prob) || !unroll_geom(prob, &g) || g.CH < 2 || !opt(L2O_OPT_PAIR_NORMAL) ||
+      opt(L2O_OPT_EXACT_GATES))
+    return L2O_OK;   // nothing to prepare (only the normal-matrix two-CU form has a per-problem pass)
   if (!workspace) return fail(L2O_ERR_ARG, "l2o_unroll_prepare: NULL workspace");
   return launch_pair_prepare(prob, g, workspace, (hipStream_t)stream);
+}
+
+int32_t l2o_coresident_workgroups(void* scratch, void* stream) {
+  if (!scratch) return fail(L2O_ERR_ARG, "l2o_coresident_workgroups: NULL scratch");
+  hipStream_t s = (hipStream_t)stream;
+  const int dev = device_ordinal(s);
+  if (dev >= 0 && dev < 64) {
+    const int m = g_measured_cus[dev].load(std::memory_order_relaxed);
+    if (m > 0) return m;
+  }
+  const int n = device_cu_count(s);
+  if (n <= 0) return fail(L2O_ERR_HIP, "l2o_coresident_workgroups: no device");
+  unsigned* d = static_cast<unsigned*>(scratch);
+  const unsigned init[2] = {0u, 0xffffffffu};
+  HIP_TRY(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, s));
+  constexpr int kLds = 100 * 1024;                           // more than half a CU's LDS: one workgroup per CU
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_coresident_probe), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  hipLaunchKernelGGL(k_coresident_probe, dim3(n), dim3(256), kLds, s, d, d + 1);
+  HIP_TRY(hipGetLastError());
+  unsigned out[2] = {0u, 0u};
+  HIP_TRY(hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int got = (int)out[1];
+  if (got <= 0 || got > n) got = n;
+  if (dev >= 0 && dev < 64) g_measured_cus[dev].store(got, std::memory_order_relaxed);
+  return got;
 }
 
 int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream) {
@@ -2074,6 +2182,7 @@ int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream) {
 }
 
 int64_t l2o_unroll_workspace_layout(const l2o_net_cfg* cfg, const l2o_problem* prob) {
+  OptScope opt_scope(cfg_optw(cfg));
   UnrollGeom g;
   if (!cfg || !prob || !l2o_unroll_supported(cfg, prob) || !unroll_geom(prob, &g) || g.CH < 2) return 0;
   return ((int64_t)prob->B_local << 8) | g.CH;            // changes whenever the granule area's layout does

@@ -82,7 +82,7 @@ __device__ __forceinline__ float mu_poll(const unsigned long long* p, unsigned t
   unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int spins = 0;
   while ((unsigned)(g >> 32) != tag && !dead) {
-    if (++spins > (1 << 20)) { dead = true; atomicExch(status, 1u); break; }
+    if (++spins > (1 << 20)) { dead = true; atomicExch(status, 2u); break; }
     __builtin_amdgcn_s_sleep(L2O_MU_SLEEP1);
     g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -106,7 +106,7 @@ __device__ __forceinline__ void mu_wait_loads() { asm volatile("s_waitcnt vmcnt(
 __device__ __forceinline__ mu_u32x4 mu_poll2(const unsigned long long* p, mu_u32x4 d, unsigned tag, bool& dead, unsigned* status) {
   int spins = 0;
   while ((d[1] != tag || d[3] != tag) && !dead) {
-    if (++spins > (1 << 17)) { dead = true; atomicExch(status, 1u); break; }
+    if (++spins > (1 << 17)) { dead = true; atomicExch(status, 2u); break; }
     __builtin_amdgcn_s_sleep(L2O_MU_SLEEP2);
     d = mu_load2(p);
     mu_wait_loads();

@@ -80,7 +80,8 @@ __device__ __forceinline__ void lds_read_f4(float4 (&v)[N], const float* p) {
 
 // HIST: also record the per-step history for the meta-gradient (l2o_unroll_record); a template
 // parameter so that the plain unroll carries none of it
-template <int PRE, int KIND, int CH, bool HIST>
+// EXACT (L2O_OPT_EXACT_GATES): the fp32 MFMA gate GEMM (bit-equal to an fmaf chain) instead of the bf16x3 split
+template <int PRE, int KIND, int CH, bool HIST, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
   constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
@@ -145,11 +146,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   const bool row_counted = gq < 2 && (half == 0 ? (myrow < NC) : (myrow >= NC));   // every row once per pair
 
   // ---- per-lane persistent registers -------------------------------------
-#ifdef L2O_PAIR_FP32
-  using Core = LstmCore<PRE, false>;
-#else
-  using Core = LstmCore<PRE, true>;      // <= 4 waves per workgroup: bf16x3 gate GEMM, weights in VGPR + AGPR
-#endif
+  using Core = LstmCore<PRE, !EXACT>;    // <= 4 waves per workgroup: bf16x3 gate GEMM, weights in VGPR + AGPR
   Core core;
   core.load(a.np.wpack, lane);
   core.pin();   // fragments -> AGPRs (MFMA reads them there): the VGPRs hold W, the state and the gate math

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 
 __global__ __launch_bounds__(256) void k_probe(unsigned* ctr, unsigned* seen, int n) {
   extern __shared__ float big[];           // 100 KB of LDS: one workgroup per CU
@@ -39,6 +40,13 @@ int main() {
   pop = 0;
   for (auto w : mask) pop += __builtin_popcount(w);
   printf(" | (null stream): %s, popcount %d\n", hipGetErrorName(e), pop);
+  {
+    hipEvent_t t0, t1; (void)t0; (void)t1;
+    auto c0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < 1000; ++i) hipExtStreamGetCUMask(s, (uint32_t)mask.size(), mask.data());
+    auto c1 = std::chrono::steady_clock::now();
+    printf("hipExtStreamGetCUMask: %.3f us per call\n", std::chrono::duration<double, std::micro>(c1 - c0).count() / 1000.0);
+  }
   unsigned* d;
   hipMalloc(&d, 16);
   hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);

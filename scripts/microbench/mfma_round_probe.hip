@@ -1,0 +1,106 @@
+// How does v_mfma_f32_16x16x32_bf16 round?  D = C + sum_k a_k b_k with hand-picked exact bf16 operands whose exact sum
+// sits between two fp32 values: the returned bits tell round-to-nearest-even from truncation, and whether addends are
+// chopped one by one at the accumulator's ulp or summed first.  (Why: every kernel with the bf16x3 gate GEMM drifts
+// ~1e-5 from the float64 oracle at T = 1000 on a converging trajectory, the fp32-MFMA kernel 1e-6 like the CPU
+// oracles -- profiles/r03c_drift_forms.txt.)
+//   hipcc --offload-arch=gfx950 -O2 mfma_round_probe.hip -o mfma_round_probe && ./mfma_round_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+
+// every row of A = a[0..31], every column of B = b[0..31]; C = c everywhere; chain = number of chained MFMAs
+__global__ void k(const unsigned short* a, const unsigned short* b, float c, int chain, float* out) {
+  const int lane = threadIdx.x, kq = lane >> 4;
+  us8 av, bv;
+  for (int i = 0; i < 8; ++i) { av[i] = a[8 * kq + i]; bv[i] = b[8 * kq + i]; }
+  f32x4 acc = {c, c, c, c};
+  for (int n = 0; n < chain; ++n)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+  if (lane == 0) out[0] = acc[0];
+}
+__global__ void k_f32(const float* a, const float* b, float c, float* out) {   // v_mfma_f32_16x16x4_f32, K = 4
+  const int lane = threadIdx.x, kq = lane >> 4;
+  f32x4 acc = {c, c, c, c};
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq], b[kq], acc, 0, 0, 0);
+  if (lane == 0) out[0] = acc[0];
+}
+static unsigned short bf(float x) { unsigned u; memcpy(&u, &x, 4); return (unsigned short)(u >> 16); }   // exact inputs only
+static std::vector<float> at(std::initializer_list<std::pair<int, float>> kv) {
+  std::vector<float> v(32, 0.f);
+  for (auto& p : kv) v[p.first] = p.second;
+  return v;
+}
+static float run(std::vector<float> a, std::vector<float> b, float c, int chain = 1) {
+  a.resize(32, 0.f); b.resize(32, 0.f);
+  unsigned short ha[32], hb[32];
+  for (int i = 0; i < 32; ++i) { ha[i] = bf(a[i]); hb[i] = bf(b[i]); }
+  unsigned short *da, *db; float* dout;
+  hipMalloc(&da, 64); hipMalloc(&db, 64); hipMalloc(&dout, 4);
+  hipMemcpy(da, ha, 64, hipMemcpyHostToDevice); hipMemcpy(db, hb, 64, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, da, db, c, chain, dout);
+  float r; hipMemcpy(&r, dout, 4, hipMemcpyDeviceToHost);
+  hipFree(da); hipFree(db); hipFree(dout);
+  return r;
+}
+static float run32(std::vector<float> a, std::vector<float> b, float c) {
+  a.resize(4, 0.f); b.resize(4, 0.f);
+  float *da, *db, *dout;
+  hipMalloc(&da, 16); hipMalloc(&db, 16); hipMalloc(&dout, 4);
+  hipMemcpy(da, a.data(), 16, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), 16, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_f32, dim3(1), dim3(64), 0, 0, da, db, c, dout);
+  float r; hipMemcpy(&r, dout, 4, hipMemcpyDeviceToHost);
+  hipFree(da); hipFree(db); hipFree(dout);
+  return r;
+}
+static void show(const char* what, float got, double exact) {
+  const float rne = (float)exact;
+  float rz = rne;
+  if (std::fabs((double)rz) > std::fabs(exact)) rz = std::nextafterf(rz, 0.0f);
+  unsigned u; memcpy(&u, &got, 4);
+  printf("%-78s got %.10g (0x%08x)  RNE %.10g  RZ %.10g  -> %s\n", what, got, u, rne, rz,
+         got == rne ? (rne == rz ? "RNE == RZ" : "RNE") : (got == rz ? "RZ (truncation)" : "NEITHER"));
+}
+int main() {
+  const float u = ldexpf(1.0f, -23);      // ulp of 1.0
+  show("bf16: C=1 + one product 0.75 ulp", run({0.75f}, {u}, 1.0f), 1.0 + 0.75 * u);
+  show("bf16: C=1 + one product 0.25 ulp", run({0.25f}, {u}, 1.0f), 1.0 + 0.25 * u);
+  show("bf16: C=1 + one product 0.5 ulp (tie)", run({0.5f}, {u}, 1.0f), 1.0 + 0.5 * u);
+  show("bf16: C=1 + one product 1.5 ulp (tie to even: up)", run({1.5f}, {u}, 1.0f), 1.0 + 1.5 * u);
+  show("bf16: C=1 - 0.25 * 2^-24", run({-0.25f}, {u / 2}, 1.0f), 1.0 - 0.25 * u / 2);
+  show("bf16: C=1 - 0.75 * 2^-24", run({-0.75f}, {u / 2}, 1.0f), 1.0 - 0.75 * u / 2);
+  show("bf16: C=-1 - 0.75 ulp", run({-0.75f}, {u}, -1.0f), -1.0 - 0.75 * u);
+  show("bf16: C=1 + 32 products of 1/8 ulp (sum 4 ulp)", run(std::vector<float>(32, 0.125f), std::vector<float>(32, u), 1.0f), 1.0 + 4.0 * u);
+  show("bf16: C=1 + 3 products of 0.3125 ulp (sum 0.9375 ulp)", run({0.3125f, 0.3125f, 0.3125f}, {u, u, u}, 1.0f), 1.0 + 0.9375 * u);
+  show("bf16: C=1 + 6 products of 0.125 ulp (sum 0.75 ulp)", run(std::vector<float>(6, 0.125f), std::vector<float>(6, u), 1.0f), 1.0 + 0.75 * u);
+  show("bf16: C=0, products 1.0 and 0.75 ulp", run({1.0f, 0.75f}, {1.0f, u}, 0.0f), 1.0 + 0.75 * u);
+  show("bf16: C=0, products 1.0 and 32 x ... (1 + 31 x 1/8 ulp = 3.875 ulp)", [&] { std::vector<float> a(32, 0.125f), b(32, u); a[0] = 1.0f; b[0] = 1.0f; return run(a, b, 0.0f); }(), 1.0 + 3.875 * u);
+  show("bf16: C=0, products 1.0, -1.0, 0.75 ulp (cancellation, exact)", run({1.0f, -1.0f, 0.75f}, {1.0f, 1.0f, u}, 0.0f), 0.75 * u);
+  show("bf16: C=1, chain of 4 MFMAs each + 0.25 ulp (exact total 1 ulp)", run({0.25f}, {u}, 1.0f, 4), 1.0 + 1.0 * u);
+  show("bf16: C=1, chain of 4 MFMAs each + 0.75 ulp (exact total 3 ulp)", run({0.75f}, {u}, 1.0f, 4), 1.0 + 3.0 * u);
+  show("bf16: C=3 + 0.75 ulp(3) (ulp = 2^-22)", run({0.75f}, {2 * u}, 3.0f), 3.0 + 1.5 * u);
+  show("bf16: C=1 + 2^-40 (far below: sticky?) + 0.5 ulp tie", run({0.5f, 1.0f}, {u, ldexpf(1.0f, -40)}, 1.0f), 1.0 + 0.5 * u + ldexp(1.0, -40));
+  // direction of the in-group truncation: a NEGATIVE small product next to 1.0 (same lane group = K slots 0..7)
+  show("bf16: C=0, same group {1.0, -0.625 ulp}: floor -> 0x3f7ffffe, chop/RNE -> 0x3f7fffff", run({1.0f, -0.625f}, {1.0f, u}, 0.0f), 1.0 - 0.625 * u);
+  show("bf16: C=0, same group {1.0, -0.875 ulp}: chop -> 0x3f7fffff, floor/RNE -> 0x3f7ffffe", run({1.0f, -0.875f}, {1.0f, u}, 0.0f), 1.0 - 0.875 * u);
+  // the combine of the four 8-slot groups: the small product in ANOTHER lane group (K slot 8)
+  show("bf16: C=0, groups {k0: 1.0} {k8: 0.75 ulp}", run(at({{0, 1.0f}, {8, 0.75f}}), at({{0, 1.0f}, {8, u}}), 0.0f), 1.0 + 0.75 * u);
+  show("bf16: C=0, groups {k0: 1.0} {k8: 0.25 ulp} {k16: 0.25} {k24: 0.25}", run(at({{0, 1.0f}, {8, 0.25f}, {16, 0.25f}, {24, 0.25f}}), at({{0, 1.0f}, {8, u}, {16, u}, {24, u}}), 0.0f), 1.0 + 0.75 * u);
+  show("bf16: C=0, groups {k0: 1.0} {k8: -0.625 ulp}", run(at({{0, 1.0f}, {8, -0.625f}}), at({{0, 1.0f}, {8, u}}), 0.0f), 1.0 - 0.625 * u);
+  show("bf16: C=0, groups {k0: 1.0} {k8: -0.875 ulp}", run(at({{0, 1.0f}, {8, -0.875f}}), at({{0, 1.0f}, {8, u}}), 0.0f), 1.0 - 0.875 * u);
+  show("bf16: C=0, groups {k0: 1.0} {k8: 2^-30}, {k16: 0.5 ulp}  (sticky across groups?)", run(at({{0, 1.0f}, {8, 1.0f}, {16, 0.5f}}), at({{0, 1.0f}, {8, ldexpf(1.f, -30)}, {16, u}}), 0.0f), 1.0 + 0.5 * u + ldexp(1.0, -30));
+  // pairs inside a group: slots (0,1) vs (0,2) vs (0,4): is there a tree with per-level truncation?
+  show("bf16: C=0, {k0: 1.0, k1: 0.75 ulp}", run(at({{0, 1.0f}, {1, 0.75f}}), at({{0, 1.0f}, {1, u}}), 0.0f), 1.0 + 0.75 * u);
+  show("bf16: C=0, {k0: 1.0, k2: 0.75 ulp}", run(at({{0, 1.0f}, {2, 0.75f}}), at({{0, 1.0f}, {2, u}}), 0.0f), 1.0 + 0.75 * u);
+  show("bf16: C=0, {k0: 1.0, k4: 0.75 ulp}", run(at({{0, 1.0f}, {4, 0.75f}}), at({{0, 1.0f}, {4, u}}), 0.0f), 1.0 + 0.75 * u);
+  show("bf16: C=0, {k0: 1.0, k4: 1.75 ulp} (keeps which bits?)", run(at({{0, 1.0f}, {4, 1.75f}}), at({{0, 1.0f}, {4, u}}), 0.0f), 1.0 + 1.75 * u);
+  show("bf16: C=0, {k0: 1.0, k1: 2^-9 (1 + 2^-7) x 2^-7 (1 + 2^-7)}: a 16-bit product 2^-16 below", run(at({{0, 1.0f}, {1, ldexpf(1.0078125f, -9)}}), at({{0, 1.0f}, {1, ldexpf(1.0078125f, -7)}}), 0.0f), 1.0 + ldexp(1.0078125 * 1.0078125, -16));
+  show("fp32 MFMA: C=1 + 0.75 ulp", run32({0.75f}, {u}, 1.0f), 1.0 + 0.75 * u);
+  show("fp32 MFMA: C=1 - 0.25 * 2^-24", run32({-0.25f}, {u / 2}, 1.0f), 1.0 - 0.25 * u / 2);
+  show("fp32 MFMA: C=1 + 4 products of 0.1875 ulp (sum 0.75)", run32(std::vector<float>(4, 0.1875f), std::vector<float>(4, u), 1.0f), 1.0 + 0.75 * u);
+  return 0;
+}

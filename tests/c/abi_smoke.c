@@ -44,11 +44,7 @@ enum { B = 4, D = 16, T = 5, H = 20 };
 int main(int argc, char** argv) {
   const int host_only = argc > 1 && strcmp(argv[1], "--host") == 0;
   CHECK(l2o_abi_version() == L2O_ABI_VERSION, "ABI version %d != header %d", l2o_abi_version(), L2O_ABI_VERSION);
-  CHECK(l2o_get_option(L2O_OPT_PAIR) == 1, "default of L2O_OPT_PAIR");
-  L2O(l2o_set_option(L2O_OPT_PAIR, 0));
-  CHECK(l2o_get_option(L2O_OPT_PAIR) == 0, "set_option");
-  L2O(l2o_set_option(L2O_OPT_PAIR, 1));
-  CHECK(l2o_set_option(1000, 1) == L2O_ERR_ARG && l2o_get_option(-3) == -1, "unknown options are rejected");
+  /* (ABI v9: no process-wide option state -- the switches of a call travel in cfg.options, see (a'') below) */
 
   /* L2O-DM: CoordinateWiseDeepLSTM, layers (20, 20), identity preprocess, scale 1 (DM/util.py:138-142) */
   l2o_net_cfg cfg;
@@ -132,6 +128,31 @@ int main(int argc, char** argv) {
     HIP(hipStreamSynchronize(s));
     HIP(hipMemcpy(fx_prep, dfx, sizeof fx_prep, hipMemcpyDeviceToHost));
     CHECK(memcmp(fx_prep, fx_fused, sizeof fx_prep) == 0, "L2O_UNROLL_PREPARED launch differs from the self-preparing one");
+  }
+  /* (a'') kernel switches are PER CALL and caller-owned (cfg.options): the same unroll on the one-CU kernel, on the
+   * normal-matrix two-CU form and with the exact (fp32 MFMA) gate GEMM -- all within the parity tolerance of (a), and
+   * a later call with options = 0 is the default kernel again (the library kept nothing) */
+  {
+    const uint64_t variants[3] = {L2O_OPTW(L2O_OPT_PAIR, 0), L2O_OPTW(L2O_OPT_PAIR_NORMAL, 1), L2O_OPTW(L2O_OPT_EXACT_GATES, 1)};
+    for (int k = 0; k < 3; ++k) {
+      float fx_v[T + 1];
+      l2o_net_cfg c2 = cfg;
+      c2.options = variants[k];
+      HIP(hipMemcpy(dx, x0, sizeof x0, hipMemcpyHostToDevice)); HIP(hipMemset(dst, 0, nst * 4));
+      L2O(l2o_unroll_reduce(&c2, dwp, &prob, NULL, dx, dst, NULL, NULL, T, 1, 0, dfxp, dfx, k == 0 ? NULL : dws, NULL, s));
+      HIP(hipStreamSynchronize(s));
+      HIP(hipMemcpy(fx_v, dfx, sizeof fx_v, hipMemcpyDeviceToHost));
+      for (int t = 0; t <= T; ++t)
+        CHECK(fabsf(fx_v[t] - fx_fused[t]) <= 1e-5f * fabsf(fx_fused[t]), "options variant %d: fx[%d] = %g vs %g", k, t, fx_v[t], fx_fused[t]);
+    }
+    float fx_again[T + 1];
+    HIP(hipMemcpy(dx, x0, sizeof x0, hipMemcpyHostToDevice)); HIP(hipMemset(dst, 0, nst * 4));
+    L2O(l2o_unroll_reduce(&cfg, dwp, &prob, NULL, dx, dst, NULL, NULL, T, 1, 0, dfxp, dfx, dws, NULL, s));
+    HIP(hipStreamSynchronize(s));
+    HIP(hipMemcpy(fx_again, dfx, sizeof fx_again, hipMemcpyDeviceToHost));
+    CHECK(memcmp(fx_again, fx_fused, sizeof fx_again) == 0, "options = 0 after other calls is not the default kernel again");
+    int32_t cus = l2o_coresident_workgroups(dfxp, s);
+    CHECK(cus > 0, "l2o_coresident_workgroups = %d", cus);
   }
   /* (b) the same unroll through the step-granular entry points */
   HIP(hipMemcpy(dx, x0, sizeof x0, hipMemcpyHostToDevice)); HIP(hipMemset(dst, 0, nst * 4));

@@ -40,9 +40,35 @@ def test_header_symbols_exported(lib):
 
 def test_struct_sizes_match_header():
     from open_l2o_amd import _abi
-    # 6 int32 + 4 double ; 6 int32 + 2 double + 4 pointers
-    assert C.sizeof(_abi.NetCfg) == 6 * 4 + 4 * 8
+    # 6 int32 + 4 double + the options word ; 6 int32 + 2 double + 4 pointers ; 8 int32 + 2 pointers
+    assert C.sizeof(_abi.NetCfg) == 6 * 4 + 4 * 8 + 8
     assert C.sizeof(_abi.Problem) == 6 * 4 + 2 * 8 + 4 * 8
+    assert C.sizeof(_abi.Mlp) == 8 * 4 + 2 * 8
+
+
+def test_options_are_caller_owned():
+    """ABI v9: the library has no option state.  The binding keeps the caller's switches and encodes them into every
+    l2o_net_cfg (L2O_OPTW words), l2o_problem.flags and l2o_mlp.flags."""
+    from open_l2o_amd import _abi
+    from open_l2o_amd._engine import NetSpec
+    spec = NetSpec(_abi.NET_CW, _abi.PRE_IDENTITY, (20, 20))
+    assert _abi.options_word() == 0 and spec.to_c().options == 0
+    assert _abi.get_option(_abi.OPT_PAIR) == 1 and _abi.get_option(_abi.OPT_PAIR_NORMAL) == 0
+    old = _abi.set_option(_abi.OPT_PAIR, 0)
+    try:
+        assert old == 1 and spec.to_c().options == (8 | 0) << (4 * _abi.OPT_PAIR)
+        _abi.set_option(_abi.OPT_EXACT_GATES, 1)
+        assert spec.to_c().options == ((8 | 0) << (4 * _abi.OPT_PAIR)) | ((8 | 1) << (4 * _abi.OPT_EXACT_GATES))
+        _abi.set_option(_abi.OPT_BWD_BLOCKS, 300)
+        assert (spec.to_c().options >> 48) == 300
+    finally:
+        _abi.set_option(_abi.OPT_PAIR, 1)
+        _abi.set_option(_abi.OPT_EXACT_GATES, 0)
+        _abi.set_option(_abi.OPT_BWD_BLOCKS, 0)
+    assert _abi.options_word() == 0
+    with pytest.raises(ValueError):
+        _abi.set_option(1000, 1)
+    assert _abi.get_option(-3) == -1
 
 
 def test_size_queries(lib):

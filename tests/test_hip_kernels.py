@@ -555,14 +555,16 @@ def test_unroll_preparation_follows_the_problem(eng):
         return eng.to_numpy(fx)
 
     res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
-    assert rel_err(launch(), res.fx) < 1e-5
-    first = eng._ws_prepared
-    assert rel_err(launch(), res.fx) < 1e-5 and eng._ws_prepared is first      # same instance: prepared once
-    pd.W.mul_(1.25); pd.y.add_(0.5)                                                # the problem changes IN PLACE
-    prob2 = O.Quadratic(prob.w * np.float32(1.25), prob.y + np.float32(0.5))
-    res2 = O.unroll(prob2, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
-    assert rel_err(res2.fx, res.fx) > 1e-2
-    assert rel_err(launch(), res2.fx) < 1e-5 and eng._ws_prepared is not first
+    with lib_option(_abi.OPT_PAIR_NORMAL, 1):                                     # (the form that HAS a preparation)
+        assert rel_err(launch(), res.fx) < 1e-5
+        first = eng._ws_prepared
+        assert rel_err(launch(), res.fx) < 1e-5 and eng._ws_prepared is first      # same instance: prepared once
+        pd.W.mul_(1.25); pd.y.add_(0.5)                                                # the problem changes IN PLACE
+        prob2 = O.Quadratic(prob.w * np.float32(1.25), prob.y + np.float32(0.5))
+        res2 = O.unroll(prob2, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+        assert rel_err(res2.fx, res.fx) > 1e-2
+        assert rel_err(launch(), res2.fx) < 1e-5 and eng._ws_prepared is not first
+    assert rel_err(launch(), res2.fx) < 1e-5                                       # the default form prepares nothing
 
 
 def test_unroll_preparation_survives_an_unprepared_launch_of_another_problem(eng):
