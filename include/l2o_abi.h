@@ -275,6 +275,34 @@ int l2o_cwlstm_step_generic(const l2o_net_cfg* cfg /* kind, preprocess, tanh_out
                             double pow1, double pow2, float* state /* device, in-out */,
                             float* x /* device [N] in-out: x += delta */, int64_t N, void* stream);
 
+/* One step of back-propagation through time for the same ANY-`layers` stack (ABI v9): what
+ * tf.train.AdamOptimizer(lr).minimize(loss) of meta_minimize (DM/meta.py:398-414) differentiates through `update`
+ * (DM/meta.py:319-336) when networks.factory built a stack other than (20, 20) (DM/networks.py:157 accepts any tuple).
+ * The step is recomputed from st_prev; emitted per layer l: act[l] [N][in_l + H_l] = [input_l | h_l(t-1)] and
+ * dz[l] [N][4 H_l] = dL/d(gate pre-activations) -- the weight gradients of the step are act[l]^T dz[l] (biases: the
+ * column sums of dz[l]), h_last^T dd for the output Linear and, RNNProp, feats^T du for the input projection.
+ * carry_in / carry_out: dL/dh_l, dL/dc_l per layer in the l2o_gen_state_floats layout (zeros into the last step).
+ * m, v: the moments AFTER the step's update.  dg (identity / LogAndSign, optional): dL/dg_t for second_derivatives. */
+typedef struct l2o_gen_bwd_io {
+  const float* g;          /* device [N]                                  */
+  const float* m;          /* device [N], RNNProp                         */
+  const float* v;
+  const float* st_prev;    /* device, l2o_gen_state_floats: state before the step */
+  const float* dx_next;    /* device [N]: dL/d(delta_t)                   */
+  const float* carry_in;   /* device, state layout                        */
+  float* carry_out;
+  float* act[3];
+  float* dz[3];
+  float* tc;               /* device scratch [N * sum_l H_l]              */
+  float* h_last;           /* device [N][H_last]                          */
+  float* dd;               /* device [N]                                  */
+  float* feats;            /* device [N][2], RNNProp                      */
+  float* du;               /* device [N][in_dim], RNNProp                 */
+  float* dg;               /* device [N] or NULL                          */
+} l2o_gen_bwd_io;
+int l2o_cwlstm_bwd_step_generic(const l2o_net_cfg* cfg, const l2o_gen_net* net, const l2o_gen_bwd_io* io, double pow1,
+                                double pow2, int64_t N, void* stream);
+
 /* The same update for several variables that share one network in ONE launch (the reference
  * applies `net` to every variable of a subset inside the same time step, DM/meta.py:330-336;
  * problems.mnist has four: mlp/linear_{0,1}/{w,b}).  `segs` is a HOST array of 1..8 panels. */

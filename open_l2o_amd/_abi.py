@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_coresident_workgroups", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
-    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_unroll_prepare", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_unroll_prepare", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
 )
 
@@ -130,6 +130,13 @@ class GenNet(C.Structure):
                 ("w_fc", C.c_void_p), ("b_fc", C.c_void_p)]
 
 
+class GenBwdIO(C.Structure):
+    """struct l2o_gen_bwd_io"""
+    _fields_ = [(n, C.c_void_p) for n in ("g", "m", "v", "st_prev", "dx_next", "carry_in", "carry_out")] + \
+               [("act", C.c_void_p * 3), ("dz", C.c_void_p * 3)] + \
+               [(n, C.c_void_p) for n in ("tc", "h_last", "dd", "feats", "du", "dg")]
+
+
 class NetWeights(C.Structure):
     """struct l2o_net_weights"""
     _fields_ = [(n, C.c_void_p) for n in ("w_gates1", "b_gates1", "w_gates2", "b_gates2", "w_lin", "b_lin",
@@ -229,6 +236,8 @@ def lib():
     L.l2o_gen_state_floats.argtypes = [C.POINTER(GenNet), i64]
     L.l2o_cwlstm_step_generic.restype = C.c_int
     L.l2o_cwlstm_step_generic.argtypes = [C.POINTER(NetCfg), C.POINTER(GenNet), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, vp]
+    L.l2o_cwlstm_bwd_step_generic.restype = C.c_int
+    L.l2o_cwlstm_bwd_step_generic.argtypes = [C.POINTER(NetCfg), C.POINTER(GenNet), C.POINTER(GenBwdIO), dbl, dbl, i64, vp]
     L.l2o_cwlstm_step_multi.restype = C.c_int
     L.l2o_cwlstm_step_multi.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(StepSeg), C.c_int32, dbl, dbl, vp]
     L.l2o_cwlstm_bwd_step.restype = C.c_int

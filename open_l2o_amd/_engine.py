@@ -338,6 +338,21 @@ class HipEngine(object):
         _abi.check(self.lib.l2o_cwlstm_step_generic(C.byref(cc), C.byref(gen.c), _ptr(g), _ptr(m_tilde), _ptr(m), _ptr(v),
                                                     float(pow1), float(pow2), _ptr(st), _ptr(x), int(N), self._stream()))
 
+    def bwd_step_generic(self, spec: NetSpec, gen, io: dict, pow1, pow2, N):
+        """One BPTT step of an ANY-`layers` stack (l2o_cwlstm_bwd_step_generic).  io: device tensors keyed by the fields
+        of struct l2o_gen_bwd_io (act / dz: lists, one tensor per layer; missing = NULL)."""
+        c = _abi.GenBwdIO()
+        for k, _ in _abi.GenBwdIO._fields_:
+            if k in ("act", "dz"):
+                for l, t in enumerate(io[k]):
+                    getattr(c, k)[l] = t.data_ptr()
+            else:
+                t = io.get(k)
+                setattr(c, k, None if t is None else t.data_ptr())
+        cc = spec.to_c()
+        _abi.check(self.lib.l2o_cwlstm_bwd_step_generic(C.byref(cc), C.byref(gen.c), C.byref(c), float(pow1), float(pow2),
+                                                        int(N), self._stream()))
+
     def lstm_step(self, spec: NetSpec, wpack, g, m, v, pow1, pow2, st, x, B, D):
         if isinstance(wpack, HipEngine.GenNet):
             return self.lstm_step_generic(spec, wpack, g, None, m, v, pow1, pow2, st, x, B * D)
@@ -354,8 +369,13 @@ class HipEngine(object):
         if isinstance(wpack, HipEngine.GenNet):              # generic-`layers` net: one launch per variable
             for seg in segs:
                 g, m, v, st, x, B, D = seg[:7]
-                if len(seg) > 7 and seg[7] is not None:
-                    raise NotImplementedError("history chaining (st_out) is implemented for the (20, 20) nets")
+                if len(seg) > 7 and seg[7] is not None:      # history chaining: the step runs in place on the copies
+                    st_out, m_out, v_out = seg[7:10]
+                    st_out.copy_(st)
+                    if m is not None:
+                        m_out.copy_(m); v_out.copy_(v)
+                        m, v = m_out, v_out
+                    st = st_out
                 self.lstm_step_generic(spec, wpack, g, None, m, v, pow1, pow2, st, x, B * D)
             return
         for i in range(0, len(segs), self.MAX_STEP_SEGS):

@@ -1718,6 +1718,42 @@ int l2o_cwlstm_step_generic(const l2o_net_cfg* cfg, const l2o_gen_net* net, cons
   return L2O_OK;
 }
 
+int l2o_cwlstm_bwd_step_generic(const l2o_net_cfg* cfg, const l2o_gen_net* net, const l2o_gen_bwd_io* io, double pow1,
+                                double pow2, int64_t N, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
+  int rc = check_gen_net(cfg, net);
+  if (rc) return rc;
+  if (!io || N <= 0 || !io->g || !io->st_prev || !io->dx_next || !io->carry_in || !io->carry_out || !io->tc ||
+      !io->h_last || !io->dd)
+    return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step_generic: bad argument");
+  if (net->direct_inputs) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_step_generic: direct inputs have no moments to chain through");
+  const bool fc = cfg->preprocess == L2O_PRE_FC_ELU;
+  if (fc && (!io->m || !io->v || !io->feats || !io->du))
+    return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step_generic: RNNProp needs m, v, feats and du");
+  if (fc && io->dg) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_step_generic: the input adjoint of RNNProp is formed by the host from du");
+  GenBwdParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.n_layers = net->n_layers;
+  for (int l = 0; l < net->n_layers; ++l) {
+    if (!io->act[l] || !io->dz[l]) return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_step_generic: NULL act / dz of layer %d", l);
+    p.H[l] = net->hidden[l]; p.wg[l] = net->w_gates[l]; p.bg[l] = net->b_gates[l];
+    p.act[l] = io->act[l]; p.dz[l] = io->dz[l];
+  }
+  p.in_dim = net->in_dim; p.pre = cfg->preprocess; p.tanh_output = cfg->tanh_output;
+  p.scale = (float)cfg->scale;
+  p.k_inv = cfg->logsign_k != 0.0 ? (float)(1.0 / cfg->logsign_k) : 0.0f;
+  p.exp_k = (float)std::exp(cfg->logsign_k);
+  p.om1 = (float)(1.0 - pow1); p.om2 = (float)(1.0 - pow2);
+  p.wl = net->w_lin; p.bl = net->b_lin; p.wfc = net->w_fc; p.bfc = net->b_fc;
+  p.g = io->g; p.m = io->m; p.v = io->v; p.st_prev = io->st_prev; p.dx_next = io->dx_next;
+  p.carry_in = io->carry_in; p.carry_out = io->carry_out; p.tc = io->tc; p.h_last = io->h_last; p.dd = io->dd;
+  p.feats = io->feats; p.du = io->du; p.dg = io->dg; p.N = (long)N;
+  hipLaunchKernelGGL(k_cwlstm_generic_bwd, dim3((unsigned)((N + kGenThreads - 1) / kGenThreads)), dim3(kGenThreads), 0,
+                     (hipStream_t)stream, p);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
 // ---- the fused persistent unroll of the MLP optimizee (csrc/l2o_mlp_unroll.h) ---------------------------
 struct MlpUnrollLayout { int n[4], tile_begin[5], nwg, nw1, R; bool fast; size_t NO, NSM, p_off, s_off, sm_off, total; };
 static bool mlp_unroll_layout(const l2o_mlp* mlp, MlpUnrollLayout* L) {

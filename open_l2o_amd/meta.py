@@ -835,10 +835,33 @@ class UnrollGraph(object):
         second = any(pn.get("second") for pn in panels)
 
         def hess_update(pn, t, N):
-            """second_derivatives: lam_t = g_t + lam_{t+1} + (d g_t / d x_t) u_t with u_t = dL/dg_t just emitted."""
+            """second_derivatives: lam_t = g_t + lam_{t+1} + (d g_t / d x_t) u_t with u_t = dL/dg_t just emitted.
+            g_t was recorded with its term's weight folded in (_run_steps), so the Hessian-vector product of the
+            UNWEIGHTED optimizee carries the same factor."""
             hv = pn.setdefault("hv", eng.empty(N))
             eng.problem_hvp(pn["desc"], pn["xs"][t], pn["dg"].view(pn["B"], pn["D"]), hv.view(pn["B"], pn["D"]))
-            pn["lam"] = pn["gs"][t].reshape(N) + pn["lam"] + hv      # (a new tensor: hv is reused)
+            w = float(pn.get("weight", 1.0))
+            pn["lam"] = pn["gs"][t].reshape(N) + pn["lam"] + (hv if w == 1.0 else hv * w)   # (a new tensor: hv is reused)
+
+        def rnnprop_input_adjoint(pn, t, N, Bt, k):
+            """second_derivatives for RNNProp (DM/meta_rnnprop_train.py:380-388 without the stop_gradient): the network
+            inputs m~ = m^/(sqrt(v^) + 1e-8), g~ = g/(sqrt(v^) + 1e-8) depend on g_t directly AND through the moment
+            recurrences m_t = b1 m_{t-1} + (1 - b1) g_t, v_t = b2 v_{t-1} + (1 - b2) g_t^2 that later steps read.  From
+            the step kernel's du (adjoint of the input projection's pre-activations) this forms u_t = dL/dg_t and the
+            adjoints carried to step t - 1; elementwise device tensor code (a training-mode side path)."""
+            du = Bt[:N, 8 * H + 1:8 * H + 1 + H]
+            wfc = wdev["w_fc"].view(2, H)
+            a0, a1 = (du * wfc[0]).sum(1), (du * wfc[1]).sum(1)                  # dL/dm~, dL/dg~
+            g, m, v = pn["gs"][t].reshape(N), pn["ms"][t].reshape(N), pn["vs"][t].reshape(N)
+            om1, om2 = 1.0 - b1 ** k, 1.0 - b2 ** k
+            m_hat, sq = m / om1, torch.sqrt(v / om2)
+            den = sq + 1e-8
+            d_den = -(a0 * m_hat + a1 * g) / (den * den)
+            d_vhat = torch.where(sq > 0, d_den * 0.5 / sq.clamp_min(1e-30), torch.zeros_like(sq))
+            dm = a0 / den / om1 + pn["dm"]
+            dv = d_vhat / om2 + pn["dv"]
+            pn["dg"] = a1 / den + dm * float(np.float32(1.0 - self.beta1)) + dv * (2.0 * float(np.float32(1.0 - self.beta2))) * g
+            pn["dm"], pn["dv"] = dm * b1, dv * b2
 
         def need_dxs():
             if second:                                      # running adjoint instead of the precomputed prefix sums
@@ -846,6 +869,7 @@ class UnrollGraph(object):
                     N = pn["B"] * pn["D"]
                     pn["lam"] = pn["g_final"].reshape(N).clone()
                     pn["dg"] = eng.empty(N)
+                    pn["dm"], pn["dv"] = eng.zeros(N), eng.zeros(N)      # RNNProp: adjoints of the carried moments
                 return
             for pn in panels:                               # loss = sum_t fx_t: dL/d(delta_t) = g_final + sum_{tau > t} g_tau
                 if pn.get("dxs") is None:
@@ -857,8 +881,42 @@ class UnrollGraph(object):
                         acc_g = acc_g + pn["gs"][t].reshape(N)
 
         if spec.generic:
-            raise NotImplementedError("meta_minimize (BPTT) is implemented for the layers=(20, 20) and () optimizer nets; "
-                                      "layers=%r runs forward only (l2o_cwlstm_step_generic)" % (spec.layers,))
+            # ANY `layers` tuple (DM/networks.py:157): the VALU backward companion of l2o_cwlstm_step_generic, one launch
+            # per (step, panel); the weight gradients of a step are act_l^T dz_l per layer (l2o_atb), accumulated over
+            # the steps.  A correct device path for the plugin contract, not a fast one.
+            if second:
+                raise NotImplementedError("second_derivatives=True is implemented for the (20, 20) and () nets")
+            if not hasattr(eng, "bwd_step_generic"):
+                raise NotImplementedError("this engine has no BPTT for layers=%r" % (spec.layers,))
+            need_dxs()
+            gen = net.wpack(eng)
+            Hs = [int(h) for h in spec.layers]
+            P = int(gen.c.in_dim)                           # (the fc width is the net's own, not the harness' 20)
+            ins = [P] + Hs[:-1]
+            for pn in panels:
+                N = pn["B"] * pn["D"]
+                nst = sum(2 * N * h for h in Hs)
+                io = dict(act=[eng.empty(N, i + h) for i, h in zip(ins, Hs)], dz=[eng.empty(N, 4 * h) for h in Hs],
+                          tc=eng.empty(N * sum(Hs)), h_last=eng.empty(N, Hs[-1]), dd=eng.empty(N))
+                if fc:
+                    io.update(feats=eng.empty(N, 2), du=eng.empty(N, P))
+                carry_in, carry_out = eng.zeros(nst), eng.zeros(nst)
+                for t in reversed(range(T)):
+                    k = step0 + t
+                    io.update(g=pn["gs"][t], m=pn["ms"][t], v=pn["vs"][t], st_prev=pn["sts"][t], dx_next=pn["dxs"][t],
+                              carry_in=carry_in, carry_out=carry_out)
+                    eng.bwd_step_generic(spec, gen, io, b1 ** k, b2 ** k, N)
+                    carry_in, carry_out = carry_out, carry_in
+                    for l in range(nl):
+                        add("lstm_%d" % (l + 1), "w_gates", eng.atb(io["act"][l], io["dz"][l]))
+                        add("lstm_%d" % (l + 1), "b_gates", io["dz"][l].sum(0))
+                    dd = io["dd"].view(N, 1)
+                    add("linear", "w", eng.atb(io["h_last"], dd))
+                    add("linear", "b", dd.sum(0))
+                    if fc:
+                        add("input_projection", "w", eng.atb(io["feats"], io["du"]))
+                        add("input_projection", "b", io["du"].sum(0))
+            return
         if not nl:                                         # Linear-only net: two tiny products per step
             need_dxs()
             for pn in panels:
@@ -916,7 +974,8 @@ class UnrollGraph(object):
                     eng.bwd_multi(spec, wdev, segs, carry_in, carry_out, At, Bt, b1 ** k, b2 ** k)
                 else:
                     pn, N = grp[0], Ns[0]
-                    io = dict(g=pn["gs"][t], dx_next=pn["lam"] if second else pn["dxs"][t], dg=pn.get("dg"),
+                    io = dict(g=pn["gs"][t], dx_next=pn["lam"] if second else pn["dxs"][t],
+                              dg=None if fc else pn.get("dg"),     # (RNNProp: formed from du below, not by the kernel)
                               st_prev=pn["sts"][t], carry_in=carry_in[:, :N],
                               carry_out=carry_out[:, :N], m=pn["ms"][t], v=pn["vs"][t], a_stride=KA, b_stride=KB,
                               act1=At[:N, 0:K1], act2=At[:N, K1:K1 + 2 * H], h2=At[:N, K1 + 2 * H:K1 + 3 * H],
@@ -929,6 +988,8 @@ class UnrollGraph(object):
                     if R != N:
                         carry_out[:, :N] = io["carry_out"]
                     if second:
+                        if fc:
+                            rnnprop_input_adjoint(pn, t, N, Bt, k)
                         hess_update(pn, t, N)
                 carry_in, carry_out = carry_out, carry_in
             # l2o_cwlstm_wgrad: every weight gradient is a block of A^T Bm (only those blocks are computed)
@@ -963,7 +1024,8 @@ class UnrollGraph(object):
             if self.second_derivatives:                    # dL/dx_t picks up H(x_t) . dL/dg_t (DM/meta.py:328-329)
                 if rec["descs"][j] is None:
                     raise NotImplementedError("second_derivatives=True is implemented for the analytic optimizees")
-                pn.update(second=True, desc=rec["descs"][j], xs=[x[j] for x in rec["x"]])
+                pn.update(second=True, desc=rec["descs"][j], xs=[x[j] for x in rec["x"]],
+                          weight=self.term_of[self.x[j].decl.name].weight)
             by_net.setdefault(s.key, (net, []))[1].append(pn)
         for key, (net, panels) in by_net.items():      # rec["plan"]: buffers of a planned unroll are reused, so is the table
             self._bptt_panels(net, out.setdefault(key, {}), T, step0, panels, cache=rec.get("plan"))
@@ -1550,9 +1612,6 @@ class MetaOptimizer(object):
 
     # -- the unroll ------------------------------------------------------------
     def _build_graph(self, make_loss, len_unroll, net_assignments, second_derivatives):
-        if second_derivatives and self._rnnprop:
-            raise NotImplementedError("second_derivatives=True is implemented for the L2O-DM nets (identity / LogAndSign "
-                                      "preprocessing); RNNProp's inputs depend on the gradient through the Adam moments")
         graph = UnrollGraph(self, make_loss, len_unroll, net_assignments, rnnprop=self._rnnprop,
                             beta1=self.beta1, beta2=self.beta2)
         # DM/meta.py:328-329: without the flag the optimizee gradients are constants of the meta-gradient

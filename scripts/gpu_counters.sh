@@ -23,4 +23,6 @@ for d in $O/trace_$TAG; do
   db=$(ls $d/*.db $d/*/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python scripts/rocprof_summary.py $db $O/kernel_trace_$TAG.txt > /dev/null
 done
-tail -30 $O/counters_$TAG.log
+# the rocpd databases are tens of MB per pass (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf $O/pmc_${TAG}_* $O/trace_$TAG
+tail -12 $O/counters_$TAG.log

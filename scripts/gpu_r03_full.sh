@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, lease 4: the whole GPU suite on the ABI-v9 build (caller-owned options, two-pass default, exact-gates option,
 # co-residency probe), drift per kernel form, counters + bench of the new default kernel.
-TAG=${1:-r03d}
+TAG=${1:-r03e}
 O=gpurun_out/$TAG; mkdir -p $O
 cd "$(dirname "$0")/.."
 (timeout 1800 python -m pytest tests -q -m gpu --durations=12 -x 2>&1 | tail -30) | tee $O/pytest.log

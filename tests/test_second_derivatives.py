@@ -149,8 +149,29 @@ def test_reference_smoke_simple_problem_linear_net(hip):
     assert np.isfinite(cost)
 
 
-def test_rnnprop_rejects_second_derivatives(hip):
-    cfg = O.RNNPROP
-    opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, make_params(cfg, seed=1), key="rp"))
-    with pytest.raises(NotImplementedError):
-        opt.meta_minimize(problems.quadratic(2, 4), 3, second_derivatives=True)
+def test_second_derivatives_of_a_weighted_term(hip):
+    """with a term weight != 1 (problems.ensemble, DM/problems.py:215-245) the recorded gradients carry
+    the weight -- so must the Hessian-vector product of the second-order term."""
+    cfg = O.NetConfig("cw", (20, 20), "identity", None, 0.05, False)
+    params = make_params(cfg, seed=53)
+    B, D, T, wgt = 3, 16, 5, 0.5
+    prob, x0, _ = make_problem("quadratic", B, D, seed=54)
+    W, y = torch.tensor(prob.w.astype(np.float64)), torch.tensor(prob.y.astype(np.float64))
+
+    def f(xx):
+        r = torch.matmul(W, xx.unsqueeze(-1)).squeeze(-1) - y
+        return wgt * torch.mean(torch.sum(r * r, 1))
+    problem = problems.ensemble([{"name": "quadratic", "options": dict(batch_size=B, num_dims=D,
+                                                                        data={"w": prob.w, "y": prob.y, "x": x0})}],
+                                weights=[wgt])
+    opt = meta.MetaOptimizer(**_cfg_opts(cfg, params))
+    ms = opt.meta_minimize(problem, T, learning_rate=1e-6, second_derivatives=True)
+    got = _captured_grads(opt, ms)
+    want = _torch_grad(cfg, params, f, x0.reshape(B, -1), T, True)
+    unweighted_hvp = _torch_grad(cfg, params, f, x0.reshape(B, -1), T, False)
+    for (mod, var), g in got.items():
+        ws = want[mod][var].reshape(g.shape)
+        scale_g = max(float(np.abs(ws).max()), 1e-12)
+        assert float(np.abs(g - ws).max()) / scale_g < 5e-4, (mod, var)
+    assert max(float(np.abs(want[m][v] - unweighted_hvp[m][v]).max()) / max(float(np.abs(want[m][v]).max()), 1e-12)
+               for m in want for v in want[m]) > 2e-3        # (the second-order term is visible in this case)
