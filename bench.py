@@ -146,15 +146,19 @@ def cpu_baseline_mnist(weights, batch, T, max_seconds=15.0):
                       "the 784-20-10 MLP, minibatch %d, %.1f s" % (steps, batch, dt)}
 
 
-TRAINED = {("quadratic", "dm", 128): "dm_quadratic_d128", ("rastrigin", "dm", 100): "dm_rastrigin_d100",
-           ("lasso", "rnnprop", 512): "rnnprop_lasso_256x512"}
+# (directory, global batch it was trained with).  The loss is a mean over the GLOBAL batch (DM/problems.py:99), so the
+# gradient scale an identity-preprocessing L2O-DM optimizer sees is 1/B_global: it transfers to a LARGER global batch
+# (smaller gradients: smaller steps, still converging) but not to a smaller one (config 4's optimizer, trained at 1024,
+# diverges on a stand-alone batch of 128).  RNNProp's inputs are normalised by the moments: scale-free.
+TRAINED = {("quadratic", "dm", 128): ("dm_quadratic_d128", 128), ("rastrigin", "dm", 100): ("dm_rastrigin_d100", 1024),
+           ("lasso", "rnnprop", 512): ("rnnprop_lasso_256x512", None)}
 
 
-def trained_weights(args, key):
+def trained_weights(args, key, Bg):
     """The committed meta-trained optimizer of this workload (tests/golden/trained/<name>/<net key>.l2l-0, the
     reference's checkpoint format, DM/networks.py:47-62), or (None, None)."""
-    name = TRAINED.get((args.problem, args.net, args.dims))
-    if name is None or args.untrained:
+    name, trained_bg = TRAINED.get((args.problem, args.net, args.dims), (None, None))
+    if name is None or args.untrained or (trained_bg is not None and Bg < trained_bg):
         return None, None
     path = os.path.join(ROOT, "tests", "golden", "trained", name, "%s.l2l-0" % key)
     if not os.path.exists(path):
@@ -163,7 +167,8 @@ def trained_weights(args, key):
     with open(path, "rb") as f:
         d = dill.load(f)
     w = {m: {v: np.asarray(a, np.float32) for v, a in mv.items()} for m, mv in d.items()}
-    return w, "trained: %s" % os.path.relpath(path, ROOT)
+    return w, "trained: %s%s" % (os.path.relpath(path, ROOT),
+                                 "" if trained_bg in (None, Bg) else " (meta-trained at global batch %d, run at %d)" % (trained_bg, Bg))
 
 
 def build_workload(args, Bg):
@@ -190,7 +195,7 @@ def build_workload(args, Bg):
         net_config = {"cw": util.get_default_net_config(None)}
     key = next(iter(net_config))
     cfg = dict(net_config[key])
-    weights, wsrc = trained_weights(args, key)
+    weights, wsrc = trained_weights(args, key, Bg)
     if weights is None:
         # Sonnet-default random init, output Linear x0.1: an UNTRAINED optimizer (its trajectory diverges)
         weights = networks.factory(cfg["net"], cfg["net_options"]).variables
@@ -587,7 +592,7 @@ def main(argv=None):
         counters = None
         if world == 1 and not shared:
             counters = counters_for([args.problem, args.net, D, B, T] + ([Mrows] if args.problem == "lasso" else []),
-                                    case["kernel"] if case["fused"] else "")
+                                    case["kernel"].split(" ")[0] if case["fused"] else "")
         roof = roofline_block(case, args, counters)
         roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms_host_sampling_plus_h2d=case["t_reset"] * 1e3)
         roof.update(time_base="kernel_ms_avg: HIP events on the launch stream of THIS run around replays of one problem "

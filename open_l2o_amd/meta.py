@@ -1062,7 +1062,8 @@ class UnrollGraph(object):
         """Adam + weight re-pack on the device (l2o_adam_step, l2o_wpack_device) for the LSTM nets when the
         engine has them; L2O_HOST_ADAM=1 keeps the NumPy meta-step."""
         return (hasattr(self.engine, "adam_step") and isinstance(net, networks.StandardDeepLSTM)
-                and len(net.spec.layers) > 0 and not os.environ.get("L2O_HOST_ADAM"))
+                and len(net.spec.layers) > 0 and not net.spec.generic      # (generic `layers`: the host meta-step)
+                and not os.environ.get("L2O_HOST_ADAM"))
 
     def _adam_apply_device(self, key, acc, st, lr_t, beta1, beta2, epsilon):
         """One network's meta-step without a host round trip: the gradients are laid out like the flat
