@@ -907,8 +907,18 @@ class UnrollGraph(object):
                               carry_in=carry_in, carry_out=carry_out)
                     eng.bwd_step_generic(spec, gen, io, b1 ** k, b2 ** k, N)
                     carry_in, carry_out = carry_out, carry_in
+                    def atb_blocks(A, Bmat):               # l2o_atb holds a KA <= 112 x KB <= 192 result in registers
+                        ka, kb = A.shape[1], Bmat.shape[1]
+                        if ka <= 112 and kb <= 192:
+                            return eng.atb(A, Bmat)
+                        rows = []
+                        for r0 in range(0, ka, 96):
+                            Ab = A[:, r0:r0 + 96].contiguous()
+                            rows.append(torch.cat([eng.atb(Ab, Bmat[:, c0:c0 + 176].contiguous())
+                                                   for c0 in range(0, kb, 176)], 1))
+                        return torch.cat(rows, 0)
                     for l in range(nl):
-                        add("lstm_%d" % (l + 1), "w_gates", eng.atb(io["act"][l], io["dz"][l]))
+                        add("lstm_%d" % (l + 1), "w_gates", atb_blocks(io["act"][l], io["dz"][l]))
                         add("lstm_%d" % (l + 1), "b_gates", io["dz"][l].sum(0))
                     dd = io["dd"].view(N, 1)
                     add("linear", "w", eng.atb(io["h_last"], dd))

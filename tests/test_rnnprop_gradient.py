@@ -146,7 +146,7 @@ def test_rnnprop_second_derivatives_vs_autograd(hip, kind):
               % (kind, mod, var, gap / scale_g, e2, e1))
         assert e2 < 1e-3 and e1 < 5e-4, (mod, var, e2, e1)
         worst_gap = max(worst_gap, gap / scale_g)
-        if gap / scale_g > 5e-3:
+        if gap / scale_g > 1e-4:                           # (the term is 2e-4 .. 3e-3 of the gradient here; fp32 noise 2e-7)
             diff_err = float(np.abs((g - got[False][(mod, var)]) - (ws - wf)).max()) / gap
             assert diff_err < 0.05, (mod, var, diff_err)
-    assert worst_gap > 5e-3                                # the second-order term was actually exercised
+    assert worst_gap > 1e-4                                # the second-order term was actually exercised
