@@ -170,6 +170,9 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
   constexpr int kN = bx::chunk_mfmas(PK);
   bx::NetWB<PRE, PK> w;
   bx::load_netw<PRE, true, PK>(w, p.wpack, lane);
+  __shared__ __attribute__((aligned(16))) float bias_s[bx::kBiasWords];     // the gate biases = accumulator inits
+  bx::stage_bias(bias_s, p.wpack, PRE, threadIdx.x, blockDim.x);          // (the loop's first __syncthreads() orders it)
+  bx::set_bias(w, bias_s, q);
 #ifndef L2O_BWD_NO_AGPR_PIN
   // the forward fragments (MFMA A operands) pinned to the AGPR half of the register file, like LstmCore::pin():
   // left to itself the allocator parked VALU operands there (212 v_accvgpr_read of the 1 678 instructions of a step)
@@ -275,6 +278,8 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     MCK();                                                  // 3: loads
     // ---- forward recompute --------------------------------------------------------------------------
     f32x4 acc1[kNT], acc2[kNT];
+    bx::preload_bias<1>(w, acc2);                            // accumulator inits = the biases (l2o_lstm_bx3.h)
+    bx::preload_bias<0>(w, acc1);
     {
       bx::BOp<PK> b;
       bx::split5<PK>(s.h2, one, b);

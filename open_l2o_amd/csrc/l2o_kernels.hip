@@ -118,6 +118,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int NL = PRE == L2O_PRE_FC_ELU ? 9 : 7;              // VMEM loads per prefetched tile
   constexpr int kSlotF4 = 5 * 64 + 64;                           // float4 per slot: state + {g,x,m,v} rows
   __shared__ float4 sbuf[4][kStepRing][kSlotF4];
+  __shared__ __attribute__((aligned(16))) float bias_s[bx::kBiasWords];   // the gate biases = accumulator inits
+  bx::stage_bias(bias_s, np.wpack, PRE, threadIdx.x, blockDim.x);       // (ordered by the __syncthreads() of the fragment staging)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: the waits below branch on it
   const int c = lane & 15, q = lane >> 4;
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   bx::load_netw<PRE, false>(w, np.wpack, lane);                  // the small fp32 weights
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // weights landed: the VMEM queue is empty
+  bx::set_bias(w, bias_s, q);
   // dead lanes (j >= D in the last tile of a problem) read the problem's last coordinate:
   // branch-free loads, masked where they are used
   auto prefetch = [&](int k, int kslot) {
@@ -713,6 +716,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   Core core;
   core.load(a.np.wpack, lane);
   core.pin();   // (bf16x3 forms: fragments -> AGPRs; without it 125-133 v_accvgpr_read per step)
+  __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];   // the gate biases = accumulator inits
+  core.stage_bias(bias_s, a.np.wpack, tid, blockDim.x, q);
   const int j = wv * kTile + c;             // this lane's coordinate (LSTM role)
   const bool live = j < D;
   const size_t idx = (size_t)b * D + j;
@@ -748,6 +753,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   // layer-2 gate math), here for step 0.
   f32x4 acc1[kNT], acc2[kNT];
   core.init(s, q);
+  __syncthreads();                                           // the bias table is staged
+  core.preload(acc1, acc2);
   core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
 
   const size_t hist_n = (size_t)pp.B_local * D;
@@ -1224,7 +1231,7 @@ static int launch_unroll_kind(const UnrollArgs& a, const UnrollGeom& g, int kind
 static bool unroll_cu_eligible(const l2o_problem* p) {
   if (!opt(L2O_OPT_UNROLL_CU)) return false;
   if (p->D < 4 || p->D > 512 || (p->D & 3) || p->M <= 0) return false;   // (D <= 128: only when the rows do not fit the LDS forms)
-  return unroll_cu_layout(p->D).lds <= 160 * 1024;
+  return unroll_cu_layout(p->D).lds + sizeof(float) * bx::kBiasWords <= 160 * 1024;   // (+ the static bias table)
 }
 template <int PRE>
 static int launch_unroll_cu(const UnrollArgs& a_in, hipStream_t s) {
@@ -1336,10 +1343,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
           else v = wg1[u * G + cA];                              // kChL1X: the fc features
           bf16_split3(v * gscale(r), sl[i]);
         }
-        if (ch == bx::kChL1H || ch == bx::kChL2A) {
-          const double bv = (double)(ch == bx::kChL1H ? bg1[cA] : bg2[cA]) + (r == 2 ? 1.0 : 0.0);   // forget_bias
-          bf16_split3(bv * gscale(r), bs);
-        }
+        // (the bias slots of the fragments stay ZERO since round 3: the bias is the accumulator init, bx::bias_off)
         // 6-product form: K-slots 0..4 = the units, slot 7 = the bias (q == 0), one fragment per split level
         for (int sp = 0; sp < 3; ++sp)
           for (int rg = 0; rg < 4; ++rg) {
@@ -1361,6 +1365,13 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
               ow[bx::frag_off(pre, true, ch, t, j) + l * 4 + rg] = word;
             }
       }
+      if ((l & 15) == 0)                                        // one lane per lane group writes its 4 gate rows
+        for (int rr = 0; rr < 4; ++rr) {
+          const int cD = col(t, 4 * q + rr);
+          const double fb = rr == 2 ? 1.0 : 0.0;                  // forget_bias
+          out[bx::bias_off(pre) + ((0 * kNT + t) * 4 + q) * 4 + rr] = (float)(((double)bg1[cD] + fb) * gscale(rr));
+          out[bx::bias_off(pre) + ((1 * kNT + t) * 4 + q) * 4 + rr] = (float)(((double)bg2[cD] + fb) * gscale(rr));
+        }
       if (!fc)
         for (int rr = 0; rr < 4; ++rr) {
           const int cD = col(t, 4 * q + rr);

@@ -73,9 +73,16 @@ __host__ __device__ constexpr int frag_off(int pre, bool pk, int ch, int t, int 
 }
 __host__ __device__ constexpr int win_off(int pre) { return base(pre) + packed_words(pre) + level_words(pre); }
 // DM nets: 2 inputs x 5 tiles rows of 64 lanes x 4 floats (the lane's four gate rows)
-__host__ __device__ constexpr int words(int pre) {
-  return packed_words(pre) + level_words(pre) + (pre == L2O_PRE_FC_ELU ? 0 : 2 * kNT * 256);
-}
+__host__ __device__ constexpr int win_words(int pre) { return pre == L2O_PRE_FC_ELU ? 0 : 2 * kNT * 256; }
+// The gate BIASES (pre-scaled like the rows, forget_bias folded in) as fp32: [layer 0 / 1][M-tile t][lane group q][gate
+// r] -- the accumulator INIT of the chunks that start a layer's accumulation (L1H, L2B), staged into LDS by every kernel
+// (stage_bias) and read as one ds_read_b128 per M-tile.  Round 3: the bias used to ride in two spare K-slots of the
+// gate GEMM (B = 1.0); v_mfma_f32_16x16x32_bf16 chops every product of an 8-slot group at 2^-24 of the group's LARGEST
+// (scripts/microbench/mfma_round_probe.hip) and the O(1) bias was that largest: it cost the unit products next to it
+// their low bits, one-sidedly -- the ~1e-5 drift of every bf16x3 kernel at T = 1000 (profiles/r03c_drift_forms.txt).
+constexpr int kBiasWords = 2 * kNT * 4 * 4;
+__host__ __device__ constexpr int bias_off(int pre) { return win_off(pre) + win_words(pre); }
+__host__ __device__ constexpr int words(int pre) { return packed_words(pre) + level_words(pre) + win_words(pre) + kBiasWords; }
 __host__ __device__ constexpr int prod_x(int p) { return p < 3 ? 0 : (p < 5 ? 1 : 2); }
 __host__ __device__ constexpr int prod_w(int p) { return p < 3 ? p : (p < 5 ? p - 3 : 0); }
 // K-slot table: slot h (0 = low, 1 = high half) of register r of MFMA j carries unit slot_unit (0..4 of the lane
@@ -180,7 +187,18 @@ struct NetWB {
   float wl[kNT];                   // output Linear
   float bl;
   float fcw0[kNT], fcw1[kNT], fcb[kNT];   // RNNProp input projection (2 -> 20)
+  const __attribute__((address_space(3))) f32x4* bias;   // LDS: this lane group's [layer][t] accumulator inits (set_bias)
 };
+
+// every thread of the workgroup copies its share of the bias table into LDS (160 floats); the caller's barrier follows
+__device__ __forceinline__ void stage_bias(float* lds, const float* __restrict__ wp, int pre, int tid, int nthreads) {
+  for (int i = tid; i < kBiasWords; i += nthreads) lds[i] = wp[bias_off(pre) + i];
+}
+template <class W>
+__device__ __forceinline__ void set_bias(W& w, const float* lds, int q) {
+  w.bias = reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(
+               (const __attribute__((address_space(3))) float*)lds) + q;
+}
 
 // FRAGS = false: the caller fills w.a itself (k_cwlstm_step stages the fragments through LDS once
 // per workgroup instead of 4 x 61 KB of L2 reads)
@@ -223,16 +241,28 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
                                                   0, 0);
 }
 
+// the accumulator init of LAYER (0 / 1): its pre-scaled bias, one ds_read_b128 per M-tile.  Issued as soon as the
+// accumulator is dead (after the gate block that consumed it, or at kernel start) so that its latency is never exposed;
+// the asm pins the loads HERE (the scheduler otherwise sinks them in front of the first MFMA that reads them)
+template <int LAYER, class W>
+__device__ __forceinline__ void preload_bias(const W& w, f32x4 (&acc)[kNT]) {
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) acc[t] = w.bias[(LAYER * kNT + t) * 4];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) asm volatile("" : "+v"(acc[t]));
+}
+
 // MFMAs [LO, HI) of chunk CH (index n: packed MFMA | product n / 5, M-tile n % 5 -- consecutive MFMAs hit
-// different accumulators).  ZERO: the first one starts the accumulator (C = inline 0).
+// different accumulators).  ZERO: the first one starts the accumulator (C = the layer's bias, see bias_off).
 template <int PRE, int CH, int LO, int HI, bool ZERO, bool PK>
 __device__ __forceinline__ void issue(const NetWB<PRE, PK>& w, const BOp<PK>& b, f32x4 (&acc)[kNT]) {
   static_for<LO, HI>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
     constexpr int p = n / kNT, t = n % kNT;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], (ZERO && p == 0) ? zero : acc[t]);
-    else acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.m[prod_x(p)], (ZERO && p == 0) ? zero : acc[t]);
+    // ZERO: this MFMA starts the layer's accumulator -- from the layer's bias, which preload_bias() put INTO acc[t]
+    // long before (the ds_read_b128 rides behind the gate block that consumed the accumulator), not from zero
+    if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], acc[t]);
+    else acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.m[prod_x(p)], acc[t]);
   });
 }
 
@@ -354,6 +384,7 @@ __device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, B
   pc.drain(acc1);
   pc.mark(5);
   gates5(acc1, s.c1, s.h1);
+  preload_bias<0>(w, acc1);                                  // acc1 is dead: the next step's layer-1 accumulator init
   pc.mark(6);
   split5<PK>(s.h1, one, b1);
   issue<PRE, kChL2A, 0, kN, false>(w, b1, acc2);
@@ -392,6 +423,7 @@ __device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, B
     gates5(acc2, s.c2, s.h2);
   }
   __builtin_amdgcn_sched_barrier(0);
+  preload_bias<1>(w, acc2);                                  // acc2 is dead: the next step's layer-2 accumulator init
   pc.mark(8);
   if (NEXT) split5<PK>(s.h2, one, b2);
   float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];
@@ -409,6 +441,8 @@ __device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s
   constexpr int kN = chunk_mfmas(PK);
   BOp<PK> b1, b2;
   f32x4 acc1[kNT], acc2[kNT];
+  preload_bias<1>(w, acc2);
+  preload_bias<0>(w, acc1);
   split5<PK>(s.h2, one, b2);
   issue<PRE, kChL2B, 0, kN, true>(w, b2, acc2);
   split5<PK>(s.h1, one, b1);
@@ -434,7 +468,10 @@ struct LstmCore<PRE, false, PK> {
   static constexpr int kTotal = 25, kHalf = 12;
   NetW<PRE> w;
   __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { load_netw<PRE>(w, wpack, lane); }
+  static constexpr int kBiasFloats = 4;
+  __device__ __forceinline__ void stage_bias(float*, const float* __restrict__, int, int, int) {}
   __device__ __forceinline__ void pin() {}
+  __device__ __forceinline__ void preload(f32x4 (&)[kNT], f32x4 (&)[kNT]) {}
   __device__ __forceinline__ void init(const TileState&, int) {}
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState& s, f32x4 (&acc1)[kNT]) {
@@ -461,6 +498,12 @@ struct LstmCore<PRE, true, PK> {
   bx::BOp<PK> b1, b2;      // split h1(t-1), h2(t-1): the recurrent chunks' B operands
   unsigned one;
   __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, true, PK>(w, wpack, lane); }
+  // the bias table -> LDS (all threads; the caller puts a barrier between this and the first issue_*), then the lane's view
+  static constexpr int kBiasFloats = bx::kBiasWords;
+  __device__ __forceinline__ void stage_bias(float* lds, const float* __restrict__ wpack, int tid, int nthreads, int q) {
+    bx::stage_bias(lds, wpack, PRE, tid, nthreads);
+    bx::set_bias(w, lds, q);
+  }
   // Pin the 180-240 fragment registers to the accumulation half of the register file.  MFMA reads its A operand
   // from AGPRs directly; left to itself the allocator parks whatever does not fit the 256 VGPRs (fragments AND
   // VALU operands) there and pays a v_accvgpr_read per use (126 of the 618 VALU instructions of a config-2 step).
@@ -478,6 +521,12 @@ struct LstmCore<PRE, true, PK> {
     one = bx::bias_one<PK>(q);
     bx::split5<PK>(s.h1, one, b1);
     bx::split5<PK>(s.h2, one, b2);
+  }
+  // the accumulators of the FIRST step start from the biases too (after the barrier that follows stage_bias); every
+  // later step's are re-armed by finish()
+  __device__ __forceinline__ void preload(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
+    bx::preload_bias<0>(w, acc1);
+    bx::preload_bias<1>(w, acc2);
   }
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {

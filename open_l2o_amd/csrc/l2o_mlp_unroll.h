@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   Core core;
   core.load(a.np.wpack, lane);
   core.pin();
+  __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];   // the gate biases = accumulator inits
+  core.stage_bias(bias_s, a.np.wpack, tid, 256, q);          // (ordered by the __syncthreads() of the prologue below)
   f32x4 acc1[kNT], acc2[kNT];
   TileState s;
   float* st_tile = a.st[var] + (size_t)tile_in_var * kStateFloatsPerTile;
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const float invB = 1.0f / (float)Bn;
   core.init(s, q);
+  core.preload(acc1, acc2);                                 // accumulator inits of the first step (the biases)
   PhaseClock pc;
   pc.start();
   for (int t = 0;; ++t) {

@@ -143,6 +143,9 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   constexpr bool PK = NV == 1 && bx::packed_default(PRE);
   bx::NetWB<PRE, PK> w;
   bx::load_netw<PRE, true, PK>(w, a.np.wpack, lane);
+  __shared__ __attribute__((aligned(16))) float bias_s[bx::kBiasWords];     // the gate biases = accumulator inits
+  bx::stage_bias(bias_s, a.np.wpack, PRE, tid, blockDim.x);               // (ordered by the __syncthreads() below)
+  bx::set_bias(w, bias_s, q);
   // pin the 180-240 fragment registers to the accumulation half of the register file (MFMA reads its A
   // operand from there directly): the architectural VGPRs stay free for the row ring and the gate math.
   // Left to itself the allocator spreads the fragments over both halves and spills the ring.

@@ -150,6 +150,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   Core core;
   core.load(a.np.wpack, lane);
   core.pin();   // fragments -> AGPRs (MFMA reads them there): the VGPRs hold W, the state and the gate math
+  __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];   // the gate biases = accumulator inits
+  core.stage_bias(bias_s, a.np.wpack, tid, blockDim.x, q);   // (the handshake's __syncthreads() below orders it)
   const int j = tile_in_prob * kTile + c;
   const bool live = j < D;
   const size_t idx = (size_t)b * D + j;
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 
   f32x4 acc1[kNT], acc2[kNT];
   core.init(s, q);
+  core.preload(acc1, acc2);                                 // accumulator inits of the first step (the biases)
 #ifdef L2O_PAIR_L1H_UNDER_GATES
   // variant: chunk L1H of step t+1 (fed by h1(t)) rides underneath the layer-2 gate block of step t
   // (Core::finish<true>); only the first step's is issued up front

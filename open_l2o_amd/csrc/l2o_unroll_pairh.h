@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
   Core core;
   core.load(a.np.wpack, lane);
   core.pin();   // fragments -> AGPRs (MFMA reads them there): the VGPRs hold H, W, the state and the gate math
+  __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];   // the gate biases = accumulator inits
+  core.stage_bias(bias_s, a.np.wpack, tid, blockDim.x, q);   // (the handshake's __syncthreads() below orders it)
   const size_t idx = (size_t)b * D + j;
   const int tpp = (D + kTile - 1) / kTile;
   const bool tile_real = tile_in_prob < tpp;            // the padded tile of an odd tile count is idle
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
 
   f32x4 acc1[kNT], acc2[kNT];
   core.init(s, q);
+  core.preload(acc1, acc2);                                 // accumulator inits of the first step (the biases)
   PhaseClock pc;
   pc.start();
 

@@ -55,7 +55,7 @@ def gates(acc, c):
 def tile_step(wpack, pre, h1, c1, h2, c2, in0, in1):
     """All per-lane arrays are [64, 5] (state) / [64] (inputs). Returns d[64] + new state."""
     R = wp_rows(pre)
-    W = np.asarray(wpack, np.float64).reshape(-1, 64)
+    W = np.asarray(wpack, np.float64).reshape(-1)[: R["total"] * 64].reshape(-1, 64)
     q = np.arange(64) >> 4
     acc2 = [np.stack([W[R["b2"] + t * 4 + r] for r in range(4)], 1) for t in range(KNT)]
     for kk in range(KNT):
@@ -159,8 +159,15 @@ def bx_level_words(pre):
     return bx_nchunks(pre) * KNT * 3 * 256
 
 
+def bx_win_words(pre):
+    return 0 if pre == 2 else 2 * KNT * 256
+
+
+BX_BIAS_WORDS = 2 * KNT * 4 * 4      # fp32 accumulator inits [layer][M-tile][lane group][gate], l2o::bx::bias_off
+
+
 def bx_words(pre):
-    return bx_packed_words(pre) + bx_level_words(pre) + (0 if pre == 2 else 2 * KNT * 256)
+    return bx_packed_words(pre) + bx_level_words(pre) + bx_win_words(pre) + BX_BIAS_WORDS
 
 
 def slot_desc(j, r, h):
@@ -296,9 +303,14 @@ def tile_step_bx3(wpack, pre, h1, c1, h2, c2, in0, in1, packed=None):
                 acc[t] = mfma_bf16(frag(ch, t, wl), b[xl], acc[t])
         return acc
 
-    zero = lambda: [np.zeros((64, 4)) for _ in range(KNT)]
-    acc2 = chunk(CH_L2B, h2, True, zero())
-    acc1 = chunk(CH_L1H, h1, True, zero())
+    # the accumulators start from the layer's pre-scaled bias (fp32 table in wpack, read per lane group), the fragments'
+    # bias slots are zero (round 3: the bias left the truncating in-group sums of the bf16 matrix pipe)
+    bias_off = win_off + bx_win_words(pre)
+    q = np.arange(64) >> 4
+    btab = wp32[bias_off:bias_off + BX_BIAS_WORDS].astype(np.float64).reshape(2, KNT, 4, 4)
+    binit = lambda layer: [btab[layer, t][q] for t in range(KNT)]
+    acc2 = chunk(CH_L2B, h2, True, binit(1))
+    acc1 = chunk(CH_L1H, h1, True, binit(0))
     if pre == 2:
         fc = np.stack([W[R["fc"] + KNT + t] * in1 + (W[R["fc"] + t] * in0 + W[R["fc"] + 2 * KNT + t])
                        for t in range(KNT)], 1)
