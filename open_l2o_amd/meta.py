@@ -411,6 +411,7 @@ class UnrollGraph(object):
             else:
                 s.state = s.net.initial_state_for_inputs(var.value)
         self._initialized = True
+        self.__dict__.pop("_fast_unrolls", None)         # prepared calls hold the old x / state buffers
         self.__dict__.pop("_hip_graphs", None)           # captured launch sequences hold the old pointers
         self.__dict__.pop("_mlp_idx", None)
 
@@ -560,6 +561,33 @@ class UnrollGraph(object):
         eng = self.engine
         T = self.len_unroll
         feed = feed or {}
+        # ---- fast path: the SAME fused restart launch as before (same x0 / problem tensors / options) replays a
+        # prepared call -- one ctypes call instead of ~0.2 ms of argument building, which is a whole config-2 unroll
+        # (an evaluation loop that re-runs a ring of problem instances would otherwise be host-bound)
+        fast_key = None
+        if (restart is not None and commit and record is None and events is None and len(self.x) == 1
+                and hasattr(eng, "prepared_unroll") and all(ph not in feed for ph in self.scale)):
+            s0 = self.slots[0] if len(self.slots) == 1 else None
+            fast_key = (T, int(feed[self.step]) if self.rnnprop and self.step in feed else 1, id(restart[0]),
+                        tuple(id(v.value) for v in self.constants), id(self.x[0].value), _abi.options_word(),
+                        id(getattr(s0, "state", None) and getattr(s0.state, "packed", None)), id(getattr(s0, "m", None)),
+                        id(getattr(getattr(s0, "net", None), "_wpack", None)))
+            ent = self.__dict__.setdefault("_fast_unrolls", {}).get(fast_key)
+            if ent is not None:
+                ring = self._fx_cache[T]
+                i = ring["i"]
+                ring["i"] = (i + 1) % len(ring["bufs"])
+                if ring["work"][i] is not None:
+                    ring["work"][i].wait()
+                    ring["work"][i] = None
+                fx = ring["bufs"][i]
+                if ent["call"](fx):
+                    self.last_path = "fused"
+                    if self.sharded:
+                        import torch.distributed as dist
+                        ring["work"][i] = dist.all_reduce(fx, async_op=True)
+                    return fx, [self.x[0].value]
+                self._fast_unrolls.pop(fast_key, None)      # stale (the engine's workspace changed): general path
         # restart = list of device tensors x0: run this unroll from x0 and the zero LSTM state / moments on the SAME
         # problem instance (rewind(x0) + launch); the fused kernels fold it in (no copy / memset pass), every other
         # path rewinds first
@@ -687,6 +715,12 @@ class UnrollGraph(object):
             if restart_fused:
                 eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
                            fx_part, fx=fx, x0=restart[0].view(panels[0].shape), zero_state=True)
+                if fast_key is not None and len(self.__dict__.get("_fast_unrolls", {})) < 64:
+                    call = eng.prepared_unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0],
+                                               T, step0, fx_part, restart[0].view(panels[0].shape), True)
+                    if call is not None:                    # (keeps every tensor of the launch alive: ids stay valid)
+                        self._fast_unrolls[fast_key] = {"call": call, "keep": (restart[0], [v.value for v in self.constants],
+                                                                                s.net.wpack(eng), states[0])}
             else:
                 eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
                            fx_part, fx=fx)                  # (the batch-mean reduction rides in the unroll's epilogue)

@@ -606,3 +606,53 @@ def test_eval_epoch_of_the_sampled_mlp_optimizee(engine, name, monkeypatch):
         np.testing.assert_allclose(got["one", L][0], got["stepwise", L][0], rtol=1e-5)
         for a, b in zip(got["one", L][1], got["stepwise", L][1]):
             np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["dm", "rnnprop"])
+def test_launch_restart_replays_a_prepared_call(engine, name):
+    """UnrollGraph.launch(restart=x0) on an unchanged problem instance replays a PREPARED call on the HIP engine (one
+    ctypes call instead of rebuilding every argument: the evaluation loops of bench.py would otherwise be host-bound).
+    Same numbers as the first (general-path) launch; a swapped problem instance, new weights or `reset` are seen."""
+    cfg = ORACLE_CFGS[name]
+    params = make_params(cfg, seed=81, trained_like=True)
+    B, D, T = 4, 24, 6
+    prob, x0, _ = make_problem("quadratic", B, D, seed=82)
+    prob2, _, _ = make_problem("quadratic", B, D, seed=83)
+    problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+    feed = {}
+    if name == "rnnprop":
+        opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+        ml, _, _, step = opt.meta_loss(problem, T)
+        feed = {step: 1}
+    else:
+        opt = meta.MetaOptimizer(**_net_config(cfg, params))
+        ml = opt.meta_loss(problem, T)
+    g = opt.graph
+    g.reset()
+    x0d = [v.value.clone() for v in g.x]
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    outs = []
+    for _ in range(3):                                      # 1st: general path; 2nd, 3rd: the prepared call (HIP)
+        fx, xs = g.launch(feed, commit=True, restart=x0d)
+        outs.append((engine.to_numpy(fx).copy(), engine.to_numpy(xs[0]).copy()))
+    assert rel_err(outs[0][0], res.fx) < 1e-5
+    for fxk, xk in outs[1:]:
+        assert np.array_equal(fxk, outs[0][0]) and np.array_equal(xk, outs[0][1])
+    if hasattr(engine, "prepared_unroll"):
+        assert 1 <= len(g.__dict__.get("_fast_unrolls", {})) <= 2        # (the first key predates the packed weights' upload)
+    # another problem instance in the same variables (what bench.py's ring does): seen, not replayed from the old one
+    g._by_name["w"].value, g._by_name["y"].value = engine.tensor(prob2.w), engine.tensor(prob2.y)
+    res2 = O.unroll(prob2, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    for _ in range(2):
+        fx, _ = g.launch(feed, commit=True, restart=x0d)
+        assert rel_err(engine.to_numpy(fx), res2.fx) < 1e-5
+    # new weights
+    net = next(iter(opt._nets.values()))
+    p2 = {m: {v: a.copy() for v, a in d.items()} for m, d in params.items()}
+    p2["linear"]["w"] = (p2["linear"]["w"] * 0.5).astype(np.float32)
+    for var, val in p2["linear"].items():
+        net.assign("linear", var, val)
+    res3 = O.unroll(prob2, cfg, p2, x0, O.net_initial_state(cfg, B * D), T)
+    for _ in range(2):
+        fx, _ = g.launch(feed, commit=True, restart=x0d)
+        assert rel_err(engine.to_numpy(fx), res3.fx) < 1e-5
