@@ -308,7 +308,9 @@ def roofline_block(case, args, counters):
     if counters is not None:
         path, c = counters
         src = os.path.relpath(path, ROOT)
-        pl = c.get("per_launch", {})
+        # (the counters are per kernel DISPATCH; a shard beyond the co-resident capacity is several dispatches per unroll)
+        nd = float(case.get("dispatches", 1))
+        pl = {k: (v * nd if isinstance(v, (int, float)) and k != "SQ_WAVES" else v) for k, v in c.get("per_launch", {}).items()}
         if "FETCH_SIZE_KiB" in pl and "WRITE_SIZE_KiB" in pl:
             traffic = (2.0 * pl["FETCH_SIZE_KiB"] + pl["WRITE_SIZE_KiB"]) * 1024.0
         if all(k in pl for k in ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVES")):
@@ -482,6 +484,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
            else alg_bytes_per_coord_step(args.problem, args.net, D, Mrows))
     fused = graph.last_path == "fused"
     streaming = fused and D > 128
+    dispatches = 1
     if args.problem == "mnist":
         kernel = "l2o_mlp_unroll (persistent)" if graph.last_path == "mlp_unroll" else "l2o_mlp_fg + l2o_cwlstm_step_multi per step"
     elif streaming:
@@ -496,6 +499,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
         cap = max(8, eng.coresident_cus // 2)
         kernel = "k_unroll" if (D <= 16 or not _abi.get_option(_abi.OPT_PAIR)) else (
             two_cu if B <= cap else "%s x %d chunk launches" % (two_cu, (B + cap - 1) // cap))
+        dispatches = 1 if (D <= 16 or not _abi.get_option(_abi.OPT_PAIR) or B <= cap) else (B + cap - 1) // cap
     else:
         kernel = "k_problem_fg1 + k_cwlstm_step per step"
     # HBM bytes per launch that a kernel of this form MUST move (used only when no PMC pass is committed):
@@ -511,7 +515,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
             "kern_ms": float(kern_all), "kern_ms_min": float(np.min(kt)), "coord_steps": coord_steps,
             "bpc": bpc, "alg_bytes": bpc * coord_steps,
             "flops": alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps,
-            "fused": fused, "kernel": kernel, "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
+            "fused": fused, "kernel": kernel, "dispatches": dispatches, "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
             "hbm_model_bytes": hbm_model, "t_reset": t_reset, "prepare_ms": prepare_ms, "D": D, "B": B, "Bg": Bg, "T": T, "Mrows": Mrows,
             "shared": shared}
 

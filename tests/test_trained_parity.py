@@ -11,7 +11,8 @@ and compares with the fp32 C oracle (and, for the long horizons, the float64 Num
     the error of the reference's own fp32 arithmetic (NumPy two-pass) -- the probe that shows what H x - q costs once
     |g| has fallen (profiles/r03a_trained_parity_probe.txt);
   * T = 1000 and T = 10 000 (DM/train_dm.py:66, DM/evaluate_dm.py:43) against the float64 oracle, bounded by 3 x the
-    drift of the fp32 oracle itself;
+    drift of the fp32 oracle itself -- the default (bf16x3 gates, reference gradient arithmetic), the exact-gates option
+    and the one-CU kernel; the opt-in normal-matrix form by a stated looser bound;
   * config 3 (RNNProp on Lasso, T = 200): the l1 term's sign(x) makes the CONVERGED trajectory chaotic -- the fp32
     oracle started one ulp away from x_0 drifts by 2e-3 in fx after ~100 steps -- so the trajectory is held to 1e-5 on
     the prefix where that sensitivity is below 1e-6, to 3 x the oracle's own one-ulp sensitivity beyond, and the
@@ -38,12 +39,14 @@ FORMS = {"two_pass": {_abi.OPT_PAIR_NORMAL: 0}, "normal": {_abi.OPT_PAIR_NORMAL:
          # L2O_OPT_EXACT_GATES: the fp32-MFMA gate GEMM (bit-equal to an fmaf chain) instead of the bf16x3 split
          "two_pass_exact": {_abi.OPT_PAIR_NORMAL: 0, _abi.OPT_EXACT_GATES: 1},
          "one_cu_exact": {_abi.OPT_PAIR: 0, _abi.OPT_EXACT_GATES: 1}}
-# What the bf16x3 gate GEMM costs at long horizons: v_mfma_f32_16x16x32_bf16 sums the 8 products of a K-slot group
-# with the small ones TRUNCATED (sign-magnitude) at 2^-24 of the largest (scripts/microbench/mfma_round_probe.hip,
-# profiles/r03c_mfma_round_probe.txt) -- an fp32-sized but DETERMINISTIC error that a converged trajectory accumulates:
-# measured 1.1e-5 .. 1.6e-5 at T = 1000 and 2.5e-5 .. 5e-5 at T = 10 000 where the fp32 oracles drift 1e-6 / 2e-5
-# (profiles/r03c_drift_forms.txt).  The exact forms are held to 3 x the oracles' drift, the bf16x3 forms to this bound.
-BF16X3_LONG_HORIZON_BOUND = 6e-5
+# Long horizons.  Every form with the reference's gradient arithmetic -- bf16x3 gates (the default) or exact gates -- is
+# held to 3 x the fp32 oracles' own drift from float64.  (Until round 3 the bf16x3 kernels drifted 1.1e-5 .. 1.6e-5 at
+# T = 1000: the gate bias rode in two K-slots of the gate GEMM and v_mfma_f32_16x16x32_bf16 truncates every product of
+# an 8-slot group at 2^-24 of the group's largest -- the O(1) bias; as the accumulator init it is outside those sums:
+# 2.9e-6.  profiles/r03c_mfma_round_probe.txt, r03c_drift_forms.txt -> r03g_drift_forms_bias_as_acc_init.txt.)
+# The normal-matrix form (opt-in) carries the H x - q gradient error on top: held to this stated bound instead
+# (measured 6.0e-6 at T = 1000, 4.1e-5 at T = 10 000 on config 2).
+NORMAL_FORM_LONG_HORIZON_BOUND = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -187,10 +190,10 @@ def test_gradient_error_in_the_converged_regime(eng, case):
 def test_trained_long_horizon(eng, case, T, Bt, which):
     """T = 1000 (the curriculum's horizon, DM/train_dm.py:66) and T = 10 000 (DM/evaluate_dm.py:43) in ONE launch, the
     trained optimizer, a slice of the batch with the 1/B of the full batch: the loss keeps falling.  HIP vs the float64
-    oracle: the kernels with an fmaf-chain-equal gate GEMM (L2O_OPT_EXACT_GATES; the one-CU kernel at d = 128 always)
-    within 3 x the worst drift of two fp32 evaluations of the same unroll from their float64 twin (the C oracle, the C
-    oracle started one ulp away); the bf16x3 forms within BF16X3_LONG_HORIZON_BOUND (see there); the first 101 steps
-    of every form hold the 1e-5 of the short tests."""
+    oracle within 3 x the worst drift of two fp32 evaluations of the same unroll from their float64 twin (the C oracle,
+    the C oracle started one ulp away) -- the default bf16x3 gates and the exact gates alike; the opt-in normal-matrix
+    form within max(that, NORMAL_FORM_LONG_HORIZON_BOUND); the first 101 steps of every form hold the 1e-5 of the
+    short tests."""
     from oracle.c_oracle import c_unroll
     kind, wname, B, D, Bg, seed = CASES[case]
     Bg = Bg or B
@@ -218,8 +221,7 @@ def test_trained_long_horizon(eng, case, T, Bt, which):
           % (case, T, which, r64.fx[0], r64.fx[-1], e64, env, rel_err(fx[:101], r64.fx[:101])))
     assert r64.fx[-1] < r64.fx[100] < r64.fx[0]
     assert rel_err(fx[:101], r64.fx[:101]) < 1e-5
-    exact = which.endswith("_exact") or (which == "one_cu" and D > 64)       # (one-CU at d = 128: 8 waves = fp32 MFMA)
-    assert e64 < (3 * env if exact else max(3 * env, BF16X3_LONG_HORIZON_BOUND)), (e64, env)
+    assert e64 < (max(3 * env, NORMAL_FORM_LONG_HORIZON_BOUND) if which == "normal" else 3 * env), (e64, env)
 
 
 def test_c3_trained_lasso_rnnprop(eng):
