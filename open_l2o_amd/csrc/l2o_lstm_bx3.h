@@ -361,7 +361,9 @@ __device__ __forceinline__ void gates5_scalar(const f32x4 (&acc)[kNT], float (&c
 // shadow(): caller work that does not feed the network (loss reductions, stores), placed behind the issue of chunk
 // L2A -- the one stretch of the step where the wave only waits for the matrix pipe.
 struct NoShadow { __device__ __forceinline__ void operator()() const {} };
-template <int PRE, bool NEXT, bool PK, class Shadow = NoShadow>
+// REARM: leave acc1 / acc2 re-initialised with the biases for the NEXT step (the persistent unroll kernels); tile_step
+// (a fresh pair of accumulators per call) switches it off -- the pinned loads would be 10 dead ds_read_b128 per tile
+template <int PRE, bool NEXT, bool PK, class Shadow = NoShadow, bool REARM = true>
 __device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, BOp<PK>& b1, BOp<PK>& b2,
                                         f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1, unsigned one,
                                         int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
@@ -384,7 +386,7 @@ __device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, B
   pc.drain(acc1);
   pc.mark(5);
   gates5(acc1, s.c1, s.h1);
-  preload_bias<0>(w, acc1);                                  // acc1 is dead: the next step's layer-1 accumulator init
+  if (REARM || NEXT) preload_bias<0>(w, acc1);               // acc1 is dead: the next step's layer-1 accumulator init
   pc.mark(6);
   split5<PK>(s.h1, one, b1);
   issue<PRE, kChL2A, 0, kN, false>(w, b1, acc2);
@@ -423,7 +425,7 @@ __device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, B
     gates5(acc2, s.c2, s.h2);
   }
   __builtin_amdgcn_sched_barrier(0);
-  preload_bias<1>(w, acc2);                                  // acc2 is dead: the next step's layer-2 accumulator init
+  if (REARM) preload_bias<1>(w, acc2);                       // acc2 is dead: the next step's layer-2 accumulator init
   pc.mark(8);
   if (NEXT) split5<PK>(s.h2, one, b2);
   float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];
@@ -448,7 +450,7 @@ __device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s
   split5<PK>(s.h1, one, b1);
   issue<PRE, kChL1H, 0, kN, true>(w, b1, acc1);
   PhaseClock pc;
-  return finish<PRE, false>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
+  return finish<PRE, false, PK, NoShadow, false>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
 }
 
 }  // namespace bx
