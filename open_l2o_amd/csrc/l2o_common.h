@@ -342,6 +342,37 @@ __device__ __forceinline__ void lstm_gates5(const f32x4 (&acc)[kNT], float (&c)[
 #endif
 }
 
+// sin / cos of an fp32 angle at libm accuracy in ~14 VALU instructions each (hipcc's sinf / cosf: ~125, most of it a
+// Payne-Hanek reduction for arguments the optimizees never produce): n = rint(a 2/pi), three-constant Cody-Waite
+// reduction to [-pi/4, pi/4] (exact for |n| < 2^13), the cephes single-precision minimax polynomials, quadrant fix-up.
+// Max abs error 9.2e-8 for |a| <= 8192 (libm's fp32 sinf: 7e-8; measured over 2M samples per decade); beyond that the
+// libm call (a wave-level branch nobody takes on a converging trajectory).  The rastrigin / square_cos terms
+// (DM/problems.py:206-211, 983-991) evaluate cos and sin of the SAME fp32 product 2 pi x as the reference does.
+struct SinCos { float s, c; };
+__device__ __forceinline__ SinCos sincos_f(float a) {
+  SinCos o;
+  if (__builtin_expect(__builtin_fabsf(a) > 8192.0f, 0)) {
+    o.s = sinf(a); o.c = cosf(a);
+    return o;
+  }
+  const float n = __builtin_rintf(a * 0.6366197723675814f);
+  float r = __builtin_fmaf(-n, 1.5703125f, a);
+  r = __builtin_fmaf(-n, 4.837512969970703125e-4f, r);
+  r = __builtin_fmaf(-n, 7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  const float sn = __builtin_fmaf(ps * z, r, r);
+  const float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  const float cs = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  const int q = (int)n;
+  const float a0 = (q & 1) ? cs : sn, b0 = (q & 1) ? sn : cs;          // sin, cos up to sign
+  o.s = (q & 2) ? -a0 : a0;
+  o.c = ((q + 1) & 2) ? -b0 : b0;
+  return o;
+}
+__device__ __forceinline__ float sin_f(float a) { return sincos_f(a).s; }
+__device__ __forceinline__ float cos_f(float a) { return sincos_f(a).c; }
+
 // everything that needs this step's gradient:
 //   PRE = IDENTITY : in0 = g
 //   PRE = LOGSIGN  : in0 = clamped log, in1 = clamped sign  (computed by the caller)

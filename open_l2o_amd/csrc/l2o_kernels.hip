@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
       if (pp.kind == L2O_PROB_SIMPLE) facc += xv * xv;
       if (pp.kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xv);
       if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
-        facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j] * cosf(pp.twopi * xv);
+        facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j] * l2o::cos_f(pp.twopi * xv);
     }
     xs[j] = xv;
   }
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg(ProbParams pp, const 
     if (!pp.hvp) {
       if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f));
       if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
-        gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xv);
+        gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * l2o::sin_f(pp.twopi * xv);
     }
     gb[j] = gj * pp.inv_bg * (sb ? sb[j] : 1.0f);
   };
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg1(ProbParams pp, const
         for (int e = 0; e < 4; ++e) {
           if (pp.kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xe[e]);
           if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
-            facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j + e] * cosf(pp.twopi * xe[e]);
+            facc += pp.alpha - pp.alpha * pp.C[(size_t)b * D + j + e] * l2o::cos_f(pp.twopi * xe[e]);
         }
       }
     }
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kFgThreads) void k_problem_fg1(ProbParams pp, const
     if (!pp.hvp) {
       if (pp.kind == L2O_PROB_LASSO) gj += pp.l1 * (xj > 0.f ? 1.f : (xj < 0.f ? -1.f : 0.f));
       if (pp.kind == L2O_PROB_RASTRIGIN || pp.kind == L2O_PROB_SQUARE_COS)
-        gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * sinf(pp.twopi * xj);
+        gj += pp.twopi * pp.alpha * pp.C[(size_t)b * D + j] * l2o::sin_f(pp.twopi * xj);
     }
     gb[j] = gj * pp.inv_bg * sc;
   }
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
     }
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
-      if (kCos) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
+      if (kCos) contrib += pp.alpha - pp.alpha * cj * l2o::cos_f(kTwoPi * xsv);
     }
     contrib = wave_sum64(contrib);
     if (lane == 0) fpart[wv] = contrib;
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
     float gv = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(gacc)));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
-    if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
+    if (kCos) gv += kTwoPi * pp.alpha * cj * l2o::sin_f(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
     if (HIST && live && q == 0) {
       if (t < a.T) a.hist_g[(size_t)t * hist_n + idx] = gv;
@@ -1540,7 +1540,7 @@ __global__ void k_hvp_sep(ProbParams pp, const float* __restrict__ x, const floa
   if (i >= n) return;
   const float sc = pp.x_scale ? pp.x_scale[i] : 1.0f;
   const float xs = x[i] * sc;
-  out[i] += sc * pp.inv_bg * (pp.twopi * pp.twopi * pp.alpha * pp.C[i] * cosf(pp.twopi * xs)) * sc * u[i];
+  out[i] += sc * pp.inv_bg * (pp.twopi * pp.twopi * pp.alpha * pp.C[i] * l2o::cos_f(pp.twopi * xs)) * sc * u[i];
 }
 
 int l2o_problem_hvp(const l2o_problem* prob, const float* x, const float* u, float* out, float* scratch, void* stream) {

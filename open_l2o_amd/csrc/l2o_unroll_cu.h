@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     const float xsv = xsL[j], sc = scL[j];
     float gj = cg * sum;
     if (kind == L2O_PROB_LASSO) gj += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
-    if (kCos) gj += pp.twopi * pp.alpha * Cb[jc] * sinf(pp.twopi * xsv);
+    if (kCos) gj += pp.twopi * pp.alpha * Cb[jc] * l2o::sin_f(pp.twopi * xsv);
     xsv_out = xsv;
     return live ? gj * pp.inv_bg * sc : 0.0f;
   };
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (kind == L2O_PROB_LASSO) facc += pp.l1 * __builtin_fabsf(xe[e]);
-            if (kCos) facc += pp.alpha - pp.alpha * Cb[j + e] * cosf(pp.twopi * xe[e]);
+            if (kCos) facc += pp.alpha - pp.alpha * Cb[j + e] * l2o::cos_f(pp.twopi * xe[e]);
           }
         }
       }

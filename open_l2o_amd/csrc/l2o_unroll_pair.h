@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     }
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
-      if (kCos) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
+      if (kCos) contrib += pp.alpha - pp.alpha * cj * l2o::cos_f(kTwoPi * xsv);
     }
     pc.mark(1);                                             // previous-h2 MFMAs + partner poll
     __syncthreads();                                        // B2: rs complete
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     float gv = quad_q_sum(hsum4(gacc4));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
-    if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
+    if (kCos) gv += kTwoPi * pp.alpha * cj * l2o::sin_f(kTwoPi * xsv);
     gv = live ? gv * cg * sc : 0.0f;
     if (HIST && live && q == 0) {
       if (t < a.T) a.hist_g[(size_t)t * hist_n + idx] = gv;

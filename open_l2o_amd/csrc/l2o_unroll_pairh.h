@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
     float contrib = q == 0 ? coef * r * r : 0.0f;
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
-      if (kCos) contrib += pp.alpha - pp.alpha * cj * cosf(kTwoPi * xsv);
+      if (kCos) contrib += pp.alpha - pp.alpha * cj * l2o::cos_f(kTwoPi * xsv);
     }
     return wave_sum64(contrib);
   };
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_unroll_pairh(UnrollPairHArgs ha) {
     float gv = quad_q_sum(hsum4(hacc)) - myq;                // = (W^T (W xs - y))_j
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
-    if (kCos) gv += kTwoPi * pp.alpha * cj * sinf(kTwoPi * xsv);
+    if (kCos) gv += kTwoPi * pp.alpha * cj * l2o::sin_f(kTwoPi * xsv);
     return live ? gv * cg * sc : 0.0f;
   };
   float* const fx_wave = pa.fx_half + (size_t)bl * (2 * NWH) + half * NWH + wv;  // + t * nb * 2 NWH
