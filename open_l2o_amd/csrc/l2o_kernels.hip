@@ -2207,17 +2207,24 @@ int32_t l2o_coresident_workgroups(void* scratch, void* stream) {
   const int n = device_cu_count(s);
   if (n <= 0) return fail(L2O_ERR_HIP, "l2o_coresident_workgroups: no device");
   unsigned* d = static_cast<unsigned*>(scratch);
-  const unsigned init[2] = {0u, 0xffffffffu};
-  HIP_TRY(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, s));
   constexpr int kLds = 100 * 1024;                           // more than half a CU's LDS: one workgroup per CU
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_coresident_probe), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-  hipLaunchKernelGGL(k_coresident_probe, dim3(n), dim3(256), kLds, s, d, d + 1);
-  HIP_TRY(hipGetLastError());
-  unsigned out[2] = {0u, 0u};
-  HIP_TRY(hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  int got = (int)out[1];
-  if (got <= 0 || got > n) got = n;
+  // A pass can only UNDER-count (a slow dispatch lets the earliest workgroup sample before the others arrived), never
+  // over-count (at most `capacity` workgroups exist until the first one leaves): the maximum of a few passes.
+  int got = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    const unsigned init[2] = {0u, 0xffffffffu};
+    HIP_TRY(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_coresident_probe, dim3(n), dim3(256), kLds, s, d, d + 1);
+    HIP_TRY(hipGetLastError());
+    unsigned out[2] = {0u, 0u};
+    HIP_TRY(hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int seen = (int)out[1];
+    if (seen > got && seen <= n) got = seen;
+    if (got == n) break;
+  }
+  if (got <= 0) got = n;
   if (dev >= 0 && dev < 64) g_measured_cus[dev].store(got, std::memory_order_relaxed);
   return got;
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # lease: final-core measurements: long-horizon numbers of every form, counters of the default kernel, bench lines
-TAG=${1:-r03m}
+TAG=${1:-r03z}
 O=gpurun_out/$TAG; mkdir -p $O
 cd "$(dirname "$0")/.."
 (timeout 900 python -m pytest tests/test_trained_parity.py -q -m gpu -s 2>&1 | grep -E "c2 |c4shard |C3 trained|segment|passed|failed" | sed 's/^\.*//') > $O/trained_parity_numbers.txt; grep -E "T=|passed|failed" $O/trained_parity_numbers.txt | cut -c1-200
