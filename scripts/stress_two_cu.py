@@ -1,5 +1,6 @@
 import sys, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import oracle as O
 from helpers import ORACLE_CFGS, device_problem, lib_option, make_params, make_problem, rel_err, spec_of, max_abs
@@ -25,8 +26,11 @@ for case in range(int(os.environ.get("N", "60"))):
     wpack = eng.pack_weights(spec, params)
     pd = device_problem(eng, arrays, B, D)
     outs = []
-    for normal in (1, 0):
-        with lib_option(_abi.OPT_PAIR_NORMAL, normal):
+    import contextlib
+    for opts in ({_abi.OPT_PAIR_NORMAL: 0}, {_abi.OPT_PAIR_NORMAL: 1}, {_abi.OPT_EXACT_GATES: 1}):
+        with contextlib.ExitStack() as es:
+            for o_, v_ in opts.items():
+                es.enter_context(lib_option(o_, v_))
             x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
             m, v = eng.zeros(B, D), eng.zeros(B, D)
             fx = eng.zeros(T + 1)
@@ -40,4 +44,4 @@ for case in range(int(os.environ.get("N", "60"))):
         assert e < tol, (case, kind, name, B, D, M, T, e)
         assert max_abs(xv, res.x.reshape(B, D)) < 1e-4 * max(1.0, float(np.abs(res.x).max())), (case, kind, name, B, D, M, T)
     n += 1
-print("stress: %d random cases (both forms of the two-CU kernel, incl. chunked launches) vs the oracle, worst rel fx err %.3g" % (n, worst))
+print("stress: %d random cases (two-CU kernel: reference form, normal-matrix form, exact gates; incl. chunked launches; B up to 159 of 16 .. 128 dims) vs the oracle, worst rel fx err %.3g" % (n, worst))
