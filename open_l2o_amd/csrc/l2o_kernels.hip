@@ -1621,9 +1621,9 @@ size_t l2o_mlp_scratch_floats(const l2o_mlp* mlp) {
 }
 
 // ---- G = A^T B, the weight-gradient contraction of the meta-gradient (csrc/l2o_atb.h) ----------------------
-static int atb_groups(int64_t R, hipStream_t s) {
+static int atb_groups(int64_t R, int wgs_per_cu, hipStream_t s) {
   const int64_t nblk = (R + kAtbRows - 1) / kAtbRows;
-  int g = L2O_ATB_WGS_PER_CU * device_cu_count(s);        // workgroups per CU (72 KB of LDS each when double-buffered)
+  int g = wgs_per_cu * device_cu_count(s);                // persistent workgroups (k_atb: 72 KB of LDS each, k_atb_bx3: 52 | 58)
   if (g <= 0 || g > kAtbMaxGroups) g = kAtbMaxGroups;
   return (int)(nblk < g ? nblk : g);
 }
@@ -1631,17 +1631,26 @@ size_t l2o_atb_workspace_bytes(int64_t R, int32_t KA, int32_t KB) {
   if (R <= 0 || KA <= 0 || KB <= 0) return 0;
   return sizeof(float) * (size_t)kAtbMaxGroups * KA * KB;
 }
+// mask 0: the dense product (fp32 matrix pipe, exact products).  mask 1 | 2: the weight-gradient blocks -- on the
+// bf16 pipe (k_atb_bx3) unless the call asks for exact gates (L2O_OPT_EXACT_GATES: the fp32 pipe, bit-equal to the
+// dense product on those blocks)
 static int atb_launch(const float* A, const float* B, int64_t R, int KA, int KB, int mask, float* out, void* workspace,
                       hipStream_t s) {
-  const int groups = atb_groups(R, s);
   float* part = static_cast<float*>(workspace);
   const int MT = (KA + 15) / 16, NT = (KB + 15) / 16;
   void (*fn)(const float*, const float*, long, int, int, float*) = nullptr;
-  if (mask == 1) fn = k_atb<6, 11, 1>;
-  else if (mask == 2) fn = k_atb<7, 12, 2>;
-  else if (MT <= 1 && NT <= 1) fn = k_atb<1, 1>;
+  int wgs = L2O_ATB_WGS_PER_CU;
+  const bool bx3 = mask != 0 && !opt(L2O_OPT_EXACT_GATES);
+  if (mask == 1) {
+    fn = bx3 ? k_atb_bx3<6, 11, 1> : k_atb<6, 11, 1>;
+    if (bx3) wgs = atb_bx3_wgs_per_cu<6, 11>();
+  } else if (mask == 2) {
+    fn = bx3 ? k_atb_bx3<7, 12, 2> : k_atb<7, 12, 2>;
+    if (bx3) wgs = atb_bx3_wgs_per_cu<7, 12>();
+  } else if (MT <= 1 && NT <= 1) fn = k_atb<1, 1>;
   else if (MT <= 6 && NT <= 11) fn = k_atb<6, 11>;
   else fn = k_atb<7, 12>;
+  const int groups = atb_groups(R, wgs, s);
   hipLaunchKernelGGL(fn, dim3(groups), dim3(256), 0, s, A, B, (long)R, KA, KB, part);
   HIP_TRY(hipGetLastError());
   const int n = KA * KB;
