@@ -418,7 +418,10 @@ int l2o_atb(const float* A, const float* B, int64_t R, int32_t KA, int32_t KB, f
  * l2o_cwlstm_bwd_unroll / _multi / _step of a layers=(20,20) net (KA, KB from l2o_cwlstm_wgrad_dims), computing only
  * the blocks  [in | h1_prev]^T dz1,  [h1 | h2_prev]^T dz2,  h2^T dd,  (RNNProp) feats^T du  and the bias row
  * 1^T [dz1 | dz2 | dd | du]  -- 38 of the 66 (43 of 84) 16 x 16 tiles; every other entry of G is written as 0.
- * Same arithmetic per tile as l2o_atb (bit-equal there), same workspace (l2o_atb_workspace_bytes(R, KA, KB)). */
+ * Arithmetic: by default the products run on the bf16 matrix pipe as a 3-way split of both operands (6 bf16 MFMAs per
+ * tile and 32-row block, fp32 accumulation; error against a float64 product ~2e-8 of sum |a||b|, the same as the fp32
+ * pipe's); with L2O_OPT_EXACT_GATES in cfg->options the fp32 pipe of l2o_atb (bit-equal to it on those blocks).  Both
+ * are bit-reproducible run to run.  Same workspace (l2o_atb_workspace_bytes(R, KA, KB)). */
 int32_t l2o_cwlstm_wgrad_dims(const l2o_net_cfg* cfg, int32_t* KA, int32_t* KB);
 int l2o_cwlstm_wgrad(const l2o_net_cfg* cfg, const float* A, const float* Bm, int64_t R, float* G /* device [KA][KB] */,
                      void* workspace, void* stream);
