@@ -226,11 +226,10 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     const unsigned tag = salt | ((unsigned)t + 1u);     // (T + 1 < 65 535 when salt != 0; the handshake tag ends in 0xffff)
     const int par = t & 1;
     if (q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
-    if (HIST && t < a.T && tile_real)
-      store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * tpp + (size_t)b * tpp + tile_in_prob) *
-                                          kStateFloatsPerTile, lane);
     pc.mark(0);
-    __syncthreads();                                        // B1: this half's xs complete
+    // (recording: barriers that wait for LDS traffic only -- a __syncthreads() also waits for the write acknowledgement
+    //  of the 5 KB of history the wave has just stored)
+    if (HIST) lds_barrier(); else __syncthreads();          // B1: this half's xs complete
     pc.mark(2);
     // ---- partial residual over this half's columns: rows 2 x 16 per wave, all SQ rows per half
     float part;
@@ -302,8 +301,15 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
       if (kCos) contrib += pp.alpha - pp.alpha * cj * l2o::cos_f(kTwoPi * xsv);
     }
+    // the state BEFORE this step's update, for the meta-gradient.  Stored HERE: the poll above is this step's last wait
+    // on vmcnt (loads and stores retire in order), the barriers of the recording kernel wait for LDS traffic only, so
+    // the 5 KB per wave drain under the gate blocks instead of sitting in front of a wait (recording kernel / plain
+    // kernel time at config-2 size: 1.26 -> 1.22, profiles/r03t_*)
+    if (HIST && t < a.T && tile_real)
+      store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * tpp + (size_t)b * tpp + tile_in_prob) *
+                                          kStateFloatsPerTile, lane);
     pc.mark(1);                                             // previous-h2 MFMAs + partner poll
-    __syncthreads();                                        // B2: rs complete
+    if (HIST) lds_barrier(); else __syncthreads();          // B2: rs complete
     pc.mark(4);
     // this wave's share of f_b(x_t): reduced AFTER the barrier (the DPP chain fills the LDS latency of the g
     // pass instead of sitting in front of the barrier) and written straight to HBM -- no LDS round, no
