@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 9
+#define L2O_ABI_VERSION 10
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -436,6 +436,13 @@ int l2o_cwlstm_wgrad(const l2o_net_cfg* cfg, const float* A, const float* Bm, in
  *   member ignored); writes l2o_wpack_floats(cfg) floats, bit-equal to the host packer's output. */
 int l2o_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1,
                   double beta2, double epsilon, void* stream);   /* fp32(beta), fp32(1 - beta), fp32(eps) are used */
+/* The same update, conditional ON THE DEVICE on the status word of the unroll the gradients come from (ABI v10):
+ * unroll_workspace = the workspace of that l2o_unroll_record call (device pointer; NULL = unconditional).  If the
+ * kernel reported a partner timeout (status != 0: its recorded history is garbage), w, m and v are left untouched.
+ * Lets a caller enqueue the meta-step BEHIND the unroll and its back-propagation without waiting for the status on
+ * the host first; it still reads the status after its sync (l2o_unroll_status) and then knows the update did not run. */
+int l2o_adam_step_guarded(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1,
+                          double beta2, double epsilon, const void* unroll_workspace, void* stream);
 int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wpack_out /* device */,
                      void* stream);
 

@@ -115,6 +115,19 @@ class HipEngine(object):
     def tensor(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
+    def sample(self, kind, shape, a, b, seed):
+        """A random fp32 device tensor: kind "normal" (mean a, stddev b) or "uniform" ([a, b)), from a device generator
+        seeded with `seed` (problem re-sampling of MetaLoss.reset without a host draw + upload)."""
+        g = self.__dict__.get("_gen")
+        if g is None:
+            g = self._gen = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        if kind == "normal":
+            t = torch.randn(shape, generator=g, device=self.device, dtype=torch.float32)
+            return t.mul_(float(b)).add_(float(a))
+        t = torch.rand(shape, generator=g, device=self.device, dtype=torch.float32)
+        return t.mul_(float(b) - float(a)).add_(float(a))
+
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
 
@@ -142,10 +155,18 @@ class HipEngine(object):
             setattr(w, k, None if (k == "wpack" or weights.get(k) is None) else weights[k].data_ptr())
         _abi.check(self.lib.l2o_wpack_device(C.byref(cc), C.byref(w), _ptr(out), self._stream()))
 
-    def adam_step(self, w, m, v, g, lr_t, beta1, beta2, epsilon):
-        """TF-1.x Adam on one flat device vector, in place (l2o_adam_step)."""
-        _abi.check(self.lib.l2o_adam_step(_ptr(w), _ptr(m), _ptr(v), _ptr(g), int(w.numel()), float(lr_t),
-                                          float(beta1), float(beta2), float(epsilon), self._stream()))
+    def adam_step(self, w, m, v, g, lr_t, beta1, beta2, epsilon, guarded=False):
+        """TF-1.x Adam on one flat device vector, in place (l2o_adam_step).  guarded: conditional, ON THE DEVICE, on the
+        status word of the last fused unroll's workspace (l2o_adam_step_guarded) -- a partner timeout of that unroll
+        leaves w, m, v untouched; the caller can then enqueue the update before it has seen the status on the host."""
+        ws = self._last_ws if guarded else None
+        if ws is not None:
+            _abi.check(self.lib.l2o_adam_step_guarded(_ptr(w), _ptr(m), _ptr(v), _ptr(g), int(w.numel()), float(lr_t),
+                                                      float(beta1), float(beta2), float(epsilon), C.c_void_p(ws.data_ptr()),
+                                                      self._stream()))
+        else:
+            _abi.check(self.lib.l2o_adam_step(_ptr(w), _ptr(m), _ptr(v), _ptr(g), int(w.numel()), float(lr_t),
+                                              float(beta1), float(beta2), float(epsilon), self._stream()))
 
     def upload(self, key, a):
         """Host array -> a PERSISTENT device tensor per key, through a pinned staging buffer with an

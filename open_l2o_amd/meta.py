@@ -110,7 +110,24 @@ class Variable(object):
         return arr
 
     def initialize(self):
-        self.value = self._graph.engine.tensor(self._local(self.initial_value()))
+        """(Re)sample the variable (MetaLoss.reset, DM/meta.py:379-383 runs the tf initializers -- device ops there too).
+        Random initializers are drawn ON THE DEVICE when the engine can (HipEngine.sample: a torch generator seeded from
+        the stream of set_random_seed): the host draw + upload of config 2's 128 x 128 x 128 matrix batch was 4 ms per
+        reset, twice the five 20-step training unrolls of an epoch.  Every rank draws the GLOBAL array from the same
+        seed and keeps its shard (the ranks together hold the problem batch a single process would).
+        L2O_HOST_SAMPLING=1: the NumPy draw."""
+        eng = self._graph.engine
+        init = self.decl.initializer
+        if (init is not None and init[0] in ("normal", "uniform") and hasattr(eng, "sample")
+                and not os.environ.get("L2O_HOST_SAMPLING")):
+            seed = int(_rng.integers(0, 2 ** 62))
+            t = eng.sample(init[0], tuple(self.shape), float(init[1]), float(init[2]), seed)
+            if self.sharded:
+                lo, hi = self._graph.shard
+                t = t[lo:hi].contiguous()
+            self.value = t
+            return
+        self.value = eng.tensor(self._local(self.initial_value()))
 
     def load(self, value, session=None):
         """tf.Variable.load: assign a value -- the GLOBAL shape, or (sharded) this rank's shard, i.e.
@@ -441,7 +458,7 @@ class UnrollGraph(object):
             eng.prefetch_unroll_status()                 # (rides on the sync below)
         fx_host = eng.to_numpy(fx)                       # host sync
         if fused:
-            eng.check_unroll_status()
+            self._check_unroll_status()
         x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
                 "x": x_out, "fx_array": fx_host}
@@ -472,7 +489,7 @@ class UnrollGraph(object):
         self.wait_fx()
         fx_host = eng.to_numpy(fx)
         if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
-            eng.check_unroll_status()
+            self._check_unroll_status()
         return [np.float32(fx_host[(k + 1) * L]) for k in range(n)]
 
     def many_ok(self):
@@ -820,12 +837,13 @@ class UnrollGraph(object):
                 bufs[k] = new
 
     # -- meta-gradient (DM/meta.py:398-414) --------------------------------------------
-    def train_step(self, feed, commit, learning_rate):
+    def train_step(self, feed, commit, learning_rate, defer=False):
         """One forward unroll (step-granular kernels, history recorded), back-propagation
         through time of loss = sum_t fx_t w.r.t. the optimizer networks' weights with the
         optimizee gradients held constant (tf.stop_gradient, DM/meta.py:328-329), and one Adam
         update of those weights (tf.train.AdamOptimizer(learning_rate).minimize(loss)).
-        Returns the same dict as execute()."""
+        Returns the same dict as execute().  defer (Session.run(_defer_loss=True)): enqueue only -- no host sync, the
+        loss entries of the result are None; honoured when every network's meta-step runs on the device."""
         record = {}
         fx, xs = self.launch(feed, commit, record=record)
         eng = self.engine
@@ -833,15 +851,45 @@ class UnrollGraph(object):
         grads = self._backward(T, record)                   # (launched before the host reads anything back)
         self.wait_fx()
         fused = self.last_path == "fused" and hasattr(eng, "check_unroll_status")
+        # The meta-step goes out BEHIND the unroll and its back-propagation, before the host waits for the loss: with
+        # every network on the device-side Adam the GPU then never idles while the host assembles the update (63 us of
+        # a 0.40 ms step at config-2 size, T = 20).  A partner timeout of a fused unroll leaves a garbage history: the
+        # device-side update is GUARDED by that unroll's status word (l2o_adam_step_guarded) and does not run; the host
+        # learns of it at the sync below, takes the Adam step count back and raises.
+        early = all(self._device_adam(self.nets[k]) for k in grads)
+        if early:
+            self._adam_apply(grads, learning_rate, guarded=fused)
+        pend = self.__dict__.setdefault("_guarded_pending", 0)
+        if defer and early:
+            # nothing is read back: a failed unroll's status word is sticky, so the guarded updates of this and of every
+            # later deferred step stay off until a synchronous step checks it, takes the step counts back and raises
+            self._guarded_pending = pend + (1 if fused else 0)
+            return {"loss": None, "fx": None, "fx_array": None,
+                    "x": _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])}
         if fused and hasattr(eng, "prefetch_unroll_status"):
             eng.prefetch_unroll_status()                    # (rides on the sync below)
         fx_host = eng.to_numpy(fx)                          # host sync
         if fused:
-            eng.check_unroll_status()                       # a partner timeout leaves a garbage history: raise BEFORE the Adam update
+            self._guarded_pending = pend + (1 if early else 0)
+            self._check_unroll_status()                     # raise BEFORE a host-side Adam update / report the skipped ones
+        self._guarded_pending = 0
         x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
-        self._adam_apply(grads, learning_rate)
+        if not early:
+            self._adam_apply(grads, learning_rate)
         return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
                 "x": x_out, "fx_array": fx_host}
+
+    def _check_unroll_status(self):
+        """engine.check_unroll_status() after a host sync; when it raises, the guarded meta-steps enqueued since the last
+        check did not run on the device (l2o_adam_step_guarded): their Adam step counts are taken back."""
+        try:
+            self.engine.check_unroll_status()
+        except Exception:
+            n = self.__dict__.get("_guarded_pending", 0)
+            if n and "_adam" in self.__dict__:
+                self.__dict__["_adam"]["t"] -= n
+            self._guarded_pending = 0
+            raise
 
     def _bptt(self, net, acc, B, D, T, step0, gs, sts, ms, vs, dxs):
         """Back-propagation through T recorded steps of ONE network on one [B, D] panel:
@@ -1109,7 +1157,7 @@ class UnrollGraph(object):
                 and len(net.spec.layers) > 0 and not net.spec.generic      # (generic `layers`: the host meta-step)
                 and not os.environ.get("L2O_HOST_ADAM"))
 
-    def _adam_apply_device(self, key, acc, st, lr_t, beta1, beta2, epsilon):
+    def _adam_apply_device(self, key, acc, st, lr_t, beta1, beta2, epsilon, guarded=False):
         """One network's meta-step without a host round trip: the gradients are laid out like the flat
         Sonnet-layout weight buffer (one torch.cat), l2o_adam_step updates that buffer in place and
         l2o_wpack_device rebuilds the MFMA-fragment copy from it.  The host dict goes stale (lazy refresh)."""
@@ -1137,11 +1185,14 @@ class UnrollGraph(object):
         if buf.numel() > pos:
             parts.append(ent["zeros"][:buf.numel() - pos])
         torch.cat(parts, out=ent["g"])
-        eng.adam_step(buf, ent["m"], ent["v"], ent["g"], lr_t, beta1, beta2, epsilon)
+        if guarded:
+            eng.adam_step(buf, ent["m"], ent["v"], ent["g"], lr_t, beta1, beta2, epsilon, guarded=True)
+        else:
+            eng.adam_step(buf, ent["m"], ent["v"], ent["g"], lr_t, beta1, beta2, epsilon)
         eng.pack_weights_device(net.spec, wdev, wdev["wpack"])
         net.mark_device_updated()
 
-    def _adam_apply(self, grads, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, slot="_adam"):
+    def _adam_apply(self, grads, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, slot="_adam", guarded=False):
         """tf.train.AdamOptimizer's update (TF 1.x `_apply_dense`): lr_t = lr sqrt(1-b2^t)/(1-b1^t);
         m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; var <- var - lr_t m / (sqrt(v) + eps).
         A few thousand weights: done on the host in fp32, then re-packed for the kernels."""
@@ -1153,7 +1204,7 @@ class UnrollGraph(object):
         for key, acc in grads.items():                     # one flat vector per network: a handful of NumPy calls
             net = self.nets[key]
             if self._device_adam(net):
-                self._adam_apply_device(key, acc, st, lr_t, beta1, beta2, epsilon)
+                self._adam_apply_device(key, acc, st, lr_t, beta1, beta2, epsilon, guarded=guarded)
                 continue
             names = list(acc.keys())
             g = np.concatenate([np.asarray(acc[k], np.float32).reshape(-1) for k in names])
@@ -1563,7 +1614,7 @@ class MtUnroll(object):
         loss = self._forward(feed, commit)
         return {"loss": np.float32(self.engine.to_numpy(loss)[0])}
 
-    def train_step(self, feed, commit, learning_rate):
+    def train_step(self, feed, commit, learning_rate, defer=False):
         """loss_mt + one step of this task's own tf.train.AdamOptimizer (DM/meta_dm_train.py:549-553)."""
         rec = {}
         loss = self._forward(feed, commit, record=rec)

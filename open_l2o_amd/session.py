@@ -48,7 +48,10 @@ class Session(object):
     def close(self):
         pass
 
-    def run(self, fetches, feed_dict=None):
+    def run(self, fetches, feed_dict=None, _defer_loss=False):
+        """_defer_loss (ours; util.run_epoch uses it for all but the last unroll of an epoch, whose cost is the only
+        one DM/util.py:31-75 returns): a meta-training step is only ENQUEUED -- no host sync, the loss fetches come
+        back as None -- so that the host runs ahead of the GPU instead of draining it once per unroll."""
         flat = _flatten(fetches, [])
         values = {}
         by_graph = {}
@@ -69,7 +72,8 @@ class Session(object):
             if do_reset:
                 graph.reset()
             if "step" in keys:                              # the Adam meta-step (meta_minimize)
-                res = graph.train_step(feed_dict, commit="update" in keys, learning_rate=graph.learning_rate)
+                res = graph.train_step(feed_dict, commit="update" in keys, learning_rate=graph.learning_rate,
+                                       defer=_defer_loss)
             else:
                 res = graph.execute(feed_dict, commit="update" in keys) if needs_unroll else {}
             for f in fs:

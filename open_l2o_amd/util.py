@@ -59,8 +59,20 @@ def run_epoch(sess, cost_op, ops, reset, num_unrolls,
         feed = feed_of(i)
         if step is not None:
             feed[step] = i * unroll_len + 1
-        cost = sess.run([cost_op] + ops, feed_dict=feed)[0]
+        # only the LAST unroll's cost is returned (DM/util.py:75): the others are enqueued without a host sync
+        if i + 1 < num_unrolls and task_i == -1 and getattr(sess, "run", None) is not None and _can_defer(sess):
+            sess.run([cost_op] + ops, feed_dict=feed, _defer_loss=True)
+        else:
+            cost = sess.run([cost_op] + ops, feed_dict=feed)[0]
     return timer() - start, cost
+
+
+def _can_defer(sess):
+    import inspect
+    try:
+        return "_defer_loss" in inspect.signature(sess.run).parameters and not os.environ.get("L2O_NO_DEFER")
+    except (TypeError, ValueError):
+        return False
 
 
 def run_eval_epoch(sess, cost_op, ops, num_unrolls, step=None, unroll_len=None):

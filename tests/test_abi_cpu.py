@@ -247,5 +247,6 @@ def test_bench_cpu_baseline_legs_run():
 def test_adam_and_device_pack_reject_bad_arguments(lib):
     from open_l2o_amd import _abi
     assert lib.l2o_adam_step(None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, None) == _abi.L2O_ERR_ARG
+    assert lib.l2o_adam_step_guarded(None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, None, None) == _abi.L2O_ERR_ARG
     cc = spec_of(O.DM_IDENTITY).to_c()
     assert lib.l2o_wpack_device(C.byref(cc), None, None, None) == _abi.L2O_ERR_ARG

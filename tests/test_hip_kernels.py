@@ -853,3 +853,27 @@ def test_unroll_reduce_restart_equals_rewind_then_unroll(eng, name, kind, B, D, 
     for a, b in ((x, x2), (st, st2), (fx_part, fx_part2), (fx, fx2)) + (((m, m2), (v, v2)) if name == "rnnprop" else ()):
         assert torch.equal(a, b)
     assert torch.equal(x0d, eng.tensor(x0.reshape(B, D)))                # x0 is read-only
+
+
+def test_guarded_adam_skips_the_update_of_a_failed_unroll(eng):
+    """l2o_adam_step_guarded: the update runs iff the status word at the head of the unroll workspace is zero -- what
+    lets meta_minimize enqueue the meta-step behind the unroll without waiting for the status on the host."""
+    rng = np.random.default_rng(9)
+    n = 1000
+    w0, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    ws = torch.zeros(64, dtype=torch.uint8, device=eng.device)
+    old = eng._last_ws
+    eng._last_ws = ws
+    try:
+        w, m, v = eng.tensor(w0), eng.zeros(n), eng.zeros(n)
+        ws[:4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8)          # "partner timeout"
+        eng.adam_step(w, m, v, eng.tensor(g), 0.01, 0.9, 0.999, 1e-8, guarded=True)
+        assert np.array_equal(eng.to_numpy(w), w0) and not eng.to_numpy(m).any() and not eng.to_numpy(v).any()
+        ws[:4] = 0
+        eng.adam_step(w, m, v, eng.tensor(g), 0.01, 0.9, 0.999, 1e-8, guarded=True)
+        w2, m2, v2 = eng.tensor(w0), eng.zeros(n), eng.zeros(n)
+        eng.adam_step(w2, m2, v2, eng.tensor(g), 0.01, 0.9, 0.999, 1e-8)
+        assert np.array_equal(eng.to_numpy(w), eng.to_numpy(w2)) and not np.array_equal(eng.to_numpy(w), w0)
+        assert np.array_equal(eng.to_numpy(m), eng.to_numpy(m2)) and np.array_equal(eng.to_numpy(v), eng.to_numpy(v2))
+    finally:
+        eng._last_ws = old

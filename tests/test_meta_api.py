@@ -656,3 +656,36 @@ def test_launch_restart_replays_a_prepared_call(engine, name):
     for _ in range(2):
         fx, _ = g.launch(feed, commit=True, restart=x0d)
         assert rel_err(engine.to_numpy(fx), res3.fx) < 1e-5
+
+
+@pytest.mark.parametrize("kind,B,D", [("quadratic", 8, 16), ("quadratic", 128, 128)])
+def test_run_epoch_defers_all_but_the_last_loss(engine, monkeypatch, kind, B, D):
+    """util.run_epoch returns the cost of the LAST unroll only (DM/util.py:75): the meta-training steps before it are
+    enqueued without a host sync (Session.run(_defer_loss=True): guarded device-side Adam behind the unroll).  Same
+    weights, same cost, bit for bit, as the epoch with one sync per unroll (L2O_NO_DEFER=1)."""
+    out = {}
+    for mode in ("sync", "defer"):
+        if mode == "sync":
+            monkeypatch.setenv("L2O_NO_DEFER", "1")
+        else:
+            monkeypatch.delenv("L2O_NO_DEFER", raising=False)
+        meta.set_random_seed(21)
+        np.random.seed(3)
+        problem, net_config, _ = util.get_config(kind, problem_options={"batch_size": B, "num_dims": D})
+        opt = meta.MetaOptimizer(**net_config)
+        ms = opt.meta_minimize(problem, 5, learning_rate=1e-3)
+        syncs = []
+        orig = engine.to_numpy
+        monkeypatch.setattr(engine, "to_numpy", lambda t, _o=orig: (syncs.append(1), _o(t))[1])
+        with Session() as sess:
+            costs = [util.run_epoch(sess, ms.fx, [ms.update, ms.step], ms.reset, 4)[1] for _ in range(2)]
+        monkeypatch.setattr(engine, "to_numpy", orig)
+        key = next(iter(opt._nets))
+        out[mode] = (costs, {m: {v: np.array(a) for v, a in d.items()} for m, d in opt._nets[key].variables.items()},
+                     len(syncs), opt.graph.__dict__["_adam"]["t"])
+    assert out["sync"][0] == out["defer"][0] and all(np.isfinite(c) for c in out["defer"][0])
+    for m, d in out["sync"][1].items():
+        for v, a in d.items():
+            assert np.array_equal(a, out["defer"][1][m][v]), (m, v)
+    assert out["sync"][3] == out["defer"][3] == 8
+    assert out["defer"][2] < out["sync"][2]                   # fewer host round trips
