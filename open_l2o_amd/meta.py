@@ -880,8 +880,9 @@ class UnrollGraph(object):
                 "x": x_out, "fx_array": fx_host}
 
     def _check_unroll_status(self):
-        """engine.check_unroll_status() after a host sync; when it raises, the guarded meta-steps enqueued since the last
-        check did not run on the device (l2o_adam_step_guarded): their Adam step counts are taken back."""
+        """engine.check_unroll_status() after a host sync; when it raises, guarded meta-steps enqueued since the last
+        check did not run on the device (l2o_adam_step_guarded): the Adam step counts of ALL of them are taken back (those
+        enqueued before the failing unroll did run -- the count errs on the low side; the caller is raising anyway)."""
         try:
             self.engine.check_unroll_status()
         except Exception:

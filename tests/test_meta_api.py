@@ -689,3 +689,43 @@ def test_run_epoch_defers_all_but_the_last_loss(engine, monkeypatch, kind, B, D)
             assert np.array_equal(a, out["defer"][1][m][v]), (m, v)
     assert out["sync"][3] == out["defer"][3] == 8
     assert out["defer"][2] < out["sync"][2]                   # fewer host round trips
+
+
+@pytest.mark.gpu
+def test_deferred_train_steps_report_a_failed_unroll_and_leave_the_weights_alone():
+    """A partner timeout of a fused unroll (injected here: the sticky status word of the workspace set by hand) while
+    training steps are being enqueued without a host sync: the guarded device-side Adam of every later step is skipped,
+    the next synchronous step raises, the weights are what they were before the failure."""
+    import torch
+    eng = _engine.HipEngine()
+    old = _engine._default_engine
+    _engine.set_default_engine(eng)
+    try:
+        meta.set_random_seed(5)
+        problem, net_config, _ = util.get_config("quadratic", problem_options={"batch_size": 128, "num_dims": 128})
+        opt = meta.MetaOptimizer(**net_config)
+        ms = opt.meta_minimize(problem, 5, learning_rate=1e-3)
+        key = next(iter(opt._nets))
+        with Session() as sess:
+            sess.run(ms.reset)
+            sess.run([ms.fx, ms.update, ms.step])
+            assert opt.graph.last_path == "fused"
+            sess.run([ms.fx, ms.update, ms.step], _defer_loss=True)          # runs: the status is clean
+            w_ok = {m: {v: np.array(a) for v, a in d.items()} for m, d in opt._nets[key].variables.items()}
+            t_ok = opt.graph.__dict__["_adam"]["t"]
+            eng._last_ws[:4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8)
+            sess.run([ms.fx, ms.update, ms.step], _defer_loss=True)          # enqueued, but its Adam is guarded off
+            with pytest.raises(Exception) as ei:
+                sess.run([ms.fx, ms.update, ms.step])
+            assert "partner" in str(ei.value) or "timeout" in str(ei.value).lower() or "status" in str(ei.value).lower()
+        w_after = opt._nets[key].variables
+        for m, d in w_ok.items():
+            for v, a in d.items():
+                assert np.array_equal(a, np.asarray(w_after[m][v])), (m, v)
+        assert opt.graph.__dict__["_adam"]["t"] <= t_ok                       # the skipped steps are not counted
+        with Session() as sess:                                              # the status was cleared by the check: training resumes
+            sess.run(ms.reset)
+            c = sess.run([ms.fx, ms.update, ms.step])[0]
+        assert np.isfinite(c)
+    finally:
+        _engine.set_default_engine(old)
