@@ -387,8 +387,10 @@ int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const
 /* ALL T steps of the back-propagation through a recorded unroll in ONE launch (the whole of what
  * tf.gradients walks back through the while_loop of DM/meta.py:361-368): a wave keeps its tile's
  * (dh, dc) carries in registers from step T-1 down to step 0, so only the recorded history comes in
- * and the rows of A / Bm go out.  Needs l2o_net_weights.wpack (matrix-core kernel) and tile-aligned
- * panels (D % 16 == 0 or B == 1).
+ * and the rows of A / Bm go out.  Needs l2o_net_weights.wpack (matrix-core kernel).  Any D (since ABI v10): the tiles
+ * of a panel are PER PROBLEM, ceil(D / 16) each with a ragged last one -- the packed-state layout the forward kernels
+ * record -- so panel s occupies B_s ceil(D_s / 16) tiles and 16 times as many rows (for D % 16 == 0 or B == 1 that is
+ * the ceil(B D / 16) of l2o_cwlstm_bwd_multi).
  *   table     device array [T][nseg][5] of device pointers: g, m, v, st_prev, dx_next of panel s at
  *             step t (same meaning as l2o_bwd_seg; m, v NULL for the DM nets).  dx_next may be NULL:
  *             then dL/d(delta_t) = g_final + sum_{tau > t} g_tau, the gradient of loss = sum_t fx_t

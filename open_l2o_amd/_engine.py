@@ -446,11 +446,13 @@ class HipEngine(object):
                                                  _ptr(carry_out), _ptr(A), _ptr(Bm), float(pow1), float(pow2),
                                                  self._stream()))
 
+    bwd_unroll_any_d = True       # l2o_cwlstm_bwd_unroll takes panels of any D (per-problem tiles, ragged last tile)
+
     def bwd_unroll(self, spec: NetSpec, weights: dict, panels, T, step0, A, Bm, carry_in=None, carry_out=None,
                    table=None):
         """All T BPTT steps of the panels that share one network in one launch (l2o_cwlstm_bwd_unroll).
         panels: list of dict(B=, D=, gs=[T tensors], sts=[T], ms=[T] | None, vs=, dxs=[T] | None,
-        g_final= tensor | None); A [T, rows, KA], Bm [T, rows, KB]."""
+        g_final= tensor | None); A [T, rows, KA], Bm [T, rows, KB], rows = 16 * sum_panels B * ceil(D / 16)."""
         cc = spec.to_c()
         w = _abi.NetWeights()
         for k, _ in _abi.NetWeights._fields_:

@@ -27,6 +27,10 @@ struct BwdParams {
   int nseg;
   int tile_end[8];
   long seg_n[8];                      // coordinates of the panel
+  // k_cwlstm_bwd_mfma: the panel's tiles are PER PROBLEM (the forward's packed-state layout): tile lt = problem
+  // lt / seg_tpp, tile seg_tpp-th of its seg_d coordinates; a flat panel (l2o_cwlstm_bwd_multi) is one problem of seg_n
+  long seg_d[8];
+  int seg_tpp[8];
   const float *seg_g[8], *seg_m[8], *seg_v[8], *seg_st[8], *seg_dx[8];
   long rows_total;                    // rows of the carry arrays ([4][rows_total][20])
   const float* wpack;                 // l2o_wpack_host output (device) or NULL: selects k_cwlstm_bwd_mfma (l2o_bwd_mfma.h)

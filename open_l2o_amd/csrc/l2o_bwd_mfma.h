@@ -197,11 +197,15 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     int sg = 0;
     while (sg + 1 < p.nseg && (int)grp >= p.tile_end[sg]) ++sg;
     const size_t lt = valid ? grp - (sg ? p.tile_end[sg - 1] : 0) : 0;
-    const size_t N = (size_t)p.seg_n[sg];
     const size_t n0 = valid ? grp * NC : 0;
-    const size_t ln0 = lt * NC;
-    const int nv = valid ? (int)(N - ln0 < (size_t)NC ? N - ln0 : (size_t)NC) : 0;
-    const size_t n = ln0 + c < N ? ln0 + c : N - 1;         // tail lanes recompute the last coordinate; nothing of theirs is stored
+    // tile lt of the panel = tile tp of problem bp (D coordinates, tpp tiles each -- any D: the last tile of a problem
+    // may be ragged, exactly as the forward kernels lay out the packed state); its lanes' coordinates in the flat
+    // [B * D] history vectors start at bp * D + 16 tp
+    const size_t Dp = (size_t)p.seg_d[sg], tpp = (size_t)p.seg_tpp[sg];
+    const size_t bp = lt / tpp, tp = lt - bp * tpp;
+    const size_t left = Dp - tp * NC;
+    const int nv = valid ? (int)(left < (size_t)NC ? left : (size_t)NC) : 0;
+    const size_t n = bp * Dp + tp * NC + ((int)c < nv ? c : (nv > 0 ? nv - 1 : 0));   // tail lanes recompute the last coordinate; nothing of theirs is stored
     // ---- the carries of the LAST step through LDS (coalesced); they stay in registers over the steps ----
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4) {

@@ -2015,6 +2015,7 @@ int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const
     if (tiles > INT32_MAX / kTile) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_multi: too many coordinates");
     p.tile_end[i] = (int)tiles;
     p.seg_n[i] = n;
+    p.seg_d[i] = n; p.seg_tpp[i] = (int)((n + kTile - 1) / kTile);   // (tile-aligned or one row: the flat numbering)
     p.seg_g[i] = sgm.g; p.seg_m[i] = sgm.m; p.seg_v[i] = sgm.v; p.seg_st[i] = sgm.st_prev; p.seg_dx[i] = sgm.dx_next;
   }
   p.rows_total = tiles * kTile;
@@ -2044,13 +2045,14 @@ int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, cons
   for (int i = 0; i < nseg; ++i) {
     const l2o_bwd_unroll_seg& sgm = segs[i];
     if (sgm.B <= 0 || sgm.D <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_unroll: bad panel %d", i);
-    if (sgm.D % kTile != 0 && sgm.B != 1)
-      return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll: panel %d needs D %% 16 == 0 or B == 1", i);
     const long n = (long)(sgm.B * sgm.D);
-    tiles += (n + kTile - 1) / kTile;
+    const long tpp = (long)tiles_per_problem(sgm.D);        // per-problem tiles, the packed-state layout of the forward
+    tiles += (long)sgm.B * tpp;
     if (tiles > INT32_MAX / kTile) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll: too many coordinates");
     p.tile_end[i] = (int)tiles;
     p.seg_n[i] = n;
+    p.seg_d[i] = (long)sgm.D;
+    p.seg_tpp[i] = (int)tpp;
     p.seg_gfinal[i] = sgm.g_final;
   }
   p.rows_total = tiles * kTile;
@@ -2119,6 +2121,7 @@ int l2o_cwlstm_bwd_step(const l2o_net_cfg* cfg, const l2o_net_weights* w, const 
       p.nseg = 1;
       p.tile_end[0] = (int)((N + kTile - 1) / kTile);
       p.seg_n[0] = (long)N;
+      p.seg_d[0] = (long)N; p.seg_tpp[0] = p.tile_end[0];
       p.seg_g[0] = io->g; p.seg_m[0] = io->m; p.seg_v[0] = io->v; p.seg_st[0] = io->st_prev; p.seg_dx[0] = io->dx_next;
       p.rows_total = (long)N;
       return launch_bwd_tile(p, pre, s);

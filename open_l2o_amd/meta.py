@@ -1033,14 +1033,22 @@ class UnrollGraph(object):
         KA = K1 + 2 * H + H + (2 if fc else 0) + 1
         KB = 4 * H + 4 * H + 1 + (H if fc else 0)
         multi = all(pn["D"] % 16 == 0 or pn["B"] == 1 for pn in panels) and len(panels) <= 8 and not second
-        fused = (multi and wdev.get("wpack") is not None and not os.environ.get("L2O_BWD_STEPWISE")
+        # the T-step launch takes ANY D (per-problem tiles with a ragged last one, the forward's packed-state layout);
+        # the step-granular multi-panel kernel needs tile-aligned panels
+        fused = (len(panels) <= 8 and not second and wdev.get("wpack") is not None
+                 and not os.environ.get("L2O_BWD_STEPWISE") and hasattr(eng, "bwd_unroll")
+                 and (multi or (getattr(eng, "bwd_unroll_any_d", False) and not os.environ.get("L2O_BWD_ALIGNED_ONLY")))
                  and _abi.get_option(_abi.OPT_BWD_KERNEL) == 0)                                   # A/B switches of the tests
-        groups = [panels] if multi else [[pn] for pn in panels]
+        groups = [panels] if (multi or fused) else [[pn] for pn in panels]
         if not fused:
             need_dxs()
         for grp in groups:
             Ns = [pn["B"] * pn["D"] for pn in grp]
-            offs = np.concatenate([[0], np.cumsum([(n + 15) // 16 * 16 for n in Ns])]).astype(int)   # row blocks (whole tiles)
+            if fused:                                       # rows = 16 x (B x ceil(D / 16)) per panel
+                rows = [pn["B"] * ((pn["D"] + 15) // 16) * 16 for pn in grp]
+            else:
+                rows = [(n + 15) // 16 * 16 for n in Ns]
+            offs = np.concatenate([[0], np.cumsum(rows)]).astype(int)   # row blocks (whole tiles)
             R = int(offs[-1])
             ragged = any(n % 16 for n in Ns)
             if fused:                                       # all T steps in one launch, the carries in registers;

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import oracle as O
-from helpers import ORACLE_CFGS, make_params, make_problem, max_abs, random_state, rel_err, spec_of
+from helpers import ORACLE_CFGS, lib_option, make_params, make_problem, max_abs, random_state, rel_err, spec_of
 from open_l2o_amd import _abi, _engine, meta, meta_rnnprop_eval, problems
 from open_l2o_amd.session import Session
 from test_meta_api import _net_config, engine  # noqa: F401  (fixture)
@@ -280,8 +280,10 @@ def test_recording_fused_unroll_equals_step_path(engine, name, B, D, monkeypatch
     for mode in ("fused", "steps"):
         if mode == "steps":
             monkeypatch.setenv("L2O_DISABLE_FUSED", "1")
+            monkeypatch.setenv("L2O_BWD_ALIGNED_ONLY", "1")             # (D = 24: the per-step BPTT kernels as reference)
         else:
             monkeypatch.delenv("L2O_DISABLE_FUSED", raising=False)
+            monkeypatch.delenv("L2O_BWD_ALIGNED_ONLY", raising=False)
         problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
         if rn:
             opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
@@ -499,6 +501,99 @@ def test_bwd_unroll_equals_stepwise_bwd_multi(name, dx_mode):
         for a in range(4):
             close(c1[a, row:row + B * D], ref_c[a, row:row + B * D], "carry %d panel %d" % (a, i))
         row += rows[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
+def test_bwd_unroll_ragged_problem_tiles(name):
+    """l2o_cwlstm_bwd_unroll on panels whose D is NOT a multiple of 16 with B > 1 (BASELINE config 4: d = 100): the
+    tiles are per problem, ceil(D / 16) each with a ragged last one -- the packed-state layout the forward records --
+    and the rows of A / Bm / the carries are 16 per tile (padding rows zero).  Reference: the one-thread-per-coordinate
+    kernel (l2o_cwlstm_bwd_step, any shape), step by step, rows mapped coordinate -> (tile, lane)."""
+    eng = _engine.HipEngine()
+    cfg = ORACLE_CFGS[name]
+    spec = spec_of(cfg)
+    params = make_params(cfg, seed=97, trained_like=True)
+    names = {"w_gates1": ("lstm_1", "w_gates"), "b_gates1": ("lstm_1", "b_gates"), "w_gates2": ("lstm_2", "w_gates"),
+             "b_gates2": ("lstm_2", "b_gates"), "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
+             "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
+    t_ = eng.tensor
+    wdev = {kk: t_(params[mm][nn]) for kk, (mm, nn) in names.items() if mm in params}
+    wfused = dict(wdev, wpack=eng.pack_weights(spec, params))
+    fc = cfg.kind == "rnnprop"
+    P = cfg.in_dim
+    K1 = P + 20
+    KA = K1 + 60 + (2 if fc else 0) + 1
+    KB = 161 + (20 if fc else 0)
+    T, step0 = 3, 2
+    shapes = [(3, 100), (2, 37), (1, 40), (4, 32)]
+    rows = [b * ((d + 15) // 16) * 16 for b, d in shapes]
+    R = sum(rows)
+    rng = np.random.default_rng(98)
+    panels, maps = [], []
+    off = 0
+    for i, (B, D) in enumerate(shapes):
+        N = B * D
+        tpp = (D + 15) // 16
+        bb, jj = np.divmod(np.arange(N), D)
+        maps.append(off + (bb * tpp + jj // 16) * 16 + jj % 16)         # row of coordinate n in the padded numbering
+        off += rows[i]
+        gs = [t_((rng.standard_normal((B, D)) * 0.5).astype(np.float32)) for _ in range(T)]
+        ms = [t_((rng.standard_normal((B, D)) * 0.1).astype(np.float32)) for _ in range(T)] if fc else [None] * T
+        vs = [t_((rng.random((B, D)) * 0.1 + 0.01).astype(np.float32)) for _ in range(T)] if fc else [None] * T
+        sts = []
+        for k in range(T):
+            state = random_state(cfg, N, 300 + 10 * i + k)
+            sts.append(eng.state_pack(*[t_(a) for hc in state for a in hc], B, D))
+        g_final = t_((rng.standard_normal(N) * 0.5).astype(np.float32))
+        dxs, acc = [None] * T, g_final.clone()
+        for k in reversed(range(T)):
+            dxs[k] = acc
+            acc = acc + gs[k].reshape(N)
+        panels.append(dict(B=B, D=D, gs=gs, ms=ms, vs=vs, sts=sts, dxs=dxs, g_final=g_final))
+    cin_rows = (rng.standard_normal((4, R, 20)) * 0.3).astype(np.float32)
+    live = np.zeros(R, bool)
+    for mp in maps:
+        live[mp] = True
+    cin_rows[:, ~live] = 0.0
+    # reference: per panel, per step, dense [N] rows
+    b1, b2 = float(np.float32(spec.beta1)), float(np.float32(spec.beta2))
+    refA, refB = np.zeros((T, R, KA), np.float32), np.zeros((T, R, KB), np.float32)
+    refC = np.zeros((4, R, 20), np.float32)
+    for pn, mp in zip(panels, maps):
+        B, D = pn["B"], pn["D"]
+        N = B * D
+        cin = t_(np.ascontiguousarray(cin_rows[:, mp]))
+        for k in reversed(range(T)):
+            At, Bt = eng.zeros(N, KA), eng.zeros(N, KB)
+            cout = eng.zeros(4, N, 20)
+            io = dict(g=pn["gs"][k], dx_next=pn["dxs"][k], st_prev=pn["sts"][k], carry_in=cin, carry_out=cout,
+                      m=pn["ms"][k], v=pn["vs"][k], a_stride=KA, b_stride=KB, act1=At[:, 0:K1], act2=At[:, K1:K1 + 40],
+                      h2=At[:, K1 + 40:K1 + 60], dz1=Bt[:, 0:80], dz2=Bt[:, 80:160], dd=Bt[:, 160:161])
+            if fc:
+                io.update(feats=At[:, K1 + 60:K1 + 62], du=Bt[:, 161:181])
+            with lib_option(_abi.OPT_BWD_KERNEL, 2):                     # the generic kernel
+                eng.bwd_step(spec, wdev, io, b1 ** (step0 + k), b2 ** (step0 + k), B, D)
+            a = eng.to_numpy(At)
+            a[:, KA - 1] = 1.0
+            refA[k, mp], refB[k, mp] = a, eng.to_numpy(Bt)
+            cin = cout
+        refC[:, mp] = eng.to_numpy(cin)
+    for dx_mode in ("g_final", "table"):
+        A1, B1 = eng.empty(T, R, KA), eng.empty(T, R, KB)
+        A1.fill_(7.0); B1.fill_(7.0)                                     # every row is written, the padding rows as zeros
+        c1 = eng.zeros(4, R, 20)
+        fused_panels = [dict(pn, dxs=None) if dx_mode == "g_final" else dict(pn, g_final=None) for pn in panels]
+        eng.bwd_unroll(spec, wfused, fused_panels, T, step0, A1, B1, carry_in=t_(cin_rows), carry_out=c1)
+        A1n, B1n, c1n = eng.to_numpy(A1), eng.to_numpy(B1), eng.to_numpy(c1)
+        for k in range(T):
+            for got, ref, what in ((A1n[k], refA[k], "A"), (B1n[k], refB[k], "Bm")):
+                tol = 2e-5 * np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30) + 1e-9
+                assert (np.abs(got - ref) <= tol).all(), (dx_mode, what, k, float(np.abs(got - ref).max()))
+            assert not A1n[k][~live].any() and not B1n[k][~live].any()
+        for a in range(4):
+            tol = 2e-5 * np.maximum(np.abs(refC[a]).max(), 1e-30) + 1e-9
+            assert (np.abs(c1n[a][live] - refC[a][live]) <= tol).all(), (dx_mode, "carry", a)
 
 
 @pytest.mark.gpu

@@ -101,7 +101,8 @@ def _problem(kind, B, D, seed):
     return (lambda: problems.rastrigin(B, D, data={"A": prob.A, "B": prob.B, "C": prob.C, "x": x0})), f, x0
 
 
-@pytest.mark.parametrize("kind,B,D,T", [("quadratic", 3, 16, 6), ("rastrigin", 2, 32, 5), ("quadratic", 4, 128, 8)])
+@pytest.mark.parametrize("kind,B,D,T", [("quadratic", 3, 16, 6), ("rastrigin", 2, 32, 5), ("quadratic", 4, 128, 8),
+                                       ("rastrigin", 3, 100, 4)])        # d = 100: ragged per-problem tiles in the fused BPTT
 def test_rnnprop_train_step_weight_gradient_vs_autograd(hip, kind, B, D, T):
     """First-order mode (the reference's default): every weight-gradient block of ONE train step at 5e-4 of its largest
     entry -- magnitudes, not signs (the post-Adam check of test_meta_gradient is a sign test)."""
