@@ -81,6 +81,9 @@ __device__ __forceinline__ void lds_read_f4(float4 (&v)[N], const float* p) {
 // HIST: also record the per-step history for the meta-gradient (l2o_unroll_record); a template
 // parameter so that the plain unroll carries none of it
 // EXACT (L2O_OPT_EXACT_GATES): the fp32 MFMA gate GEMM (bit-equal to an fmaf chain) instead of the bf16x3 split
+#ifndef L2O_PAIR_LDS_BARRIERS
+#define L2O_PAIR_LDS_BARRIERS 0
+#endif
 template <int PRE, int KIND, int CH, bool HIST, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     pc.mark(0);
     // (recording: barriers that wait for LDS traffic only -- a __syncthreads() also waits for the write acknowledgement
     //  of the 5 KB of history the wave has just stored)
-    if (HIST) lds_barrier(); else __syncthreads();          // B1: this half's xs complete
+    if (HIST || L2O_PAIR_LDS_BARRIERS) lds_barrier(); else __syncthreads();          // B1: this half's xs complete
     pc.mark(2);
     // ---- partial residual over this half's columns: rows 2 x 16 per wave, all SQ rows per half
     float part;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * tpp + (size_t)b * tpp + tile_in_prob) *
                                           kStateFloatsPerTile, lane);
     pc.mark(1);                                             // previous-h2 MFMAs + partner poll
-    if (HIST) lds_barrier(); else __syncthreads();          // B2: rs complete
+    if (HIST || L2O_PAIR_LDS_BARRIERS) lds_barrier(); else __syncthreads();          // B2: rs complete
     pc.mark(4);
     // this wave's share of f_b(x_t): reduced AFTER the barrier (the DPP chain fills the LDS latency of the g
     // pass instead of sitting in front of the barrier) and written straight to HBM -- no LDS round, no
