@@ -616,7 +616,7 @@ def main(argv=None):
             counters = counters_for([args.problem, args.net, D, B, T] + ([Mrows] if args.problem == "lasso" else []),
                                     case["kernel"].split(" ")[0] if case["fused"] else "")
         roof = roofline_block(case, args, counters)
-        roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms_host_sampling_plus_h2d=case["t_reset"] * 1e3)
+        roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms=case["t_reset"] * 1e3)   # MetaLoss.reset: the problem re-sampled on the device (4 ms with the host draw + upload of round 2)
         roof.update(time_base="kernel_ms_avg: HIP events on the launch stream of THIS run around replays of one problem "
                               "instance (the unroll kernel + its epilogue, no preparation); counters (traffic, issue): the "
                               "committed rocprofv3 --pmc passes named in counters_source, collected on an earlier lease "
