@@ -227,12 +227,31 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices /* device [batch] rows
  *             header as for l2o_unroll (sticky status word -> l2o_unroll_status, launch sequence word)
  * One workgroup per 64 coordinates, all co-resident (n_tiles / 4 <= #CUs): l2o_mlp_unroll_supported() == 0
  * otherwise (and for n_in * H % 64 != 0, H outside [8, 32], O > 16, batch > 128) -- callers then run
- * l2o_mlp_fg + l2o_cwlstm_step_multi per step. */
+ * l2o_mlp_fg + l2o_cwlstm_step_multi per step.  Returns 2 (since ABI v10) when the FAST instantiation applies (the
+ * reference's shape: hidden 20, 10 classes, minibatch 64: 11 us per step against 22 us of the step-granular launches),
+ * 1 for the generic loops (at minibatch 128 no faster than the step-granular path: 39 vs 38 us per step). */
 int l2o_mlp_unroll_supported(const l2o_net_cfg* cfg, const l2o_mlp* mlp, void* stream);
 size_t l2o_mlp_unroll_workspace_bytes(const l2o_mlp* mlp);
 int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_mlp* mlp,
                    const int32_t* indices, float* const* x, float* const* st, float* const* m, float* const* v,
                    const float* const* x_scale, int32_t T, int32_t step0, float* fx, void* workspace, void* stream);
+/* The same unroll, also recording what the meta-gradient needs (ABI v10; the MLP counterpart of l2o_unroll_record):
+ * T optimizer steps and T + 1 gradient evaluations (indices must hold T + 1 rows: the one at x_T is the g_final of
+ * l2o_cwlstm_bwd_unroll).  Per variable k (w1, b1, w2, b2; n_k coordinates):
+ *   hist.st[k]  [T][l2o_state_floats(1, n_k)]  the packed LSTM state BEFORE step t
+ *   hist.g[k]   [T + 1][n_k]                   the gradient at x_t (times x_scale), slot T = at x_T
+ *   hist.m[k], hist.v[k]  [T + 1][n_k]         RNNProp: the moments AFTER step t in slot t + 1 (slot 0 is not written);
+ *                                              NULL for the DM nets */
+typedef struct l2o_mlp_hist {
+  float* st[4];
+  float* g[4];
+  float* m[4];
+  float* v[4];
+} l2o_mlp_hist;
+int l2o_mlp_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_mlp* mlp,
+                          const int32_t* indices, float* const* x, float* const* st, float* const* m, float* const* v,
+                          const float* const* x_scale, int32_t T, int32_t step0, float* fx, const l2o_mlp_hist* hist,
+                          void* workspace, void* stream);
 
 /* ---- one optimizer step on a gradient panel: the closure `update`
  * (DM/meta.py:319-336; RNNProp DM/meta_rnnprop_train.py:371-395) for ONE variable:

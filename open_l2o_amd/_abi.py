@@ -25,7 +25,7 @@ PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_M
 SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_coresident_workgroups", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
-    "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
+    "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_record", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_unroll_prepare", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
 )
@@ -121,6 +121,10 @@ class Mlp(C.Structure):
         ("activation", C.c_int32), ("n_data", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
         ("images", C.c_void_p), ("labels", C.c_void_p),
     ]
+
+
+class MlpHist(C.Structure):            # l2o_mlp_hist: per variable (w1, b1, w2, b2) history of l2o_mlp_unroll_record
+    _fields_ = [("st", C.c_void_p * 4), ("g", C.c_void_p * 4), ("m", C.c_void_p * 4), ("v", C.c_void_p * 4)]
 
 
 class GenNet(C.Structure):
@@ -230,6 +234,9 @@ def lib():
     L.l2o_mlp_unroll_workspace_bytes.argtypes = [C.POINTER(Mlp)]
     L.l2o_mlp_unroll.restype = C.c_int
     L.l2o_mlp_unroll.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Mlp), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.l2o_mlp_unroll_record.restype = C.c_int
+    L.l2o_mlp_unroll_record.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Mlp), vp, vp, vp, vp, vp, vp, i32, i32, vp,
+                                        C.POINTER(MlpHist), vp, vp]
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
     L.l2o_gen_state_floats.restype = C.c_size_t

@@ -254,11 +254,13 @@ class HipEngine(object):
     def mlp_unroll_supported(self, spec: NetSpec, d: MlpDesc):
         """A fused persistent unroll exists for this (net, MLP optimizee) pair on this device (l2o_mlp_unroll)."""
         cc, cm = spec.to_c(), self._cmlp(d)
-        return bool(self.lib.l2o_mlp_unroll_supported(C.byref(cc), C.byref(cm), self._stream()))
+        return int(self.lib.l2o_mlp_unroll_supported(C.byref(cc), C.byref(cm), self._stream()))   # 2: the FAST form
 
-    def mlp_unroll(self, spec: NetSpec, wpack, d: MlpDesc, indices, xs, sts, ms, vs, scales, T, step0, fx):
+    def mlp_unroll(self, spec: NetSpec, wpack, d: MlpDesc, indices, xs, sts, ms, vs, scales, T, step0, fx, hist=None):
         """T optimizer steps on the MLP optimizee in ONE launch.  indices: device int32 [T + 1, batch]; xs / sts /
-        ms / vs / scales: lists of 4 device tensors (w1, b1, w2, b2; ms / vs / scales entries may be None)."""
+        ms / vs / scales: lists of 4 device tensors (w1, b1, w2, b2; ms / vs / scales entries may be None).
+        hist: None, or dict(st=, g=, m=, v=) of lists of 4 device tensors ([T, state], [T + 1, n], [T + 1, n] x 2;
+        m / v None for the DM nets) that receive the history the meta-gradient needs (l2o_mlp_unroll_record)."""
         cc, cm = spec.to_c(), self._cmlp(d)
         n = int(self.lib.l2o_mlp_unroll_workspace_bytes(C.byref(cm)))
         ws = self.__dict__.get("_mlp_ws")
@@ -272,6 +274,16 @@ class HipEngine(object):
                 a[k] = None if t is None else t.data_ptr()
             return a
         ax, ast, am, av, asc = arr(xs), arr(sts), arr(ms), arr(vs), arr(scales)
+        if hist is not None:
+            h = _abi.MlpHist()
+            for k in range(4):
+                h.st[k], h.g[k] = hist["st"][k].data_ptr(), hist["g"][k].data_ptr()
+                h.m[k] = None if hist.get("m") is None or hist["m"][k] is None else hist["m"][k].data_ptr()
+                h.v[k] = None if hist.get("v") is None or hist["v"][k] is None else hist["v"][k].data_ptr()
+            _abi.check(self.lib.l2o_mlp_unroll_record(C.byref(cc), _ptr(wpack), C.byref(cm), C.c_void_p(indices.data_ptr()),
+                                                      ax, ast, am, av, asc, int(T), int(step0), _ptr(fx), C.byref(h),
+                                                      C.c_void_p(ws.data_ptr()), self._stream()))
+            return
         _abi.check(self.lib.l2o_mlp_unroll(C.byref(cc), _ptr(wpack), C.byref(cm), C.c_void_p(indices.data_ptr()), ax, ast,
                                            am, av, asc, int(T), int(step0), _ptr(fx), C.c_void_p(ws.data_ptr()),
                                            self._stream()))

@@ -1822,7 +1822,8 @@ int l2o_mlp_unroll_supported(const l2o_net_cfg* cfg, const l2o_mlp* mlp, void* s
   OptScope opt_scope(cfg_optw(cfg));
   MlpUnrollLayout L;
   if (!cfg || !net_ok_for_mfma(cfg) || !opt(L2O_OPT_MLP_UNROLL) || !mlp_unroll_layout(mlp, &L)) return 0;
-  return L.nwg <= coresident_cus((hipStream_t)stream) ? 1 : 0;   // one workgroup per CU, all co-resident
+  if (L.nwg > coresident_cus((hipStream_t)stream)) return 0;     // one workgroup per CU, all co-resident
+  return L.fast ? 2 : 1;                                           // 2: the reference's shape (static loop bounds, paired granules)
 }
 
 size_t l2o_mlp_unroll_workspace_bytes(const l2o_mlp* mlp) {
@@ -1830,9 +1831,10 @@ size_t l2o_mlp_unroll_workspace_bytes(const l2o_mlp* mlp) {
   return mlp_unroll_layout(mlp, &L) ? L.total : 0;
 }
 
-int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* mlp, const int32_t* indices,
-                   float* const* x, float* const* st, float* const* m, float* const* v, const float* const* x_scale,
-                   int32_t T, int32_t step0, float* fx, void* workspace, void* stream) {
+static int mlp_unroll_launch(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* mlp, const int32_t* indices,
+                             float* const* x, float* const* st, float* const* m, float* const* v,
+                             const float* const* x_scale, int32_t T, int32_t step0, float* fx, const l2o_mlp_hist* hist,
+                             void* workspace, void* stream) {
   OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !wpack || !mlp || !indices || !x || !st || !fx || !workspace || T < 0 || !mlp->images || !mlp->labels)
     return fail(L2O_ERR_ARG, "l2o_mlp_unroll: bad argument");
@@ -1865,17 +1867,46 @@ int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* ml
   a.Sm = reinterpret_cast<unsigned long long*>(wsb + L.sm_off);
   a.nwg = L.nwg; a.nw1 = L.nw1; a.R = L.R;
   a.use_salt = T + 1 < 0xffff ? 1u : 0u;
+  if (hist) {
+    for (int k = 0; k < 4; ++k) {
+      if (!hist->st[k] || !hist->g[k] || (rn && (!hist->m[k] || !hist->v[k])))
+        return fail(L2O_ERR_ARG, "l2o_mlp_unroll_record: NULL history buffer of variable %d", k);
+      a.hist_st[k] = hist->st[k]; a.hist_g[k] = hist->g[k];
+      a.hist_m[k] = rn ? hist->m[k] : nullptr; a.hist_v[k] = rn ? hist->v[k] : nullptr;
+    }
+  }
   HIP_TRY(hipMemsetAsync(wsb + L.p_off, 0, L.total - L.p_off, s));   // the granules only: the header survives
   const dim3 grid(L.nwg), block(256);
   void (*fn)(MlpUnrollArgs) = nullptr;
-  switch (cfg->preprocess) {
-    case L2O_PRE_IDENTITY: fn = L.fast ? k_mlp_unroll<L2O_PRE_IDENTITY, true> : k_mlp_unroll<L2O_PRE_IDENTITY, false>; break;
-    case L2O_PRE_LOGSIGN: fn = L.fast ? k_mlp_unroll<L2O_PRE_LOGSIGN, true> : k_mlp_unroll<L2O_PRE_LOGSIGN, false>; break;
-    default: fn = L.fast ? k_mlp_unroll<L2O_PRE_FC_ELU, true> : k_mlp_unroll<L2O_PRE_FC_ELU, false>;
+  if (hist) {
+    switch (cfg->preprocess) {
+      case L2O_PRE_IDENTITY: fn = L.fast ? k_mlp_unroll<L2O_PRE_IDENTITY, true, true> : k_mlp_unroll<L2O_PRE_IDENTITY, false, true>; break;
+      case L2O_PRE_LOGSIGN: fn = L.fast ? k_mlp_unroll<L2O_PRE_LOGSIGN, true, true> : k_mlp_unroll<L2O_PRE_LOGSIGN, false, true>; break;
+      default: fn = L.fast ? k_mlp_unroll<L2O_PRE_FC_ELU, true, true> : k_mlp_unroll<L2O_PRE_FC_ELU, false, true>;
+    }
+  } else {
+    switch (cfg->preprocess) {
+      case L2O_PRE_IDENTITY: fn = L.fast ? k_mlp_unroll<L2O_PRE_IDENTITY, true> : k_mlp_unroll<L2O_PRE_IDENTITY, false>; break;
+      case L2O_PRE_LOGSIGN: fn = L.fast ? k_mlp_unroll<L2O_PRE_LOGSIGN, true> : k_mlp_unroll<L2O_PRE_LOGSIGN, false>; break;
+      default: fn = L.fast ? k_mlp_unroll<L2O_PRE_FC_ELU, true> : k_mlp_unroll<L2O_PRE_FC_ELU, false>;
+    }
   }
   hipLaunchKernelGGL(fn, grid, block, 0, s, a);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
+}
+
+int l2o_mlp_unroll(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* mlp, const int32_t* indices,
+                   float* const* x, float* const* st, float* const* m, float* const* v, const float* const* x_scale,
+                   int32_t T, int32_t step0, float* fx, void* workspace, void* stream) {
+  return mlp_unroll_launch(cfg, wpack, mlp, indices, x, st, m, v, x_scale, T, step0, fx, nullptr, workspace, stream);
+}
+int l2o_mlp_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* mlp, const int32_t* indices,
+                          float* const* x, float* const* st, float* const* m, float* const* v,
+                          const float* const* x_scale, int32_t T, int32_t step0, float* fx, const l2o_mlp_hist* hist,
+                          void* workspace, void* stream) {
+  if (!hist) return fail(L2O_ERR_ARG, "l2o_mlp_unroll_record: NULL hist");
+  return mlp_unroll_launch(cfg, wpack, mlp, indices, x, st, m, v, x_scale, T, step0, fx, hist, workspace, stream);
 }
 
 int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_step_seg* segs, int32_t nseg,

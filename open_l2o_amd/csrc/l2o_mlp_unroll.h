@@ -72,6 +72,11 @@ struct MlpUnrollArgs {
   unsigned long long* Sm;      // [2][H + H * O + O]      b1, w2, b2 (scaled), by step parity
   int nwg, nw1, R;             // workgroups; workgroups that own w1 coordinates; outputs per reducer
   unsigned use_salt;
+  // HIST instantiation (l2o_mlp_unroll_record): per variable, the history the meta-gradient needs
+  float* hist_st[4];           // [T][packed state]   the LSTM state BEFORE step t
+  float* hist_g[4];            // [T + 1][n]          the (scaled) gradient at x_t; slot T = the gradient at x_T
+  float* hist_m[4];            // [T + 1][n]          RNNProp moments AFTER step t in slot t + 1 (slot 0 untouched)
+  float* hist_v[4];
 };
 
 __device__ __forceinline__ unsigned long long mu_granule(float v, unsigned tag) {
@@ -116,7 +121,9 @@ __device__ __forceinline__ mu_u32x4 mu_poll2(const unsigned long long* p, mu_u32
 
 // FAST: the reference's shape (hidden 20, 10 classes, minibatch 64 = one sample per lane) with static loop bounds,
 // pairwise 16-byte granule traffic and a barrier-free forward tail; else the generic loops.
-template <int PRE, bool FAST>
+// HIST: also record the per-step history for the meta-gradient (l2o_mlp_unroll_record): T + 1 gradient evaluations
+// (the one at x_T included), T optimizer steps.
+template <int PRE, bool FAST, bool HIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_unroll(MlpUnrollArgs a) {
   __shared__ float xwg_p[32 + 64 + 64];               // the workgroup's 64 scaled coordinates, zero margins (w1 owners)
   float* xwg = xwg_p + 32;
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
       pc.mark(4);
-      if (t == a.T) break;
+      if (t == a.T && !HIST) break;
       // ---- dH for hidden units 5 wv .. 5 wv + 4 of the lane's sample
 #pragma unroll
       for (int hh = 0; hh < 5; ++hh) {
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     if (wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
     pc.mark(4);                                        // activation, layer 2, softmax, loss
-    if (t == a.T) break;
+    if (t == a.T && !HIST) break;
     for (int o = tid; o < NO; o += 256) {              // dH = (dZ w2^T) * act'
       const int sidx = o / H, h = o - sidx * H;
       float d = 0.0f;
@@ -536,10 +543,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     gv = quad_q_sum(gv);
     gv = live ? gv * sc : 0.0f;
     pc.mark(6);                                        // gradient
+    if constexpr (HIST) {
+      if (live && q == 0) a.hist_g[var][(size_t)t * a.n[var] + jl] = gv;
+      if (t == a.T) break;                             // (the gradient at x_T was still needed)
+      if (tile_real)                                   // the state BEFORE this step's update
+        store_tile_state(s, a.hist_st[var] + ((size_t)t * (a.tile_begin[var + 1] - a.tile_begin[var]) + tile_in_var) *
+                                                 kStateFloatsPerTile, lane);
+    }
     // ---- optimizer step on the tile
     float in0, in1;
     if (PRE == L2O_PRE_FC_ELU) {
       rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, 1.0f - p1h, 1.0f - p2h, in0, in1);
+      if (HIST && live && q == 0) {                    // the moments AFTER the step
+        a.hist_m[var][(size_t)(t + 1) * a.n[var] + jl] = mv;
+        a.hist_v[var][(size_t)(t + 1) * a.n[var] + jl] = vv;
+      }
       if (!live) { in0 = 0.0f; in1 = 0.0f; }
       float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
       float lo = __builtin_fmaf(p1l, a.np.beta1, er), sum = hi + lo;

@@ -6,9 +6,10 @@ from open_l2o_amd import meta, meta_rnnprop_train, problems, util
 from open_l2o_amd.session import Session
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 meta.set_random_seed(3)
 problem, net_config, assignments = util.get_config("mnist", net_name="RNNprop",
-                                                   problem_options={"data": problems.synthetic_mnist(4096, seed=5)})
+                                                   problem_options={"data": problems.synthetic_mnist(4096, seed=5), "batch_size": BATCH})
 opt = meta_rnnprop_train.MetaOptimizer(0, 0.95, 0.95, **net_config)
 out = opt.meta_minimize(problem, T, learning_rate=1e-3, net_assignments=assignments)
 ms, step_ph = out[0], out[5]
@@ -41,7 +42,16 @@ with Session() as sess:
         sess.run([ms.fx, ms.update, ms.step], feed_dict={step_ph: 1 + (i + 3) * T})
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-print("mnist 784-20-10 RNNProp T=%d path=%s: train step %.3f ms" % (T, g.last_path, dt * 1e3))
+print("mnist 784-20-10 RNNProp T=%d minibatch %d path=%s: train step %.3f ms" % (T, BATCH, g.last_path, dt * 1e3))
+with Session() as sess:                                       # forward only (evaluation pattern)
+    for i in range(3):
+        sess.run([ms.fx, ms.update], feed_dict={step_ph: 1})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20):
+        sess.run([ms.fx, ms.update], feed_dict={step_ph: 1})
+    torch.cuda.synchronize()
+    print("  forward-only unroll (path %s): %.3f ms" % (g.last_path, (time.perf_counter() - t0) / 20 * 1e3))
 tot = 0.0
 for k, v in acc.items():
     print("  %-46s %7.1f us" % (k, v / n * 1e6))

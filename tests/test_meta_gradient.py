@@ -597,12 +597,14 @@ def test_bwd_unroll_ragged_problem_tiles(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch", [16, 64])
 @pytest.mark.parametrize("name", ["dm_logsign", "rnnprop"])
-def test_planned_mlp_unroll_equals_step_path(name, monkeypatch):
-    """The recorded unroll of problems.mnist as a plan (history buffers chained through the steps,
-    ctypes arguments prepared once, BPTT in one launch) gives the same costs and the same
-    meta-gradient as the plain step-by-step path with cloned history (L2O_NO_STEP_PLAN=1), for two
-    consecutive training steps (the second one re-uses the plan)."""
+def test_planned_mlp_unroll_equals_step_path(name, batch, monkeypatch):
+    """The recorded unroll of problems.mnist three ways: ONE persistent launch that also records the history
+    (l2o_mlp_unroll_record, the default where the fused MLP unroll applies; batch 64 = its FAST instantiation), the
+    step-granular PLAN (history buffers chained through the steps, ctypes arguments prepared once;
+    L2O_NO_MLP_UNROLL_RECORD=1) and the plain step-by-step path with cloned history (+ L2O_NO_STEP_PLAN=1): same costs,
+    same iterates and the same meta-gradient for two consecutive training steps (the second re-uses the buffers)."""
     eng = _engine.HipEngine()
     old = _engine._default_engine
     _engine.set_default_engine(eng)
@@ -611,7 +613,7 @@ def test_planned_mlp_unroll_equals_step_path(name, monkeypatch):
         rn = cfg.kind == "rnnprop"
         params = make_params(cfg, seed=83, trained_like=True)
         data = problems.synthetic_mnist(200, seed=4)
-        T, batch = 3, 16
+        T = 3
         idx = np.random.default_rng(5).integers(0, 200, size=(64, batch))
 
         def sampler(n_evals, b, n_data, _state={"k": 0}):
@@ -620,11 +622,14 @@ def test_planned_mlp_unroll_equals_step_path(name, monkeypatch):
             return idx[k:k + n_evals, :b]
 
         got = {}
-        for mode in ("plan", "steps"):
+        for mode in ("fused", "plan", "steps"):
+            monkeypatch.delenv("L2O_NO_STEP_PLAN", raising=False)
+            monkeypatch.delenv("L2O_NO_MLP_UNROLL_RECORD", raising=False)
+            monkeypatch.setenv("L2O_MLP_UNROLL_RECORD_GENERIC", "1")   # (minibatch 16: the kernel's generic loops -- not the default there)
+            if mode != "fused":
+                monkeypatch.setenv("L2O_NO_MLP_UNROLL_RECORD", "1")
             if mode == "steps":
                 monkeypatch.setenv("L2O_NO_STEP_PLAN", "1")
-            else:
-                monkeypatch.delenv("L2O_NO_STEP_PLAN", raising=False)
             st = {"k": 0}
             problem = problems.mnist(layers=(20,), batch_size=batch, data=data,
                                      sampler=lambda n, b, nd, _s=st: sampler(n, b, nd, _s))
@@ -647,16 +652,21 @@ def test_planned_mlp_unroll_equals_step_path(name, monkeypatch):
                     costs.append(sess.run([ms.fx, ms.update, ms.step], feed_dict={step_ph: 1 + i * T} if rn else {})[0])
                 xs = [v.eval() for v in graph.x]
             assert ("_step_plan" in graph.__dict__) == (mode == "plan")
+            if mode == "fused":
+                assert graph.last_path == "mlp_unroll" and "_mlp_record_plan" in graph.__dict__
+            else:
+                assert graph.last_path == "steps"
             got[mode] = (costs, xs, caps)
-        for a, b in zip(got["plan"][0], got["steps"][0]):
-            assert rel_err(a, b) < 1e-6
-        for a, b in zip(got["plan"][1], got["steps"][1]):
-            assert max_abs(a, b) < 1e-6
         key = "rp" if rn else "cw"
-        for ga, gb in zip(got["plan"][2], got["steps"][2]):
-            for k, gref in gb[key].items():
-                scale = max(float(np.abs(gref).max()), 1e-12)
-                assert float(np.abs(np.asarray(ga[key][k]) - np.asarray(gref)).max()) / scale < 1e-4, k
+        for mode in ("fused", "plan"):
+            for a, b in zip(got[mode][0], got["steps"][0]):
+                assert rel_err(a, b) < 2e-6, mode
+            for a, b in zip(got[mode][1], got["steps"][1]):
+                assert max_abs(a, b) < 2e-6, mode
+            for ga, gb in zip(got[mode][2], got["steps"][2]):
+                for k, gref in gb[key].items():
+                    scale = max(float(np.abs(gref).max()), 1e-12)
+                    assert float(np.abs(np.asarray(ga[key][k]) - np.asarray(gref)).max()) / scale < 1e-4, (mode, k)
     finally:
         _engine.set_default_engine(old)
 
