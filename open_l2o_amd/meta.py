@@ -895,7 +895,7 @@ class UnrollGraph(object):
         T = self.len_unroll
         grads = self._backward(T, record)                   # (launched before the host reads anything back)
         self.wait_fx()
-        fused = self.last_path == "fused" and hasattr(eng, "check_unroll_status")
+        fused = self.last_path in ("fused", "mlp_unroll") and hasattr(eng, "check_unroll_status")   # kernels with a status word
         # The meta-step goes out BEHIND the unroll and its back-propagation, before the host waits for the loss: with
         # every network on the device-side Adam the GPU then never idles while the host assembles the update (63 us of
         # a 0.40 ms step at config-2 size, T = 20).  A partner timeout of a fused unroll leaves a garbage history: the
