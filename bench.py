@@ -417,8 +417,20 @@ def run_case(args, eng, world, rank, Bg, B, label):
     # runs hundreds of launches ahead of the GPU; the FIRST time a process has that many commands in flight the HIP
     # runtime grows its command pools -- one ~37 ms host stall (host-timestamp trace: profiles/r03l_host_enqueue_trace.txt)
     # that would otherwise land inside the timed region.  One rehearsal of the timed region's launch count removes it.
-    for _ in range(args.steps * reps if args.warmup > 0 else 0):
+    # (config 4's chunked unroll -- 16 launches each -- showed a second one-time stall, 40-50 ms, at the process's ~55th
+    #  unroll whatever the flags: `--steps 10` put it at enqueue #3 of the timed region.  At least 128 untimed unrolls
+    #  per process keep it out: profiles/r03last_host_trace_c4.txt)
+    rehearse = max(args.steps * reps, 128 - args.warmup * reps) if args.warmup > 0 else 0
+    rtrace = [time.perf_counter()] if os.environ.get("L2O_BENCH_HOST_TRACE") else None
+    for _ in range(rehearse):
         one_unroll()
+        if rtrace is not None:
+            rtrace.append(time.perf_counter())
+    if rtrace is not None and len(rtrace) > 1:
+        d = np.diff(np.array(rtrace)) * 1e3
+        big = np.argsort(d)[-4:][::-1]
+        print("host trace (rehearsal): %d enqueues, median %.4f ms; largest: %s" %
+              (len(d), float(np.median(d)), ", ".join("#%d %.2f ms" % (int(k), float(d[k])) for k in big)), file=sys.stderr)
     fence()
     t0 = time.perf_counter()
     ev_all[0].record()
