@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void k_atb(const float* __restrict__ A, const 
 //     waits in registers while this one is multiplied, other workgroups of the CU cover the barriers.
 //   * tiles of a wave: CONTIGUOUS pieces of the row-major list of needed tiles (a wave stays on one or two tile rows:
 //     the A-side operands are read once per tile row).
+//   * (tried: s_setprio 1 / 3 around the MFMA phase: 304 / 310 vs 305 us -- nothing)
 //   * fetch: clamped addresses instead of predicated loads (straight-line code, scalar base + 32-bit lane offset; the
 //     predicated form of k_atb compiles to a branch per load).
 template <int MT, int NT>
