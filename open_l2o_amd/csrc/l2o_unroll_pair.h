@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     // on vmcnt (loads and stores retire in order), the barriers of the recording kernel wait for LDS traffic only, so
     // the 5 KB per wave drain under the gate blocks instead of sitting in front of a wait (recording kernel / plain
     // kernel time at config-2 size: 1.26 -> 1.22, profiles/r03t_*)
+    // (non-temporal stores for these records: 240 -> 338 us per recording unroll -- they stall the store path)
     if (HIST && t < a.T && tile_real)
       store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * tpp + (size_t)b * tpp + tile_in_prob) *
                                           kStateFloatsPerTile, lane);
