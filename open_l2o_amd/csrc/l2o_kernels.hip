@@ -1280,17 +1280,21 @@ __host__ __device__ static inline void bf16_split3(double v, uint16_t (&out)[3])
 // The lanes write disjoint words.
 // [t_lo, t_hi): unit slices of the forward sections, [tile_lo, tile_hi): M-tiles of the BPTT section (the device
 // packer gives every (lane, slice) and (lane, tile) its own thread: the float64 splits are the cost).
+// (ch_lo, ch_hi): the gate-GEMM chunks of slices [t_lo, t_hi) this call packs -- everything of a slice that is not a
+// chunk fragment rides with chunk 0; (r_lo, r_hi): the gate types of the BPTT M-tiles [tile_lo, tile_hi).  The host
+// packer passes the full ranges; k_wpack one (slice, chunk) or one (tile, gate type) per block.
 __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, int tile_lo, int tile_hi,
                                            const float* wg1, const float* bg1, const float* wg2,
                                            const float* bg2, const float* wl, const float* bl, const float* wfc,
-                                           const float* bfc, float* out) {
+                                           const float* bfc, float* out, int ch_lo = 0, int ch_hi = 4, int r_lo = 0,
+                                           int r_hi = 4) {
   const bool fc = pre == L2O_PRE_FC_ELU;
   const int P = fc ? kH : (pre == L2O_PRE_LOGSIGN ? 2 : 1);
   const int G = 4 * kH;
   auto col = [](int t, int rho) { return (rho & 3) * kH + 4 * t + (rho >> 2); };
   const int rho = l & 15, kq = l >> 4;   // A-fragment view of the lane
   const int q = l >> 4;                  // C/D + B view of the lane
-  for (int t = t_lo; t < t_hi; ++t) {
+  for (int t = t_lo; t < t_hi && ch_lo == 0; ++t) {
     const int cA = col(t, rho);
     // layer 1
     if (fc) {
@@ -1324,7 +1328,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
       out[(wp_row_fc(pre) + 2 * kNT + t) * 64 + l] = bfc[4 * t + q];
     }
   }
-  if (t_lo == 0 && t_hi > 0) out[wp_row_bl(pre) * 64 + l] = bl[0];
+  if (t_lo == 0 && t_hi > 0 && ch_lo == 0) out[wp_row_bl(pre) * 64 + l] = bl[0];
   // ---- bf16x3 fragments: gate rows pre-scaled to exp2 arguments, split from float64 ----
   {
     uint32_t* ow = reinterpret_cast<uint32_t*>(out);
@@ -1332,7 +1336,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
     auto gscale = [&](int r) { return r == 1 ? 2.0 * kL2E : -kL2E; };      // rows i, j, f, o
     for (int t = t_lo; t < t_hi; ++t) {
       const int cA = col(t, rho), r = rho & 3;
-      for (int ch = 0; ch < bx::nchunks(pre); ++ch) {
+      for (int ch = ch_lo; ch < ch_hi && ch < bx::nchunks(pre); ++ch) {
         uint16_t sl[5][3], bs[3] = {0, 0, 0};
         for (int i = 0; i < 5; ++i) {
           const int u = 4 * i + kq;
@@ -1365,6 +1369,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
               ow[bx::frag_off(pre, true, ch, t, j) + l * 4 + rg] = word;
             }
       }
+      if (ch_lo != 0) continue;                                 // (the rest of the slice rides with chunk 0)
       if ((l & 15) == 0)                                        // one lane per lane group writes its 4 gate rows
         for (int rr = 0; rr < 4; ++rr) {
           const int cD = col(t, 4 * q + rr);
@@ -1392,7 +1397,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
       const int first = l2 ? 0 : (fc ? 0 : -1), second = l2 ? kH : (fc ? kH : P);
       const int row = bxb::src_row(m, rho, first, second);
       if (row < 0) continue;
-      for (int r = 0; r < 4; ++r) {
+      for (int r = r_lo; r < r_hi; ++r) {
         uint16_t sl[8][3];
         for (int i = 0; i < 8; ++i)
           for (int sp = 0; sp < 3; ++sp) sl[i][sp] = 0;
@@ -1407,9 +1412,16 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
 
 __global__ void k_wpack(int pre, const float* wg1, const float* bg1, const float* wg2, const float* bg2, const float* wl,
                         const float* bl, const float* wfc, const float* bfc, float* out) {
-  const int b = blockIdx.x;                                   // kNT slice blocks, then one block per BPTT M-tile
-  if (b < kNT) wpack_lane(pre, threadIdx.x, b, b + 1, 0, 0, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
-  else wpack_lane(pre, threadIdx.x, 0, 0, b - kNT, b - kNT + 1, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out);
+  // one block per (slice, chunk), then one per (BPTT M-tile, gate type): 35 / 44 blocks of one wave (10 / 11 blocks
+  // before: 12.5 us on the critical path between the meta-step and the next unroll)
+  const int b = blockIdx.x, nch = bx::nchunks(pre);
+  if (b < kNT * nch) {
+    const int t = b / nch, ch = b - t * nch;
+    wpack_lane(pre, threadIdx.x, t, t + 1, 0, 0, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out, ch, ch + 1, 0, 0);
+  } else {
+    const int e = b - kNT * nch, tile = e >> 2, r = e & 3;
+    wpack_lane(pre, threadIdx.x, 0, 0, tile, tile + 1, wg1, bg1, wg2, bg2, wl, bl, wfc, bfc, out, 0, 0, r, r + 1);
+  }
 }
 
 // tf.train.AdamOptimizer._apply_dense (TF 1.x) on one flat fp32 vector, every operation rounded separately
@@ -1466,7 +1478,7 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
     return fail(L2O_ERR_ARG, "l2o_wpack_device: NULL weight pointer");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(wpack, 0, sizeof(float) * l2o_wpack_floats(cfg), s));
-  hipLaunchKernelGGL(k_wpack, dim3(kNT + bxb::ntiles(cfg->preprocess)), dim3(64), 0, s, (int)cfg->preprocess, w->w_gates1, w->b_gates1, w->w_gates2,
+  hipLaunchKernelGGL(k_wpack, dim3(kNT * bx::nchunks(cfg->preprocess) + 4 * bxb::ntiles(cfg->preprocess)), dim3(64), 0, s, (int)cfg->preprocess, w->w_gates1, w->b_gates1, w->w_gates2,
                      w->b_gates2, w->w_lin, w->b_lin, w->w_fc, w->b_fc, wpack);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
