@@ -464,6 +464,12 @@ int l2o_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float
  * the host first; it still reads the status after its sync (l2o_unroll_status) and then knows the update did not run. */
 int l2o_adam_step_guarded(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1,
                           double beta2, double epsilon, const void* unroll_workspace, void* stream);
+/* The same update with the gradient GATHERED (ABI v10): g_i = map[i] >= 0 ? G[map[i]] : 0, map a device int32 [n].
+ * With G = the [KA][KB] result of l2o_cwlstm_wgrad and map = the position of every weight of the flat Sonnet-layout
+ * buffer inside its gradient block, the meta-step reads the contraction's output in place (no slicing / concatenation
+ * launches in between).  unroll_workspace: as for l2o_adam_step_guarded (NULL = unconditional). */
+int l2o_adam_step_gather(float* w, float* m, float* v, const float* G, const int32_t* map, int64_t n, float lr_t,
+                         double beta1, double beta2, double epsilon, const void* unroll_workspace, void* stream);
 int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wpack_out /* device */,
                      void* stream);
 

@@ -168,6 +168,14 @@ class HipEngine(object):
             _abi.check(self.lib.l2o_adam_step(_ptr(w), _ptr(m), _ptr(v), _ptr(g), int(w.numel()), float(lr_t),
                                               float(beta1), float(beta2), float(epsilon), self._stream()))
 
+    def adam_step_gather(self, w, m, v, G, gmap, lr_t, beta1, beta2, epsilon, guarded=False):
+        """adam_step with the gradient read in place from the contraction's result: g_i = G.flat[gmap[i]] (gmap: device
+        int32 [n], -1 = zero) -- l2o_adam_step_gather."""
+        ws = self._last_ws if guarded else None
+        _abi.check(self.lib.l2o_adam_step_gather(_ptr(w), _ptr(m), _ptr(v), _ptr(G), C.c_void_p(gmap.data_ptr()),
+                                                 int(w.numel()), float(lr_t), float(beta1), float(beta2), float(epsilon),
+                                                 None if ws is None else C.c_void_p(ws.data_ptr()), self._stream()))
+
     def upload(self, key, a):
         """Host array -> a PERSISTENT device tensor per key, through a pinned staging buffer with an
         asynchronous copy (the meta-training step re-uploads the packed weights after every Adam update:

@@ -1428,13 +1428,17 @@ __global__ void k_wpack(int pre, const float* wg1, const float* bg1, const float
 // like the NumPy expression it replaces (no contraction): bit-equal to the host update
 // guard != nullptr: the status word of the unroll whose gradients these are (the head of its workspace); a non-zero
 // status (a partner timeout: the recorded history is garbage) leaves w, m, v untouched
+// map != nullptr: the gradient of weight i is g[map[i]] (map[i] < 0: zero) -- the weight-gradient blocks are read
+// straight out of the contraction's [KA][KB] result (l2o_adam_step_gather)
 __global__ void k_adam(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
                        long n, float lr_t, float b1, float omb1, float b2, float omb2, float eps,
-                       const unsigned* __restrict__ guard) {
+                       const unsigned* __restrict__ guard, const int* __restrict__ map) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (guard && __builtin_nontemporal_load(guard) != 0u) return;
-  const float gi = g[i];
+  float gi;
+  if (map) { const int j = map[i]; gi = j >= 0 ? g[j] : 0.0f; }
+  else gi = g[i];
   const float mi = __fadd_rn(__fmul_rn(b1, m[i]), __fmul_rn(omb1, gi));
   const float vi = __fadd_rn(__fmul_rn(b2, v[i]), __fmul_rn(__fmul_rn(omb2, gi), gi));
   m[i] = mi; v[i] = vi;
@@ -1485,17 +1489,22 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
 }
 
 static int adam_launch(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1, double beta2,
-                       double epsilon, const unsigned* guard, void* stream) {
+                       double epsilon, const unsigned* guard, void* stream, const int* map = nullptr) {
   if (!w || !m || !v || !g || n < 0) return fail(L2O_ERR_ARG, "l2o_adam_step: bad argument");
   if (n == 0) return L2O_OK;
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, m, v, g, (long)n,
-                     lr_t, (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)epsilon, guard);
+                     lr_t, (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)epsilon, guard, map);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
 }
 int l2o_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1, double beta2,
                   double epsilon, void* stream) {
   return adam_launch(w, m, v, g, n, lr_t, beta1, beta2, epsilon, nullptr, stream);
+}
+int l2o_adam_step_gather(float* w, float* m, float* v, const float* G, const int32_t* map, int64_t n, float lr_t,
+                         double beta1, double beta2, double epsilon, const void* unroll_workspace, void* stream) {
+  if (!map) return fail(L2O_ERR_ARG, "l2o_adam_step_gather: NULL map");
+  return adam_launch(w, m, v, G, n, lr_t, beta1, beta2, epsilon, static_cast<const unsigned*>(unroll_workspace), stream, map);
 }
 int l2o_adam_step_guarded(float* w, float* m, float* v, const float* g, int64_t n, float lr_t, double beta1,
                           double beta2, double epsilon, const void* unroll_workspace, void* stream) {

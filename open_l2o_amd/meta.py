@@ -242,10 +242,11 @@ _DEFAULT_CONFIG = {
 class _DevGrad(object):
     """A weight gradient that stays on the device (the meta-step consumes it there); NumPy sees it as an
     array (copied to the host on demand: tests, the host Adam path)."""
-    __slots__ = ("t",)
+    __slots__ = ("t", "src")
 
-    def __init__(self, t):
+    def __init__(self, t, src=None):
         self.t = t
+        self.src = src          # (G, row0, col0): t is the block G[row0:row0 + r, col0:col0 + c] of a contraction result
 
     def __array__(self, dtype=None, copy=None):
         a = self.t.detach().cpu().numpy()
@@ -1140,15 +1141,22 @@ class UnrollGraph(object):
                 carry_in, carry_out = carry_out, carry_in
             # l2o_cwlstm_wgrad: every weight gradient is a block of A^T Bm (only those blocks are computed)
             Gm = eng.wgrad(spec, A.view(T * R, KA), Bm.view(T * R, KB))
-            add("lstm_1", "w_gates", Gm[0:K1, 0:4 * H])
-            add("lstm_1", "b_gates", Gm[KA - 1, 0:4 * H])
-            add("lstm_2", "w_gates", Gm[K1:K1 + 2 * H, 4 * H:8 * H])
-            add("lstm_2", "b_gates", Gm[KA - 1, 4 * H:8 * H])
-            add("linear", "w", Gm[K1 + 2 * H:K1 + 3 * H, 8 * H:8 * H + 1])
-            add("linear", "b", Gm[KA - 1, 8 * H:8 * H + 1])
+            blocks = [("lstm_1", "w_gates", 0, K1, 0, 4 * H), ("lstm_1", "b_gates", KA - 1, KA, 0, 4 * H),
+                      ("lstm_2", "w_gates", K1, K1 + 2 * H, 4 * H, 8 * H), ("lstm_2", "b_gates", KA - 1, KA, 4 * H, 8 * H),
+                      ("linear", "w", K1 + 2 * H, K1 + 3 * H, 8 * H, 8 * H + 1), ("linear", "b", KA - 1, KA, 8 * H, 8 * H + 1)]
             if fc:
-                add("input_projection", "w", Gm[K1 + 3 * H:K1 + 3 * H + 2, 8 * H + 1:8 * H + 1 + H])
-                add("input_projection", "b", Gm[KA - 1, 8 * H + 1:8 * H + 1 + H])
+                blocks += [("input_projection", "w", K1 + 3 * H, K1 + 3 * H + 2, 8 * H + 1, 8 * H + 1 + H),
+                           ("input_projection", "b", KA - 1, KA, 8 * H + 1, 8 * H + 1 + H)]
+            # (when this is the network's only contraction the meta-step reads the blocks in place: _adam_apply_device)
+            only = len(groups) == 1 and not acc
+            for mod, var, r0, r1, c0, c1 in blocks:
+                blk = Gm[r0:r1, c0:c1] if var != "b_gates" and var != "b" else Gm[r0, c0:c1]
+                add(mod, var, blk)
+            srcs = self.__dict__.setdefault("_gm_src", {})
+            if only:
+                srcs[id(acc)] = (Gm, KB, {(mod, var): (r0, c0) for mod, var, r0, r1, c0, c1 in blocks})
+            else:
+                srcs.pop(id(acc), None)
 
     def _backward(self, T, rec):
         eng = self.engine
@@ -1189,9 +1197,15 @@ class UnrollGraph(object):
                     n = acc[k].numel()
                     acc[k] = flat[off:off + n].view(acc[k].shape)
                     off += n
+        srcs = self.__dict__.get("_gm_src", {})
         if all(self._device_adam(self.nets[key]) for key in out):
             # the meta-step runs on the device: the gradients never visit the host
-            return {key: {k: _DevGrad(v) for k, v in acc.items()} for key, acc in out.items()}
+            res = {}
+            for key, acc in out.items():
+                src = None if self.sharded else srcs.pop(id(acc), None)
+                res[key] = {k: _DevGrad(v, None if src is None else (src[0], src[1]) + src[2][k]) for k, v in acc.items()}
+            return res
+        srcs.clear()
         # ONE device-to-host copy for all weight gradients (each .cpu() is a stream sync + a transfer)
         items = [(key, k, v) for key, acc in out.items() for k, v in acc.items()]
         if not items:
@@ -1224,6 +1238,27 @@ class UnrollGraph(object):
         if ent is None or ent["g"].numel() != buf.numel():
             ent = ds[key] = {"g": eng.zeros(buf.numel()), "m": eng.zeros(buf.numel()), "v": eng.zeros(buf.numel()),
                              "zeros": eng.zeros(8)}
+        # every gradient a block of ONE contraction result (the usual case: one l2o_cwlstm_wgrad per network): the update
+        # reads them in place through a static index map -- no slicing copies, no concatenation, no zero fills
+        srcs = [getattr(acc.get(names[k]), "src", None) for k in offs]
+        if (hasattr(eng, "adam_step_gather") and all(sr is not None for sr in srcs)
+                and all(sr[0] is srcs[0][0] for sr in srcs) and not os.environ.get("L2O_NO_ADAM_GATHER")):
+            G, KB = srcs[0][0], srcs[0][1]
+            mkey = (KB, tuple((k, o, tuple(shp), srcs[i][2], srcs[i][3]) for i, (k, (o, shp)) in enumerate(offs.items())))
+            gmap = ent.get("gmap")
+            if gmap is None or gmap[0] != mkey:
+                idx = np.full(buf.numel(), -1, np.int32)
+                for i, (k, (o, shp)) in enumerate(offs.items()):
+                    r0, c0 = srcs[i][2], srcs[i][3]
+                    n = int(np.prod(shp))
+                    cols = int(shp[-1]) if len(shp) > 1 else n            # a bias is ONE row of G
+                    e = np.arange(n)
+                    idx[o:o + n] = (r0 + (e // cols if len(shp) > 1 else 0)) * KB + c0 + e % cols
+                gmap = ent["gmap"] = (mkey, eng.int_tensor(idx))
+            eng.adam_step_gather(buf, ent["m"], ent["v"], G, gmap[1], lr_t, beta1, beta2, epsilon, guarded=guarded)
+            eng.pack_weights_device(net.spec, wdev, wdev["wpack"])
+            net.mark_device_updated()
+            return
         parts, pos = [], 0
         for k, (o, shp) in offs.items():                   # buffer order; 16-byte aligned parts
             n = int(np.prod(shp))
