@@ -129,7 +129,10 @@ const char* l2o_last_error(void);
                                         but the matrix pipe TRUNCATES small products inside an 8-slot group: a deterministic
                                         bias that shows as ~1e-5 drift at T = 1000); 1: v_mfma_f32_16x16x4_f32 (bit-equal to
                                         an fmaf chain) in the fused unroll kernels -- slower, for long-horizon evaluation    */
-#define L2O_OPT_COUNT_ 10            /* (* = default) */
+#define L2O_OPT_WPACK_NO_CLEAR 10     /* 0*: l2o_wpack_device clears the output buffer before it packs (the padding words of the
+                                        fragment layout must be zero); 1: the caller vouches that this buffer already holds a
+                                        pack of the same net configuration -- the padding is zero, the memset is skipped          */
+#define L2O_OPT_COUNT_ 11            /* (* = default) */
 #define L2O_OPTW(o, v) ((uint64_t)(8u | ((unsigned)(v) & 7u)) << (4 * (o)))
 #define L2O_OPTW_BWD_BLOCKS(n) (((uint64_t)(n) & 0xffffu) << 48)
 

@@ -36,9 +36,10 @@ SYMBOLS = (
 # environment variables once at import, changed by set_option) that NetSpec.to_c() / the problem and MLP descriptors
 # encode into every struct they hand to the library.
 OPT_PAIR, OPT_PAIR_PLAIN_STORES, OPT_UNROLL_CU, OPT_FG_TWO_PASS, OPT_MLP_GENERIC, OPT_BWD_BLOCKS, OPT_BWD_KERNEL, \
-    OPT_MLP_UNROLL, OPT_PAIR_NORMAL, OPT_EXACT_GATES = range(10)
+    OPT_MLP_UNROLL, OPT_PAIR_NORMAL, OPT_EXACT_GATES, OPT_WPACK_NO_CLEAR = range(11)
 OPT_DEFAULTS = {OPT_PAIR: 1, OPT_PAIR_PLAIN_STORES: 1, OPT_UNROLL_CU: 1, OPT_FG_TWO_PASS: 0, OPT_MLP_GENERIC: 0,
-                OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_PAIR_NORMAL: 0, OPT_EXACT_GATES: 0}
+                OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_PAIR_NORMAL: 0, OPT_EXACT_GATES: 0,
+                OPT_WPACK_NO_CLEAR: 0}
 PROB_FG_TWO_PASS = 2      # l2o_problem.flags
 MLP_GENERIC = 1           # l2o_mlp.flags
 _options = {}

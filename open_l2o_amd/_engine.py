@@ -153,7 +153,16 @@ class HipEngine(object):
         w = _abi.NetWeights()
         for k, _ in _abi.NetWeights._fields_:
             setattr(w, k, None if (k == "wpack" or weights.get(k) is None) else weights[k].data_ptr())
+        # a buffer this engine has packed before for the same configuration: its padding words are zero already
+        # (L2O_OPT_WPACK_NO_CLEAR: no memset in front of the pack kernel on the meta-step's critical path)
+        sig = (spec.preprocess, tuple(spec.layers), spec.kind)
+        if getattr(out, "_l2o_packed", None) == sig:
+            cc.options |= (8 | 1) << (4 * _abi.OPT_WPACK_NO_CLEAR)
         _abi.check(self.lib.l2o_wpack_device(C.byref(cc), C.byref(w), _ptr(out), self._stream()))
+        try:
+            out._l2o_packed = sig
+        except AttributeError:
+            pass
 
     def adam_step(self, w, m, v, g, lr_t, beta1, beta2, epsilon, guarded=False):
         """TF-1.x Adam on one flat device vector, in place (l2o_adam_step).  guarded: conditional, ON THE DEVICE, on the

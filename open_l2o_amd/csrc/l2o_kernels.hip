@@ -994,7 +994,8 @@ static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
 static const int64_t kOptDefault[L2O_OPT_COUNT_] = {
     /* L2O_OPT_PAIR */ 1, /* L2O_OPT_PAIR_PLAIN_STORES */ 1, /* L2O_OPT_UNROLL_CU */ 1,
     /* L2O_OPT_FG_TWO_PASS */ 0, /* L2O_OPT_MLP_GENERIC */ 0, /* L2O_OPT_BWD_BLOCKS */ 0,
-    /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* L2O_OPT_PAIR_NORMAL */ 0, /* L2O_OPT_EXACT_GATES */ 0};
+    /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* L2O_OPT_PAIR_NORMAL */ 0, /* L2O_OPT_EXACT_GATES */ 0,
+    /* L2O_OPT_WPACK_NO_CLEAR */ 0};
 static thread_local uint64_t t_optw = 0;
 struct OptScope {
   uint64_t saved;
@@ -1481,7 +1482,7 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
       (fc && (!w->w_fc || !w->b_fc)))
     return fail(L2O_ERR_ARG, "l2o_wpack_device: NULL weight pointer");
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(wpack, 0, sizeof(float) * l2o_wpack_floats(cfg), s));
+  if (!opt(L2O_OPT_WPACK_NO_CLEAR)) HIP_TRY(hipMemsetAsync(wpack, 0, sizeof(float) * l2o_wpack_floats(cfg), s));
   hipLaunchKernelGGL(k_wpack, dim3(kNT * bx::nchunks(cfg->preprocess) + 4 * bxb::ntiles(cfg->preprocess)), dim3(64), 0, s, (int)cfg->preprocess, w->w_gates1, w->b_gates1, w->w_gates2,
                      w->b_gates2, w->w_lin, w->b_lin, w->w_fc, w->b_fc, wpack);
   HIP_TRY(hipGetLastError());
