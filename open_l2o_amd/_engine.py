@@ -573,18 +573,19 @@ class HipEngine(object):
                                                   _ptr(v), int(T), int(step0), _ptr(fx_part), wsp, C.byref(h),
                                                   self._stream()))
 
-    def prepared_unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, step0, fx_part, x0, zero_state):
-        """l2o_unroll_reduce with every argument object built ONCE: returns call(fx) for launches that repeat with the
-        same buffers (an evaluation loop that re-runs one problem instance from x0; bench.py's ring of instances) --
+    def prepared_unroll(self, spec: NetSpec, wpack, p: ProblemDesc, x, st, m, v, T, fx_part, x0, zero_state):
+        """l2o_unroll_reduce with every argument object built ONCE: returns call(fx, step0) for launches that repeat with
+        the same buffers (an evaluation loop that re-runs one problem instance from x0; bench.py's ring of instances) --
         per call the host does one ctypes call (~10 us) instead of rebuilding the structs (~0.2 ms, which is a whole
         config-2 unroll).  Returns None when the launch needs the general path (a workspace that must be (re)initialised,
-        the normal-matrix form's preparation cache).  The closure is valid while the engine's workspace is unchanged
-        (it checks) and the option settings are the ones it was built under (the caller keys its cache on them)."""
+        the normal-matrix form's preparation cache).  The closure is valid while the engine's workspace AND its layout
+        are unchanged (it checks both and returns False otherwise) and the option settings are the ones it was built
+        under (the caller keys its cache on them)."""
         if _abi.get_option(_abi.OPT_PAIR_NORMAL) and not _abi.get_option(_abi.OPT_EXACT_GATES):
             return None                                      # (per-instance preparation: unroll() keeps that cache)
         cc, cp = spec.to_c(), self._cprob(p)
         nbytes = int(self.lib.l2o_unroll_workspace_bytes(C.byref(cc), C.byref(cp), int(T)))
-        ws = None
+        ws, layout = None, None
         if nbytes:
             ws = self._workspace
             layout = int(self.lib.l2o_unroll_workspace_layout(C.byref(cc), C.byref(cp)))
@@ -592,16 +593,19 @@ class HipEngine(object):
                 return None                                  # unroll() allocates / re-initialises it first
         wsp = None if ws is None else C.c_void_p(ws.data_ptr())
         flags = _abi.UNROLL_ZERO_STATE if zero_state else 0
-        args_a = (C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x0), _ptr(x), _ptr(st), _ptr(m), _ptr(v), int(T), int(step0),
-                  flags, _ptr(fx_part))
+        args_a = (C.byref(cc), _ptr(wpack), C.byref(cp), _ptr(x0), _ptr(x), _ptr(st), _ptr(m), _ptr(v), int(T))
+        args_b = (flags, _ptr(fx_part))
         fn, check, stream = self.lib.l2o_unroll_reduce, _abi.check, self._stream
         keep = (cc, cp, wpack, p, x, st, m, v, fx_part, x0, ws)
         eng = self
 
-        def call(fx, _keep=keep):
-            if eng._workspace is not ws:
-                return False                                 # the workspace was replaced: rebuild
-            rc = fn(*args_a, C.c_void_p(fx.data_ptr()), wsp, None, stream())
+        def call(fx, step0=1, _keep=keep):
+            if eng._workspace is not ws or (ws is not None and eng.__dict__.get("_ws_layout") != layout):
+                # the workspace was replaced, or another graph / problem size re-initialised it for a different
+                # (B_local, CH) layout since this call was prepared (its granule area may now overlap
+                # that layout's loss partials -- stale tags): the caller rebuilds through unroll()
+                return False
+            rc = fn(*args_a, int(step0), *args_b, C.c_void_p(fx.data_ptr()), wsp, None, stream())
             if rc:
                 check(rc)
             eng._last_ws = ws

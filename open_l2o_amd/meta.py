@@ -124,7 +124,7 @@ class Variable(object):
             t = eng.sample(init[0], tuple(self.shape), float(init[1]), float(init[2]), seed)
             if self.sharded:
                 lo, hi = self._graph.shard
-                t = t[lo:hi].contiguous()
+                t = t[lo:hi].clone()       # (a slice view would keep the whole global draw alive)
             self.value = t
             return
         self.value = eng.tensor(self._local(self.initial_value()))
@@ -137,6 +137,7 @@ class Variable(object):
             self.value = self._graph.engine.tensor(np.ascontiguousarray(value))
         else:
             self.value = self._graph.engine.tensor(self._local(value))
+        self._graph.__dict__.pop("_fast_unrolls", None)      # prepared calls point into the old buffer
 
     def eval(self, session=None):
         """This rank's shard as an ndarray."""
@@ -579,17 +580,21 @@ class UnrollGraph(object):
         eng = self.engine
         T = self.len_unroll
         feed = feed or {}
-        # ---- fast path: the SAME fused restart launch as before (same x0 / problem tensors / options) replays a
-        # prepared call -- one ctypes call instead of ~0.2 ms of argument building, which is a whole config-2 unroll
-        # (an evaluation loop that re-runs a ring of problem instances would otherwise be host-bound)
+        # ---- fast path: the SAME fused launch as before (same buffers / problem tensors / options) replays a
+        # prepared call -- one ctypes call instead of ~0.2 ms of argument building, which is a whole config-2 unroll.
+        # Both the committed launch of Session.run([fx, update]) (the product path: evaluate_*.py, util.run_eval_epoch)
+        # and the restart= form (an evaluation loop over a ring of problem instances) take it; RNNProp's fed `step`
+        # is a call-time argument.  The key is the identity of every object the call points into, and the cache entry
+        # keeps ALL of them alive, so an id cannot be recycled behind the key.
         fast_key = None
-        if (restart is not None and commit and record is None and events is None and len(self.x) == 1
-                and hasattr(eng, "prepared_unroll") and all(ph not in feed for ph in self.scale)):
-            s0 = self.slots[0] if len(self.slots) == 1 else None
-            fast_key = (T, int(feed[self.step]) if self.rnnprop and self.step in feed else 1, id(restart[0]),
-                        tuple(id(v.value) for v in self.constants), id(self.x[0].value), _abi.options_word(),
-                        id(getattr(s0, "state", None) and getattr(s0.state, "packed", None)), id(getattr(s0, "m", None)),
-                        id(getattr(getattr(s0, "net", None), "_wpack", None)))
+        if (commit and record is None and events is None and len(self.x) == 1 and len(self.slots) == 1
+                and hasattr(eng, "prepared_unroll") and all(ph not in feed for ph in self.scale)
+                and isinstance(self.slots[0].state, PackedState) and self.slots[0].state.packed is not None
+                and (not self.rnnprop or self.step in feed)):
+            s0 = self.slots[0]
+            fast_objs = (None if restart is None else restart[0], self.x[0].value, s0.state.packed, s0.m, s0.v,
+                         getattr(s0.net, "_wpack", None)) + tuple(v.value for v in self.constants)
+            fast_key = (T, restart is not None, _abi.options_word()) + tuple(id(o) for o in fast_objs)
             ent = self.__dict__.setdefault("_fast_unrolls", {}).get(fast_key)
             if ent is not None:
                 ring = self._fx_cache[T]
@@ -599,13 +604,13 @@ class UnrollGraph(object):
                     ring["work"][i].wait()
                     ring["work"][i] = None
                 fx = ring["bufs"][i]
-                if ent["call"](fx):
+                if ent["call"](fx, int(feed[self.step]) if self.rnnprop else 1):
                     self.last_path = "fused"
                     if self.sharded:
                         import torch.distributed as dist
                         ring["work"][i] = dist.all_reduce(fx, async_op=True)
                     return fx, [self.x[0].value]
-                self._fast_unrolls.pop(fast_key, None)      # stale (the engine's workspace changed): general path
+                self._fast_unrolls.pop(fast_key, None)      # stale (the engine's workspace / layout changed): general path
         # restart = list of device tensors x0: run this unroll from x0 and the zero LSTM state / moments on the SAME
         # problem instance (rewind(x0) + launch); the fused kernels fold it in (no copy / memset pass), every other
         # path rewinds first
@@ -742,18 +747,17 @@ class UnrollGraph(object):
             self.last_path = "fused"
             s, d = slots[0], descs[0]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
-            if restart_fused:
-                eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
-                           fx_part, fx=fx, x0=restart[0].view(panels[0].shape), zero_state=True)
-                if fast_key is not None and len(self.__dict__.get("_fast_unrolls", {})) < 64:
-                    call = eng.prepared_unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0],
-                                               T, step0, fx_part, restart[0].view(panels[0].shape), True)
-                    if call is not None:                    # (keeps every tensor of the launch alive: ids stay valid)
-                        self._fast_unrolls[fast_key] = {"call": call, "keep": (restart[0], [v.value for v in self.constants],
-                                                                                s.net.wpack(eng), states[0])}
-            else:
-                eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
-                           fx_part, fx=fx)                  # (the batch-mean reduction rides in the unroll's epilogue)
+            x0v = restart[0].view(panels[0].shape) if restart_fused else None
+            eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
+                       fx_part, fx=fx, x0=x0v, zero_state=restart_fused)   # (the batch-mean reduction rides in the epilogue)
+            if fast_key is not None and (restart is None or restart_fused) and d.x_scale is None:
+                fu = self._fast_unrolls
+                if len(fu) >= 16:
+                    fu.pop(next(iter(fu)))                  # (oldest first: a bounded set of pinned buffers)
+                call = eng.prepared_unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0],
+                                           T, fx_part, x0v, restart_fused)
+                if call is not None and getattr(s.net, "_wpack", None) is fast_objs[5]:
+                    fu[fast_key] = {"call": call, "keep": fast_objs}
             if events is not None:
                 events[1].record()
         elif self._mlp_unroll_ok(slots, states, scales):
@@ -928,7 +932,10 @@ class UnrollGraph(object):
     def _check_unroll_status(self):
         """engine.check_unroll_status() after a host sync; when it raises, guarded meta-steps enqueued since the last
         check did not run on the device (l2o_adam_step_guarded): the Adam step counts of ALL of them are taken back (those
-        enqueued before the failing unroll did run -- the count errs on the low side; the caller is raising anyway)."""
+        enqueued before the failing unroll did run -- the count errs on the low side).  The exception is FATAL for the
+        optimizer state: Adam's step count no longer matches m / v, and in a sharded run only the failing rank
+        skipped its update -- a caller that wants to continue must `restore` the last checkpoint (the training drivers do
+        not catch it)."""
         try:
             self.engine.check_unroll_status()
         except Exception:

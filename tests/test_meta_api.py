@@ -658,6 +658,43 @@ def test_launch_restart_replays_a_prepared_call(engine, name):
         assert rel_err(engine.to_numpy(fx), res3.fx) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["dm", "rnnprop"])
+def test_session_run_replays_a_prepared_call(engine, name):
+    """The PRODUCT path -- sess.run([fx, update]) in a loop, what evaluate_*.py does (DM/evaluate_dm.py:88-91) -- goes
+    through the same prepared-call cache as bench.py's restart= launches (the headline must be what an API
+    user gets): five consecutive committed unrolls of L steps equal ONE oracle unroll of 5 L steps (x, LSTM state and
+    RNNProp's moments carry; RNNProp's fed step is a call-time argument of the prepared call); Variable.load and a new
+    engine workspace layout drop / invalidate the cache."""
+    cfg = ORACLE_CFGS[name]
+    params = make_params(cfg, seed=91, trained_like=True)
+    B, D, L, n = 4, 24, 3, 5
+    prob, x0, _ = make_problem("quadratic", B, D, seed=92)
+    problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
+    if name == "rnnprop":
+        opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+        ml, _, _, step = opt.meta_loss(problem, L)
+    else:
+        opt = meta.MetaOptimizer(**_net_config(cfg, params))
+        ml, step = opt.meta_loss(problem, L), None
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), n * L)
+    g = opt.graph
+    with Session() as sess:
+        sess.run(ml.reset)
+        got = [sess.run([ml.fx, ml.update], feed_dict={} if step is None else {step: 1 + k * L})[0] for k in range(n)]
+        xT = g.x[0].eval()
+        assert rel_err(got, [res.fx[(k + 1) * L] for k in range(n)]) < 1e-5
+        np.testing.assert_allclose(xT.reshape(B, D), np.asarray(res.x).reshape(B, D), rtol=1e-4, atol=1e-6)
+        if hasattr(engine, "prepared_unroll"):
+            assert len(g.__dict__.get("_fast_unrolls", {})) == 1            # one entry serves every step0
+            # another graph re-initialises the shared workspace for a different layout: the stale closure must say so
+            ent = next(iter(g._fast_unrolls.values()))
+            engine._ws_layout = -12345
+            assert ent["call"](g._fx_cache[L]["bufs"][0], 1) is False
+            engine._ws_layout = None                                         # (the next general launch re-initialises)
+            g.x[0].load(x0)
+            assert "_fast_unrolls" not in g.__dict__
+
+
 @pytest.mark.parametrize("kind,B,D", [("quadratic", 8, 16), ("quadratic", 128, 128)])
 def test_run_epoch_defers_all_but_the_last_loss(engine, monkeypatch, kind, B, D):
     """util.run_epoch returns the cost of the LAST unroll only (DM/util.py:75): the meta-training steps before it are
