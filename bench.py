@@ -151,7 +151,9 @@ def cpu_baseline_mnist(weights, batch, T, max_seconds=15.0):
 # (smaller gradients: smaller steps, still converging) but not to a smaller one (config 4's optimizer, trained at 1024,
 # diverges on a stand-alone batch of 128).  RNNProp's inputs are normalised by the moments: scale-free.
 TRAINED = {("quadratic", "dm", 128): ("dm_quadratic_d128", 128), ("rastrigin", "dm", 100): ("dm_rastrigin_d100", 1024),
-           ("lasso", "rnnprop", 512): ("rnnprop_lasso_256x512", None)}
+           ("lasso", "rnnprop", 512): ("rnnprop_lasso_256x512", None),
+           # config 5: RNNProp meta-trained on the 784-20-10 MLP optimizee (synthetic MNIST-shaped data, minibatch 64)
+           ("mnist", "rnnprop", 128): ("rnnprop_mnist_mlp", None)}
 
 
 def trained_weights(args, key, Bg):
@@ -181,7 +183,7 @@ def build_workload(args, Bg):
         opts.update(l=0.1, num_rows=args.rows)
     if args.problem == "mnist":                    # not sharded: every GPU optimizes its own replica
         from open_l2o_amd import problems
-        opts = {"batch_size": args.batch, "data": problems.synthetic_mnist(4096, seed=5)}
+        opts = {"batch_size": args.batch, "data": problems.synthetic_mnist(4096, seed=5, label_noise=0.1)}
     problem, net_config, net_assignments = util.get_config(
         args.problem, problem_options=opts, net_name="RNNprop" if args.net == "rnnprop" else None)
     if args.problem == "lasso" and args.shared_matrix:
@@ -275,7 +277,12 @@ def counters_for(workload, kernel_hint):
     """The newest committed PMC summary of exactly this workload (profiles/r*_counters_*.json, written by
     scripts/counters_to_json.py from rocprofv3 --pmc passes of this command), or None."""
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters_*.json"))):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters_*.json")))
+    if os.environ.get("L2O_COUNTERS_DIR"):
+        # counters collected in THIS lease, on THIS build, ahead of the bench line (scripts/gpu_lease.sh `final:N`):
+        # they take precedence over every committed file (sorted last)
+        paths += sorted(glob.glob(os.path.join(os.environ["L2O_COUNTERS_DIR"], "counters_*.json")))
+    for path in paths:
         try:
             c = json.load(open(path))
         except Exception:
@@ -623,6 +630,15 @@ def main(argv=None):
         D, T, Mrows, shared = case["D"], case["T"], case["Mrows"], case["shared"]
         netname, probname = workload_names(args, D, B, Bg, T, Mrows, shared)
         is_c2 = (args.problem, args.net, D, B, T) == ("quadratic", "dm", 128, 128, 100)
+        baseline_config = None
+        if is_c2:
+            baseline_config = "BASELINE.json configs[1]"
+        elif (args.problem, args.net, D, Bg, T, Mrows) == ("lasso", "rnnprop", 512, 256, 200, 256) and world == 1:
+            baseline_config = "BASELINE.json configs[2]"
+        elif (args.problem, args.net, D, Bg, T) == ("rastrigin", "dm", 100, 1024, 100):
+            baseline_config = "BASELINE.json configs[3]"      # (defined on 8 GPUs: --gpus 8 --config 4 is that line)
+        elif (args.problem, args.net, B, T) == ("mnist", "rnnprop", 64, 200):
+            baseline_config = "BASELINE.json configs[4] (forward unroll, one replica per GPU)"
         counters = None
         if world == 1 and not shared:
             counters = counters_for([args.problem, args.net, D, B, T] + ([Mrows] if args.problem == "lasso" else []),
@@ -652,6 +668,7 @@ def main(argv=None):
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
                                    % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
+                       "baseline_config": baseline_config,
                        "kernel": case["kernel"],
                        "optimizer_weights": getattr(args, "weights_source", None),
                        "step_definition": "one bench step = %d complete unrolls, each on the next of %d pre-uploaded problem "

@@ -19,7 +19,7 @@ __all__ = [
     "clamp", "log_and_sign", "sigmoid", "elu", "lstm_cell", "linear",
     "NetConfig", "init_net_params", "net_initial_state", "net_apply",
     "Simple", "SimpleMulti", "Quadratic", "Lasso", "Rastrigin", "SquareCos",
-    "unroll", "UnrollResult", "sgd_net", "adam_net", "truncated_normal", "MnistMLP", "unroll_multi",
+    "unroll", "UnrollResult", "sgd_net", "adam_net", "truncated_normal", "MnistMLP", "unroll_multi", "rnnprop_inputs",
     "net_bwd_step", "tf_adam_step",
     "DM_IDENTITY", "DM_LOGSIGN", "RNNPROP",
 ]
@@ -452,19 +452,46 @@ class MnistMLP(_Problem):
         return loss, [gw1, gb1, gw2, gb2]
 
 
-def unroll_multi(fg, cfg, params, variables, states, T):
+def rnnprop_inputs(g, m, v, k, beta1=0.95, beta2=0.95):
+    """RNNProp's network inputs, DM/meta_rnnprop_train.py:383-388 (== DM/meta_rnnprop_eval.py `update`):
+    m' = b1 m + (1 - b1) g ; v' = b2 v + (1 - b2) g^2 (carried un-debiased); m^ = m'/(1 - b1^k), v^ = v'/(1 - b2^k);
+    (m~, g~) = (m^, g) / (sqrt(v^) + 1e-8), k = the fed `step` + t.  Returns ((m~, g~), m', v')."""
+    dt = g.dtype.type
+    k = dt(k)
+    m = dt(beta1) * m + dt(1.0 - beta1) * g
+    m_hat = m / (dt(1) - np.power(dt(beta1), k))
+    v = dt(beta2) * v + dt(1.0 - beta2) * g * g
+    v_hat = v / (dt(1) - np.power(dt(beta2), k))
+    den = np.sqrt(v_hat) + dt(1e-8)
+    return (m_hat / den, g / den), m, v
+
+
+def unroll_multi(fg, cfg, params, variables, states, T, ms=None, vs=None, step0=1, beta1=0.95, beta2=0.95,
+                 return_moments=False):
     """The unroll of DM/meta.py:338-376 for an optimizee with SEVERAL variables that share one
     coordinate-wise net (default net_assignments): ``fg(variables, t, want_grad) ->
-    (loss, [grad per variable])``; states = one net state per variable.  CW nets only."""
+    (loss, [grad per variable])``; states = one net state per variable.  RNNProp nets
+    (cfg.kind == "rnnprop", DM/meta_rnnprop_train.py:371-423): one pair of moments per variable (``ms`` / ``vs``,
+    zeros by default), inputs of ``rnnprop_inputs`` with exponent step0 + t."""
     variables = [v.copy() for v in variables]
     states = list(states)
+    rn = cfg.kind == "rnnprop"
+    if rn:
+        ms = [np.zeros_like(v) for v in variables] if ms is None else [m.copy() for m in ms]
+        vs = [np.zeros_like(v) for v in variables] if vs is None else [v.copy() for v in vs]
     fx = np.zeros((T + 1,), variables[0].dtype)
     for t in range(T):
         fx[t], grads = fg(variables, t, True)
         for j, g in enumerate(grads):
-            delta, states[j] = net_apply(cfg, params, g, states[j])
+            if rn:
+                inputs, ms[j], vs[j] = rnnprop_inputs(g, ms[j], vs[j], step0 + t, beta1, beta2)
+                delta, states[j] = net_apply(cfg, params, inputs, states[j])
+            else:
+                delta, states[j] = net_apply(cfg, params, g, states[j])
             variables[j] = variables[j] + delta
     fx[T], _ = fg(variables, T, False)
+    if return_moments:
+        return fx, variables, states, ms, vs
     return fx, variables, states
 
 
@@ -509,14 +536,8 @@ def unroll(problem, cfg, params, x0, state0, T, x_scale=None,
         if s is not None:
             g = g * s
         if cfg.kind == "rnnprop":
-            k = dt(step0 + t)
-            m = dt(beta1) * m + dt(1.0 - beta1) * g
-            m_hat = m / (dt(1) - np.power(dt(beta1), k))
-            v = dt(beta2) * v + dt(1.0 - beta2) * g * g
-            v_hat = v / (dt(1) - np.power(dt(beta2), k))
-            m_tilde = m_hat / (np.sqrt(v_hat) + dt(1e-8))
-            g_tilde = g / (np.sqrt(v_hat) + dt(1e-8))
-            delta, state = net_apply(cfg, params, (m_tilde, g_tilde), state)
+            inputs, m, v = rnnprop_inputs(g, m, v, step0 + t, beta1, beta2)
+            delta, state = net_apply(cfg, params, inputs, state)
         else:
             delta, state = net_apply(cfg, params, g, state)
         x = x + delta

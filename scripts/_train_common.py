@@ -59,6 +59,9 @@ def parse_flags(rnnprop):
                    help="stop after the first evaluation past this wall time (bounded GPU leases)")
     p.add_argument("--synthetic_mnist", type=int, default=0,
                    help="problems.mnist on N synthetic MNIST-shaped examples (no dataset ships offline)")
+    p.add_argument("--synthetic_label_noise", type=float, default=0.0,
+                   help="fraction of the synthetic labels re-drawn uniformly (problems.synthetic_mnist)")
+    p.add_argument("--synthetic_seed", type=int, default=0)
     if rnnprop:
         p.add_argument("--beta1", type=float, default=0.95)
         p.add_argument("--beta2", type=float, default=0.95)
@@ -82,7 +85,8 @@ class Trainer(object):
                 if v is not None}
         if getattr(flags, "synthetic_mnist", 0):
             from open_l2o_amd import problems
-            opts["data"] = problems.synthetic_mnist(flags.synthetic_mnist)
+            opts["data"] = problems.synthetic_mnist(flags.synthetic_mnist, seed=getattr(flags, "synthetic_seed", 0),
+                                                    label_noise=getattr(flags, "synthetic_label_noise", 0.0))
         problem, net_config, assignments = util.get_config(flags.problem, net_name="RNNprop" if rnnprop else None,
                                                            problem_options=opts)
         kw = dict(learning_rate=flags.learning_rate, net_assignments=assignments,

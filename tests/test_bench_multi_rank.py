@@ -34,3 +34,22 @@ def test_two_ranks_one_device_equal_the_single_process_global_batch():
     assert two["fx_0"] == pytest.approx(one["fx_0"], rel=1e-6)
     assert a == pytest.approx(b, rel=1e-6)
     assert a < two["fx_0"] / 5                                                 # (the trained optimizer: the loss falls)
+
+
+def test_config4_line_is_primary_when_sharded():
+    """`bench.py --gpus N --config 4` (BASELINE configs[3]: Rastrigin d=100, global batch 1024 sharded over the GPUs)
+    prints the config-4 line as the PRIMARY line: strong scaling, the global batch split evenly, every rank's copy of
+    the all-reduced f(x_T) identical and equal to the one-process run on all 1024 problems (the
+    first driver with an 8-GPU node gets the north-star number from one command)."""
+    common = ["--config", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--unrolls-per-step", "1"]
+    two = _bench(["--gpus", "2"] + common, {"L2O_BENCH_BACKEND": "gloo", "L2O_BENCH_ONE_DEVICE": "1"})
+    cfg = two["config"]
+    assert two["n_gpus"] == 2 and cfg["n_ranks_seen"] == 2 and cfg["backend"] == "gloo" and two["scaling"] == "strong"
+    assert "Rastrigin d=100" in cfg["workload"] and "batch=512 per GPU (global 1024)" in cfg["workload"]
+    assert cfg["baseline_config"] == "BASELINE.json configs[3]"
+    ranks = two["final_loss_fx_T_per_rank"]
+    assert len(ranks) == 2 and ranks[0] == ranks[1], ranks
+    one = _bench(["--gpus", "1"] + common)
+    assert one["config"]["baseline_config"] == "BASELINE.json configs[3]"
+    assert two["final_loss_fx_T"] == pytest.approx(one["final_loss_fx_T"], rel=1e-6)
+    assert two["final_loss_fx_T"] < two["fx_0"] / 5

@@ -257,3 +257,204 @@ def test_c3_trained_lasso_rnnprop(eng):
         print("   segment from the oracle's state at t=%d: rel fx %.3g (oracle one-ulp sensitivity %.3g), x %.3g (f %.4g -> %.4g)"
               % (t0, e, rel_err(seg_p, seg_ref), ex, seg_ref[0], seg_ref[-1]))
         assert e < max(1e-5, 3 * rel_err(seg_p, seg_ref))
+
+
+def test_c3_teacher_forced_every_step(eng):
+    """VERDICT r03 "the one place the 1e-5 bar is not asserted": the CONVERGED regime of trained config 3 (RNNProp on
+    Lasso 256 x 512), where whole-trajectory parity can only be stated relative to the oracle's own chaos.  Here NO
+    sensitivity escape hatch: at EVERY step t of the trained T = 200 trajectory the HIP path starts from the C oracle's
+    own (x_t, LSTM state_t, m_t, v_t, step 1 + t) and takes ONE step -- the streaming fused kernel (k_unroll_cu, T = 1)
+    and the step-granular kernels (l2o_problem_fg + l2o_cwlstm_step) -- and is compared with the oracle's step:
+    f(x_t), f(x_{t+1}) 1e-6 relative, x_{t+1} 1e-6 of max |x|, the moments 2e-6 of their largest entry, the new LSTM
+    state 3e-6 absolute (measured: 6.6e-7 / 1.5e-8 / 1.4e-6 / 2.4e-6).  The state and moment figures are above 1e-6
+    because RNNProp's inputs g / (sqrt(v^) + 1e-8) turn the fp32 summation-order difference of the 256-row GEMV (1e-6
+    of max |g|) into an O(1e-6) difference of an O(1) network input wherever |g| is small; that this is the arithmetic's
+    own floor and not a kernel defect is asserted on every 8th step against the FLOAT64 oracle's step from the same
+    inputs: the HIP step is within 2 x the fp32 C oracle's own distance from float64 (+ 2e-7) in every quantity.
+    The oracle's chained single steps are checked to BE its T = 200 unroll, bit for bit.
+    DM/meta_rnnprop_train.py:371-395, DM/problems.py:103-131."""
+    from oracle.c_oracle import c_unroll
+    cfg = O.RNNPROP
+    params = load_l2l("rnnprop_lasso_256x512", "rp")
+    p64 = {k: {v: a.astype(np.float64) for v, a in d.items()} for k, d in params.items()}
+    B, D, M, T = 256, 512, 256, 200
+    prob, x0, arrays = make_problem("lasso", B, D, seed=18, M=M)
+    prob64 = O.Lasso(prob.w.astype(np.float64), prob.y.astype(np.float64), l=prob.l)
+    fx_whole, x_whole = c_unroll("lasso", cfg, params, arrays, x0, T)[:2]
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D)
+    b95 = float(np.float32(0.95))
+    fx_part, fx = eng.zeros(2 * B), eng.zeros(2)
+    f_s, g_s = eng.zeros(B), eng.zeros(B, D)
+    x_t = np.asarray(x0, np.float32).reshape(B, D)
+    st_t = tuple((np.zeros((B * D, 20), np.float32), np.zeros((B * D, 20), np.float32)) for _ in range(2))
+    m_t, v_t = np.zeros((B, D), np.float32), np.zeros((B, D), np.float32)
+    keys = [a + "_" + b for a in ("fused", "step") for b in ("fx", "x", "state", "mv")]
+    worst, where = dict.fromkeys(keys, 0.0), dict.fromkeys(keys, -1)
+    worst64 = {k: (0.0, 0.0) for k in keys}                 # (HIP vs float64, C oracle vs float64) at the worst ratio
+    chained = []
+
+    def errs(r, fx_r, x_r, st_r, m_r, v_r):
+        xs = max(1.0, float(np.abs(x_r).max()))
+        return dict(fx=rel_err(r["fx"], fx_r), x=max_abs(r["x"], x_r) / xs,
+                    state=max(max_abs(a, b) for a, b in zip(r["st"], st_r)),
+                    mv=max(max_abs(r["m"], m_r) / max(1e-30, float(np.abs(m_r).max())),
+                           max_abs(r["v"], v_r) / max(1e-30, float(np.abs(v_r).max()))))
+
+    for t in range(T):
+        seg, x_n, st_n, m_n, v_n, _ = c_unroll("lasso", cfg, params, arrays, x_t, 1, state0=st_t, m0=m_t, v0=v_t,
+                                              step0=1 + t)
+        chained.append(seg[0])
+        st_ref = [st_n[0][0], st_n[0][1], st_n[1][0], st_n[1][1]]
+        xd0 = eng.tensor(x_t)
+        std0 = eng.state_pack(*[eng.tensor(a) for hc in st_t for a in hc], B, D)
+        md0, vd0 = eng.tensor(m_t), eng.tensor(v_t)
+        # (a) the streaming fused kernel, one step
+        xd, std, md, vd = xd0.clone(), std0.clone(), md0.clone(), vd0.clone()
+        eng.unroll(spec, wpack, pd, xd, std, md, vd, 1, 1 + t, fx_part)
+        eng.reduce_fx(fx_part, 2, B, B, fx)
+        got = dict(fx=eng.to_numpy(fx).copy(), x=eng.to_numpy(xd), m=eng.to_numpy(md), v=eng.to_numpy(vd),
+                   st=[eng.to_numpy(a).reshape(-1, 20) for a in eng.state_unpack(std, B, D)])
+        # (b) the step-granular kernels, one step
+        xd, std, md, vd = xd0, std0, md0, vd0
+        eng.problem_fg(pd, xd, f_s, g_s)
+        eng.reduce_fx(f_s, 1, B, B, fx[0:1])
+        eng.lstm_step(spec, wpack, g_s, md, vd, b95 ** (1 + t), b95 ** (1 + t), std, xd, B, D)
+        eng.problem_fg(pd, xd, f_s, None)
+        eng.reduce_fx(f_s, 1, B, B, fx[1:2])
+        got2 = dict(fx=eng.to_numpy(fx).copy(), x=eng.to_numpy(xd), m=eng.to_numpy(md), v=eng.to_numpy(vd),
+                    st=[eng.to_numpy(a).reshape(-1, 20) for a in eng.state_unpack(std, B, D)])
+        r64 = None
+        if t % 8 == 0 or t == T - 1:                        # the same step in float64 from the same fp32 inputs
+            s64 = tuple((h.astype(np.float64), c.astype(np.float64)) for h, c in st_t)
+            u = O.unroll(prob64, cfg, p64, x_t.astype(np.float64), s64, 1, m0=m_t.astype(np.float64),
+                         v0=v_t.astype(np.float64), step0=1 + t)
+            r64 = (u.fx, u.x.reshape(B, D), [u.state[0][0], u.state[0][1], u.state[1][0], u.state[1][1]],
+                   u.m.reshape(B, D), u.v.reshape(B, D))
+            c64 = errs(dict(fx=seg, x=x_n, st=st_ref, m=m_n, v=v_n), *r64)
+        for tag, r in (("fused", got), ("step", got2)):
+            e = errs(r, seg, x_n, st_ref, m_n, v_n)
+            for k, val in e.items():
+                if val > worst[tag + "_" + k]:
+                    worst[tag + "_" + k], where[tag + "_" + k] = val, t
+            if r64 is not None:
+                e64 = errs(r, *r64)
+                for k in e64:
+                    assert e64[k] <= 2 * c64[k] + 2e-7, (tag, k, t, e64[k], c64[k])
+                    if e64[k] - 2 * c64[k] > worst64[tag + "_" + k][0] - 2 * worst64[tag + "_" + k][1] or worst64[tag + "_" + k] == (0.0, 0.0):
+                        worst64[tag + "_" + k] = (e64[k], c64[k])
+        x_t, st_t, m_t, v_t = x_n, st_n, m_n, v_n
+    chained.append(seg[1])
+    eng.check_unroll_status()
+    print("C3 trained, teacher-forced at every t of %d (f %.4g -> %.4g): worst vs the C oracle's step: " % (T, fx_whole[0], fx_whole[-1]) +
+          ", ".join("%s %.3g (t=%d)" % (k, v, where[k]) for k, v in sorted(worst.items())))
+    print("   vs the float64 step (every 8th t; HIP / fp32 C oracle): " +
+          ", ".join("%s %.3g / %.3g" % ((k,) + v) for k, v in sorted(worst64.items())))
+    assert np.array_equal(np.asarray(chained, np.float32), fx_whole) and np.array_equal(x_t, x_whole)
+    assert fx_whole[-1] < fx_whole[0] / 5
+    bound = dict(fx=1e-6, x=1e-6, state=3e-6, mv=2e-6)
+    for k, v in worst.items():
+        assert v < bound[k.split("_")[1]], (k, v, where[k])
+
+
+def _c5_hip(hip, data, params, batch, T, idx, start=None, step0=1):
+    """T steps of the trained RNNProp optimizer on the MLP optimizee through the product API (ONE l2o_mlp_unroll
+    launch); start = None (the problem's own initial weights, zero state) or the oracle's (variables, LSTM states,
+    m, v) to continue from.  Returns (initial variables, fx[0..T], final variables)."""
+    from open_l2o_amd import meta, meta_rnnprop_eval, problems
+    from open_l2o_amd.session import Session
+    cfg = O.RNNPROP
+    calls = {"n": 0}
+
+    def sampler(n_evals, b, n_data):
+        out = idx[calls["n"]:calls["n"] + n_evals]
+        calls["n"] += n_evals
+        return out
+
+    meta.set_random_seed(19)
+    problem = problems.mnist(layers=(20,), batch_size=batch, data=data, sampler=sampler)
+    opts = {"layers": cfg.layers, "initializer": params, "preprocess_name": "fc", "preprocess_options": {"dim": 20},
+            "scale": cfg.scale, "tanh_output": True}
+    opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, rp={"net": "RNNprop", "net_options": opts})
+    ml, _, _, step = opt.meta_loss(problem, T)
+    g = opt.graph
+    with Session() as sess:
+        sess.run(ml.reset)
+        if start is not None:
+            vs0, sts0, ms0, vv0 = start
+            for var, a in zip(g.x, vs0):
+                var.load(a)
+            for sl in g.slots:
+                j = sl.var_index
+                sl.state.load(sts0[j])
+                sl.m, sl.v = hip.tensor(ms0[j].reshape(1, -1)), hip.tensor(vv0[j].reshape(1, -1))
+        v0 = [v.eval() for v in g.x]
+        sess.run([ml.fx, ml.update], feed_dict={step: step0})
+        fx = hip.to_numpy(g._fx_cache[T]["bufs"][0]).copy()
+        xT = [v.eval() for v in g.x]
+    assert g.last_path == "mlp_unroll"
+    return v0, fx, xT
+
+
+def test_c5_trained_rnnprop_on_the_mlp_optimizee():
+    """Config 5 in the CONVERGING regime (VERDICT r03 missing item 3): the committed RNNProp optimizer meta-trained on
+    the 784-20-10 MLP optimizee (tests/golden/trained/rnnprop_mnist_mlp, scripts/train_rnnprop.py --problem mnist on
+    the label-noised synthetic digits bench.py uses), minibatch 64, T = 200, ONE persistent launch (l2o_mlp_unroll)
+    through the product API, against the oracle's multi-variable RNNProp unroll (O.unroll_multi: one pair of moments
+    and one LSTM state per variable, DM/meta_rnnprop_train.py:371-395, DM/problems.py:254-288) on the same minibatch
+    sequence.  The loss FALLS (2.30 -> ~0.35).  RNNProp's inputs g / sqrt(v) amplify rounding differences of near-zero
+    gradients, so -- as for config 3 -- the whole trajectory is chaotic past ~50 steps (the oracle started one ulp
+    away drifts by 3e-4); asserted: (a) 1e-5 on the prefix where that sensitivity is below 1e-6, (b) 1e-5 (or 3 x the
+    segment's own one-ulp sensitivity) on TEN re-synchronised 20-step segments that start from the oracle's variables /
+    LSTM states / moments at t = 0, 20, ..., 180 and together cover the whole converged regime."""
+    from open_l2o_amd import _engine, problems
+    hip = _engine.HipEngine()
+    old = _engine._default_engine
+    _engine.set_default_engine(hip)
+    try:
+        data = problems.synthetic_mnist(4096, seed=5, label_noise=0.1)      # (bench.py's config-5 data)
+        T, batch, L = 200, 64, 20
+        idx = np.random.default_rng(170).integers(0, 4096, size=(T + 1, batch))
+        cfg = O.RNNPROP
+        params = load_l2l("rnnprop_mnist_mlp", "rp")
+        ref = O.MnistMLP(data["images"], data["labels"].astype(np.int32), "sigmoid")
+        v0, fx, xT = _c5_hip(hip, data, params, batch, T, idx)
+        fg = lambda vs, t, wg: ref.fg(vs, idx[t], wg)
+        states = [O.net_initial_state(cfg, a.size) for a in v0]
+        fx_ref = O.unroll_multi(fg, cfg, params, v0, states, T)[0]
+        fx_p = O.unroll_multi(fg, cfg, params, [one_ulp(a) for a in v0], states, T)[0]
+        sens = np.abs(fx_p.astype(np.float64) - fx_ref) / np.abs(fx_ref)
+        err = np.abs(fx.astype(np.float64) - fx_ref) / np.abs(fx_ref)
+        env = np.maximum.accumulate(sens)
+        stable = int(np.argmax(env > 1e-6)) if np.any(env > 1e-6) else T + 1
+        print("C5 trained: fx %.4g -> %.4g (min %.4g); oracle one-ulp sensitivity > 1e-6 from step %d (max %.3g); HIP: "
+              "prefix %.3g, whole trajectory %.3g" % (fx_ref[0], fx_ref[-1], fx_ref.min(), stable, sens.max(),
+                                                       err[:stable].max() if stable else 0.0, err.max()))
+        assert fx_ref[-1] < 0.6 * fx_ref[0] and fx[-1] < 0.6 * fx[0]      # the trained optimizer does optimize
+        assert stable >= 20 and err[:stable].max() < 1e-5
+        # (b) re-synchronised segments: the oracle's chained 20-step unrolls ARE its 200-step unroll (checked)
+        cur = ([a.copy() for a in v0], states, None, None)
+        chained, worst = [], 0.0
+        for k in range(T // L):
+            t0 = k * L
+            fgk = lambda vs, t, wg, _t0=t0: ref.fg(vs, idx[_t0 + t], wg)
+            seg_ref, v_n, st_n, m_n, vv_n = O.unroll_multi(fgk, cfg, params, cur[0], cur[1], L, ms=cur[2], vs=cur[3],
+                                                           step0=1 + t0, return_moments=True)
+            seg_p = O.unroll_multi(fgk, cfg, params, [one_ulp(a) for a in cur[0]], cur[1], L, ms=cur[2], vs=cur[3],
+                                   step0=1 + t0)[0]
+            start = None if k == 0 else (cur[0], cur[1], cur[2], cur[3])
+            _, seg, xs = _c5_hip(hip, data, params, batch, L, idx[t0:t0 + L + 1], start=start, step0=1 + t0)
+            e, es = rel_err(seg, seg_ref), rel_err(seg_p, seg_ref)
+            ex = max(max_abs(a.reshape(b.shape), b) for a, b in zip(xs, v_n))
+            worst = max(worst, e)
+            print("   segment from the oracle's state at t=%3d: rel fx %.3g (oracle one-ulp sensitivity %.3g), weights %.3g "
+                  "(f %.4g -> %.4g)" % (t0, e, es, ex, seg_ref[0], seg_ref[-1]))
+            assert e < max(1e-5, 3 * es), (t0, e, es)
+            chained.extend(seg_ref[:L])
+            cur = (v_n, st_n, m_n, vv_n)
+        chained.append(seg_ref[L])
+        assert np.array_equal(np.asarray(chained, np.float32), fx_ref)
+        print("   worst segment: %.3g" % worst)
+    finally:
+        _engine.set_default_engine(old)
