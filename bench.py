@@ -80,6 +80,67 @@ def alg_flops_per_coord_step(problem, net, D, M):
     return lstm + 4 * (M if problem == "lasso" else D)
 
 
+# ---- work-based roofline figure --------------------------------------------------------------
+# Measured ISSUE cost in shader cycles of one wave64 instruction per class, one wave per SIMD, independent operands
+# (scripts/microbench/valu_issue_cost.hip; profiles/r04c_valu_issue_cost.txt).  MFMA: its issue slot; the matrix pipe's
+# own occupancy (16 cycles per v_mfma_f32_16x16x32_bf16) is reported separately as mfma_pipe_floor.
+# Measured (r04c): v_fma_f32 / v_pk_fma_f32 / v_cvt_pk_bf16_f32 5.2-5.3 cycles (ONE wave per SIMD issues a plain VALU
+# instruction every ~5.3 cycles, not every 4: the 4-cycle rate needs a second wave), v_exp_f32 / v_rcp_f32 8.5,
+# v_permlane*_swap 10.3 (counted as plain: 6 per step), v_mfma_f32_16x16x32_bf16 back to back 17.9 (the pipe).
+ISSUE_COST = {"valu": 5.26, "trans": 8.51, "mfma": 5.26}
+MFMA_PIPE_CYCLES = 17.89
+
+
+def work_model(problem, net, D, M):
+    """The MINIMAL instruction counts of ONE tile-step (16 coordinates, one wave) of the fused unroll, by class -- a
+    statement about the algorithm, not a count of what the compiler emitted (the ISA executes ~30 % more plain VALU:
+    register copies, masks, address arithmetic), so the figure cannot be raised by executing more instructions:
+      GEMV     two passes over the problem's matrix slice owned by the wave: M*D/(tiles per problem * 64 lanes) FMAs each
+               (two-CU form, d = 128: 32 + 32), + the in-lane / cross-lane reductions and the residual / scaling (26)
+      inputs   the gradient features into the 20 layer-1 gate rows of the lane's five units: 10 packed FMAs per feature
+      gates    two layers x five units per lane: 8 transcendentals (5 v_exp + 3 v_rcp) and 6 plain (packed pairs) each
+      split    two 5-vectors -> three bf16 levels: 27 each
+      MFMA     60 (packed DM form) / 90 (6-product form) / 120 (RNNProp, 4 chunks)
+      rest     output Linear 9, update + scaled iterate 3, loss terms + wave reduction 15 (+ RNNProp inputs 20)"""
+    rn = net == "rnnprop"
+    tiles = max(1, (D + 15) // 16)
+    if problem == "mnist":
+        gemv = 2 * 16 + 26                                   # gradient of the lane's coordinate: 16 samples x 4 q lanes
+    else:
+        rows = M if problem == "lasso" else D
+        gemv = 2 * int(round(rows * D / (tiles * 64.0))) + 26
+    feats = 2 if net == "dm_logsign" else (0 if rn else 1)
+    plain = gemv + 10 * feats + 2 * 5 * 6 + 2 * 27 + 27 + (20 + 27 + 20 if rn else 0)
+    trans = 2 * 5 * 8 + (2 if rn else 0) + (20 if rn else 0)     # (+ tanh output, + the ELU of the 20 input features)
+    mfma = 120 if rn else 60
+    return {"valu_plain": plain, "transcendental": trans, "mfma": mfma}
+
+
+def work_block(case, issue, args):
+    """cycles_per_tile_step (measured), valu_insts_per_tile_step (PMC), the stated issue-port floor of the tile-step and
+    frac_work = floor / measured -- next to the utilisation-type `frac`."""
+    if issue is None or not issue.get("one_wave_per_simd") or case["hbm_bound"]:
+        return None                                           # (the streaming kernels: several tiles per wave, HBM-bound)
+    T, dispatches = case["T"], float(case.get("dispatches", 1))
+    net = args.net
+    wm = work_model(args.problem, net, case["D"], case["Mrows"])
+    floor = (wm["valu_plain"] * ISSUE_COST["valu"] + wm["transcendental"] * ISSUE_COST["trans"] + wm["mfma"] * ISSUE_COST["mfma"])
+    # one launch = T tile-steps per wave (the T + 1-st loss evaluation is ~1/3 of a step); chunk launches run back to back
+    cyc = case["kern_ms"] * 1e-3 * issue["clock_hz"] / (dispatches * (T + 0.3))
+    out = {"cycles_per_tile_step": cyc, "work_model_instructions_per_tile_step": wm,
+           "issue_cost_cycles": dict(ISSUE_COST), "issue_floor_cycles_per_tile_step": floor,
+           "mfma_pipe_floor_cycles_per_tile_step": wm["mfma"] * MFMA_PIPE_CYCLES,
+           "frac_work": floor / cyc,
+           "frac_work_note": "stated minimal instruction counts of one tile-step (bench.py: work_model) x measured per-class "
+                             "issue cost (profiles/r04c_valu_issue_cost.txt) / measured cycles per tile-step: the share of "
+                             "the step the wave's issue port NEEDS; the rest is dependency / LDS / exchange latency that one "
+                             "wave per SIMD cannot hide (profiles/r04b_coresident_split_bench.txt: a second wave per SIMD "
+                             "makes the step 24 % slower)"}
+    if issue.get("insts_valu") and issue.get("waves"):
+        out["valu_insts_per_tile_step"] = issue["insts_valu"] / issue["waves"] / (T + 0.3)
+    return out
+
+
 def cpu_baseline(problem, net, arrays, weights, x0, T, max_seconds=20.0):
     """The reference path restated for the CPU (oracle/, test infrastructure), timed on this
     host's cores on the SAME inputs (whole unrolls, bounded to ~max_seconds): the plain-C +
@@ -327,7 +388,10 @@ def roofline_block(case, args, counters):
                      "mfma_busy_cycles": pl["SQ_VALU_MFMA_BUSY_CYCLES"],
                      "mfma_issue_cycles": 4.0 * pl.get("SQ_INSTS_MFMA", 0.0),
                      "kernel_us_profiled": (sum(c["kernel_ns_profiled"].values()) / max(1, len(c["kernel_ns_profiled"])) / 1e3
-                                            if c.get("kernel_ns_profiled") else None)}
+                                            if c.get("kernel_ns_profiled") else None),
+                     "one_wave_per_simd": bool(c.get("one_wave_per_simd")),
+                     "insts_valu": c.get("per_launch", {}).get("SQ_INSTS_VALU"),        # (per DISPATCH, like `waves`)
+                     "waves": c.get("per_launch", {}).get("SQ_WAVES")}
     if case["hbm_bound"]:
         out.update(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, traffic=traffic)
         if traffic is not None:
@@ -352,6 +416,9 @@ def roofline_block(case, args, counters):
         if traffic is not None:
             out["hbm_frac_measured"] = traffic / kern_s / HBM_PEAK
     out["counters_source"] = src
+    wb = work_block(case, issue, args)
+    if wb is not None:
+        out.update(wb)
     return out
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 10
+#define L2O_ABI_VERSION 11
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -568,6 +568,32 @@ int l2o_unroll_record_supported(const l2o_net_cfg* cfg, const l2o_problem* prob)
  * (bit-reproducible).  With B sharded, all-reduce(sum) fx over ranks afterwards. */
 int l2o_reduce_fx(const float* fx_part, int32_t T1, int32_t B_local, int32_t B_global,
                   float* fx /* device [T1] */, void* stream);
+
+/* ---- small vector passes of the meta-gradient (ABI v11): what tf.gradients emits around the optimizer network when
+ * MetaOptimizer.meta_minimize differentiates loss = sum_t f(x_t) (DM/meta.py:372-376, 398-414).  Until v10 the host
+ * layer ran them as tensor arithmetic of its array library; the training path now calls l2o_* entry points only.
+ *
+ * l2o_suffix_sums: out[t][i] = g_final[i] + sum_{tau > t} g[tau][i], t = 0..T-1 -- dL/d(delta_t) with the optimizee
+ *   gradients held constant (tf.stop_gradient, DM/meta.py:328-329).  g: DEVICE table of T device pointers to [n] floats
+ *   (the recorded gradients live in per-step buffers), out: device [T][n].
+ * l2o_colsum: out[b][k] (+)= sum_r A[b][r][k] for `batch` row-major [rows, cols] matrices -- bias gradients dz^T 1
+ *   (DM/networks.py:192-203: b_gates, Linear b), the column sums of square_cos' wcos (DM/problems.py:959-994).  Fixed
+ *   summation order.  scratch: device, >= l2o_colsum_scratch_floats(batch, cols) floats.
+ * l2o_lincomb: out = ca a + cb b + cc c (b, c may be NULL; out may alias an input), n floats.
+ * l2o_rnnprop_input_adjoint: second_derivatives=True for RNNProp (DM/meta_rnnprop_train.py:380-388 without the
+ *   stop_gradient): from the BPTT step's du (H columns starting at column du_col of the Bm rows, leading dimension ldb)
+ *   forms dg = dL/dg_t through (m~, g~) AND the moment recurrences, and updates the carried adjoints dm, dv in place.
+ *   pow1 = beta1^k, pow2 = beta2^k, k = step + t; w_fc: device [2][H] (Sonnet layout of input_projection/w). */
+int l2o_suffix_sums(const float* const* g /* device table */, const float* g_final, float* out, int64_t n, int32_t T,
+                    void* stream);
+size_t l2o_colsum_scratch_floats(int64_t batch, int32_t cols);
+int l2o_colsum(const float* A, int64_t batch, int64_t rows, int32_t cols, float* out /* device [batch][cols] */,
+               int32_t accumulate, float* scratch, void* stream);
+int l2o_lincomb(float* out, const float* a, float ca, const float* b, float cb, const float* c, float cc, int64_t n,
+                void* stream);
+int l2o_rnnprop_input_adjoint(const float* Bm, int64_t ldb, int32_t du_col, int32_t H, const float* w_fc,
+                              const float* g, const float* m, const float* v, double pow1, double pow2,
+                              double beta1, double beta2, float* dm, float* dv, float* dg, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

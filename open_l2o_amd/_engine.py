@@ -128,6 +128,20 @@ class HipEngine(object):
         t = torch.rand(shape, generator=g, device=self.device, dtype=torch.float32)
         return t.mul_(float(b) - float(a)).add_(float(a))
 
+    def sample_int(self, out, high, seed):
+        """Uniform int32 draws in [0, high) into the device tensor `out`, from a device generator seeded with `seed`: the
+        minibatch index rows of the neural optimizee (DM/problems.py:282-284 draws them with tf.random_uniform -- a device
+        op there too) without a host draw + upload, which as a pageable H2D copy waited for the previous unroll to
+        finish (host enqueue 2.1 ms per 2.3 ms config-5 unroll)."""
+        g = self.__dict__.get("_gen_int")
+        if g is None:
+            g = self._gen_int = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        return torch.randint(0, int(high), tuple(out.shape), generator=g, device=self.device, dtype=torch.int32, out=out)
+
+    def empty_int(self, *shape):
+        return torch.empty(*shape, dtype=torch.int32, device=self.device)
+
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
 
@@ -278,19 +292,39 @@ class HipEngine(object):
         ms / vs / scales: lists of 4 device tensors (w1, b1, w2, b2; ms / vs / scales entries may be None).
         hist: None, or dict(st=, g=, m=, v=) of lists of 4 device tensors ([T, state], [T + 1, n], [T + 1, n] x 2;
         m / v None for the DM nets) that receive the history the meta-gradient needs (l2o_mlp_unroll_record)."""
-        cc, cm = spec.to_c(), self._cmlp(d)
-        n = int(self.lib.l2o_mlp_unroll_workspace_bytes(C.byref(cm)))
-        ws = self.__dict__.get("_mlp_ws")
-        if ws is None or ws.numel() < n:
-            ws = self._mlp_ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        self._last_ws = ws
+        # the argument objects of a repeated launch (same buffers, same options: an evaluation loop, bench.py) are built
+        # ONCE -- per call the host does a dict lookup and one ctypes call instead of ~0.1 ms of struct building
+        def ptr(t):
+            return 0 if t is None else t.data_ptr()
+        key = (_abi.options_word(), id(d), spec.kind, spec.preprocess, tuple(spec.layers), float(spec.scale), bool(spec.tanh_output),
+               float(spec.logsign_k), float(spec.beta1), float(spec.beta2), wpack.data_ptr(), indices.data_ptr(), int(T), hist is None,
+               tuple(ptr(t) for ts in (xs, sts, ms, vs, scales) for t in ts))
+        memo = self.__dict__.setdefault("_mlp_unroll_memo", {})
+        ent = memo.get(key) if hist is None else None
+        if ent is None:
+            cc, cm = spec.to_c(), self._cmlp(d)
+            n = int(self.lib.l2o_mlp_unroll_workspace_bytes(C.byref(cm)))
+            ws = self.__dict__.get("_mlp_ws")
+            if ws is None or ws.numel() < n:
+                ws = self._mlp_ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
 
-        def arr(ts):
-            a = (C.c_void_p * 4)()
-            for k, t in enumerate(ts):
-                a[k] = None if t is None else t.data_ptr()
-            return a
-        ax, ast, am, av, asc = arr(xs), arr(sts), arr(ms), arr(vs), arr(scales)
+            def arr(ts):
+                a = (C.c_void_p * 4)()
+                for k, t in enumerate(ts):
+                    a[k] = None if t is None else t.data_ptr()
+                return a
+            ent = dict(cc=cc, cm=cm, ws=ws, arrs=(arr(xs), arr(sts), arr(ms), arr(vs), arr(scales)),
+                       keep=(d, wpack, indices, list(xs), list(sts), list(ms), list(vs), list(scales)))
+            if hist is None:
+                if len(memo) >= 8:
+                    memo.pop(next(iter(memo)))
+                memo[key] = ent
+        cc, cm, ws = ent["cc"], ent["cm"], ent["ws"]
+        if self.__dict__.get("_mlp_ws") is not ws:           # (a larger workspace replaced it since)
+            memo.pop(key, None)
+            return self.mlp_unroll(spec, wpack, d, indices, xs, sts, ms, vs, scales, T, step0, fx, hist=hist)
+        self._last_ws = ws
+        ax, ast, am, av, asc = ent["arrs"]
         if hist is not None:
             h = _abi.MlpHist()
             for k in range(4):

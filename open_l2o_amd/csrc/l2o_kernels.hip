@@ -862,6 +862,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 #include "l2o_bwd.h"
 
 #include "l2o_bwd_mfma.h"
+#include "l2o_vecops.h"
 
 // ---------------------------------------------------------------------------
 // small utility kernels
@@ -2376,6 +2377,55 @@ int l2o_reduce_fx(const float* fx_part, int32_t T1, int32_t B_local, int32_t B_g
     return fail(L2O_ERR_ARG, "l2o_reduce_fx: bad argument");
   hipLaunchKernelGGL(k_reduce_fx, dim3(T1), dim3(64), 0, (hipStream_t)stream, fx_part, (int)T1, (int)B_local,
                      1.0f / (float)B_global, fx);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+
+// ---- small vector passes of the meta-gradient (csrc/l2o_vecops.h; ABI v11) ---------------------------------
+int l2o_suffix_sums(const float* const* g, const float* g_final, float* out, int64_t n, int32_t T, void* stream) {
+  if (!g || !g_final || !out || n <= 0 || T < 0) return fail(L2O_ERR_ARG, "l2o_suffix_sums: bad argument");
+  if (T == 0) return L2O_OK;
+  hipLaunchKernelGGL(k_suffix_sums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, g_final, out,
+                     (long)n, (int)T);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+size_t l2o_colsum_scratch_floats(int64_t batch, int32_t cols) {
+  if (batch <= 0 || cols <= 0) return 0;
+  return (size_t)batch * kColsumSplit * (size_t)cols;
+}
+int l2o_colsum(const float* A, int64_t batch, int64_t rows, int32_t cols, float* out, int32_t accumulate, float* scratch,
+               void* stream) {
+  if (!A || !out || !scratch || batch <= 0 || rows <= 0 || cols <= 0 || batch > 65535)
+    return fail(L2O_ERR_ARG, "l2o_colsum: bad argument");
+  const unsigned gx = (unsigned)((cols + 255) / 256);
+  hipLaunchKernelGGL(k_colsum_part, dim3(gx, kColsumSplit, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, A, (long)rows,
+                     (int)cols, scratch);
+  hipLaunchKernelGGL(k_colsum_final, dim3(gx, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, scratch, (int)cols, out,
+                     (int)accumulate);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+int l2o_lincomb(float* out, const float* a, float ca, const float* b, float cb, const float* c, float cc, int64_t n,
+                void* stream) {
+  if (!out || !a || n <= 0) return fail(L2O_ERR_ARG, "l2o_lincomb: bad argument");
+  hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, a, ca, b, cb, c, cc,
+                     (long)n);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
+int l2o_rnnprop_input_adjoint(const float* Bm, int64_t ldb, int32_t du_col, int32_t H, const float* w_fc, const float* g,
+                              const float* m, const float* v, double pow1, double pow2, double beta1, double beta2,
+                              float* dm, float* dv, float* dg, int64_t n, void* stream) {
+  if (!Bm || !w_fc || !g || !m || !v || !dm || !dv || !dg || n <= 0 || H <= 0 || du_col < 0 || ldb < du_col + H)
+    return fail(L2O_ERR_ARG, "l2o_rnnprop_input_adjoint: bad argument");
+  RnnpropAdjArgs a;
+  a.Bm = Bm; a.ldb = (long)ldb; a.du_col = du_col; a.H = H; a.w_fc = w_fc; a.g = g; a.m = m; a.v = v;
+  a.om1 = (float)(1.0 - pow1); a.om2 = (float)(1.0 - pow2);
+  a.b1 = (float)beta1; a.b2 = (float)beta2;
+  a.omb1 = 1.0f - a.b1; a.omb2 = 1.0f - a.b2;               // (fp32, like the forward's 1 - beta)
+  a.dm = dm; a.dv = dv; a.dg = dg; a.n = (long)n;
+  hipLaunchKernelGGL(k_rnnprop_input_adjoint, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
 }

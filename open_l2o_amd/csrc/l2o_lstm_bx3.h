@@ -483,7 +483,7 @@ struct LstmCore<PRE, false, PK> {
   __device__ __forceinline__ void issue_l2_prev(const TileState& s, f32x4 (&acc2)[kNT]) {
     lstm_issue_l2_prev<PRE, LO, HI>(w, s, acc2);
   }
-  template <bool NEXT, class Shadow = bx::NoShadow>
+  template <bool NEXT, class Shadow = bx::NoShadow, bool REARM = true>
   __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
                                           int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
     shadow();
@@ -538,10 +538,13 @@ struct LstmCore<PRE, true, PK> {
   __device__ __forceinline__ void issue_l2_prev(const TileState&, f32x4 (&acc2)[kNT]) {
     bx::issue<PRE, bx::kChL2B, LO, HI, true>(w, b2, acc2);
   }
-  template <bool NEXT, class Shadow = bx::NoShadow>
+  // REARM = false: the caller re-arms the accumulators itself (preload()) at a point where the bias reads' latency is
+  // free -- finish<.., true> issues them right behind the gate blocks and the pinning asm WAITS for them there, i.e.
+  // in front of the split of h1 and in front of the output Linear / the x update (round 4, k_unroll_pair)
+  template <bool NEXT, class Shadow = bx::NoShadow, bool REARM = true>
   __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
                                           int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
-    return bx::finish<PRE, NEXT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, shadow);
+    return bx::finish<PRE, NEXT, PK, Shadow, REARM>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, static_cast<Shadow&&>(shadow));
   }
   // after finish<false>: b1 already holds split h1(t) (finish builds it for chunk L2A); split h2(t) for chunk L2B
   __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<PK>(s.h2, one, b2); }

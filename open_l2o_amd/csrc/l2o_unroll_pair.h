@@ -78,6 +78,26 @@ __device__ __forceinline__ void lds_read_f4(float4 (&v)[N], const float* p) {
                  : "v"(addr) : "memory");
 }
 
+// Round 4: compiler-visible 16-byte LDS reads (the compiler places the s_waitcnt itself) in front of independent VALU
+// work of the caller, ordered with sched_group_barrier: N ds_read_b128 back to back, then the VALU block that hides their
+// latency.  (A first attempt with two asm statements -- issue / wait with the destinations as tied operands -- was WRONG:
+// the register allocator split the live ranges and copied the destinations between the two statements, i.e. before the
+// data had landed.)
+template <int N>
+__device__ __forceinline__ void lds_load_f4(l2o::f32x4 (&v)[N], const float* p) {
+  const auto* q = reinterpret_cast<const __attribute__((address_space(3))) l2o::f32x4*>(
+      (const __attribute__((address_space(3))) float*)p);
+#pragma unroll
+  for (int m = 0; m < N; ++m) v[m] = q[4 * m];             // (+64 bytes per read: the row / column chunk of tile m)
+}
+// (dot4 of l2o_kernels.hip with the LDS operand as an ext-vector register quad: no float4 <-> f32x4 copies)
+__device__ __forceinline__ void dot4v(const float4 a, const l2o::f32x4 b, float4& acc) {
+  acc.x = __builtin_fmaf(a.x, b[0], acc.x);
+  acc.y = __builtin_fmaf(a.y, b[1], acc.y);
+  acc.z = __builtin_fmaf(a.z, b[2], acc.z);
+  acc.w = __builtin_fmaf(a.w, b[3], acc.w);
+}
+
 // HIST: also record the per-step history for the meta-gradient (l2o_unroll_record); a template
 // parameter so that the plain unroll carries none of it
 // EXACT (L2O_OPT_EXACT_GATES): the fp32 MFMA gate GEMM (bit-equal to an fmaf chain) instead of the bf16x3 split
@@ -89,8 +109,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
   constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
   constexpr int NC = 16 * NWH;           // columns (coordinates) owned by a half = SQ / 2
-  __shared__ float xs[NC];               // this half's scaled iterate
-  __shared__ float rs[SQ];               // the full residual
+  __shared__ __attribute__((aligned(16))) float xs[NC];   // this half's scaled iterate
+  __shared__ __attribute__((aligned(16))) float rs[SQ];   // the full residual
   const UnrollArgs& a = pa.u;
   const ProbParams& pp = a.pp;
   const int D = pp.D, M = pp.M;
@@ -223,12 +243,23 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   PhaseClock pc;
   pc.start();
 
+  // Round 4 step order (L2O_PAIR_R3_ORDER restores round 3's for A/B runs): the scaled iterate goes to LDS the moment
+  // the update exists -- at the END of a step, ahead of the split of h2 (27 VALU + the register copies of the loop-carried
+  // B operands sat between the update and its LDS write: ~200 cycles of the step's critical path) -- and the split runs
+  // at the top of the next step UNDER the xs reads; the loss reduction runs under the residual reads of the g pass; the two
+  // row partials share one swap butterfly.
+#ifndef L2O_PAIR_R3_ORDER
+  constexpr bool kR4 = true;
+  if (q == 0) xs[wv * kTile + c] = live ? xv * sc : 0.0f;
+#else
+  constexpr bool kR4 = false;
+#endif
   const size_t hist_n = (size_t)pp.B_local * D;
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     const unsigned tag = salt | ((unsigned)t + 1u);     // (T + 1 < 65 535 when salt != 0; the handshake tag ends in 0xffff)
     const int par = t & 1;
-    if (q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
+    if (!kR4 && q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
     pc.mark(0);
     // (recording: barriers that wait for LDS traffic only -- a __syncthreads() also waits for the write acknowledgement
     //  of the 5 KB of history the wave has just stored)
@@ -237,16 +268,39 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     // ---- partial residual over this half's columns: rows 2 x 16 per wave, all SQ rows per half
     float part;
     {
-      float4 x4[NWH];
-      lds_read_f4<NWH>(x4, xsq);
       float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+      if (kR4) {
+        l2o::f32x4 x4v[NWH];
+        lds_load_f4<NWH>(x4v, xsq);
+        core.refresh(s);                     // split h2(t-1) -> chunk L2B operand, under the LDS latency (t = 0: repeats core.init)
+        __builtin_amdgcn_sched_group_barrier(0x100, NWH, 0);     // the DS reads first ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);      // ... then the split's VALU block, then the FMAs
 #pragma unroll
-      for (int m = 0; m < NWH; ++m) {
-        dot4(wr[0][m], x4[m], r0);
-        dot4(wr[1][m], x4[m], r1);
+        for (int m = 0; m < NWH; ++m) {
+          dot4v(wr[0][m], x4v[m], r0);
+          dot4v(wr[1][m], x4v[m], r1);
+        }
+      } else {
+        float4 x4[NWH];
+        lds_read_f4<NWH>(x4, xsq);
+#pragma unroll
+        for (int m = 0; m < NWH; ++m) {
+          dot4(wr[0][m], x4[m], r0);
+          dot4(wr[1][m], x4[m], r1);
+        }
       }
-      const float p0 = quad_q_sum(hsum4(r0)), p1 = quad_q_sum(hsum4(r1));
-      part = (gq & 1) ? p1 : p0;
+      if (kR4) {
+        // both row partials through ONE butterfly: the 16-lane swap pairs row groups (0,1) and (2,3) of p0 AND p1 at once,
+        // the 32-lane swap finishes both; odd lane groups end with the p1 sum, even ones with the p0 sum -- the lanes
+        // that publish them.  Same additions in the same order as two quad_q_sum calls (bit-identical), 5 instead of 13
+        // instructions and one dependent swap chain instead of two.
+        const float h0 = hsum4(r0), h1 = hsum4(r1);
+        const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h0), __float_as_uint(h1), false, false);
+        part = xor32_add(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+      } else {
+        const float p0 = quad_q_sum(hsum4(r0)), p1 = quad_q_sum(hsum4(r1));
+        part = (gq & 1) ? p1 : p0;
+      }
     }
     // ---- exchange the partial sums (one granule per row), the previous-h2 matrix work covers the latency
     if (gq < 2) {
@@ -318,8 +372,16 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     // this wave's share of f_b(x_t): reduced AFTER the barrier (the DPP chain fills the LDS latency of the g
     // pass instead of sitting in front of the barrier) and written straight to HBM -- no LDS round, no
     // thread-0 sum on the step's critical path; k_combine_halves adds the 2 x NWH partials per (step, problem)
+    // (round 4: the residual reads of the g pass go out FIRST; the reduction's DPP chain and the store fill their latency --
+    //  in round 3's ISA the chain sat in front of reads that carried their own wait)
+    l2o::f32x4 rv4v[CH];
+    if (kR4) lds_load_f4<CH>(rv4v, rsq);
     {
       const float fw = wave_sum64(contrib);
+      if (kR4) {
+        __builtin_amdgcn_sched_group_barrier(0x100, CH, 0);    // the DS reads, then the reduction's DPP chain
+        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
+      }
       if (lane == 0) pa.fx_half[((size_t)t * pa.nb + bl) * (2 * NWH) + half * NWH + wv] = fw;
     }
     if (t == a.T && !HIST) break;
@@ -327,11 +389,16 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     // ---- g = W^T r for this wave's 16 coordinates ------------------------------
     // all CH residual reads are issued back to back (hipcc serialises them on one register
     // quad otherwise: CH x LDS latency on the critical path), one wait, then the FMAs
-    float4 rv4[CH];
-    lds_read_f4<CH>(rv4, rsq);
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
+    if (kR4) {
 #pragma unroll
-    for (int m = 0; m < CH; ++m) dot4(wt[m], rv4[m], gacc4);
+      for (int m = 0; m < CH; ++m) dot4v(wt[m], rv4v[m], gacc4);
+    } else {
+      float4 rv4[CH];
+      lds_read_f4<CH>(rv4, rsq);
+#pragma unroll
+      for (int m = 0; m < CH; ++m) dot4(wt[m], rv4[m], gacc4);
+    }
     float gv = quad_q_sum(hsum4(gacc4));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
@@ -361,17 +428,31 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     }
 #ifdef L2O_PAIR_L1H_UNDER_GATES
     float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);
-#else
+#elif defined(L2O_PAIR_R3_ORDER) || defined(L2O_PAIR_REARM_IN_FINISH)
     float d = core.template finish<false>(s, acc1, acc2, in0, in1, q, pc);
+#else
+    float d = core.template finish<false, bx::NoShadow, false>(s, acc1, acc2, in0, in1, q, pc);   // (re-armed below)
 #endif
 #ifndef L2O_PAIR_L1H_UNDER_GATES
-    core.refresh(s);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
+    if (!kR4) core.refresh(s);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
 #endif
     if (a.np.tanh_output) {                                 // a real (uniform) branch: as a select hipcc computes the
       asm volatile("");                                      // exp + rcp of tanh on every step of the nets without it
       d = tanhf_(d);
     }
     xv = __builtin_fmaf(d, a.np.scale, xv);
+    if (kR4) {
+      // the next step's scaled iterate -> LDS NOW (its readers sit behind barrier B1; this step's readers of xs all
+      // passed barrier B2 before any wave gets here)
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == 0) xs[wv * kTile + c] = live ? xv * sc : 0.0f;
+      __builtin_amdgcn_sched_barrier(0);
+#if !defined(L2O_PAIR_L1H_UNDER_GATES) && !defined(L2O_PAIR_REARM_IN_FINISH)
+      // the next step's accumulator inits (the gate biases: 10 ds_read_b128) go out HERE: their latency overlaps the wait
+      // for barrier B1, which drains this wave's LDS queue anyway
+      core.preload(acc1, acc2);
+#endif
+    }
     pc.mark(9);
   }
 #ifdef L2O_PROFILE_PHASES

@@ -519,13 +519,17 @@ class UnrollGraph(object):
         term = self.terms[0]
         d = self._mlp_desc(term)
         sampler = term.hyper.get("sampler")
-        rows = []
-        for _ in range(n):                                   # the same draws, in the same order, as n x _draw_minibatches(L)
-            if sampler is None:
-                rows.append(_rng.integers(0, d.images.shape[0], size=(L + 1, d.batch)))
-            else:
-                rows.append(np.asarray(sampler(L + 1, d.batch, d.images.shape[0])).reshape(L + 1, d.batch))
-        idx = eng.int_tensor(np.stack(rows))                 # [n, L + 1, batch]
+        if sampler is None and hasattr(eng, "sample_int") and not os.environ.get("L2O_HOST_SAMPLING"):
+            idx = eng.empty_int(n, L + 1, d.batch)           # drawn on the device, like _draw_minibatches (one call)
+            eng.sample_int(idx, d.images.shape[0], int(_rng.integers(0, 2 ** 62)))
+        else:
+            rows = []
+            for _ in range(n):                               # the same draws, in the same order, as n x _draw_minibatches(L)
+                if sampler is None:
+                    rows.append(_rng.integers(0, d.images.shape[0], size=(L + 1, d.batch)))
+                else:
+                    rows.append(np.asarray(sampler(L + 1, d.batch, d.images.shape[0])).reshape(L + 1, d.batch))
+            idx = eng.int_tensor(np.stack(rows))             # [n, L + 1, batch]
         index_of = {v.decl.name: j for j, v in enumerate(self.x)}
         js = [index_of[tv.name] for tv in _term_vars(term)]
         panels = []
@@ -867,20 +871,29 @@ class UnrollGraph(object):
                     ring["work"][k] = None
 
     def _draw_minibatches(self, T):
-        """A fresh uniform minibatch per evaluation of a neural optimizee (DM/problems.py:282-286):
-        indices [T+1, batch] drawn on the host, copied into a PERSISTENT device buffer (so that a
-        captured launch sequence sees the new indices)."""
+        """A fresh uniform minibatch per evaluation of a neural optimizee (DM/problems.py:282-286: tf.random_uniform
+        indices -- a device op there): indices [T+1, batch] in a PERSISTENT device buffer (so that a captured launch
+        sequence sees the new indices).  Drawn ON THE DEVICE when the engine can (HipEngine.sample_int: a torch
+        generator seeded from the stream of set_random_seed -- no host draw, no pageable upload that waits for the
+        previous unroll); a `sampler` of the problem (parity tests) or L2O_HOST_SAMPLING=1: the host draw + upload."""
         bufs = self.__dict__.setdefault("_mlp_idx", {})
+        eng = self.engine
         for k, term in enumerate(self.terms):
             if term.kind != _abi.PROB_MLP:
                 continue
             d = self._mlp_desc(term)
             sampler = term.hyper.get("sampler")
+            shape = (T + 1, d.batch)
+            if sampler is None and hasattr(eng, "sample_int") and not os.environ.get("L2O_HOST_SAMPLING"):
+                if k not in bufs or tuple(bufs[k].shape) != shape:
+                    bufs[k] = eng.empty_int(*shape)
+                eng.sample_int(bufs[k], d.images.shape[0], int(_rng.integers(0, 2 ** 62)))
+                continue
             if sampler is None:
-                idx = _rng.integers(0, d.images.shape[0], size=(T + 1, d.batch))
+                idx = _rng.integers(0, d.images.shape[0], size=shape)
             else:
                 idx = np.asarray(sampler(T + 1, d.batch, d.images.shape[0]))
-            new = self.engine.int_tensor(idx.reshape(T + 1, d.batch))
+            new = eng.int_tensor(idx.reshape(shape))
             if k in bufs and bufs[k].shape == new.shape:
                 bufs[k].copy_(new)
             else:

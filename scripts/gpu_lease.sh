@@ -5,7 +5,8 @@
 #
 # Every job writes under gpurun_out/TAG/ (merged back by gpurun; copy what should be judged into profiles/).
 # Jobs (run in the order given; a failing job does not stop the next one):
-#   tests[:PYTEST_ARGS]      python -m pytest tests -m gpu  (extra args after the colon, '+' separates words)
+#   tests[:PYTEST_ARGS]      python -m pytest tests -m gpu  (extra args after the colon, '+' separates words, '%' is a
+#                            space INSIDE a word: tests:-s+-k+teacher_forced%or%c5_trained)
 #   smoke                    __graft_entry__.smoke()
 #   bench:CFG[:ARGS]         python bench.py --config CFG (CFG = 2|3|4|5; 2 = default line incl. cpu_baseline)
 #   trace:CFG[:ARGS]         rocprofv3 --kernel-trace --stats of the same bench command -> kernel_trace_cCFG.txt
@@ -57,7 +58,8 @@ for job in "$@"; do
   case $kind in
     tests)
       n=$((n + 1))
-      timeout 2400 python -m pytest tests -q -m gpu --durations=5 $(words "$rest") > $O/pytest_full_$n.log 2>&1
+      IFS='+' read -ra targs <<< "$rest"; targs=("${targs[@]//%/ }")
+      timeout 2400 python -m pytest tests -q -m gpu --durations=5 "${targs[@]}" > $O/pytest_full_$n.log 2>&1
       tail -25 $O/pytest_full_$n.log | tee $O/pytest.log ;;
     smoke)
       (timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1) | tee $O/smoke.log ;;

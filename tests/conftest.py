@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: minutes of meta-training on the GPU (skipped unless L2O_RUN_SLOW=1)")
 
 
 def pytest_collection_modifyitems(config, items):

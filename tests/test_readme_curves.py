@@ -1,0 +1,48 @@
+"""The reference's only published quantities for this path are the README's convergence FIGURES
+(/root/reference/README.md:34-42, Figs/ras.png: generalized Rastrigin n = 2 / n = 10, every optimizer plateaus at
+f ~ 5.5-6.2 / ~ 50-57 after 10^3 iterations).  scripts/readme_curves.py meta-trains L2O-DM and L2O-RNNProp with the
+reference's schedule on the repo's drivers, evaluates 1000 steps and records the curves next to bands read off the
+figure (profiles/r04_readme_curves.json).  Weak evidence -- but the only reference-held quantity that exercises a
+non-zero LSTM (the Sonnet cell itself is unpinned)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BANDS = {2: (5.0, 7.0), 10: (45.0, 62.0)}          # f at iteration 1000, read off Figs/ras.png (insets 5.0-6.5 / 40-65)
+START = {2: 18.0, 10: 125.0}                       # lower edge of where the figure's curves start (~22 / ~150)
+
+
+def test_committed_curves_are_inside_the_readme_bands():
+    """The committed record of the MI355X run: every case inside the stated band, the loss fell below half of the figure's starting level, and the
+    kernels that produced it were the fused HIP path."""
+    path = os.path.join(ROOT, "profiles", "r04_readme_curves.json")
+    if not os.path.exists(path):
+        pytest.skip("profiles/r04_readme_curves.json not recorded yet")
+    rec = json.load(open(path))
+    assert rec["all_inside_readme_bands"]
+    for name, case in rec["cases"].items():
+        n = int(name.rsplit("n", 1)[1])
+        f = case["f_after_k_steps"]
+        assert BANDS[n][0] <= f["1000"] <= BANDS[n][1], (name, f["1000"])
+        assert case["kernel_path"] == "fused"
+        assert f["1000"] < 0.5 * START[n], (name, f["1000"])       # fell to less than half of where every curve starts
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("L2O_RUN_SLOW"), reason="~1 min of meta-training: set L2O_RUN_SLOW=1")
+def test_rastrigin_n2_plateau_matches_the_readme_figure(tmp_path):
+    """Stated band: mean f after 1000 steps of a freshly meta-trained L2O-DM on Rastrigin n = 2 in [5.0, 7.0]."""
+    out = tmp_path / "curves.json"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "readme_curves.py"), "--out", str(out), "--dims", "2",
+                        "--kinds", "dm", "--num_epochs", "4000", "--eval_epochs", "4"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    rec = json.load(open(out))
+    f = rec["cases"]["dm_rastrigin_n2"]["f_after_k_steps"]
+    print("L2O-DM on Rastrigin n=2: f after 1 / 10 / 100 / 1000 steps: %.3f %.3f %.3f %.3f" % (f["1"], f["10"], f["100"], f["1000"]))
+    assert BANDS[2][0] <= f["1000"] <= BANDS[2][1]
