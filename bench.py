@@ -712,10 +712,15 @@ def main(argv=None):
                                     case["kernel"].split(" ")[0] if case["fused"] else "")
         roof = roofline_block(case, args, counters)
         roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms=case["t_reset"] * 1e3)   # MetaLoss.reset: the problem re-sampled on the device (4 ms with the host draw + upload of round 2)
+        same_lease = bool(os.environ.get("L2O_COUNTERS_DIR")) and roof.get("counters_source") and \
+            not str(roof["counters_source"]).startswith("profiles")
         roof.update(time_base="kernel_ms_avg: HIP events on the launch stream of THIS run around replays of one problem "
                               "instance (the unroll kernel + its epilogue, no preparation); counters (traffic, issue): the "
-                              "committed rocprofv3 --pmc passes named in counters_source, collected on an earlier lease "
-                              "of the same bench command")
+                              "rocprofv3 --pmc passes named in counters_source, " +
+                              ("collected in THIS lease on THIS build by the same bench command (scripts/gpu_lease.sh final:N; "
+                               "committed as profiles/<tag>_counters_cN.json)" if same_lease else
+                               "collected on an earlier lease of the same bench command"),
+                    counters_same_lease=bool(same_lease))
         if case.get("prepare_ms") is not None:
             roof.update(problem_prepare_ms=case["prepare_ms"],
                         problem_prepare_note="l2o_unroll_prepare (H = W^T W, q = W^T y of the sampled problems): once per "

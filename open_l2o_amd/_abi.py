@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # L2O_HIP_LIB: alternative build of the SAME library (timing ablations, scripts/ablate.sh)
 LIB_PATH = os.environ.get("L2O_HIP_LIB") or os.path.join(_HERE, "libl2o_hip.so")
 
-L2O_ABI_VERSION = 10
+L2O_ABI_VERSION = 11
 L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
 
 NET_CW, NET_RNNPROP = 0, 1
@@ -28,6 +28,7 @@ SYMBOLS = (
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_record", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_unroll_prepare", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_adam_step_gather", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
+    "l2o_suffix_sums", "l2o_colsum", "l2o_colsum_scratch_floats", "l2o_lincomb", "l2o_rnnprop_input_adjoint",
 )
 
 
@@ -297,6 +298,16 @@ def lib():
     L.l2o_atb.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp]
     L.l2o_reduce_fx.restype = C.c_int
     L.l2o_reduce_fx.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.l2o_suffix_sums.restype = C.c_int
+    L.l2o_suffix_sums.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.l2o_colsum_scratch_floats.restype = C.c_size_t
+    L.l2o_colsum_scratch_floats.argtypes = [i64, i32]
+    L.l2o_colsum.restype = C.c_int
+    L.l2o_colsum.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp]
+    L.l2o_lincomb.restype = C.c_int
+    L.l2o_lincomb.argtypes = [vp, vp, C.c_float, vp, C.c_float, vp, C.c_float, i64, vp]
+    L.l2o_rnnprop_input_adjoint.restype = C.c_int
+    L.l2o_rnnprop_input_adjoint.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, i64, vp]
     if L.l2o_abi_version() != L2O_ABI_VERSION:
         raise RuntimeError("libl2o_hip.so ABI version %d != binding version %d"
                            % (L.l2o_abi_version(), L2O_ABI_VERSION))

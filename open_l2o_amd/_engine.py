@@ -703,6 +703,44 @@ class HipEngine(object):
         _abi.check(self.lib.l2o_cwlstm_wgrad(C.byref(cc), _ptr(A), _ptr(B), int(R), _ptr(out), _ptr(ws), self._stream()))
         return out
 
+    # -- small vector passes of the meta-gradient (ABI v11, csrc/l2o_vecops.h) -------------------------------
+    def suffix_sums(self, gs, g_final, out):
+        """out[t] = g_final + sum_{tau > t} gs[tau] (gs: list of T device tensors of n floats; out: [T, n])."""
+        T, n = len(gs), g_final.numel()
+        if T == 0:
+            return out
+        table = torch.tensor([g.data_ptr() for g in gs], dtype=torch.int64).to(self.device)
+        _abi.check(self.lib.l2o_suffix_sums(C.c_void_p(table.data_ptr()), _ptr(g_final), _ptr(out), n, T, self._stream()))
+        self._keep_table = table                         # (alive until the next call: the launch is asynchronous)
+        return out
+
+    def colsum(self, A, out=None, accumulate=False):
+        """Column sums of a [rows, cols] (or batched [b, rows, cols]) device matrix, fixed summation order."""
+        A3 = A if A.dim() == 3 else A.unsqueeze(0)
+        assert A3.is_contiguous()
+        b, rows, cols = A3.shape
+        if out is None:
+            out = self.empty(b, cols) if A.dim() == 3 else self.empty(cols)
+        n = int(self.lib.l2o_colsum_scratch_floats(b, cols))
+        scr = self.__dict__.get("_colsum_scratch")
+        if scr is None or scr.numel() < n:
+            scr = self._colsum_scratch = self.empty(n)
+        _abi.check(self.lib.l2o_colsum(_ptr(A3), b, rows, cols, _ptr(out), 1 if accumulate else 0, _ptr(scr), self._stream()))
+        return out
+
+    def lincomb(self, out, a, ca=1.0, b=None, cb=0.0, c=None, cc=0.0):
+        """out = ca a + cb b + cc c (elementwise; out may alias an input)."""
+        _abi.check(self.lib.l2o_lincomb(_ptr(out), _ptr(a), float(ca), _ptr(b), float(cb), _ptr(c), float(cc), out.numel(),
+                                        self._stream()))
+        return out
+
+    def rnnprop_input_adjoint(self, Bm, du_col, H, w_fc, g, m, v, pow1, pow2, beta1, beta2, dm, dv, dg):
+        """second_derivatives for RNNProp: dg = dL/dg_t through (m~, g~) and the moment recurrences; dm, dv in place."""
+        n = g.numel()
+        _abi.check(self.lib.l2o_rnnprop_input_adjoint(_ptr(Bm), int(Bm.stride(0)), int(du_col), int(H), _ptr(w_fc), _ptr(g),
+                                                      _ptr(m), _ptr(v), float(pow1), float(pow2), float(beta1), float(beta2),
+                                                      _ptr(dm), _ptr(dv), _ptr(dg), n, self._stream()))
+
     def reduce_fx(self, fx_part, T1, B_local, B_global, fx):
         _abi.check(self.lib.l2o_reduce_fx(_ptr(fx_part), int(T1), int(B_local), int(B_global), _ptr(fx),
                                           self._stream()))

@@ -244,12 +244,18 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
 // the accumulator init of LAYER (0 / 1): its pre-scaled bias, one ds_read_b128 per M-tile.  Issued as soon as the
 // accumulator is dead (after the gate block that consumed it, or at kernel start) so that its latency is never exposed;
 // the asm pins the loads HERE (the scheduler otherwise sinks them in front of the first MFMA that reads them)
-template <int LAYER, class W>
+// PIN = false: no pinning asm -- that empty asm is a USE of the loaded registers, so the compiler waits for the five reads
+// right there (s_waitcnt lgkmcnt(4..0) directly behind them: one exposed LDS round trip per call).  A caller that issues
+// the reads in front of a point that drains the LDS queue anyway (the step's barrier) fences them with
+// __builtin_amdgcn_sched_barrier(0) instead and pays nothing (round 4, k_unroll_pair).
+template <int LAYER, class W, bool PIN = true>
 __device__ __forceinline__ void preload_bias(const W& w, f32x4 (&acc)[kNT]) {
 #pragma unroll
   for (int t = 0; t < kNT; ++t) acc[t] = w.bias[(LAYER * kNT + t) * 4];
+  if constexpr (PIN) {
 #pragma unroll
-  for (int t = 0; t < kNT; ++t) asm volatile("" : "+v"(acc[t]));
+    for (int t = 0; t < kNT; ++t) asm volatile("" : "+v"(acc[t]));
+  }
 }
 
 // MFMAs [LO, HI) of chunk CH (index n: packed MFMA | product n / 5, M-tile n % 5 -- consecutive MFMAs hit
@@ -474,6 +480,7 @@ struct LstmCore<PRE, false, PK> {
   __device__ __forceinline__ void stage_bias(float*, const float* __restrict__, int, int, int) {}
   __device__ __forceinline__ void pin() {}
   __device__ __forceinline__ void preload(f32x4 (&)[kNT], f32x4 (&)[kNT]) {}
+  __device__ __forceinline__ void preload_unpinned(f32x4 (&)[kNT], f32x4 (&)[kNT]) {}
   __device__ __forceinline__ void init(const TileState&, int) {}
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState& s, f32x4 (&acc1)[kNT]) {
@@ -529,6 +536,11 @@ struct LstmCore<PRE, true, PK> {
   __device__ __forceinline__ void preload(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
     bx::preload_bias<0>(w, acc1);
     bx::preload_bias<1>(w, acc2);
+  }
+  // the same ten reads without the pinning asm (see preload_bias): the caller fences them and drains the LDS queue later
+  __device__ __forceinline__ void preload_unpinned(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
+    bx::preload_bias<0, bx::NetWB<PRE, PK>, false>(w, acc1);
+    bx::preload_bias<1, bx::NetWB<PRE, PK>, false>(w, acc2);
   }
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 #if !defined(L2O_PAIR_L1H_UNDER_GATES) && !defined(L2O_PAIR_REARM_IN_FINISH)
       // the next step's accumulator inits (the gate biases: 10 ds_read_b128) go out HERE: their latency overlaps the wait
       // for barrier B1, which drains this wave's LDS queue anyway
-      core.preload(acc1, acc2);
+      core.preload_unpinned(acc1, acc2);
+      __builtin_amdgcn_sched_barrier(0);
 #endif
     }
     pc.mark(9);

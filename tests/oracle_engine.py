@@ -57,6 +57,47 @@ class OracleEngine(object):
         """The HIP engine's l2o_cwlstm_wgrad: the callers read the weight-gradient blocks of A^T B only."""
         return self.atb(A, B)
 
+    # the HIP engine's ABI v11 vector passes (csrc/l2o_vecops.h), CPU torch restatements of the same formulas
+    def suffix_sums(self, gs, g_final, out):
+        acc = g_final.reshape(-1).clone()
+        for t in reversed(range(len(gs))):
+            out[t] = acc
+            acc = acc + gs[t].reshape(-1)
+        return out
+
+    def colsum(self, A, out=None, accumulate=False):
+        r = A.sum(dim=-2)
+        if out is None:
+            return r
+        out.copy_(out + r if accumulate else r)
+        return out
+
+    def lincomb(self, out, a, ca=1.0, b=None, cb=0.0, c=None, cc=0.0):
+        r = ca * a.reshape(-1)
+        if b is not None:
+            r = r + cb * b.reshape(-1)
+        if c is not None:
+            r = r + cc * c.reshape(-1)
+        out.reshape(-1).copy_(r)
+        return out
+
+    def rnnprop_input_adjoint(self, Bm, du_col, H, w_fc, g, m, v, pow1, pow2, beta1, beta2, dm, dv, dg):
+        f = np.float32
+        du = Bm[:g.numel(), du_col:du_col + H]
+        wfc = w_fc.view(2, H)
+        a0, a1 = (du * wfc[0]).sum(1), (du * wfc[1]).sum(1)
+        g, m, v = g.reshape(-1), m.reshape(-1), v.reshape(-1)
+        om1, om2 = float(f(1.0 - pow1)), float(f(1.0 - pow2))
+        m_hat, sq = m / om1, torch.sqrt(v / om2)
+        den = sq + 1e-8
+        d_den = -(a0 * m_hat + a1 * g) / (den * den)
+        d_vhat = torch.where(sq > 0, d_den * 0.5 / sq.clamp_min(1e-30), torch.zeros_like(sq))
+        dmn = a0 / den / om1 + dm
+        dvn = d_vhat / om2 + dv
+        dg.copy_(a1 / den + dmn * float(f(1.0) - f(beta1)) + dvn * (2.0 * float(f(1.0) - f(beta2))) * g)
+        dm.copy_(dmn * float(f(beta1)))
+        dv.copy_(dvn * float(f(beta2)))
+
     def tensor(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).copy())
 
