@@ -282,11 +282,15 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     MCK();                                                  // 3: loads
     // ---- forward recompute --------------------------------------------------------------------------
     f32x4 acc1[kNT], acc2[kNT];
-    bx::preload_bias<1>(w, acc2);                            // accumulator inits = the biases (l2o_lstm_bx3.h)
-    bx::preload_bias<0>(w, acc1);
+    // accumulator inits = the biases (l2o_lstm_bx3.h); round 4: unpinned (the pinning asm waited for the ten reads on the
+    // spot), the split of h2 hides their latency -- see bx::tile_step
+    bx::preload_bias<1, bx::NetWB<PRE, PK>, false>(w, acc2);
+    bx::preload_bias<0, bx::NetWB<PRE, PK>, false>(w, acc1);
     {
       bx::BOp<PK> b;
       bx::split5<PK>(s.h2, one, b);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * kNT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
       bx::issue<PRE, bx::kChL2B, 0, kN, true>(w, b, acc2);
       bx::split5<PK>(s.h1, one, b);
       bx::issue<PRE, bx::kChL1H, 0, kN, true>(w, b, acc1);

@@ -449,9 +449,20 @@ __device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s
   constexpr int kN = chunk_mfmas(PK);
   BOp<PK> b1, b2;
   f32x4 acc1[kNT], acc2[kNT];
+#ifdef L2O_TILE_STEP_PINNED
   preload_bias<1>(w, acc2);
   preload_bias<0>(w, acc1);
   split5<PK>(s.h2, one, b2);
+#else
+  // round 4: the ten bias reads go out first, UNPINNED (the pinning asm made the wave wait for them on the spot: one
+  // exposed LDS round trip per tile-step, eight per step and wave in the streaming unroll), the split of h2 hides their
+  // latency; the group barriers keep the scheduler from sinking the reads to the first MFMA that needs them
+  preload_bias<1, NetWB<PRE, PK>, false>(w, acc2);
+  preload_bias<0, NetWB<PRE, PK>, false>(w, acc1);
+  split5<PK>(s.h2, one, b2);
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 * kNT, 0);
+  __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+#endif
   issue<PRE, kChL2B, 0, kN, true>(w, b2, acc2);
   split5<PK>(s.h1, one, b1);
   issue<PRE, kChL1H, 0, kN, true>(w, b1, acc1);
