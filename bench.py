@@ -119,8 +119,12 @@ def work_model(problem, net, D, M):
 def work_block(case, issue, args):
     """cycles_per_tile_step (measured), valu_insts_per_tile_step (PMC), the stated issue-port floor of the tile-step and
     frac_work = floor / measured -- next to the utilisation-type `frac`."""
-    if issue is None or not issue.get("one_wave_per_simd") or case["hbm_bound"]:
-        return None                                           # (the streaming kernels: several tiles per wave, HBM-bound)
+    # one tile per wave, one wave per SIMD by construction (464 / 512 registers per lane; amdgpu_waves_per_eu(1, 1)): the
+    # two-CU fused unroll and the persistent MLP unroll.  (rocprofv3's kernels view reports the architectural VGPR count
+    # only, so the counters file cannot tell.)  The streaming kernels run several tiles per wave and are HBM-bound.
+    one_tile_per_wave = (case["fused"] and not case["hbm_bound"] and case["D"] > 16) or "l2o_mlp_unroll" in case["kernel"]
+    if issue is None or not one_tile_per_wave:
+        return None
     T, dispatches = case["T"], float(case.get("dispatches", 1))
     net = args.net
     wm = work_model(args.problem, net, case["D"], case["Mrows"])

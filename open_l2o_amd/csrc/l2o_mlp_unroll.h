@@ -129,9 +129,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float* xwg = xwg_p + 32;
   __shared__ float imgs[2][kMuMaxBatch][kMuMaxKR];    // the image columns the workgroup's w1 rows touch, by step parity
   __shared__ int labs[2][kMuMaxBatch];
-  __shared__ float Hs[kMuMaxBatch][kMuMaxH];          // hidden activations
-  __shared__ float dHs[kMuMaxBatch][kMuMaxH];
-  __shared__ float dZs[kMuMaxBatch][kMuMaxO];         // logits, then dZ
+  __shared__ __attribute__((aligned(16))) float Hs[kMuMaxBatch][kMuMaxH];          // hidden activations
+  __shared__ __attribute__((aligned(16))) float dHs[kMuMaxBatch][kMuMaxH];
+  __shared__ __attribute__((aligned(16))) float dZs[kMuMaxBatch][kMuMaxO];         // logits, then dZ
   __shared__ float small[kMuMaxH + kMuMaxH * kMuMaxO + kMuMaxO];   // b1 | w2 | b2 (scaled)
   __shared__ __attribute__((aligned(16))) float w2p[kMuMaxH][12];   // FAST: w2 rows padded to 48 bytes
   __shared__ float red[4][kMuMaxR];
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __syncthreads();
       pc.mark(3);
       prefetch_next();
+#ifdef L2O_MU_TAIL_VALU
       // ---- forward tail, every wave for all 64 samples (lane = sample): logits, softmax, loss, dZ in registers
       float hrow[FH], dz[FO];
       {
@@ -391,6 +392,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float hv = Hs[lane][h];
         dHs[lane][h] = a.act == 0 ? d * hv * (1.0f - hv) : (hv > 0.0f ? d : 0.0f);
       }
+#else
+      // ---- forward tail + dH on the fp32 matrix cores (round 4).  Until round 3 every wave evaluated the layer-2 forward,
+      // the softmax and dH for ALL 64 samples with 400 dependent FMAs against w2 rows read from LDS one s_waitcnt at a time
+      // (5.0 k + 2.7 k of the step's 27 k ticks, four-fold redundant).  Now wave w owns samples 16 w .. 16 w + 15 and runs
+      // the two small products as v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
+      //   logits  Z[class][sample] = b2 + sum_h w2[h][class] H[sample][h]    M = classes (10 of 16 rows), K = 20: 5 MFMAs
+      //           D lands as lane (sample c, q) <- classes 4q + r, r = 0..3: the softmax is in-lane over r and two swaps over q
+      //   dH      dHraw[h][sample] = sum_o w2[h][o] dZ[o][sample]            M = hidden (2 tiles), K-slot (kk, q) := class 4q + kk,
+      //           so the B operand of k-step kk IS register kk of the dZ the lane has just formed -- no transpose: 8 MFMAs
+      // dZ, dH go to LDS for the gradient phase (every workgroup needs all 64 samples of both) exactly as before.
+      {
+        const int s_l = 16 * wv + c;                   // this lane's sample
+        f32x4 zacc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zacc[r] = 4 * q + r < FO ? small[FH + FH * FO + 4 * q + r] : 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < FH / 4; ++kk) {
+          const int h = 4 * kk + q;
+          const float av = c < FO ? small[FH + h * FO + c] : 0.0f;     // A[row = class c][k]: w2[h][c]
+          zacc = mfma16(av, Hs[s_l][h], zacc);                         // B[k][col = sample c]
+        }
+        constexpr float kLog2e = 1.4426950408889634f;
+        const int lab = labs[par][s_l];
+        float zmax = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zmax = 4 * q + r < FO ? fmaxf(zmax, zacc[r]) : zmax;
+        {                                                               // max over the four q lanes of the sample
+          u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(zmax), __float_as_uint(zmax), false, false);
+          zmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+          sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(zmax), __float_as_uint(zmax), false, false);
+          zmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        float se = 0.0f, zl = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = 4 * q + r < FO;
+          se += ok ? fast_exp2((zacc[r] - zmax) * kLog2e) : 0.0f;
+          zl += (ok && 4 * q + r == lab) ? zacc[r] : 0.0f;
+        }
+        se = quad_q_sum(se);
+        zl = quad_q_sum(zl);
+        const float lse = zmax + __builtin_amdgcn_logf(se) * 0.6931471805599453f;      // v_log_f32 (log2), 1 ulp
+        f32x4 dzv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dzv[r] = 4 * q + r < FO ? (fast_exp2((zacc[r] - lse) * kLog2e) - (4 * q + r == lab ? 1.0f : 0.0f)) * invB : 0.0f;
+        *reinterpret_cast<f32x4*>(&dZs[s_l][4 * q]) = dzv;             // (classes 10..15: zeros)
+        // loss: the wave's 16 samples (one copy per sample: the q == 0 row), the four waves meet in LDS
+        const float lw = row_sum16(lse - zl);
+        if (lane == 0) red[wv][0] = lw;
+        if (t == a.T && !HIST) {
+          __syncthreads();
+          if (wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
+          pc.mark(4);
+          break;
+        }
+        pc.mark(4);
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int o = 4 * q + kk;                                     // K-slot (kk, q) <-> class 4q + kk
+          const float a0 = o < FO ? w2p[c][o] : 0.0f;                   // A[row = hidden c][k]
+          const float a1 = (o < FO && c < FH - 16) ? w2p[16 + c][o] : 0.0f;
+          d0 = mfma16(a0, dzv[kk], d0);
+          d1 = mfma16(a1, dzv[kk], d1);
+        }
+        // D: lane (sample c, q) <- hidden 4q + r (tile 0), 16 + 4q + r (tile 1: q == 0 only)
+        const f32x4 hv0 = *reinterpret_cast<const f32x4*>(&Hs[s_l][4 * q]);
+        f32x4 o0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o0[r] = a.act == 0 ? d0[r] * hv0[r] * (1.0f - hv0[r]) : (hv0[r] > 0.0f ? d0[r] : 0.0f);
+        *reinterpret_cast<f32x4*>(&dHs[s_l][4 * q]) = o0;
+        if (q == 0) {
+          const f32x4 hv1 = *reinterpret_cast<const f32x4*>(&Hs[s_l][16]);
+          f32x4 o1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o1[r] = a.act == 0 ? d1[r] * hv1[r] * (1.0f - hv1[r]) : (hv1[r] > 0.0f ? d1[r] : 0.0f);
+          *reinterpret_cast<f32x4*>(&dHs[s_l][16]) = o1;
+        }
+      }
+#endif
     } else {
     // ---- partial hidden pre-activations over the workgroup's own w1 coordinates
     if (owns_w1) {
@@ -514,6 +596,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     }
     __syncthreads();
+#ifndef L2O_MU_TAIL_VALU
+    if (FAST && wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
+#endif
     pc.mark(5);                                        // dH
     // ---- the gradient of this lane's coordinate: a sum over the samples, split over the four q lanes
     float gv = 0.0f;
