@@ -132,7 +132,10 @@ const char* l2o_last_error(void);
 #define L2O_OPT_WPACK_NO_CLEAR 10     /* 0*: l2o_wpack_device clears the output buffer before it packs (the padding words of the
                                         fragment layout must be zero); 1: the caller vouches that this buffer already holds a
                                         pack of the same net configuration -- the padding is zero, the memset is skipped          */
-#define L2O_OPT_COUNT_ 11            /* (* = default) */
+#define L2O_OPT_MLP_HIER 11          /* 1*: l2o_mlp_unroll's fast form reduces the hidden pre-activations XCD-hierarchically (one
+                                        fabric hop per step; falls back by itself when the workgroups are not placed round-robin
+                                        over the XCDs); 0: the flat two-hop protocol */
+#define L2O_OPT_COUNT_ 12            /* (* = default) */
 #define L2O_OPTW(o, v) ((uint64_t)(8u | ((unsigned)(v) & 7u)) << (4 * (o)))
 #define L2O_OPTW_BWD_BLOCKS(n) (((uint64_t)(n) & 0xffffu) << 48)
 

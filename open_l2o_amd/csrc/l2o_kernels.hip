@@ -996,7 +996,7 @@ static const int64_t kOptDefault[L2O_OPT_COUNT_] = {
     /* L2O_OPT_PAIR */ 1, /* L2O_OPT_PAIR_PLAIN_STORES */ 1, /* L2O_OPT_UNROLL_CU */ 1,
     /* L2O_OPT_FG_TWO_PASS */ 0, /* L2O_OPT_MLP_GENERIC */ 0, /* L2O_OPT_BWD_BLOCKS */ 0,
     /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* L2O_OPT_PAIR_NORMAL */ 0, /* L2O_OPT_EXACT_GATES */ 0,
-    /* L2O_OPT_WPACK_NO_CLEAR */ 0};
+    /* L2O_OPT_WPACK_NO_CLEAR */ 0, /* L2O_OPT_MLP_HIER */ 1};
 static thread_local uint64_t t_optw = 0;
 struct OptScope {
   uint64_t saved;
@@ -1811,7 +1811,7 @@ int l2o_cwlstm_bwd_step_generic(const l2o_net_cfg* cfg, const l2o_gen_net* net, 
 }
 
 // ---- the fused persistent unroll of the MLP optimizee (csrc/l2o_mlp_unroll.h) ---------------------------
-struct MlpUnrollLayout { int n[4], tile_begin[5], nwg, nw1, R; bool fast; size_t NO, NSM, p_off, s_off, sm_off, total; };
+struct MlpUnrollLayout { int n[4], tile_begin[5], nwg, nw1, R, hier_R1; bool fast; size_t NO, NSM, p_off, s_off, sm_off, hs_off, x_off, s1_off, total; };
 static bool mlp_unroll_layout(const l2o_mlp* mlp, MlpUnrollLayout* L) {
   if (!mlp) return false;
   const int H = mlp->n_hidden, O = mlp->n_out;
@@ -1833,11 +1833,26 @@ static bool mlp_unroll_layout(const l2o_mlp* mlp, MlpUnrollLayout* L) {
   if (L->R > kMuMaxR) return false;
   L->fast = H == 20 && O == 10 && mlp->batch == 64;
   L->p_off = sizeof(MlpWs);
-  // P: generic [nw1][NO]; fast path: one inbox per reducing workgroup, [nwg][nw1][R]
+  // XCD-hierarchical all-reduce (fast path; l2o_mlp_unroll.h): group g = wg % 8, every group needs enough w1 owners to
+  // reduce all NO outputs in slices of R1 (even) <= kMuHierR1Max
+  L->hier_R1 = 0;
+  if (L->fast && opt(L2O_OPT_MLP_HIER) && L->nwg <= 256 && L->nw1 >= 2 * kMuHierG && (L->nwg + kMuHierG - 1) / kMuHierG <= kMuHierM) {
+    const int min_cnt = L->nw1 / kMuHierG;                 // the smallest group
+    int r1 = (int)((L->NO + min_cnt - 1) / min_cnt);
+    r1 = (r1 + 1) & ~1;
+    if (r1 <= kMuHierR1Max) L->hier_R1 = r1;
+  }
+  // P: generic [nw1][NO]; fast path: one inbox per reducing workgroup, [nwg][nw1][R]; hierarchical: [8][M][M][R1]
   const size_t pg = (size_t)L->nw1 * L->NO, pf = (size_t)L->nwg * L->nw1 * L->R;
-  L->s_off = L->p_off + sizeof(unsigned long long) * (pg > pf ? pg : pf);
+  const size_t ph = L->hier_R1 ? (size_t)kMuHierG * kMuHierM * kMuHierM * L->hier_R1 : 0;
+  size_t pmax = pg > pf ? pg : pf;
+  if (ph > pmax) pmax = ph;
+  L->s_off = L->p_off + sizeof(unsigned long long) * pmax;
   L->sm_off = L->s_off + sizeof(unsigned long long) * 2 * L->NO;
-  L->total = L->sm_off + sizeof(unsigned long long) * 2 * ((L->NSM + 1) & ~(size_t)1);
+  L->hs_off = L->sm_off + sizeof(unsigned long long) * 2 * ((L->NSM + 1) & ~(size_t)1);
+  L->x_off = L->hs_off + sizeof(unsigned long long) * 256;
+  L->s1_off = L->x_off + sizeof(unsigned long long) * 2 * kMuHierG * kMuHierM * kMuHierR1Max;
+  L->total = L->s1_off + sizeof(unsigned long long) * 2 * kMuHierG * kMuHierS;
   return true;
 }
 
@@ -1889,6 +1904,10 @@ static int mlp_unroll_launch(const l2o_net_cfg* cfg, const float* wpack, const l
   a.S = reinterpret_cast<unsigned long long*>(wsb + L.s_off);
   a.Sm = reinterpret_cast<unsigned long long*>(wsb + L.sm_off);
   a.nwg = L.nwg; a.nw1 = L.nw1; a.R = L.R;
+  a.hier_R1 = L.hier_R1;
+  a.HS = reinterpret_cast<unsigned long long*>(wsb + L.hs_off);
+  a.X = reinterpret_cast<unsigned long long*>(wsb + L.x_off);
+  a.S1 = reinterpret_cast<unsigned long long*>(wsb + L.s1_off);
   a.use_salt = T + 1 < 0xffff ? 1u : 0u;
   if (hist) {
     for (int k = 0; k < 4; ++k) {

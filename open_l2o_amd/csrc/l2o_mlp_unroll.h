@@ -42,6 +42,17 @@ constexpr int kMuMinH = 8;                 // (bounds the k-rows a workgroup's 6
 constexpr int kMuMaxKR = 64 / kMuMinH + 2; // k-rows of the image a workgroup needs per sample
 constexpr int kMuMaxR = 16;                // outputs per reducing workgroup: batch * H <= 16 * workgroups
 constexpr int kMuMaxG = (kMuMaxBatch * kMuMaxH + 255) / 256;   // sums gathered per thread
+// ---- XCD-hierarchical all-reduce of the FAST form (round 4).  The flat protocol crosses the fabric twice per step
+// (partials -> reducers, sums -> everybody: 5.0 k + 6.2 k of the step's ticks).  Workgroups are placed round-robin over
+// the 8 XCDs (verified per launch through an XCC_ID handshake; any mismatch -> the flat protocol), so group g = wg % 8
+// shares one L2: (A) the partials go to a reducer of the SAME XCD with plain stores (the line stays in that L2, the
+// reader's L1-bypassing load finds it there -- the trick of k_unroll_pair), (B) the 8 per-XCD partial sums of an output
+// cross the fabric ONCE and every XCD adds them in the same order (bit-identical sums on all XCDs), (C) the sums are
+// gathered from the XCD's own copy, again through L2.  Local hop + fabric hop + local hop instead of two fabric hops.
+constexpr int kMuHierG = 8;                // groups = XCDs
+constexpr int kMuHierM = 32;               // members (workgroups) per group, max
+constexpr int kMuHierR1Max = 48;           // outputs per local reducer, max (even)
+constexpr int kMuHierS = kMuHierM * kMuHierR1Max;
 
 struct MlpWs {                 // header of the caller-owned workspace (never cleared by the library)
   unsigned status;             // STICKY: 1 = a publisher never showed up
@@ -72,6 +83,11 @@ struct MlpUnrollArgs {
   unsigned long long* Sm;      // [2][H + H * O + O]      b1, w2, b2 (scaled), by step parity
   int nwg, nw1, R;             // workgroups; workgroups that own w1 coordinates; outputs per reducer
   unsigned use_salt;
+  // XCD-hierarchical all-reduce (round 4, FAST only; hier_R1 == 0: off): outputs per LOCAL reducer, and its buffers
+  int hier_R1;
+  unsigned long long* HS;      // [nwg]                         XCC_ID handshake granules
+  unsigned long long* X;       // [2][8][kMuHierM][hier_R1]     per-XCD partial sums, by step parity (the ONE fabric hop)
+  unsigned long long* S1;      // [2][8][kMuHierS]              every XCD's own copy of the sums, by step parity
   // HIST instantiation (l2o_mlp_unroll_record): per variable, the history the meta-gradient needs
   float* hist_st[4];           // [T][packed state]   the LSTM state BEFORE step t
   float* hist_g[4];            // [T + 1][n]          the (scaled) gradient at x_t; slot T = the gradient at x_T
@@ -99,6 +115,11 @@ typedef unsigned mu_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mu_store2(unsigned long long* p, float v0, float v1, unsigned tag) {
   mu_u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+}
+// the same two granules with a PLAIN store: the line stays (dirty) in the writer's L2 -- for readers on the same XCD only
+__device__ __forceinline__ void mu_store2_local(unsigned long long* p, float v0, float v1, unsigned tag) {
+  mu_u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory");
 }
 __device__ __forceinline__ mu_u32x4 mu_load2(const unsigned long long* p) {
   mu_u32x4 d;
@@ -197,8 +218,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
   load_eval(0, 0);
   __syncthreads();
+  // ---- XCD handshake (hierarchical all-reduce): every workgroup publishes its XCC_ID, reads everybody's and checks
+  // that workgroup i sits on the XCD of workgroup i % 8.  All workgroups read the same table: one consistent decision.
+  __shared__ int hier_s;
+  __shared__ unsigned xcc_s[256];
+  __shared__ float redh[16][kMuHierR1Max];             // stage A: [source chunk][output] partial sums
+  __shared__ float redx[kMuHierG][kMuHierR1Max];       // stage B: [XCD][output] per-XCD partial sums
+  bool hier = false;                                   // (constant false when the protocol is compiled out)
+#ifdef L2O_MU_NO_HIER
+  constexpr bool kHierBuilt = false;
+#else
+  constexpr bool kHierBuilt = true;
+#endif
+  if constexpr (FAST && kHierBuilt) {
+    if (a.hier_R1 > 0) {
+      const unsigned kHs = 0x80000000u | salt | 0xfffeu;
+      if (tid == 0) {
+        unsigned my_xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        __hip_atomic_store(a.HS + wg, ((unsigned long long)kHs << 32) | (my_xcc & 0xfu), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        hier_s = 1;
+      }
+      __syncthreads();
+      if (tid < a.nwg) xcc_s[tid] = __float_as_uint(mu_poll(a.HS + tid, kHs, dead, status)) & 0xfu;
+      __syncthreads();
+      if (tid < a.nwg && (dead || xcc_s[tid] != xcc_s[tid & (kMuHierG - 1)])) hier_s = 0;
+      __syncthreads();
+      hier = hier_s != 0;
+    }
+  }
 
   const float invB = 1.0f / (float)Bn;
+  // this thread's slots of the image-column panel: slot e = tid + 256 u -> (sample e / KR, k-row e % KR).  The two per-step
+  // loops over the panel divided by the runtime KR ten times per step (~350 instructions); round 4: one multiply by a
+  // 16-bit reciprocal (exact for e < 2^12, KR <= 10) -- or, -DL2O_MU_SLOT_REGS, the slots kept in five registers
+  constexpr int kPre = (kMuMaxBatch * kMuMaxKR + 255) / 256;
+  const unsigned kr_rcp = KR > 0 ? (65536u + (unsigned)KR - 1u) / (unsigned)KR : 0u;
+#ifdef L2O_MU_SLOT_REGS
+  int pre_slot[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int e = tid + 256 * u;
+    pre_slot[u] = -1;
+    if (KR > 0 && e < Bn * KR) { const int sidx = e / KR; pre_slot[u] = (sidx << 8) | (e - sidx * KR); }
+  }
+  auto slot_of = [&](int u) { return pre_slot[u]; };
+#else
+  auto slot_of = [&](int u) {
+    const int e = tid + 256 * u;
+    if (e >= Bn * KR) return -1;
+    const int sidx = (int)(((unsigned)e * kr_rcp) >> 16);
+    return (sidx << 8) | (e - sidx * KR);
+  };
+#endif
+  __shared__ int idx_s[kMuMaxBatch];                     // the NEXT evaluation's minibatch indices (see prefetch_next)
   core.init(s, q);
   core.preload(acc1, acc2);                                 // accumulator inits of the first step (the biases)
   PhaseClock pc;
@@ -215,27 +289,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     if (q == 0 && !tile_real && owns_w1) xwg[wv * kTile + c] = 0.0f;
-    float pre_img[(kMuMaxBatch * kMuMaxKR + 255) / 256];
+    float pre_img[kPre];
     int pre_lab = 0;
     const bool have_next = t < a.T;
     // the next evaluation's image columns / labels -> registers: requested once the sums of THIS evaluation are in
     // (vector-memory returns in order: ahead of the polls the gather would delay them, and in front of the step's
     // first barrier its two dependent latencies sat on the critical path), completed under the forward tail
+    // (-DL2O_MU_IDX_LDS: the indices of the next minibatch are requested at the TOP of the step -- nidx below -- and passed
+    //  through LDS behind the reduce phase's barrier instead of being loaded here, in front of the image / label loads that
+    //  depend on them.  Measured 2 % SLOWER (kernel 1.904 vs 1.867 ms per T = 200 unroll, profiles/r04j_*): not the default)
     auto prefetch_next = [&]() {
       if (have_next) {
-        const int* ix = a.idx + (size_t)(t + 1) * Bn;
 #pragma unroll
-        for (int u = 0; u < (kMuMaxBatch * kMuMaxKR + 255) / 256; ++u) {
-          const int e = tid + 256 * u;
+        for (int u = 0; u < kPre; ++u) {
           pre_img[u] = 0.0f;
-          if (e < Bn * KR) {
-            const int sidx = e / KR, kk = e - sidx * KR;
-            pre_img[u] = a.images[(size_t)ix[sidx] * n_in + k0 + kk];
-          }
+          const int sl = slot_of(u);
+#ifndef L2O_MU_IDX_LDS
+          if (sl >= 0) pre_img[u] = a.images[(size_t)a.idx[(size_t)(t + 1) * Bn + (sl >> 8)] * n_in + k0 + (sl & 0xff)];
+#else
+          if (sl >= 0) pre_img[u] = a.images[(size_t)idx_s[sl >> 8] * n_in + k0 + (sl & 0xff)];
+#endif
         }
-        if (tid < Bn) pre_lab = a.labels[ix[tid]];
+#ifndef L2O_MU_IDX_LDS
+        if (tid < Bn) pre_lab = a.labels[a.idx[(size_t)(t + 1) * Bn + tid]];
+#else
+        if (tid < Bn) pre_lab = a.labels[idx_s[tid]];
+#endif
       }
     };
+    int nidx = 0;
+#ifdef L2O_MU_IDX_LDS
+    if (have_next && tid < Bn) nidx = a.idx[(size_t)(t + 1) * Bn + tid];
+#endif
     __syncthreads();                                   // xwg complete
     pc.mark(0);
     if constexpr (FAST) {
@@ -257,8 +342,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               acc0 = __builtin_fmaf(im, xwg[jj], acc0);
               acc1 = __builtin_fmaf(im, xwg[jj + 1], acc1);
             }
-            const int r = o / R;
-            mu_store2(a.P + ((size_t)r * a.nw1 + wg) * R + (o - r * R), acc0, acc1, tag);
+            if (hier) {                                  // -> the inbox of the reducer of these outputs on THIS XCD
+              const int mr = o / a.hier_R1;
+              mu_store2_local(a.P + ((((size_t)(wg & (kMuHierG - 1)) * kMuHierM + mr) * kMuHierM + (wg >> 3)) * a.hier_R1 +
+                                     (o - mr * a.hier_R1)), acc0, acc1, tag);
+            } else {
+              const int r = o / R;
+              mu_store2(a.P + ((size_t)r * a.nw1 + wg) * R + (o - r * R), acc0, acc1, tag);
+            }
           }
         }
       }
@@ -273,6 +364,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (tid >= FH && tid < FH + FH * FO) { const int e = tid - FH; w2p[e / FO][e % FO] = val; }
       }
       pc.mark(1);
+#ifdef L2O_MU_IDX_LDS
+      if (have_next && tid < Bn) idx_s[tid] = nidx;      // (its readers sit behind the reduce phase's barrier)
+#endif
+      if (hier) {
+        // ---- (A) local reduce: member (g, mr) sums outputs [mr R1, mr R1 + R1) over the w1 owners of ITS XCD.
+        // thread = (output pair p, source chunk ch): sources ch, ch + nch, ... in ascending order, then the chunks in
+        // ascending order -- a fixed summation order.  (B) publish the XCD's partial through the fabric, collect the 8
+        // XCDs' partials of the same outputs, add them in the order g = 0..7 on EVERY XCD.  (C) the sums -> this XCD's copy.
+        // (indices through opaque zeros: LICM otherwise hoists every per-thread 64-bit address of this block out of the
+        //  step loop and keeps it in registers for the whole unroll -- 60 more spilled registers in a kernel at its limit)
+        int oz = 0, soz = 0;
+        asm volatile("" : "+v"(oz));
+        asm volatile("" : "+s"(soz));
+        const int tid = threadIdx.x + oz, wg = blockIdx.x + soz;
+        const int R1 = a.hier_R1, g = wg & (kMuHierG - 1), mr = wg >> 3;
+        const int cnt = (a.nw1 - 1 - g) / kMuHierG + 1;          // w1 owners in group g
+        const int o0 = mr * R1;
+        const int nr = min(R1, FNO - o0);                        // <= 0: no outputs left for this member (workgroup-uniform)
+        if (owns_w1 && nr > 0) {
+          const int np = nr / 2, nch = min(256 / np, 16);
+          const int pq = tid % np, ch = tid / np;
+          float s0 = 0.0f, s1 = 0.0f;
+          if (ch < nch) {
+            const unsigned long long* inbox = a.P + (((size_t)g * kMuHierM + mr) * kMuHierM) * R1 + 2 * pq;
+            for (int base = ch; base < cnt; base += 3 * nch) {   // up to 3 sources in flight per thread, then their tags
+              mu_u32x4 d[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                if (base + k * nch < cnt) d[k] = mu_load2(inbox + (size_t)(base + k * nch) * R1);
+              mu_wait_loads();
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                if (base + k * nch < cnt) {
+                  d[k] = mu_poll2(inbox + (size_t)(base + k * nch) * R1, d[k], tag, dead, status);
+                  s0 += __uint_as_float(d[k][0]);
+                  s1 += __uint_as_float(d[k][2]);
+                }
+            }
+            redh[ch][2 * pq] = s0;
+            redh[ch][2 * pq + 1] = s1;
+          }
+          __syncthreads();
+          float x0 = 0.0f, x1 = 0.0f;
+          if (tid < np) {
+            for (int k = 0; k < nch; ++k) { x0 += redh[k][2 * tid]; x1 += redh[k][2 * tid + 1]; }
+            mu_store2(a.X + (((size_t)par * kMuHierG + g) * kMuHierM + mr) * R1 + 2 * tid, x0, x1, tag);   // (B) the one fabric hop
+            redx[g][2 * tid] = x0;
+            redx[g][2 * tid + 1] = x1;
+          }
+          // thread = (XCD g2, pair): ONE granule pair each from the other XCDs' partials of these outputs
+          if (tid < kMuHierG * np) {
+            const int g2 = tid / np, p2 = tid - g2 * np;
+            if (g2 != g) {
+              const unsigned long long* xp = a.X + (((size_t)par * kMuHierG + g2) * kMuHierM + mr) * R1 + 2 * p2;
+              mu_u32x4 d = mu_load2(xp);
+              mu_wait_loads();
+              d = mu_poll2(xp, d, tag, dead, status);
+              redx[g2][2 * p2] = __uint_as_float(d[0]);
+              redx[g2][2 * p2 + 1] = __uint_as_float(d[2]);
+            }
+          }
+          __syncthreads();
+          if (tid < np) {                                          // the same order g = 0..7 on every XCD: identical sums
+            float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+            for (int g2 = 0; g2 < kMuHierG; ++g2) { t0 += redx[g2][2 * tid]; t1 += redx[g2][2 * tid + 1]; }
+            mu_store2_local(a.S1 + ((size_t)par * kMuHierG + g) * kMuHierS + o0 + 2 * tid, t0, t1, tag);   // (C)
+          }
+        } else {
+          __syncthreads();
+          __syncthreads();
+        }
+      } else
       // ---- reduce-scatter: thread = source workgroup, R granules contiguous in this workgroup's inbox
       {
         const int o0 = wg * R;
@@ -314,7 +478,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       pc.mark(2);
       // ---- gather the sums (pairs), bias + activation fused into the LDS write
       {
-        const unsigned long long* Sp = a.S + (size_t)par * FNO;
+        const unsigned long long* Sp = hier ? a.S1 + ((size_t)par * kMuHierG + (wg & (kMuHierG - 1))) * kMuHierS
+                                            : a.S + (size_t)par * FNO;
         mu_u32x4 g[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -490,6 +655,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
     core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
     pc.mark(1);                                        // partial + publish
+#ifdef L2O_MU_IDX_LDS
+    if (have_next && tid < Bn) idx_s[tid] = nidx;      // (its readers sit behind the gather's barrier)
+#endif
     // ---- reduce-scatter: this workgroup sums outputs [wg R, wg R + R) over all partials, fixed order.
     // All R granules of a source are requested before the first tag is checked (one L2 / fabric round trip
     // per source, not R of them)
@@ -660,12 +828,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pc.mark(7);                                        // LSTM tile step
     // ---- the prefetched next evaluation -> the other parity buffer (its previous readers finished two barriers ago)
 #pragma unroll
-    for (int u = 0; u < (kMuMaxBatch * kMuMaxKR + 255) / 256; ++u) {
-      const int e = tid + 256 * u;
-      if (e < Bn * KR) {
-        const int sidx = e / KR, kk = e - sidx * KR;
-        imgs[par ^ 1][sidx][kk] = pre_img[u];
-      }
+    for (int u = 0; u < kPre; ++u) {
+      const int sl = slot_of(u);
+      if (sl >= 0) imgs[par ^ 1][sl >> 8][sl & 0xff] = pre_img[u];
     }
     if (tid < Bn) labs[par ^ 1][tid] = pre_lab;
     pc.mark(8);
