@@ -127,6 +127,18 @@ __device__ __forceinline__ mu_u32x4 mu_load2(const unsigned long long* p) {
   return d;
 }
 __device__ __forceinline__ void mu_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The step loop's workgroup barrier.  -DL2O_MU_LDS_BARRIERS: wait for LDS traffic only (the barriers order LDS data; the
+// cross-workgroup protocol is self-validating granules) instead of __syncthreads(), which also drains the vector-memory
+// queue -- e.g. the next minibatch's image columns at the barrier behind dH.  Measured 1 % SLOWER (kernel 1.885 vs 1.869 ms
+// per T = 200 unroll, profiles/r04k_c5_barriers_ab.txt): not the default.
+__device__ __forceinline__ void mu_barrier() {
+#ifdef L2O_MU_LDS_BARRIERS
+  lds_barrier();
+#else
+  __syncthreads();
+#endif
+}
+
 // two granules at p until both carry `tag` (bounded, with back-off: a failed poll is a fabric request that competes
 // with the stores it waits for)
 __device__ __forceinline__ mu_u32x4 mu_poll2(const unsigned long long* p, mu_u32x4 d, unsigned tag, bool& dead, unsigned* status) {
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef L2O_MU_IDX_LDS
     if (have_next && tid < Bn) nidx = a.idx[(size_t)(t + 1) * Bn + tid];
 #endif
-    __syncthreads();                                   // xwg complete
+    mu_barrier();                                   // xwg complete
     pc.mark(0);
     if constexpr (FAST) {
       constexpr int FH = 20, FO = 10, FB = 64, FNO = FB * FH;
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             redh[ch][2 * pq] = s0;
             redh[ch][2 * pq + 1] = s1;
           }
-          __syncthreads();
+          mu_barrier();
           float x0 = 0.0f, x1 = 0.0f;
           if (tid < np) {
             for (int k = 0; k < nch; ++k) { x0 += redh[k][2 * tid]; x1 += redh[k][2 * tid + 1]; }
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               redx[g2][2 * p2 + 1] = __uint_as_float(d[2]);
             }
           }
-          __syncthreads();
+          mu_barrier();
           if (tid < np) {                                          // the same order g = 0..7 on every XCD: identical sums
             float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
@@ -433,8 +445,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             mu_store2_local(a.S1 + ((size_t)par * kMuHierG + g) * kMuHierS + o0 + 2 * tid, t0, t1, tag);   // (C)
           }
         } else {
-          __syncthreads();
-          __syncthreads();
+          mu_barrier();
+          mu_barrier();
         }
       } else
       // ---- reduce-scatter: thread = source workgroup, R granules contiguous in this workgroup's inbox
@@ -466,13 +478,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               const float ws_ = wave_sum64(part[r]);
               if (lane == 0) red[wv][r] = ws_;
             }
-          __syncthreads();
+          mu_barrier();
           if (2 * tid < nr)
             mu_store2(a.S + (size_t)par * FNO + o0 + 2 * tid,
                       (red[0][2 * tid] + red[1][2 * tid]) + (red[2][2 * tid] + red[3][2 * tid]),
                       (red[0][2 * tid + 1] + red[1][2 * tid + 1]) + (red[2][2 * tid + 1] + red[3][2 * tid + 1]), tag);
         } else {
-          __syncthreads();
+          mu_barrier();
         }
       }
       pc.mark(2);
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
         }
       }
-      __syncthreads();
+      mu_barrier();
       pc.mark(3);
       prefetch_next();
 #ifdef L2O_MU_TAIL_VALU
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float lw = row_sum16(lse - zl);
         if (lane == 0) red[wv][0] = lw;
         if (t == a.T && !HIST) {
-          __syncthreads();
+          mu_barrier();
           if (wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
           pc.mark(4);
           break;
@@ -687,7 +699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float ws_ = wave_sum64(part[r]);
             if (lane == 0) red[wv][r] = ws_;
           }
-        __syncthreads();
+        mu_barrier();
         if (tid < nr)
           __hip_atomic_store(a.S + (size_t)par * NO + o0 + tid,
                              mu_granule((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]), tag),
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
     }
-    __syncthreads();
+    mu_barrier();
     pc.mark(3);                                        // gather
     prefetch_next();
     const float* b1s = small;
@@ -730,14 +742,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float av = Hs[sidx][h] + b1s[h];
       Hs[sidx][h] = a.act == 0 ? 1.0f / (1.0f + expf(-av)) : fmaxf(av, 0.0f);
     }
-    __syncthreads();
+    mu_barrier();
     for (int e = tid; e < Bn * O; e += 256) {          // logits
       const int sidx = e / O, o = e - sidx * O;
       float z = b2s[o];
       for (int h = 0; h < H; ++h) z = __builtin_fmaf(Hs[sidx][h], w2s[h * O + o], z);
       dZs[sidx][o] = z;
     }
-    __syncthreads();
+    mu_barrier();
     float lossn = 0.0f;
     if (tid < Bn) {                                    // softmax cross-entropy of sample tid
       const int lab = labs[par][tid];
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     lossn = wave_sum64(lossn);
     if (lane == 0) red[wv][0] = lossn;
-    __syncthreads();
+    mu_barrier();
     if (wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
     pc.mark(4);                                        // activation, layer 2, softmax, loss
     if (t == a.T && !HIST) break;
@@ -763,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       dHs[sidx][h] = a.act == 0 ? d * hv * (1.0f - hv) : (hv > 0.0f ? d : 0.0f);
     }
     }
-    __syncthreads();
+    mu_barrier();
 #ifndef L2O_MU_TAIL_VALU
     if (FAST && wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
 #endif
