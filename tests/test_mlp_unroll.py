@@ -103,3 +103,36 @@ def test_unsupported_shapes_fall_back(hip):
         sess.run(ml.reset)
         fx = sess.run([ml.fx, ml.update])[0]
     assert opt.graph.last_path == "steps" and np.isfinite(fx)
+
+
+def test_hierarchical_allreduce_equals_flat(hip):
+    """L2O_OPT_MLP_HIER (round 4, default on): the XCD-hierarchical all-reduce of the hidden pre-activations (per-XCD
+    partial sums through L2, ONE fabric hop, 8-way sum in a fixed order) against the flat two-hop protocol on the same
+    minibatches -- same losses and weights up to the fp32 summation order of the 245 partial products; and the hierarchical
+    run is bit-reproducible (fixed orders everywhere)."""
+    data = problems.synthetic_mnist(300, seed=4)
+    T, batch = 12, 64
+    idx = np.random.default_rng(90).integers(0, 300, size=(2 * (T + 1), batch))
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=91, trained_like=True)
+    res = {}
+    for mode in ("hier", "hier_again", "flat"):
+        with lib_option(_abi.OPT_MLP_HIER, 0 if mode == "flat" else 1):
+            meta.set_random_seed(13)
+            problem = problems.mnist(layers=(20,), batch_size=batch, data=data, sampler=_sampler(idx))
+            opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+            ml, _, _, step = opt.meta_loss(problem, T)
+            out = []
+            with Session() as sess:
+                sess.run(ml.reset)
+                for i in range(2):
+                    out.append(sess.run([ml.loss, ml.fx, ml.update], feed_dict={step: 1 + i * T})[:2])
+                xs = [v.eval() for v in opt.graph.x]
+            assert opt.graph.last_path == "mlp_unroll"
+            res[mode] = (np.array(out, np.float64), xs)
+    assert np.array_equal(res["hier"][0], res["hier_again"][0])
+    for a, b in zip(res["hier"][1], res["hier_again"][1]):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(res["hier"][0], res["flat"][0], rtol=2e-5)
+    for a, b in zip(res["hier"][1], res["flat"][1]):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6)
