@@ -247,10 +247,14 @@ struct PhaseClock {
 #pragma unroll
     for (int t = 0; t < 5; ++t) asm volatile("" : "+v"(a[t]));
   }
+  template <class V>
+  __device__ __forceinline__ void drain1(V& v) { asm volatile("" : "+v"(v)); }
   __device__ __forceinline__ void dump(long long* out) {
     for (int i = 0; i < 12; ++i) out[i] = acc[i];
   }
 #else
+  template <class V>
+  __device__ __forceinline__ void drain1(V&) {}
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void mark(int) {}
   template <class A>

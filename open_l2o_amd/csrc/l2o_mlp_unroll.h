@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       mu_barrier();
       pc.mark(3);
       prefetch_next();
+      pc.mark(9);                                      // (profiling build: the next minibatch's loads are requested)
 #ifdef L2O_MU_TAIL_VALU
       // ---- forward tail, every wave for all 64 samples (lane = sample): logits, softmax, loss, dZ in registers
       float hrow[FH], dz[FO];
@@ -590,6 +591,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const float av = c < FO ? small[FH + h * FO + c] : 0.0f;     // A[row = class c][k]: w2[h][c]
           zacc = mfma16(av, Hs[s_l][h], zacc);                         // B[k][col = sample c]
         }
+        pc.drain1(zacc);
+        pc.mark(10);                                   // (profiling build: the logits' five MFMAs)
         constexpr float kLog2e = 1.4426950408889634f;
         const int lab = labs[par][s_l];
         float zmax = -3.0e38f;
@@ -635,6 +638,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           d0 = mfma16(a0, dzv[kk], d0);
           d1 = mfma16(a1, dzv[kk], d1);
         }
+        pc.drain1(d0);
+        pc.drain1(d1);
+        pc.mark(11);                                   // (profiling build: dH's eight MFMAs)
         // D: lane (sample c, q) <- hidden 4q + r (tile 0), 16 + 4q + r (tile 1: q == 0 only)
         const f32x4 hv0 = *reinterpret_cast<const f32x4*>(&Hs[s_l][4 * q]);
         f32x4 o0;
