@@ -135,7 +135,10 @@ const char* l2o_last_error(void);
 #define L2O_OPT_MLP_HIER 11          /* 1*: l2o_mlp_unroll's fast form reduces the hidden pre-activations XCD-hierarchically (one
                                         fabric hop per step; falls back by itself when the workgroups are not placed round-robin
                                         over the XCDs); 0: the flat two-hop protocol */
-#define L2O_OPT_COUNT_ 12            /* (* = default) */
+#define L2O_OPT_ONE_LDS 12           /* large shards of the fused unroll (DM nets, 65 <= padded size <= 128): 0: consecutive chunk
+                                        launches of the two-CU kernel; 1*: one problem per CU, two waves per SIMD, the gate-GEMM
+                                        fragments in LDS (k_unroll_lds) whenever the shard exceeds #CU / 2 problems; 2: always */
+#define L2O_OPT_COUNT_ 13            /* (* = default) */
 #define L2O_OPTW(o, v) ((uint64_t)(8u | ((unsigned)(v) & 7u)) << (4 * (o)))
 #define L2O_OPTW_BWD_BLOCKS(n) (((uint64_t)(n) & 0xffffu) << 48)
 

@@ -37,10 +37,10 @@ SYMBOLS = (
 # environment variables once at import, changed by set_option) that NetSpec.to_c() / the problem and MLP descriptors
 # encode into every struct they hand to the library.
 OPT_PAIR, OPT_PAIR_PLAIN_STORES, OPT_UNROLL_CU, OPT_FG_TWO_PASS, OPT_MLP_GENERIC, OPT_BWD_BLOCKS, OPT_BWD_KERNEL, \
-    OPT_MLP_UNROLL, OPT_PAIR_NORMAL, OPT_EXACT_GATES, OPT_WPACK_NO_CLEAR, OPT_MLP_HIER = range(12)
+    OPT_MLP_UNROLL, OPT_PAIR_NORMAL, OPT_EXACT_GATES, OPT_WPACK_NO_CLEAR, OPT_MLP_HIER, OPT_ONE_LDS = range(13)
 OPT_DEFAULTS = {OPT_PAIR: 1, OPT_PAIR_PLAIN_STORES: 1, OPT_UNROLL_CU: 1, OPT_FG_TWO_PASS: 0, OPT_MLP_GENERIC: 0,
                 OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_PAIR_NORMAL: 0, OPT_EXACT_GATES: 0,
-                OPT_WPACK_NO_CLEAR: 0, OPT_MLP_HIER: 1}
+                OPT_WPACK_NO_CLEAR: 0, OPT_MLP_HIER: 1, OPT_ONE_LDS: 1}
 PROB_FG_TWO_PASS = 2      # l2o_problem.flags
 MLP_GENERIC = 1           # l2o_mlp.flags
 _options = {}
@@ -59,6 +59,7 @@ _ENV_OPTIONS = (
     ("L2O_PAIR_NORMAL", OPT_PAIR_NORMAL, lambda v: 1),
     ("L2O_EXACT_GATES", OPT_EXACT_GATES, lambda v: 1),
     ("L2O_NO_MLP_HIER", OPT_MLP_HIER, lambda v: 0),
+    ("L2O_ONE_LDS", OPT_ONE_LDS, lambda v: int(v)),
 )
 for _name, _opt, _conv in _ENV_OPTIONS:
     if os.environ.get(_name):

@@ -846,6 +846,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   store_tile_state(s, st_tile, lane);
 }
 
+#include "l2o_unroll_lds.h"
 #include "l2o_unroll_pair.h"
 #include "l2o_unroll_pairh.h"
 
@@ -996,7 +997,7 @@ static const int64_t kOptDefault[L2O_OPT_COUNT_] = {
     /* L2O_OPT_PAIR */ 1, /* L2O_OPT_PAIR_PLAIN_STORES */ 1, /* L2O_OPT_UNROLL_CU */ 1,
     /* L2O_OPT_FG_TWO_PASS */ 0, /* L2O_OPT_MLP_GENERIC */ 0, /* L2O_OPT_BWD_BLOCKS */ 0,
     /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* L2O_OPT_PAIR_NORMAL */ 0, /* L2O_OPT_EXACT_GATES */ 0,
-    /* L2O_OPT_WPACK_NO_CLEAR */ 0, /* L2O_OPT_MLP_HIER */ 1};
+    /* L2O_OPT_WPACK_NO_CLEAR */ 0, /* L2O_OPT_MLP_HIER */ 1, /* L2O_OPT_ONE_LDS */ 1};
 static thread_local uint64_t t_optw = 0;
 struct OptScope {
   uint64_t saved;
@@ -1134,7 +1135,22 @@ template <int PRE, int KIND>
 static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_t s, const l2o_problem* prob,
                             void* workspace, float* fx, bool* fx_done) {
   const bool hist = a.hist_st != nullptr;
-  const int chunk = workspace ? pair_chunk(prob, g, s) : 0;
+  int chunk = workspace ? pair_chunk(prob, g, s) : 0;
+  // Large shards (round 4): one problem per CU with two waves per SIMD and the fragments in LDS (k_unroll_lds) instead of
+  // consecutive chunk launches of the two-CU kernel -- L2O_OPT_ONE_LDS: 0 never, 1 when the shard needs chunk launches
+  // (more problems than #CU / 2), 2 always (A/B runs).  DM nets, 5..8 tiles, no exact-gates request.
+  if constexpr (PRE != L2O_PRE_FC_ELU) {
+    const int one_lds = (int)opt(L2O_OPT_ONE_LDS);
+    const bool wants = one_lds == 2 || (one_lds == 1 && chunk > 0 && a.pp.B_local > chunk);
+    if (wants && g.CH == 8 && g.nw >= 5 && !(opt(L2O_OPT_EXACT_GATES) && !hist)) {
+      void (*fl)(UnrollArgs) = hist ? k_unroll_lds<PRE, KIND, true> : k_unroll_lds<PRE, KIND, false>;
+      const size_t lds = sizeof(float) * ((size_t)LstmCoreLds<PRE>::kFragWords + 2 * 128 + 8);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(fl, dim3(a.pp.B_local), dim3(64 * g.nw), lds, s, a);
+      HIP_TRY(hipGetLastError());
+      return L2O_OK;
+    }
+  }
   if (chunk > 0) {
     const PairLayout L = pair_layout(prob, g, a.T);
     UnrollPairArgs pa;

@@ -188,6 +188,16 @@ struct NetWB {
   float bl;
   float fcw0[kNT], fcw1[kNT], fcb[kNT];   // RNNProp input projection (2 -> 20)
   const __attribute__((address_space(3))) f32x4* bias;   // LDS: this lane group's [layer][t] accumulator inits (set_bias)
+  static constexpr bool kLdsFrags = false;               // (NetWBL: the A operands are read from LDS at issue time)
+};
+// The packed DM network with its weight FRAGMENTS IN LDS (round 4, k_unroll_lds): `a` is never loaded (no registers), an
+// MFMA's A operand is one ds_read_b128 from the workgroup's 60 KB fragment image -- what lets TWO waves share a SIMD
+// (256 registers each) where the register-resident form needs 240 AGPRs per wave.  lfr points at this lane's 16 bytes of
+// fragment 0; fragment (chunk, M-tile, MFMA j) sits at a compile-time offset (ds_read_b128 immediate, < 64 KB).
+template <int PRE>
+struct NetWBL : NetWB<PRE, true> {
+  static constexpr bool kLdsFrags = true;
+  const __attribute__((address_space(3))) u32x4* lfr;
 };
 
 // every thread of the workgroup copies its share of the bias table into LDS (160 floats); the caller's barrier follows
@@ -260,14 +270,17 @@ __device__ __forceinline__ void preload_bias(const W& w, f32x4 (&acc)[kNT]) {
 
 // MFMAs [LO, HI) of chunk CH (index n: packed MFMA | product n / 5, M-tile n % 5 -- consecutive MFMAs hit
 // different accumulators).  ZERO: the first one starts the accumulator (C = the layer's bias, see bias_off).
-template <int PRE, int CH, int LO, int HI, bool ZERO, bool PK>
-__device__ __forceinline__ void issue(const NetWB<PRE, PK>& w, const BOp<PK>& b, f32x4 (&acc)[kNT]) {
+template <int PRE, int CH, int LO, int HI, bool ZERO, bool PK, class W>
+__device__ __forceinline__ void issue(const W& w, const BOp<PK>& b, f32x4 (&acc)[kNT]) {
   static_for<LO, HI>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
     constexpr int p = n / kNT, t = n % kNT;
     // ZERO: this MFMA starts the layer's accumulator -- from the layer's bias, which preload_bias() put INTO acc[t]
     // long before (the ds_read_b128 rides behind the gate block that consumed the accumulator), not from zero
-    if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], acc[t]);
+    if constexpr (W::kLdsFrags) {
+      static_assert(PK, "LDS-resident fragments: the packed form");
+      acc[t] = mfma_bf(w.lfr[((CH * kNT + t) * kPack + p) * 64], b.m[p], acc[t]);
+    } else if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], acc[t]);
     else acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.m[prod_x(p)], acc[t]);
   });
 }
@@ -369,8 +382,8 @@ __device__ __forceinline__ void gates5_scalar(const f32x4 (&acc)[kNT], float (&c
 struct NoShadow { __device__ __forceinline__ void operator()() const {} };
 // REARM: leave acc1 / acc2 re-initialised with the biases for the NEXT step (the persistent unroll kernels); tile_step
 // (a fresh pair of accumulators per call) switches it off -- the pinned loads would be 10 dead ds_read_b128 per tile
-template <int PRE, bool NEXT, bool PK, class Shadow = NoShadow, bool REARM = true>
-__device__ __forceinline__ float finish(const NetWB<PRE, PK>& w, TileState& s, BOp<PK>& b1, BOp<PK>& b2,
+template <int PRE, bool NEXT, bool PK, class Shadow = NoShadow, bool REARM = true, class W = NetWB<PRE, PK>>
+__device__ __forceinline__ float finish(const W& w, TileState& s, BOp<PK>& b1, BOp<PK>& b2,
                                         f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1, unsigned one,
                                         int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
   constexpr int kN = chunk_mfmas(PK);
@@ -571,6 +584,54 @@ struct LstmCore<PRE, true, PK> {
   }
   // after finish<false>: b1 already holds split h1(t) (finish builds it for chunk L2A); split h2(t) for chunk L2B
   __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<PK>(s.h2, one, b2); }
+};
+
+// BX packed form with the fragments in LDS (bx::NetWBL): the same interface as LstmCore, <= 256 registers per lane
+template <int PRE>
+struct LstmCoreLds {
+  static constexpr int kTotal = bx::chunk_mfmas(true), kHalf = kTotal / 2;
+  static constexpr int kFragWords = bx::packed_words(PRE);            // 3 chunks x 5 M-tiles x 4 MFMAs x 256 words = 60 KB
+  bx::NetWBL<PRE> w;
+  bx::BOp<true> b1, b2;
+  unsigned one;
+  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, false, true>(w, wpack, lane); }
+  // every thread copies its share of the packed fragment section of wpack into LDS (16-byte pieces); a barrier follows
+  __device__ __forceinline__ void stage_frags(float* lds, const float* __restrict__ wpack, int tid, int nthreads, int lane) {
+    const bx::u32x4* src = reinterpret_cast<const bx::u32x4*>(wpack + bx::base(PRE));
+    bx::u32x4* dst = reinterpret_cast<bx::u32x4*>(lds);
+    for (int i = tid; i < kFragWords / 4; i += nthreads) dst[i] = src[i];
+    w.lfr = reinterpret_cast<const __attribute__((address_space(3))) bx::u32x4*>(
+                (const __attribute__((address_space(3))) float*)lds) + lane;
+  }
+  static constexpr int kBiasFloats = bx::kBiasWords;
+  __device__ __forceinline__ void stage_bias(float* lds, const float* __restrict__ wpack, int tid, int nthreads, int q) {
+    bx::stage_bias(lds, wpack, PRE, tid, nthreads);
+    bx::set_bias(w, lds, q);
+  }
+  __device__ __forceinline__ void pin() {}
+  __device__ __forceinline__ void init(const TileState& s, int q) {
+    one = bx::bias_one<true>(q);
+    bx::split5<true>(s.h1, one, b1);
+    bx::split5<true>(s.h2, one, b2);
+  }
+  __device__ __forceinline__ void preload(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
+    bx::preload_bias<0>(w, acc1);
+    bx::preload_bias<1>(w, acc2);
+  }
+  template <int LO, int HI>
+  __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {
+    bx::issue<PRE, bx::kChL1H, LO, HI, true>(w, b1, acc1);
+  }
+  template <int LO, int HI>
+  __device__ __forceinline__ void issue_l2_prev(const TileState&, f32x4 (&acc2)[kNT]) {
+    bx::issue<PRE, bx::kChL2B, LO, HI, true>(w, b2, acc2);
+  }
+  template <bool NEXT, class Shadow = bx::NoShadow, bool REARM = true>
+  __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
+                                          int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
+    return bx::finish<PRE, NEXT, true, Shadow, REARM>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, static_cast<Shadow&&>(shadow));
+  }
+  __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<true>(s.h2, one, b2); }
 };
 
 }  // namespace l2o

@@ -14,6 +14,7 @@
 #   final:CFG[:ARGS]         bench + trace + counters of ONE config back to back in this lease (same build, same box):
 #                            what the roofline block of the round's bench line is recomputed from
 #   train:NAME[:SECONDS]     meta-train one committed optimizer (NAME = c2|c3|c4|c5) -> trained/<dir>/
+#   env:VAR=VALUE            export VAR=VALUE for the jobs that follow (env:VAR= unsets it), e.g. env:L2O_ONE_LDS=2 tests:-k+fused
 #   bench2ranks              the N > 1 bench path as two gloo ranks on this one device
 #   py:SCRIPT[:ARGS]         python SCRIPT ARGS  > SCRIPT-basename.txt
 #   sh:COMMAND               bash -c COMMAND      > sh_N.txt   ('+' separates words, as above)
@@ -40,7 +41,7 @@ workload_json() { # the `workload` key scripts/counters_to_json.py stores and be
     5) echo '["mnist", "rnnprop", 15910, 64, 200]' ;;
   esac
 }
-kernel_of() { case $1 in 2|4) echo 'k_unroll_pair<' ;; 3) echo 'k_unroll_cu<' ;; 5) echo 'k_mlp_unroll<' ;; esac; }
+kernel_of() { case $1 in 2) echo 'k_unroll_pair<' ;; 4) echo 'k_unroll_lds<' ;; 3) echo 'k_unroll_cu<' ;; 5) echo 'k_mlp_unroll<' ;; esac; }
 train_cmd() { # NAME SECONDS -> command line (the ones recorded in tests/golden/trained/README.md)
   local S=$2
   case $1 in
@@ -83,6 +84,8 @@ for job in "$@"; do
       mkdir -p $O/trained
       timeout 900 python $(train_cmd $a1 $a2) > $O/train_$a1.log 2>&1
       grep -E "eval_loss|Saving|total time" $O/train_$a1.log | tail -6 ;;
+    env)
+      if [ -z "${rest#*=}" ]; then unset "${rest%%=*}"; else export "$rest"; fi ;;
     bench2ranks)
       L2O_BENCH_BACKEND=gloo L2O_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
         --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 2>$O/bench2.err | tee $O/bench_2ranks_one_device.json | cut -c1-260 ;;

@@ -343,6 +343,15 @@ def test_two_cu_form_big_batches_random(eng):
     """Seeded sweep of the two-CU form where it runs as SEVERAL launches (more than #CU / 2 problems: equal chunks
     of whole launch groups), with x scaling, B_global > B_local and a non-unit step0, against the oracle; the
     chunked launches also agree bit for bit with the same problems run in two separate smaller batches."""
+    from open_l2o_amd import _abi
+    old_opt = _abi.set_option(_abi.OPT_ONE_LDS, 0)      # (this test is about the CHUNKED two-CU form; k_unroll_lds: test_unroll_lds.py)
+    try:
+        _two_cu_big_batches(eng)
+    finally:
+        _abi.set_option(_abi.OPT_ONE_LDS, old_opt)
+
+
+def _two_cu_big_batches(eng):
     rng = np.random.default_rng(77)
     worst = 0.0
     for case in range(6):

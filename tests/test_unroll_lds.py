@@ -1,0 +1,108 @@
+"""k_unroll_lds (round 4): the fused unroll for LARGE shards -- one problem per CU, two waves per SIMD, the bf16x3 gate
+GEMM's fragments in LDS, the matrix in registers (csrc/l2o_unroll_lds.h; L2O_OPT_ONE_LDS: default 1 = whenever a shard of a
+DM net with 5..8 tiles exceeds #CU / 2 problems, 2 = always).  Parity against the oracle for every optimizee and both DM
+preprocessings, ragged sizes, x scaling / B_global / continuation, the recording form, and against the chunked two-CU form."""
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import ORACLE_CFGS, device_problem, lib_option, make_params, make_problem, max_abs, rel_err, spec_of
+from open_l2o_amd import _abi
+from test_hip_kernels import _run_fused
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from open_l2o_amd._engine import HipEngine
+    return HipEngine()
+
+
+@pytest.mark.parametrize("name", ["dm", "dm_logsign"])
+@pytest.mark.parametrize("kind,B,D,M", [("quadratic", 5, 128, None), ("quadratic", 3, 65, None), ("lasso", 4, 100, 70),
+                                        ("lasso", 3, 128, 128), ("rastrigin", 6, 100, None), ("square_cos", 3, 81, None),
+                                        ("rastrigin", 2, 113, None)])
+def test_forced_lds_form_vs_oracle(eng, name, kind, B, D, M):
+    cfg = ORACLE_CFGS[name]
+    params = make_params(cfg, seed=16, trained_like=True)
+    prob, x0, arrays = make_problem(kind, B, D, seed=17, M=M)
+    T = 20
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=1)
+    with lib_option(_abi.OPT_ONE_LDS, 2):
+        fx, x, st, _, _ = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
+    e_fx, e_x = rel_err(fx, res.fx), max_abs(x, res.x.reshape(B, D))
+    print("k_unroll_lds %s/%s B=%d D=%d: rel fx=%.3g |dx|=%.3g" % (name, kind, B, D, e_fx, e_x))
+    assert e_fx < 1e-5
+    assert e_x < 1e-5 * max(1.0, float(np.abs(res.x).max()))
+    for l in range(2):
+        for i in range(2):
+            assert max_abs(st[l][i], res.state[l][i]) < 1e-5 * max(1.0, float(np.abs(res.state[l][i]).max()))
+
+
+def test_large_shard_default_equals_chunked_two_cu_form_and_oracle(eng):
+    """A shard of 300 problems (more than #CU / 2): the default now runs k_unroll_lds; against the oracle (x scaling,
+    B_global > B_local, step0) and against the chunked two-CU form (L2O_OPT_ONE_LDS = 0) -- same trajectory up to the
+    fp32 summation order of the two GEMV forms; continuation (2 x T/2 == T) bit for bit."""
+    cfg = ORACLE_CFGS["dm"]
+    params = make_params(cfg, seed=21, trained_like=True)
+    B, D, T = 300, 128, 10
+    prob, x0, arrays = make_problem("quadratic", B, D, seed=22)
+    prob.batch_global = 2 * B
+    xs = np.exp(np.random.default_rng(3).uniform(-0.3, 0.3, (B, D))).astype(np.float32)
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, x_scale=xs, step0=1)
+    out = {}
+    for mode in (1, 0):
+        with lib_option(_abi.OPT_ONE_LDS, mode):
+            out[mode] = _run_fused(eng, cfg, params, arrays, x0, B, D, T, Bg=2 * B, x_scale=xs)
+    for mode in (1, 0):
+        assert rel_err(out[mode][0], res.fx) < 1e-5, mode
+        assert max_abs(out[mode][1], res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max()))
+    assert rel_err(out[1][0], out[0][0]) < 2e-6
+    # continuation: two launches of T / 2 carrying x and the LSTM state == one launch of T
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D, B_global=2 * B, x_scale=xs)
+    x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
+    m, v = eng.zeros(B, D), eng.zeros(B, D)
+    fxp = eng.zeros((T // 2 + 1) * B)
+    for _ in range(2):
+        eng.unroll(spec, wpack, pd, x, st, m, v, T // 2, 1, fxp)
+    assert np.array_equal(eng.to_numpy(x), out[1][1])
+
+
+def test_recording_form_equals_plain_unroll_prefixes(eng):
+    """HIST instantiation (l2o_unroll_record on a large shard of a DM net): the recording launch leaves the same x / fx as
+    the plain one (a different instantiation: same arithmetic, the compiler may contract differently -> 1e-5), the
+    recorded state BEFORE step t is the state a t-step plain unroll ends with, the recorded gradients are the optimizee's
+    gradients at the recorded iterates."""
+    cfg = ORACLE_CFGS["dm_logsign"]
+    params = make_params(cfg, seed=31, trained_like=True)
+    B, D, T = 160, 100, 6
+    prob, x0, arrays = make_problem("rastrigin", B, D, seed=32)
+    spec = spec_of(cfg)
+    wpack = eng.pack_weights(spec, params)
+    pd = device_problem(eng, arrays, B, D)
+    assert eng.unroll_supported(spec, pd, record=True)
+
+    def run(t, hist=None):
+        x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
+        fxp = eng.zeros((t + 1) * B)
+        eng.unroll(spec, wpack, pd, x, st, eng.zeros(B, D), eng.zeros(B, D), t, 1, fxp, hist=hist)
+        return eng.to_numpy(x), eng.to_numpy(fxp), eng.to_numpy(st)
+
+    hist = dict(st=eng.zeros(T, eng.state_floats(B, D)), g=eng.zeros(T, B * D), g_final=eng.zeros(B * D))
+    x_rec, fx_rec, _ = run(T, hist)
+    x_pl, fx_pl, _ = run(T)
+    np.testing.assert_allclose(x_rec, x_pl, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(fx_rec, fx_pl, rtol=1e-5)
+    for t in (1, 3, 5):
+        x_t, _, st_t = run(t)
+        assert max_abs(eng.to_numpy(hist["st"][t]), st_t) < 3e-6, t
+        g_t = prob.grad(x_t.reshape(x0.shape)).reshape(-1)
+        assert max_abs(eng.to_numpy(hist["g"][t]), g_t) < 2e-5 * float(np.abs(g_t).max()), t
+    g0 = prob.grad(x0).reshape(-1)
+    assert max_abs(eng.to_numpy(hist["g"][0]), g0) < 2e-6 * float(np.abs(g0).max())
+    gT = prob.grad(x_pl.reshape(x0.shape)).reshape(-1)
+    assert max_abs(eng.to_numpy(hist["g_final"]), gT) < 2e-5 * float(np.abs(gT).max())
+    eng.check_unroll_status()
