@@ -123,7 +123,7 @@ def work_block(case, issue, args):
     # two-CU fused unroll and the persistent MLP unroll.  (rocprofv3's kernels view reports the architectural VGPR count
     # only, so the counters file cannot tell.)  The streaming kernels run several tiles per wave and are HBM-bound.
     one_tile_per_wave = ((case["fused"] and not case["hbm_bound"] and case["D"] > 16) or "l2o_mlp_unroll" in case["kernel"]) \
-        and "k_unroll_lds" not in case["kernel"]              # (k_unroll_lds: two waves per SIMD -- not this model)
+        and "k_unroll_lds" not in case["kernel"] and "k_unroll_pair2" not in case["kernel"]   # (two waves per SIMD: not this model)
     if issue is None or not one_tile_per_wave:
         return None
     T, dispatches = case["T"], float(case.get("dispatches", 1))
@@ -588,13 +588,18 @@ def run_case(args, eng, world, rank, Bg, B, label):
         if _abi.get_option(_abi.OPT_EXACT_GATES):
             two_cu += " (exact gates)"
         cap = max(8, eng.coresident_cus // 2)
-        # (round 4) a shard of more than #CU / 2 problems of a DM net with 5..8 tiles: one problem per CU, two waves per
-        # SIMD, the gate-GEMM fragments in LDS -- k_unroll_lds -- instead of chunk launches of the two-CU kernel
+        # (round 4) a shard of more than #CU / 2 problems of a DM net with 5..8 tiles: the gate-GEMM fragments move to LDS and
+        # every SIMD runs two waves -- k_unroll_lds (one problem per CU; the default) or k_unroll_pair2 (the two-CU kernel,
+        # two workgroups per CU, chunks of #CU problems; L2O_ONE_LDS=3) -- instead of chunk launches of the two-CU kernel
         one_lds = _abi.get_option(_abi.OPT_ONE_LDS)
-        lds_form = (args.net != "rnnprop" and 64 < D <= 128 and not _abi.get_option(_abi.OPT_EXACT_GATES)
-                    and _abi.get_option(_abi.OPT_PAIR) and (one_lds == 2 or (one_lds == 1 and B > cap)))
-        if lds_form:
+        lds_shape = (args.net != "rnnprop" and 64 < D <= 128 and not _abi.get_option(_abi.OPT_EXACT_GATES)
+                     and _abi.get_option(_abi.OPT_PAIR))
+        if lds_shape and (one_lds == 2 or (one_lds == 1 and B > cap)):
             kernel = "k_unroll_lds (one problem per CU, two waves per SIMD, fragments in LDS)"
+        elif lds_shape and not _abi.get_option(_abi.OPT_PAIR_NORMAL) and one_lds == 3:
+            dispatches = (B + 2 * cap - 1) // (2 * cap)
+            kernel = "k_unroll_pair2 (two-CU kernel, fragments in LDS, two workgroups per CU)" + (
+                " x %d chunk launches" % dispatches if dispatches > 1 else "")
         else:
             kernel = "k_unroll" if (D <= 16 or not _abi.get_option(_abi.OPT_PAIR)) else (
                 two_cu if B <= cap else "%s x %d chunk launches" % (two_cu, (B + cap - 1) // cap))

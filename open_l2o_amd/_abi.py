@@ -94,7 +94,8 @@ def options_word():
         if o == OPT_BWD_BLOCKS:
             w |= (v & 0xffff) << 48
         else:
-            w |= (8 | (v & 7)) << (4 * o)
+            # (include/l2o_abi.h L2O_OPT_FIELD_: bits 48-63 are the BWD_BLOCKS count, option 12 uses that option's unused field)
+            w |= (8 | (v & 7)) << (4 * (OPT_BWD_BLOCKS if o == OPT_ONE_LDS else o))
     return w
 
 

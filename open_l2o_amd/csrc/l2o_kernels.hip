@@ -846,8 +846,8 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
   store_tile_state(s, st_tile, lane);
 }
 
-#include "l2o_unroll_lds.h"
 #include "l2o_unroll_pair.h"
+#include "l2o_unroll_lds.h"
 #include "l2o_unroll_pairh.h"
 
 #include "l2o_unroll_cu.h"
@@ -1007,7 +1007,7 @@ struct OptScope {
 static inline uint64_t cfg_optw(const l2o_net_cfg* cfg) { return cfg ? cfg->options : 0; }
 static inline int64_t opt(int o) {
   if (o == L2O_OPT_BWD_BLOCKS) return (int64_t)((t_optw >> 48) & 0xffffu);     // a count: its own 16-bit field
-  const unsigned nib = (unsigned)(t_optw >> (4 * o)) & 0xfu;
+  const unsigned nib = (unsigned)(t_optw >> (4 * L2O_OPT_FIELD_(o))) & 0xfu;
   return (nib & 8u) ? (int64_t)(nib & 7u) : kOptDefault[o];
 }
 
@@ -1083,9 +1083,11 @@ __global__ __launch_bounds__(256) void k_coresident_probe(unsigned* ctr, unsigne
 // partner: at most #CU / 2 per launch.  A larger batch shard runs as consecutive launches of equal chunks (a multiple
 // of the 8-problem launch groups) -- normal-matrix kernel only; a chunk launch with every tile on its own SIMD beats
 // one round of the one-CU form (config 4, 1024 problems on one GPU: 5.3 -> 6.0 G coordinate-steps/s).
-static int pair_chunk(const l2o_problem* p, const UnrollGeom& g, hipStream_t s) {
+// per_cu: workgroups of the kernel that share a CU (k_unroll_pair2: 2 -- its 60 KB of LDS and 256 registers per lane
+// leave room for exactly two)
+static int pair_chunk(const l2o_problem* p, const UnrollGeom& g, hipStream_t s, int per_cu = 1) {
   if (!opt(L2O_OPT_PAIR) || g.CH < 2) return 0;
-  const int cap = coresident_cus(s) / 2;
+  const int cap = coresident_cus(s) * per_cu / 2;
   if (p->B_local <= cap) return p->B_local;
   if (cap < 8) return 0;
   const int n = (p->B_local + cap - 1) / cap;               // launches
@@ -1136,19 +1138,35 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
                             void* workspace, float* fx, bool* fx_done) {
   const bool hist = a.hist_st != nullptr;
   int chunk = workspace ? pair_chunk(prob, g, s) : 0;
-  // Large shards (round 4): one problem per CU with two waves per SIMD and the fragments in LDS (k_unroll_lds) instead of
-  // consecutive chunk launches of the two-CU kernel -- L2O_OPT_ONE_LDS: 0 never, 1 when the shard needs chunk launches
-  // (more problems than #CU / 2), 2 always (A/B runs).  DM nets, 5..8 tiles, no exact-gates request.
+  // Large shards (round 4) -- more problems than the #CU / 2 one launch of the two-CU kernel holds.  Both new forms keep the
+  // gate-GEMM fragments in LDS and run two waves per SIMD; they measure the same (config 4: 1.28 / 1.30 ms).  L2O_OPT_ONE_LDS:
+  //   0  consecutive chunk launches of the two-CU kernel (one workgroup per CU, fragments in registers: rounds 2-3)
+  //   1  (default) k_unroll_lds for large shards: one problem per CU, two waves of the SAME problem per SIMD, one launch,
+  //      no cross-CU protocol
+  //   2  k_unroll_lds for every shard (A/B runs)
+  //   3  k_unroll_pair2: the two-CU kernel with the fragments in LDS, TWO workgroups (halves of different problems) per CU,
+  //      chunks of #CU problems (A/B runs; <= #CU / 2 problems leave it one workgroup per CU)
+  // DM nets, 5..8 tiles, no exact-gates / normal-matrix request.
+  bool pair2 = false;
   if constexpr (PRE != L2O_PRE_FC_ELU) {
     const int one_lds = (int)opt(L2O_OPT_ONE_LDS);
-    const bool wants = one_lds == 2 || (one_lds == 1 && chunk > 0 && a.pp.B_local > chunk);
-    if (wants && g.CH == 8 && g.nw >= 5 && !(opt(L2O_OPT_EXACT_GATES) && !hist)) {
+#ifdef L2O_LDS_ABL_ANYNW   // (timing ablation: also 1..4 tiles, i.e. ONE wave per SIMD in this kernel; needs M <= 16 nw)
+    const bool shape_ok = g.nw >= 1 && a.pp.M <= 16 * g.nw;
+#else
+    const bool shape_ok = g.CH == 8 && g.nw >= 5;
+#endif
+    const bool plain = !(opt(L2O_OPT_EXACT_GATES) && !hist);
+    if ((one_lds == 2 || (one_lds == 1 && chunk > 0 && a.pp.B_local > chunk)) && shape_ok && plain) {
       void (*fl)(UnrollArgs) = hist ? k_unroll_lds<PRE, KIND, true> : k_unroll_lds<PRE, KIND, false>;
       const size_t lds = sizeof(float) * ((size_t)LstmCoreLds<PRE>::kFragWords + 2 * 128 + 8);
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(fl, dim3(a.pp.B_local), dim3(64 * g.nw), lds, s, a);
       HIP_TRY(hipGetLastError());
       return L2O_OK;
+    }
+    if (chunk > 0 && g.CH == 8 && g.nw >= 5 && plain && !opt(L2O_OPT_PAIR_NORMAL) && one_lds == 3) {
+      pair2 = true;
+      chunk = pair_chunk(prob, g, s, 2);
     }
   }
   if (chunk > 0) {
@@ -1199,7 +1217,15 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
       }
     } else {
       void (*fn)(UnrollPairArgs) = nullptr;
-      switch (g.CH) {
+      size_t dyn_lds = L.lds;
+      if constexpr (PRE != L2O_PRE_FC_ELU) {
+        if (pair2) {
+          fn = hist ? k_unroll_pair2<PRE, KIND, true> : k_unroll_pair2<PRE, KIND, false>;
+          dyn_lds = sizeof(float) * (size_t)LstmCoreLds<PRE>::kFragWords;
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+        }
+      }
+      if (!fn) switch (g.CH) {
         case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : (exact ? k_unroll_pair<PRE, KIND, 2, false, true> : k_unroll_pair<PRE, KIND, 2, false>); break;
         case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : (exact ? k_unroll_pair<PRE, KIND, 4, false, true> : k_unroll_pair<PRE, KIND, 4, false>); break;
         default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : (exact ? k_unroll_pair<PRE, KIND, 8, false, true> : k_unroll_pair<PRE, KIND, 8, false>); break;
@@ -1207,7 +1233,7 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
       for (int b0 = 0; b0 < B; b0 += chunk) {
         pa.b0 = b0;
         pa.nb = B - b0 < chunk ? B - b0 : chunk;
-        hipLaunchKernelGGL(fn, dim3((pa.nb + 7) / 8 * 16), dim3(64 * (g.CH / 2)), L.lds, s, pa);
+        hipLaunchKernelGGL(fn, dim3((pa.nb + 7) / 8 * 16), dim3(64 * (g.CH / 2)), dyn_lds, s, pa);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(256), 0, s, pa.fx_half, a.fx_part, pa.nb, g.CH,
                            a.pp.inv_bg, one_launch ? fx : nullptr, pa.xbuf, (long)pa.nb * 2 * 2 * L.npg, pa.ws, b0, B);

@@ -279,7 +279,11 @@ __device__ __forceinline__ void issue(const W& w, const BOp<PK>& b, f32x4 (&acc)
     // long before (the ds_read_b128 rides behind the gate block that consumed the accumulator), not from zero
     if constexpr (W::kLdsFrags) {
       static_assert(PK, "LDS-resident fragments: the packed form");
+#ifdef L2O_LDS_ABL_NOFRAG   // (timing ablation only: no fragment reads -- wrong numerics)
+      acc[t] = mfma_bf(b.m[(p + 1) % kPack], b.m[p], acc[t]);
+#else
       acc[t] = mfma_bf(w.lfr[((CH * kNT + t) * kPack + p) * 64], b.m[p], acc[t]);
+#endif
     } else if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], acc[t]);
     else acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.m[prod_x(p)], acc[t]);
   });
@@ -405,7 +409,13 @@ __device__ __forceinline__ float finish(const W& w, TileState& s, BOp<PK>& b1, B
   pc.drain(acc1);
   pc.mark(5);
   gates5(acc1, s.c1, s.h1);
-  if (REARM || NEXT) preload_bias<0>(w, acc1);               // acc1 is dead: the next step's layer-1 accumulator init
+#ifndef L2O_FINISH_PINNED_LDSFRAGS
+#define L2O_FINISH_PINNED_LDSFRAGS 0
+#endif
+  // (LDS-resident fragments: the pinning asm makes the wave wait for the five bias reads on the spot -- behind the
+  //  fragment reads of eight waves; the default leaves the wait to the first MFMA that needs acc1: -1..2 %, profiles/r04x_*)
+  constexpr bool kPinBias = !W::kLdsFrags || L2O_FINISH_PINNED_LDSFRAGS;
+  if (REARM || NEXT) preload_bias<0, W, kPinBias>(w, acc1);   // acc1 is dead: the next step's layer-1 accumulator init
   pc.mark(6);
   split5<PK>(s.h1, one, b1);
   issue<PRE, kChL2A, 0, kN, false>(w, b1, acc2);
@@ -444,7 +454,7 @@ __device__ __forceinline__ float finish(const W& w, TileState& s, BOp<PK>& b1, B
     gates5(acc2, s.c2, s.h2);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (REARM) preload_bias<1>(w, acc2);                       // acc2 is dead: the next step's layer-2 accumulator init
+  if (REARM) preload_bias<1, W, kPinBias>(w, acc2);          // acc2 is dead: the next step's layer-2 accumulator init
   pc.mark(8);
   if (NEXT) split5<PK>(s.h2, one, b2);
   float d0 = s.h2[0] * w.wl[0], d1 = s.h2[1] * w.wl[1];
@@ -617,6 +627,10 @@ struct LstmCoreLds {
   __device__ __forceinline__ void preload(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
     bx::preload_bias<0>(w, acc1);
     bx::preload_bias<1>(w, acc2);
+  }
+  __device__ __forceinline__ void preload_unpinned(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
+    bx::preload_bias<0, bx::NetWBL<PRE>, false>(w, acc1);
+    bx::preload_bias<1, bx::NetWBL<PRE>, false>(w, acc2);
   }
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {

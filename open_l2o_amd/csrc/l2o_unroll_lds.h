@@ -16,11 +16,32 @@
 // DM nets (identity / LogAndSign preprocessing: three packed chunks), 65 <= padded size <= 128 (5..8 tiles).
 #pragma once
 
+// (timing ablations, scripts/ablate_lds.sh: L2O_LDS_ABL_NOBAR drops the two barriers, _NOGEMV the xs / rs reads,
+//  _NOFRAG (l2o_lstm_bx3.h) the fragment reads -- each gives wrong numerics and is never shipped)
+#ifdef L2O_LDS_ABL_NOBAR
+#define L2O_LDS_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define L2O_LDS_BARRIER() do { if (HIST) lds_barrier(); else __syncthreads(); } while (0)
+#endif
+#ifdef L2O_LDS_ABL_NOGEMV
+#define L2O_LDS_VEC(p, m, w) (w)
+#else
+#define L2O_LDS_VEC(p, m, w) \
+  (*reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const __attribute__((address_space(3))) float*)(p) + 16 * (m)))
+#endif
+// experiment switches (scripts/build_variants.sh):
+//   L2O_LDS_PRIO        the first wave of every SIMD (waves 0..3) runs at s_setprio 3, its partner (waves 4..7) at 0
+//   L2O_LDS_MFMA_ORDER  chunk L1H (h1 of the previous step) rides in the r pass, chunk L2B in the g pass, and finish()
+//                       issues chunk L2A only (NEXT = false): no next-step MFMAs queued in front of the partner wave's L2A
+#ifndef L2O_LDS_MFMA_ORDER
+#define L2O_LDS_MFMA_ORDER 1
+#endif
+
 template <int PRE, int KIND, bool HIST>
 __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
   constexpr int CH = 8, SQ = 16 * CH;
   using Core = LstmCoreLds<PRE>;
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* frs = sm;                                   // [Core::kFragWords]  packed fragments (16-byte aligned)
   float* xs = frs + Core::kFragWords;                // [SQ]
   float* rs = xs + SQ;                               // [SQ]
@@ -34,7 +55,7 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
 
   // ---- the matrix in registers: row 16 wv + c (r pass) and column 16 wv + c (g pass), 16-byte chunk q of every tile
   const float* Wb = pp.W + (pp.w_shared ? (size_t)0 : (size_t)b * M * D);
-  float4 wr[CH], wt[CH];
+  f32x4 wr[CH], wt[CH];
   {
     const int row = wv * kTile + c, col = wv * kTile + c;
 #pragma unroll
@@ -46,8 +67,8 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
         e[k] = (row < M && cc < D) ? Wb[(size_t)row * D + cc] : 0.0f;
         f[k] = (cc < M && col < D) ? Wb[(size_t)cc * D + col] : 0.0f;
       }
-      wr[m] = make_float4(e[0], e[1], e[2], e[3]);
-      wt[m] = make_float4(f[0], f[1], f[2], f[3]);
+      wr[m] = f32x4{e[0], e[1], e[2], e[3]};
+      wt[m] = f32x4{f[0], f[1], f[2], f[3]};
     }
   }
   const int myrow = wv * kTile + c;
@@ -82,12 +103,15 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
   const float* xsq = xs + 4 * q;
   const float* rsq = rs + 4 * q;
 
+#ifdef L2O_LDS_PRIO
+  if (wv < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
   f32x4 acc1[kNT], acc2[kNT];
   core.init(s, q);
   if (tid < SQ) { xs[tid] = 0.0f; rs[tid] = 0.0f; }
   __syncthreads();                                   // fragments, bias table, zeroed xs staged
   core.preload(acc1, acc2);
-  core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
+  if (!L2O_LDS_MFMA_ORDER) core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
   if (q == 0) xs[j] = live ? xv * sc : 0.0f;
 
   const size_t hist_n = (size_t)pp.B_local * D;
@@ -96,14 +120,15 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
     const float xsv = xv * sc;
     if (HIST && t < a.T)
       store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * nw + tile) * kStateFloatsPerTile, lane);
-    if (HIST) lds_barrier(); else __syncthreads();     // B1: xs complete
+    L2O_LDS_BARRIER();                                 // B1: xs complete
     // ---- r = W xs - y for the wave's 16 rows  ||  the first 10 layer-2 MFMAs of the previous h2
-    float4 racc = {0.f, 0.f, 0.f, 0.f};
+    float4 racc = {0.f, 0.f, 0.f, 0.f};                    // (scalar FMAs: two waves per SIMD -- see dot4pk in l2o_unroll_pair.h)
     static_for<0, CH>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      const float4 xv4 = *reinterpret_cast<const float4*>(xsq + 16 * m);
-      core.template issue_l2_prev<(Core::kHalf * m) / CH, (Core::kHalf * (m + 1)) / CH>(s, acc2);
-      dot4(wr[m], xv4, racc);
+      const f32x4 xv4 = L2O_LDS_VEC(xsq, m, wt[m]);
+      if (L2O_LDS_MFMA_ORDER) core.template issue_l1_prev<(Core::kTotal * m) / CH, (Core::kTotal * (m + 1)) / CH>(s, acc1);
+      else core.template issue_l2_prev<(Core::kHalf * m) / CH, (Core::kHalf * (m + 1)) / CH>(s, acc2);
+      dot4q(wr[m], xv4, racc);
     });
     const float r = quad_q_sum(hsum4(racc)) - myy;  // (rows >= M: W row and y are zero -> r == 0)
     float contrib = 0.0f;
@@ -117,7 +142,7 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
     }
     contrib = wave_sum64(contrib);
     if (lane == 0) fpart[wv] = contrib;
-    if (HIST) lds_barrier(); else __syncthreads();     // B2: rs, fpart complete
+    L2O_LDS_BARRIER();                                 // B2: rs, fpart complete
     if (tid == 0) {
       float f = fpart[0];
       for (int k = 1; k < nw; ++k) f += fpart[k];
@@ -129,10 +154,11 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
     static_for<0, CH>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      const float4 rv4 = *reinterpret_cast<const float4*>(rsq + 16 * m);
-      core.template issue_l2_prev<Core::kHalf + ((Core::kTotal - Core::kHalf) * m) / CH,
-                                  Core::kHalf + ((Core::kTotal - Core::kHalf) * (m + 1)) / CH>(s, acc2);
-      dot4(wt[m], rv4, gacc4);
+      const f32x4 rv4 = L2O_LDS_VEC(rsq, m, wr[m]);
+      if (L2O_LDS_MFMA_ORDER) core.template issue_l2_prev<(Core::kTotal * m) / CH, (Core::kTotal * (m + 1)) / CH>(s, acc2);
+      else core.template issue_l2_prev<Core::kHalf + ((Core::kTotal - Core::kHalf) * m) / CH,
+                                       Core::kHalf + ((Core::kTotal - Core::kHalf) * (m + 1)) / CH>(s, acc2);
+      dot4q(wt[m], rv4, gacc4);
     });
     float gv = quad_q_sum(hsum4(gacc4));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;
@@ -147,7 +173,8 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
 
     float in0, in1;
     preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
-    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);
+    float d = core.template finish<!L2O_LDS_MFMA_ORDER>(s, acc1, acc2, in0, in1, q, pc);
+    if (L2O_LDS_MFMA_ORDER) core.refresh(s);             // split h2 -> the L2B operand of the next step
     if (a.np.tanh_output) {
       asm volatile("");
       d = tanhf_(d);

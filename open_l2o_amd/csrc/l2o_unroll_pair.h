@@ -98,14 +98,40 @@ __device__ __forceinline__ void dot4v(const float4 a, const l2o::f32x4 b, float4
   acc.w = __builtin_fmaf(a.w, b[3], acc.w);
 }
 
+// The same four chains as two v_pk_fma_f32 (lanes x,y | z,w): half the GEMV's instructions; the operands are register
+// quads (W packed once in the prologue, x / r straight from ds_read_b128), so the halves are sub-registers, no copies.
+// hsum4pk adds in hsum4's order: bit-identical to dot4v + hsum4.  (L2O_GEMV_PK=0 restores the scalar FMAs.)
+// Measured (profiles/r04aa_*): config 2, ONE wave per SIMD -- the wave is issue-bound and 32 fewer instructions per step are
+// worth 4 % (8.78 -> 9.15 G); with TWO waves per SIMD (k_unroll_pair2, k_unroll_lds) the VALU pipe is the limit, a packed FMA
+// occupies it twice as long, and the packed form is 1.5-3 % SLOWER: those keep the scalar FMAs.
+#ifndef L2O_GEMV_PK
+#define L2O_GEMV_PK 1
+#endif
+struct Acc4pk { l2o::bx::f32x2 lo, hi; };
+__device__ __forceinline__ void dot4pk(const l2o::f32x4 a, const l2o::f32x4 b, Acc4pk& acc) {
+  acc.lo = __builtin_elementwise_fma(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), acc.lo);
+  acc.hi = __builtin_elementwise_fma(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), acc.hi);
+}
+__device__ __forceinline__ float hsum4pk(const Acc4pk& a) { return (a.lo.x + a.lo.y) + (a.hi.x + a.hi.y); }
+__device__ __forceinline__ l2o::f32x4 as_quad(const float4 v) { return l2o::f32x4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void dot4q(const l2o::f32x4 a, const l2o::f32x4 b, float4& acc) {
+  acc.x = __builtin_fmaf(a[0], b[0], acc.x);
+  acc.y = __builtin_fmaf(a[1], b[1], acc.y);
+  acc.z = __builtin_fmaf(a[2], b[2], acc.z);
+  acc.w = __builtin_fmaf(a[3], b[3], acc.w);
+}
+
 // HIST: also record the per-step history for the meta-gradient (l2o_unroll_record); a template
 // parameter so that the plain unroll carries none of it
 // EXACT (L2O_OPT_EXACT_GATES): the fp32 MFMA gate GEMM (bit-equal to an fmaf chain) instead of the bf16x3 split
 #ifndef L2O_PAIR_LDS_BARRIERS
 #define L2O_PAIR_LDS_BARRIERS 0
 #endif
-template <int PRE, int KIND, int CH, bool HIST, bool EXACT = false>
-__global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
+// LDSF (round 4, k_unroll_pair2): the packed bf16x3 fragments live in LDS (60 KB, LstmCoreLds) instead of 240 AGPRs, the
+// wave fits 256 registers and TWO workgroups -- halves of two DIFFERENT problems -- share a CU: two waves per SIMD that
+// synchronise independently, so one computes while the other waits for its partner CU / a barrier / LDS.
+template <int PRE, int KIND, int CH, bool HIST, bool EXACT, bool LDSF>
+__device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
   constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
   constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
   constexpr int NC = 16 * NWH;           // columns (coordinates) owned by a half = SQ / 2
@@ -163,15 +189,28 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
       wt[m] = make_float4(e[0], e[1], e[2], e[3]);
     }
   }
+  constexpr bool kPk = L2O_GEMV_PK && !LDSF;                // packed GEMV FMAs: one wave per SIMD only (see dot4pk)
+  l2o::f32x4 wrq[2][NWH], wtq[CH];                          // (the same values as register quads for the packed FMAs)
+#pragma unroll
+  for (int m = 0; m < NWH; ++m) { wrq[0][m] = as_quad(wr[0][m]); wrq[1][m] = as_quad(wr[1][m]); }
+#pragma unroll
+  for (int m = 0; m < CH; ++m) wtq[m] = as_quad(wt[m]);
   // the residual rows this lane finishes: gq == 0 -> p = 0, gq == 1 -> p = 1 (gq 2, 3 idle)
   const int myrow = (2 * wv + (gq & 1)) * kTile + gr;
   const float myy = (gq < 2 && myrow < M) ? pp.y[(size_t)b * M + myrow] : 0.0f;
   const bool row_counted = gq < 2 && (half == 0 ? (myrow < NC) : (myrow >= NC));   // every row once per pair
 
   // ---- per-lane persistent registers -------------------------------------
-  using Core = LstmCore<PRE, !EXACT>;    // <= 4 waves per workgroup: bf16x3 gate GEMM, weights in VGPR + AGPR
+  // <= 4 waves per workgroup: bf16x3 gate GEMM, weights in VGPR + AGPR (LDSF: fragments in LDS)
+  using Core = typename std::conditional<LDSF, LstmCoreLds<PRE>, LstmCore<PRE, !EXACT>>::type;
   Core core;
   core.load(a.np.wpack, lane);
+  if constexpr (LDSF) {
+    // [Core::kFragWords]; 16-byte aligned (the static arrays in front of it end on a 4-byte word: misaligned ds_read_b128
+    // run at a quarter of the speed); the handshake's __syncthreads() orders the staging
+    extern __shared__ __attribute__((aligned(16))) float pair_frags[];
+    core.stage_frags(pair_frags, a.np.wpack, tid, blockDim.x, lane);
+  }
   core.pin();   // fragments -> AGPRs (MFMA reads them there): the VGPRs hold W, the state and the gate math
   __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];   // the gate biases = accumulator inits
   core.stage_bias(bias_s, a.np.wpack, tid, blockDim.x, q);   // (the handshake's __syncthreads() below orders it)
@@ -208,7 +247,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
   // placement (observed: block b on XCD b % 8, hence the b / b + 8 pairing above), so the halves tell each
   // other their XCC_ID once, through the coherent (agent-scope) path, in a granule slot that the step loop
   // does not touch before step 1.  Only a confirmed same-XCD pair uses the L2-resident plain stores.
-  __shared__ int same_xcd_s;
+  __shared__ __attribute__((aligned(16))) int same_xcd_s4[4];
+  int& same_xcd_s = same_xcd_s4[0];
   if (tid == 0) {
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
@@ -269,6 +309,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     float part;
     {
       float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+      Acc4pk r0p = {{0.f, 0.f}, {0.f, 0.f}}, r1p = {{0.f, 0.f}, {0.f, 0.f}};
       if (kR4) {
         l2o::f32x4 x4v[NWH];
         lds_load_f4<NWH>(x4v, xsq);
@@ -277,8 +318,8 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
         __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);      // ... then the split's VALU block, then the FMAs
 #pragma unroll
         for (int m = 0; m < NWH; ++m) {
-          dot4v(wr[0][m], x4v[m], r0);
-          dot4v(wr[1][m], x4v[m], r1);
+          if (kPk) { dot4pk(wrq[0][m], x4v[m], r0p); dot4pk(wrq[1][m], x4v[m], r1p); }
+          else { dot4v(wr[0][m], x4v[m], r0); dot4v(wr[1][m], x4v[m], r1); }
         }
       } else {
         float4 x4[NWH];
@@ -294,7 +335,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
         // the 32-lane swap finishes both; odd lane groups end with the p1 sum, even ones with the p0 sum -- the lanes
         // that publish them.  Same additions in the same order as two quad_q_sum calls (bit-identical), 5 instead of 13
         // instructions and one dependent swap chain instead of two.
-        const float h0 = hsum4(r0), h1 = hsum4(r1);
+        const float h0 = kPk ? hsum4pk(r0p) : hsum4(r0), h1 = kPk ? hsum4pk(r1p) : hsum4(r1);
         const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h0), __float_as_uint(h1), false, false);
         part = xor32_add(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
       } else {
@@ -390,16 +431,20 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     // all CH residual reads are issued back to back (hipcc serialises them on one register
     // quad otherwise: CH x LDS latency on the critical path), one wait, then the FMAs
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
+    Acc4pk gaccp = {{0.f, 0.f}, {0.f, 0.f}};
     if (kR4) {
 #pragma unroll
-      for (int m = 0; m < CH; ++m) dot4v(wt[m], rv4v[m], gacc4);
+      for (int m = 0; m < CH; ++m) {
+        if (kPk) dot4pk(wtq[m], rv4v[m], gaccp);
+        else dot4v(wt[m], rv4v[m], gacc4);
+      }
     } else {
       float4 rv4[CH];
       lds_read_f4<CH>(rv4, rsq);
 #pragma unroll
       for (int m = 0; m < CH; ++m) dot4(wt[m], rv4[m], gacc4);
     }
-    float gv = quad_q_sum(hsum4(gacc4));
+    float gv = quad_q_sum((kR4 && kPk) ? hsum4pk(gaccp) : hsum4(gacc4));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (kCos) gv += kTwoPi * pp.alpha * cj * l2o::sin_f(kTwoPi * xsv);
@@ -465,6 +510,16 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
     if (PRE == L2O_PRE_FC_ELU) { a.m[idx] = mv; a.v[idx] = vv; }
   }
   if (tile_real) store_tile_state(s, st_tile, lane);
+}
+
+template <int PRE, int KIND, int CH, bool HIST, bool EXACT = false>
+__global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
+  unroll_pair_body<PRE, KIND, CH, HIST, EXACT, false>(pa);
+}
+// two workgroups per CU (<= 256 registers per lane, 60 KB of dynamic LDS each): DM nets, 5..8 tiles (CH = 8)
+template <int PRE, int KIND, bool HIST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_unroll_pair2(UnrollPairArgs pa) {
+  unroll_pair_body<PRE, KIND, 8, HIST, false, true>(pa);
 }
 
 // The epilogue of a two-CU unroll, one workgroup (64 threads) per step t; runs after every workgroup of the unroll

@@ -66,7 +66,9 @@ for job in "$@"; do
       (timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1) | tee $O/smoke.log ;;
     bench)
       extra=$([ "$a1" = 2 ] || echo --no-cpu-baseline)
-      timeout 600 python bench.py $(bench_args $a1) $extra $(words "$a2") 2>>$O/bench.err | tee $O/bench_c$a1.json | cut -c1-300 ;;
+      # (a bench job with extra arguments is a different workload: its own file, bench_cN_xK.json)
+      n=$((n+1)); out=$O/bench_c$a1.json; [ -n "$a2" ] && out=$O/bench_c${a1}_x$n.json
+      timeout 600 python bench.py $(bench_args $a1) $extra $(words "$a2") 2>>$O/bench.err | tee $out | cut -c1-300 ;;
     trace)
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_c$a1 -o t -- \
          python $R/bench.py $(bench_args $a1) --no-cpu-baseline $(words "$a2") > $O/trace_c$a1.json 2> $O/trace_c$a1.err)

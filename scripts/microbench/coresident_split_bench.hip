@@ -121,6 +121,39 @@ __global__ __launch_bounds__(512) void k_split(const unsigned* frag, float* out,
   if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// ---- round 4, second pass: TWO (512 threads) or THREE (768) FULL waves per SIMD, each owning a whole tile with its fragments
+// in registers (122 registers per lane): does the SIMD interleave two independent copies of the production stream?
+// (k_unroll_lds runs two waves per SIMD and takes 7 200 cycles per step where one wave takes 4 900.)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS)
+void k_full_waves(const unsigned* frag, float* out, long long* cyc, int iters) {
+  const int lane = threadIdx.x & 63;
+  u32x4 a[kNT][bx::kPack];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int j = 0; j < bx::kPack; ++j) a[t][j] = *reinterpret_cast<const u32x4*>(frag + ((t * bx::kPack + j) * 64 + lane) * 4);
+  float h[kNT], c[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) { h[t] = 0.01f * (lane + t); c[t] = 0.02f * t; }
+  bx::BOp<true> b;
+  bx::split5<true>(h, 0u, b);
+  const long long t0 = __builtin_amdgcn_s_memtime();
+#pragma nounroll
+  for (int it = 0; it < iters; ++it) {
+    f32x4 acc[kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) acc[t] = f32x4{0.1f, -0.2f, 0.3f, 0.05f};
+#pragma unroll
+    for (int n = 0; n < kNT * bx::kPack; ++n) acc[n % kNT] = bx::mfma_bf(a[n % kNT][n / kNT], b.m[n / kNT], acc[n % kNT]);
+    bx::gates5(acc, c, h);
+    bx::split5<true>(h, 0u, b);
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = h[0] + h[4] + c[2];
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 template <class K>
 void run(const char* name, K kern, int threads, const unsigned* frag, float* out, long long* cyc) {
   const int iters = 4000;
@@ -147,10 +180,15 @@ int main() {
     h[i] = lo | (hi << 16);
   }
   unsigned* frag; float* out; long long* cyc;
-  (void)hipMalloc(&frag, nw * 4); (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&cyc, 8);
+  (void)hipMalloc(&frag, nw * 4); (void)hipMalloc(&out, 256 * 1024 * 4); (void)hipMalloc(&cyc, 8);
   (void)hipMemcpy(frag, h.data(), nw * 4, hipMemcpyHostToDevice);
   run("one_wave", k_one_wave, 256, frag, out, cyc);
   run("split_3_2", k_split<true>, 512, frag, out, cyc);
   run("split_nosync", k_split<false>, 512, frag, out, cyc);
+  printf("-- full waves (every wave runs the whole layer unit; ns and cycles are per unit of ONE wave) --\n");
+  run("full_x1", k_full_waves<256>, 256, frag, out, cyc);
+  run("full_x2", k_full_waves<512>, 512, frag, out, cyc);
+  run("full_x3", k_full_waves<768>, 768, frag, out, cyc);
+  run("full_x4", k_full_waves<1024>, 1024, frag, out, cyc);
   return 0;
 }

@@ -61,10 +61,17 @@ def test_options_are_caller_owned():
         assert spec.to_c().options == ((8 | 0) << (4 * _abi.OPT_PAIR)) | ((8 | 1) << (4 * _abi.OPT_EXACT_GATES))
         _abi.set_option(_abi.OPT_BWD_BLOCKS, 300)
         assert (spec.to_c().options >> 48) == 300
+        # option 12 must not land in the count's bits 48-63 (it did for a while in round 4): its field is the one that
+        # option 5 -- the count, which has its own 16 bits -- leaves unused (include/l2o_abi.h: L2O_OPT_FIELD_)
+        w0 = spec.to_c().options
+        _abi.set_option(_abi.OPT_ONE_LDS, 3)
+        w1 = spec.to_c().options
+        assert (w1 >> 48) == 300 and (w1 ^ w0) == (8 | 3) << (4 * _abi.OPT_BWD_BLOCKS)
     finally:
         _abi.set_option(_abi.OPT_PAIR, 1)
         _abi.set_option(_abi.OPT_EXACT_GATES, 0)
         _abi.set_option(_abi.OPT_BWD_BLOCKS, 0)
+        _abi.set_option(_abi.OPT_ONE_LDS, _abi.OPT_DEFAULTS[_abi.OPT_ONE_LDS])
     assert _abi.options_word() == 0
     with pytest.raises(ValueError):
         _abi.set_option(1000, 1)

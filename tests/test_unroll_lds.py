@@ -1,7 +1,10 @@
-"""k_unroll_lds (round 4): the fused unroll for LARGE shards -- one problem per CU, two waves per SIMD, the bf16x3 gate
-GEMM's fragments in LDS, the matrix in registers (csrc/l2o_unroll_lds.h; L2O_OPT_ONE_LDS: default 1 = whenever a shard of a
-DM net with 5..8 tiles exceeds #CU / 2 problems, 2 = always).  Parity against the oracle for every optimizee and both DM
-preprocessings, ragged sizes, x scaling / B_global / continuation, the recording form, and against the chunked two-CU form."""
+"""The fused unroll for LARGE shards (round 4; DM nets, 5..8 tiles), both forms with the bf16x3 gate GEMM's fragments in LDS
+and two waves per SIMD (L2O_OPT_ONE_LDS):
+  2 / default 1 above #CU / 2 problems   k_unroll_lds   -- one problem per CU, two waves of the same problem per SIMD
+  3                                      k_unroll_pair2 -- the two-CU kernel, TWO workgroups (halves of two different
+                                         problems) per CU (csrc/l2o_unroll_pair.h, LDSF), chunks of #CU problems
+Parity against the oracle for every optimizee and both DM preprocessings, ragged sizes, x scaling / B_global /
+continuation, the recording form, and against the chunked two-CU form (0)."""
 import numpy as np
 import pytest
 
@@ -19,31 +22,36 @@ def eng():
     return HipEngine()
 
 
+@pytest.mark.parametrize("form", [2, 3])
 @pytest.mark.parametrize("name", ["dm", "dm_logsign"])
 @pytest.mark.parametrize("kind,B,D,M", [("quadratic", 5, 128, None), ("quadratic", 3, 65, None), ("lasso", 4, 100, 70),
                                         ("lasso", 3, 128, 128), ("rastrigin", 6, 100, None), ("square_cos", 3, 81, None),
                                         ("rastrigin", 2, 113, None)])
-def test_forced_lds_form_vs_oracle(eng, name, kind, B, D, M):
+def test_forced_lds_form_vs_oracle(eng, name, kind, B, D, M, form):
     cfg = ORACLE_CFGS[name]
     params = make_params(cfg, seed=16, trained_like=True)
     prob, x0, arrays = make_problem(kind, B, D, seed=17, M=M)
     T = 20
     res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=1)
-    with lib_option(_abi.OPT_ONE_LDS, 2):
+    with lib_option(_abi.OPT_ONE_LDS, form):
         fx, x, st, _, _ = _run_fused(eng, cfg, params, arrays, x0, B, D, T)
     e_fx, e_x = rel_err(fx, res.fx), max_abs(x, res.x.reshape(B, D))
-    print("k_unroll_lds %s/%s B=%d D=%d: rel fx=%.3g |dx|=%.3g" % (name, kind, B, D, e_fx, e_x))
+    print("%s %s/%s B=%d D=%d: rel fx=%.3g |dx|=%.3g" % ({2: "k_unroll_lds", 3: "k_unroll_pair2"}[form], name, kind, B, D, e_fx, e_x))
     assert e_fx < 1e-5
     assert e_x < 1e-5 * max(1.0, float(np.abs(res.x).max()))
+    # (the cos optimizees turn an fp32-rounding difference of x into a larger one of the LSTM state: alpha = 10 times the
+    #  curvature 4 pi^2 of the cos term; the losses and iterates above hold 1e-5, the states 1e-5 / 5e-5)
+    st_tol = 5e-5 if kind in ("rastrigin", "square_cos") else 1e-5
     for l in range(2):
         for i in range(2):
-            assert max_abs(st[l][i], res.state[l][i]) < 1e-5 * max(1.0, float(np.abs(res.state[l][i]).max()))
+            assert max_abs(st[l][i], res.state[l][i]) < st_tol * max(1.0, float(np.abs(res.state[l][i]).max()))
 
 
-def test_large_shard_default_equals_chunked_two_cu_form_and_oracle(eng):
-    """A shard of 300 problems (more than #CU / 2): the default now runs k_unroll_lds; against the oracle (x scaling,
-    B_global > B_local, step0) and against the chunked two-CU form (L2O_OPT_ONE_LDS = 0) -- same trajectory up to the
-    fp32 summation order of the two GEMV forms; continuation (2 x T/2 == T) bit for bit."""
+def test_large_shard_forms_equal_chunked_two_cu_form_and_oracle(eng):
+    """A shard of 300 problems (more than #CU / 2): the default (1) runs k_unroll_lds, 3 k_unroll_pair2 in chunks of #CU
+    problems, 0 the chunked two-CU form; each against the oracle (x scaling, B_global > B_local, step0); pair2 runs
+    the two-CU kernel's arithmetic in its order (same body, fragments read from LDS): the trajectory of the chunked form to
+    fp32 contraction differences; k_unroll_lds sums the GEMVs in another order; continuation (2 x T/2 == T) bit for bit."""
     cfg = ORACLE_CFGS["dm"]
     params = make_params(cfg, seed=21, trained_like=True)
     B, D, T = 300, 128, 10
@@ -52,26 +60,31 @@ def test_large_shard_default_equals_chunked_two_cu_form_and_oracle(eng):
     xs = np.exp(np.random.default_rng(3).uniform(-0.3, 0.3, (B, D))).astype(np.float32)
     res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, x_scale=xs, step0=1)
     out = {}
-    for mode in (1, 0):
+    for mode in (1, 3, 0):
         with lib_option(_abi.OPT_ONE_LDS, mode):
             out[mode] = _run_fused(eng, cfg, params, arrays, x0, B, D, T, Bg=2 * B, x_scale=xs)
-    for mode in (1, 0):
         assert rel_err(out[mode][0], res.fx) < 1e-5, mode
         assert max_abs(out[mode][1], res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max()))
-    assert rel_err(out[1][0], out[0][0]) < 2e-6
+    print("pair2 vs chunked two-CU: rel fx %.3g, identical x: %s; k_unroll_lds vs chunked: rel fx %.3g"
+          % (rel_err(out[3][0], out[0][0]), np.array_equal(out[3][1], out[0][1]), rel_err(out[1][0], out[0][0])))
+    assert rel_err(out[3][0], out[0][0]) < 1e-6 and rel_err(out[1][0], out[0][0]) < 2e-6
     # continuation: two launches of T / 2 carrying x and the LSTM state == one launch of T
     spec = spec_of(cfg)
     wpack = eng.pack_weights(spec, params)
     pd = device_problem(eng, arrays, B, D, B_global=2 * B, x_scale=xs)
-    x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
-    m, v = eng.zeros(B, D), eng.zeros(B, D)
-    fxp = eng.zeros((T // 2 + 1) * B)
-    for _ in range(2):
-        eng.unroll(spec, wpack, pd, x, st, m, v, T // 2, 1, fxp)
-    assert np.array_equal(eng.to_numpy(x), out[1][1])
+    for mode in (1, 3):
+        with lib_option(_abi.OPT_ONE_LDS, mode):
+            x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
+            m, v = eng.zeros(B, D), eng.zeros(B, D)
+            fxp = eng.zeros((T // 2 + 1) * B)
+            for _ in range(2):
+                eng.unroll(spec, wpack, pd, x, st, m, v, T // 2, 1, fxp)
+            assert np.array_equal(eng.to_numpy(x), out[mode][1]), mode
+    eng.check_unroll_status()
 
 
-def test_recording_form_equals_plain_unroll_prefixes(eng):
+@pytest.mark.parametrize("form", [1, 3])
+def test_recording_form_equals_plain_unroll_prefixes(eng, form):
     """HIST instantiation (l2o_unroll_record on a large shard of a DM net): the recording launch leaves the same x / fx as
     the plain one (a different instantiation: same arithmetic, the compiler may contract differently -> 1e-5), the
     recorded state BEFORE step t is the state a t-step plain unroll ends with, the recorded gradients are the optimizee's
@@ -88,7 +101,8 @@ def test_recording_form_equals_plain_unroll_prefixes(eng):
     def run(t, hist=None):
         x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
         fxp = eng.zeros((t + 1) * B)
-        eng.unroll(spec, wpack, pd, x, st, eng.zeros(B, D), eng.zeros(B, D), t, 1, fxp, hist=hist)
+        with lib_option(_abi.OPT_ONE_LDS, form):
+            eng.unroll(spec, wpack, pd, x, st, eng.zeros(B, D), eng.zeros(B, D), t, 1, fxp, hist=hist)
         return eng.to_numpy(x), eng.to_numpy(fxp), eng.to_numpy(st)
 
     hist = dict(st=eng.zeros(T, eng.state_floats(B, D)), g=eng.zeros(T, B * D), g_final=eng.zeros(B * D))
