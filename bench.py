@@ -89,6 +89,11 @@ def alg_flops_per_coord_step(problem, net, D, M):
 # v_permlane*_swap 10.3 (counted as plain: 6 per step), v_mfma_f32_16x16x32_bf16 back to back 17.9 (the pipe).
 ISSUE_COST = {"valu": 5.26, "trans": 8.51, "mfma": 5.26}
 MFMA_PIPE_CYCLES = 17.89
+# What the SIMD's PIPES take per instruction once two or more waves feed them (scripts/microbench/two_wave_issue.hip,
+# profiles/r04w_two_wave_issue.txt: 1.220 / 3.496 / 6.744 ns per instruction per SIMD, x 2.4 GHz like every cycle figure
+# here): a plain VALU instruction 2.93 cycles (one wave alone: 5.6), a transcendental 8.39 (the same pipe: their times add),
+# the bf16 MFMA 16.2 on its own pipe (overlaps another wave's VALU).  The floor of the two-waves-per-SIMD kernels.
+PIPE_COST = {"valu": 2.93, "trans": 8.39, "mfma": 16.2}
 
 
 def work_model(problem, net, D, M):
@@ -124,6 +129,26 @@ def work_block(case, issue, args):
     # only, so the counters file cannot tell.)  The streaming kernels run several tiles per wave and are HBM-bound.
     one_tile_per_wave = ((case["fused"] and not case["hbm_bound"] and case["D"] > 16) or "l2o_mlp_unroll" in case["kernel"]) \
         and "k_unroll_lds" not in case["kernel"] and "k_unroll_pair2" not in case["kernel"]   # (two waves per SIMD: not this model)
+    two_waves = "k_unroll_lds" in case["kernel"] or "k_unroll_pair2" in case["kernel"]
+    if issue is not None and two_waves:
+        # two waves (tiles) per SIMD: the floor is the SIMD's pipe time for TWO tile-steps per step
+        T, dispatches = case["T"], float(case.get("dispatches", 1))
+        wm = work_model(args.problem, args.net, case["D"], case["Mrows"])
+        per_tile = wm["valu_plain"] * PIPE_COST["valu"] + wm["transcendental"] * PIPE_COST["trans"]
+        # k_unroll_lds: one launch, ceil(B / #CU) problems per CU one after the other; pair2: `dispatches` chunk launches
+        rounds = -(-case["B"] // max(1, case.get("n_cus", 256))) if "k_unroll_lds" in case["kernel"] else 1
+        cyc = case["kern_ms"] * 1e-3 * issue["clock_hz"] / (dispatches * rounds * (T + 0.3))
+        return {"cycles_per_step": cyc, "tiles_per_simd": 2, "work_model_instructions_per_tile_step": wm,
+                "pipe_cost_cycles": dict(PIPE_COST), "pipe_floor_cycles_per_step": 2 * per_tile,
+                "mfma_pipe_cycles_per_step": 2 * wm["mfma"] * PIPE_COST["mfma"],
+                "frac_work": 2 * per_tile / cyc,
+                "frac_work_note": "two tile-steps per SIMD and step: stated minimal VALU + transcendental counts (bench.py: "
+                                  "work_model) x the measured PIPE time per instruction with two waves per SIMD "
+                                  "(profiles/r04w_two_wave_issue.txt) / measured cycles per step (kernel time / rounds of "
+                                  "problems per CU / T).  The timing-only build of the kernel without barriers and LDS operand "
+                                  "reads runs at 0.78 of the shipped one's step time (profiles/r04u_ablate_k_unroll_lds.txt): "
+                                  "the ISA executes ~30 % more VALU instructions than the stated minimum and its dependency "
+                                  "chains keep two waves from filling the pipe"}
     if issue is None or not one_tile_per_wave:
         return None
     T, dispatches = case["T"], float(case.get("dispatches", 1))
@@ -619,7 +644,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
             "kern_ms": float(kern_all), "kern_ms_min": float(np.min(kt)), "coord_steps": coord_steps,
             "bpc": bpc, "alg_bytes": bpc * coord_steps,
             "flops": alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps,
-            "fused": fused, "kernel": kernel, "dispatches": dispatches, "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
+            "fused": fused, "kernel": kernel, "dispatches": dispatches, "n_cus": int(getattr(eng, "coresident_cus", 256)), "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
             "hbm_model_bytes": hbm_model, "t_reset": t_reset, "prepare_ms": prepare_ms, "D": D, "B": B, "Bg": Bg, "T": T, "Mrows": Mrows,
             "shared": shared}
 

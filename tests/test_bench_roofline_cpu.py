@@ -60,3 +60,16 @@ def test_work_block_and_same_lease_lookup(tmp_path, monkeypatch):
     # a streaming (HBM-bound) kernel carries no work block
     case3 = dict(case, hbm_bound=True, kernel="k_unroll_cu")
     assert "frac_work" not in b.roofline_block(case3, A, found)
+    # a two-waves-per-SIMD kernel (k_unroll_lds): the floor is the SIMD's PIPE time for two tile-steps per step
+    case4 = dict(case, kernel="k_unroll_lds (one problem per CU, two waves per SIMD, fragments in LDS)", kern_ms=1.2263,
+                 D=100, Mrows=100, B=1024, n_cus=256)
+
+    class A4:
+        problem, net = "rastrigin", "dm"
+    roof4 = b.roofline_block(case4, A4, found)
+    wm = b.work_model("rastrigin", "dm", 100, 100)
+    floor4 = 2 * (wm["valu_plain"] * b.PIPE_COST["valu"] + wm["transcendental"] * b.PIPE_COST["trans"])
+    cyc4 = 1.2263e-3 * 2.43e9 / (4 * 100.3)                                   # four rounds of problems per CU
+    assert abs(roof4["cycles_per_step"] - cyc4) < 1e-6 * cyc4 and roof4["tiles_per_simd"] == 2
+    assert abs(roof4["pipe_floor_cycles_per_step"] - floor4) < 1e-9 and abs(roof4["frac_work"] - floor4 / cyc4) < 1e-9
+    assert 0.3 < roof4["frac_work"] < 0.45 and "cycles_per_tile_step" not in roof4
