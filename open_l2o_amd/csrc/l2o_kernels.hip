@@ -1156,7 +1156,9 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     const bool shape_ok = g.CH == 8 && g.nw >= 5;
 #endif
     const bool plain = !(opt(L2O_OPT_EXACT_GATES) && !hist);
-    if ((one_lds == 2 || (one_lds == 1 && chunk > 0 && a.pp.B_local > chunk)) && shape_ok && plain) {
+    // (also when the two-CU form is not available at all -- no workspace, L2O_OPT_PAIR = 0: the alternative there is k_unroll's
+    //  fp32-MFMA form for 5..8 tiles, 11 200 cycles per step against 7 200)
+    if ((one_lds == 2 || (one_lds == 1 && (chunk == 0 || a.pp.B_local > chunk))) && shape_ok && plain) {
       void (*fl)(UnrollArgs) = hist ? k_unroll_lds<PRE, KIND, true> : k_unroll_lds<PRE, KIND, false>;
       const size_t lds = sizeof(float) * ((size_t)LstmCoreLds<PRE>::kFragWords + 2 * 128 + 8);
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
