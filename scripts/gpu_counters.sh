@@ -15,6 +15,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$TAG -o t -- python $R/
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sq2 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM
 run sq3 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA
+# LDS-array occupancy and conflicts (the kernels with their gate-GEMM fragments in LDS: DESIGN 3.1d); L2O_COUNTERS_LDS=1
+[ -n "$L2O_COUNTERS_LDS" ] && run lds SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 cd $R
