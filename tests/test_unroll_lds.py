@@ -120,3 +120,64 @@ def test_recording_form_equals_plain_unroll_prefixes(eng, form):
     gT = prob.grad(x_pl.reshape(x0.shape)).reshape(-1)
     assert max_abs(eng.to_numpy(hist["g_final"]), gT) < 2e-5 * float(np.abs(gT).max())
     eng.check_unroll_status()
+
+
+@pytest.mark.parametrize("form", [2, 3])
+def test_shared_matrix_equals_replicated(eng, form):
+    """L2O_PROB_W_SHARED (one [M, D] matrix for the whole batch, DM/problems.py lasso_fixed) through the LDS-fragment
+    kernels == the same matrix replicated per problem, bit for bit."""
+    cfg = ORACLE_CFGS["dm_logsign"]
+    params = make_params(cfg, seed=41, trained_like=True)
+    B, D, M, T = 5, 100, 70, 8
+    prob, x0, arrays = make_problem("lasso", B, D, seed=42, M=M)
+    W0 = np.ascontiguousarray(arrays["W"][0])
+    rep = dict(arrays, W=np.broadcast_to(W0, arrays["W"].shape).copy())
+    sh = dict(arrays, W=W0, w_shared=True)
+    with lib_option(_abi.OPT_ONE_LDS, form):
+        a = _run_fused(eng, cfg, params, rep, x0, B, D, T)
+        b = _run_fused(eng, cfg, params, sh, x0, B, D, T)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    prob.w[:] = W0
+    res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, step0=1)
+    assert rel_err(a[0], res.fx) < 1e-5
+
+
+def test_large_shard_through_the_product_api(eng):
+    """MetaOptimizer.meta_loss on 300 Rastrigin problems of d = 100 (config 4's shape, a shard larger than #CU / 2): the
+    default path is k_unroll_lds; Session.run([loss, fx, x, update]) twice (continuation) and UnrollGraph.launch(restart=)
+    -- the prepared-call path bench.py uses, with the zero-state / x0 rewind folded into the launch -- against the oracle."""
+    from open_l2o_amd import _engine, meta, problems
+    from open_l2o_amd.session import Session
+    from test_meta_api import _net_config
+    old = _engine._default_engine
+    _engine.set_default_engine(eng)
+    try:
+        cfg = ORACLE_CFGS["dm"]
+        params = make_params(cfg, seed=51, trained_like=True)
+        B, D, T = 300, 100, 10
+        prob, x0, _ = make_problem("rastrigin", B, D, seed=52)
+        problem = problems.rastrigin(batch_size=B, num_dims=D, data={"A": prob.A, "B": prob.B, "C": prob.C, "x": x0})
+        optimizer = meta.MetaOptimizer(**_net_config(cfg, params))
+        ml = optimizer.meta_loss(problem, T)
+        res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+        res2 = O.unroll(prob, cfg, params, res.x, res.state, T)
+        with Session() as sess:
+            sess.run(ml.reset)
+            l1, f1, x1, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
+            l2, f2, _, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update])
+        g = optimizer.graph
+        assert g.last_path == "fused"
+        assert rel_err(l1, res.loss) < 1e-5 and rel_err(f1, res.fx[-1]) < 1e-5
+        assert rel_err(l2, res2.loss) < 2e-5 and rel_err(f2, res2.fx[-1]) < 2e-5
+        np.testing.assert_allclose(x1[0], res.x, rtol=1e-4, atol=2e-6)
+        x0d = [eng.tensor(x0)]
+        outs = []
+        for _ in range(3):
+            fx, xs = g.launch({}, commit=True, restart=x0d)
+            outs.append((eng.to_numpy(fx).copy(), eng.to_numpy(xs[0]).copy()))
+        assert rel_err(outs[0][0], res.fx) < 1e-5
+        for fxk, xk in outs[1:]:
+            assert np.array_equal(fxk, outs[0][0]) and np.array_equal(xk, outs[0][1])
+        eng.check_unroll_status()
+    finally:
+        _engine.set_default_engine(old)
