@@ -102,6 +102,9 @@ __device__ __forceinline__ unsigned long long mu_granule(float v, unsigned tag) 
 __device__ __forceinline__ float mu_poll(const unsigned long long* p, unsigned tag, bool& dead, unsigned* status) {
   unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int spins = 0;
+#ifdef L2O_MU_ABL_NOWAIT   // (timing ablation: every granule of the STEP LOOP counts as arrived -- wrong numerics; the step
+  if ((tag & 0xffffu) != 0xfffeu) return __uint_as_float((unsigned)g);   //  without waiting for partners; the handshake still waits)
+#endif
   while ((unsigned)(g >> 32) != tag && !dead) {
     if (++spins > (1 << 20)) { dead = true; atomicExch(status, 2u); break; }
     __builtin_amdgcn_s_sleep(L2O_MU_SLEEP1);
@@ -143,6 +146,9 @@ __device__ __forceinline__ void mu_barrier() {
 // with the stores it waits for)
 __device__ __forceinline__ mu_u32x4 mu_poll2(const unsigned long long* p, mu_u32x4 d, unsigned tag, bool& dead, unsigned* status) {
   int spins = 0;
+#ifdef L2O_MU_ABL_NOWAIT
+  return d;
+#endif
   while ((d[1] != tag || d[3] != tag) && !dead) {
     if (++spins > (1 << 17)) { dead = true; atomicExch(status, 2u); break; }
     __builtin_amdgcn_s_sleep(L2O_MU_SLEEP2);
@@ -311,6 +317,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //  through LDS behind the reduce phase's barrier instead of being loaded here, in front of the image / label loads that
     //  depend on them.  Measured 2 % SLOWER (kernel 1.904 vs 1.867 ms per T = 200 unroll, profiles/r04j_*): not the default)
     auto prefetch_next = [&]() {
+#ifdef L2O_MU_ABL_NOPREFETCH   // (timing ablation: no minibatch gather -- wrong numerics; what do the two dependent loads cost?)
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) pre_img[u] = 0.25f;
+      return;
+#endif
       if (have_next) {
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
