@@ -130,6 +130,23 @@ __device__ __forceinline__ mu_u32x4 mu_load2(const unsigned long long* p) {
   return d;
 }
 __device__ __forceinline__ void mu_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// A failed first poll costs a whole L2 / fabric round trip before the retry can see the granule (the no-wait build says
+// waiting is 19 % of the config-5 step, i.e. about half a round trip per hop): -DL2O_MU_DELAY_{A,B,C}=n holds the FIRST load
+// of a hop back by n x 64 clocks so that it arrives just after the granules do (A: local reduce, B: the fabric hop, C: gather)
+#ifndef L2O_MU_DELAY_A
+#define L2O_MU_DELAY_A 0
+#endif
+#ifndef L2O_MU_DELAY_B
+#define L2O_MU_DELAY_B 0
+#endif
+#ifndef L2O_MU_DELAY_C
+#define L2O_MU_DELAY_C 0
+#endif
+template <int N>
+__device__ __forceinline__ void mu_nap() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) __builtin_amdgcn_s_sleep(1);
+}
 // The step loop's workgroup barrier.  -DL2O_MU_LDS_BARRIERS: wait for LDS traffic only (the barriers order LDS data; the
 // cross-workgroup protocol is self-validating granules) instead of __syncthreads(), which also drains the vector-memory
 // queue -- e.g. the next minibatch's image columns at the barrier behind dH.  Measured 1 % SLOWER (kernel 1.885 vs 1.869 ms
@@ -411,6 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           float s0 = 0.0f, s1 = 0.0f;
           if (ch < nch) {
             const unsigned long long* inbox = a.P + (((size_t)g * kMuHierM + mr) * kMuHierM) * R1 + 2 * pq;
+            mu_nap<L2O_MU_DELAY_A>();
             for (int base = ch; base < cnt; base += 3 * nch) {   // up to 3 sources in flight per thread, then their tags
               mu_u32x4 d[3];
 #pragma unroll
@@ -441,6 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int g2 = tid / np, p2 = tid - g2 * np;
             if (g2 != g) {
               const unsigned long long* xp = a.X + (((size_t)par * kMuHierG + g2) * kMuHierM + mr) * R1 + 2 * p2;
+              mu_nap<L2O_MU_DELAY_B>();
               mu_u32x4 d = mu_load2(xp);
               mu_wait_loads();
               d = mu_poll2(xp, d, tag, dead, status);
@@ -504,6 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned long long* Sp = hier ? a.S1 + ((size_t)par * kMuHierG + (wg & (kMuHierG - 1))) * kMuHierS
                                             : a.S + (size_t)par * FNO;
         mu_u32x4 g[3];
+        mu_nap<L2O_MU_DELAY_C>();
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int pr = tid + 256 * u;
