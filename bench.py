@@ -617,11 +617,11 @@ def run_case(args, eng, world, rank, Bg, B, label):
         # every SIMD runs two waves -- k_unroll_lds (one problem per CU; the default) or k_unroll_pair2 (the two-CU kernel,
         # two workgroups per CU, chunks of #CU problems; L2O_ONE_LDS=3) -- instead of chunk launches of the two-CU kernel
         one_lds = _abi.get_option(_abi.OPT_ONE_LDS)
-        lds_shape = args.net != "rnnprop" and 64 < D <= 128 and not _abi.get_option(_abi.OPT_EXACT_GATES)
+        lds_shape = 64 < D <= 128 and not _abi.get_option(_abi.OPT_EXACT_GATES)            # (5..8 tiles)
         pair_on = bool(_abi.get_option(_abi.OPT_PAIR))
         if lds_shape and (one_lds == 2 or (one_lds == 1 and (B > cap or not pair_on))):
             kernel = "k_unroll_lds (one problem per CU, two waves per SIMD, fragments in LDS)"
-        elif lds_shape and pair_on and not _abi.get_option(_abi.OPT_PAIR_NORMAL) and one_lds == 3:
+        elif lds_shape and args.net != "rnnprop" and pair_on and not _abi.get_option(_abi.OPT_PAIR_NORMAL) and one_lds == 3:
             dispatches = (B + 2 * cap - 1) // (2 * cap)
             kernel = "k_unroll_pair2 (two-CU kernel, fragments in LDS, two workgroups per CU)" + (
                 " x %d chunk launches" % dispatches if dispatches > 1 else "")

@@ -135,12 +135,12 @@ const char* l2o_last_error(void);
 #define L2O_OPT_MLP_HIER 11          /* 1*: l2o_mlp_unroll's fast form reduces the hidden pre-activations XCD-hierarchically (one
                                         fabric hop per step; falls back by itself when the workgroups are not placed round-robin
                                         over the XCDs); 0: the flat two-hop protocol */
-#define L2O_OPT_ONE_LDS 12           /* large shards of the fused unroll (DM nets, 65 <= padded size <= 128) -- more problems than
+#define L2O_OPT_ONE_LDS 12           /* large shards of the fused unroll (65 <= padded size <= 128) -- more problems than
                                         the #CU / 2 that one launch of the two-CU kernel holds: 0: consecutive chunk launches of
                                         that kernel (one workgroup per CU, fragments in registers); 1*: one problem per CU, two
                                         waves per SIMD, the gate-GEMM fragments in LDS (k_unroll_lds); 2: k_unroll_lds for every
                                         shard; 3: the two-CU kernel with the fragments in LDS and TWO workgroups per CU
-                                        (k_unroll_pair2; chunks of #CU problems) for every shard -- measures like 1 */
+                                        (k_unroll_pair2; chunks of #CU problems; DM nets only) for every shard -- measures like 1 */
 #define L2O_OPT_COUNT_ 13            /* (* = default) */
 /* an option's 4-bit field in l2o_net_cfg.options: bit 3 = "set", bits 0-2 = the value.  Fields 0..11 sit at 4 * option;
  * bits 48-63 are the L2O_OPT_BWD_BLOCKS count, so option 12 uses the field that option 5 (that count) leaves unused */

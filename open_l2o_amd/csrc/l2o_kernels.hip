@@ -1148,7 +1148,7 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
   //      chunks of #CU problems (A/B runs; <= #CU / 2 problems leave it one workgroup per CU)
   // DM nets, 5..8 tiles, no exact-gates / normal-matrix request.
   bool pair2 = false;
-  if constexpr (PRE != L2O_PRE_FC_ELU) {
+  {
     const int one_lds = (int)opt(L2O_OPT_ONE_LDS);
 #ifdef L2O_LDS_ABL_ANYNW   // (timing ablation: also 1..4 tiles, i.e. ONE wave per SIMD in this kernel; needs M <= 16 nw)
     const bool shape_ok = g.nw >= 1 && a.pp.M <= 16 * g.nw;
@@ -1166,7 +1166,8 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
       HIP_TRY(hipGetLastError());
       return L2O_OK;
     }
-    if (chunk > 0 && g.CH == 8 && g.nw >= 5 && plain && !opt(L2O_OPT_PAIR_NORMAL) && one_lds == 3) {
+    // (k_unroll_pair2: DM nets only -- two workgroups with RNNProp's 80 KB of fragments each do not fit a CU's LDS)
+    if (PRE != L2O_PRE_FC_ELU && chunk > 0 && g.CH == 8 && g.nw >= 5 && plain && !opt(L2O_OPT_PAIR_NORMAL) && one_lds == 3) {
       pair2 = true;
       chunk = pair_chunk(prob, g, s, 2);
     }
@@ -1401,7 +1402,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
             ow[bx::frag_off(pre, false, ch, t, sp) + l * 4 + rg] = slot(2 * rg) | (slot(2 * rg + 1) << 16);
           }
         // packed K-slots (l2o_lstm_bx3.h, slot_desc): the weight level that multiplies the slot's activation level
-        if (bx::packed_default(pre))
+        {
           for (int j = 0; j < bx::kPack; ++j)
             for (int rg = 0; rg < 4; ++rg) {
               uint32_t word = 0;
@@ -1414,6 +1415,7 @@ __host__ __device__ static void wpack_lane(int pre, int l, int t_lo, int t_hi, i
               }
               ow[bx::frag_off(pre, true, ch, t, j) + l * 4 + rg] = word;
             }
+        }
       }
       if (ch_lo != 0) continue;                                 // (the rest of the slice rides with chunk 0)
       if ((l & 15) == 0)                                        // one lane per lane group writes its 4 gate rows

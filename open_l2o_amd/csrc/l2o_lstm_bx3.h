@@ -63,10 +63,11 @@ __host__ __device__ constexpr int frags(bool pk) { return pk ? kPack : 3; }     
 __host__ __device__ constexpr int chunk_mfmas(bool pk) { return (pk ? kPack : kProducts) * kNT; }   // 20 | 30
 
 __host__ __device__ constexpr int nchunks(int pre) { return pre == L2O_PRE_FC_ELU ? 4 : 3; }
-// word offsets inside wpack (the bf16 section follows the fp32 rows of l2o_common.h): packed fragments (DM nets
-// only), 6-product fragments, then the input rows
+// word offsets inside wpack (the bf16 section follows the fp32 rows of l2o_common.h): packed fragments, 6-product
+// fragments, then the input rows.  (Round 4: RNNProp's wpack carries the packed section too -- 80 KB; its register-resident
+// kernels keep the 6-product form, packed_default above, but k_unroll_lds reads the packed fragments from LDS.)
 __host__ __device__ constexpr int base(int pre) { return wp_rows(pre) * 64; }
-__host__ __device__ constexpr int packed_words(int pre) { return packed_default(pre) ? nchunks(pre) * kNT * kPack * kFragWords : 0; }
+__host__ __device__ constexpr int packed_words(int pre) { return nchunks(pre) * kNT * kPack * kFragWords; }
 __host__ __device__ constexpr int level_words(int pre) { return nchunks(pre) * kNT * 3 * kFragWords; }
 __host__ __device__ constexpr int frag_off(int pre, bool pk, int ch, int t, int j) {
   return base(pre) + (pk ? 0 : packed_words(pre)) + ((ch * kNT + t) * frags(pk) + j) * kFragWords;

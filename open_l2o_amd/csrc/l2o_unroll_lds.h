@@ -13,7 +13,8 @@
 //              -> rs, per-wave loss partial | B2 | g = W^T r for the wave's 16 coordinates (8 reads of rs, 32 FMAs; 10 more)
 //              -> preprocess -> input FMAs -> layer-1 gates -> split h1 -> 20 MFMAs (L2A) + the next step's 20 (L1H)
 //              under the layer-2 gate block -> Linear -> x += delta -> xs -> LDS
-// DM nets (identity / LogAndSign preprocessing: three packed chunks), 65 <= padded size <= 128 (5..8 tiles).
+// 65 <= padded size <= 128 (5..8 tiles); DM nets (identity / LogAndSign preprocessing: three packed chunks, 60 KB) and
+// RNNProp (fc + ELU: four chunks, 80 KB).
 #pragma once
 
 // (timing ablations, scripts/ablate_lds.sh: L2O_LDS_ABL_NOBAR drops the two barriers, _NOGEMV the xs / rs reads,
@@ -96,6 +97,11 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
   float cj = 0.0f;
   constexpr bool kCos = KIND == L2O_PROB_RASTRIGIN || KIND == L2O_PROB_SQUARE_COS;
   if (kCos) cj = live ? pp.C[idx] : 0.0f;
+  // RNNProp (fc + ELU preprocessing, four packed chunks = 80 KB of fragments): Adam moments in registers, the bias
+  // corrections beta^(step0 + t) as double-float products, exactly as k_unroll / k_unroll_pair carry them
+  float mv = 0.0f, vv = 0.0f;
+  if (PRE == L2O_PRE_FC_ELU && !a.zero_state) { mv = live ? a.m[idx] : 0.0f; vv = live ? a.v[idx] : 0.0f; }
+  float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   constexpr bool kSq = KIND == L2O_PROB_QUADRATIC || KIND == L2O_PROB_SQUARE_COS;
   const float coef = kSq ? 1.0f : 0.5f;
   const float cg = (KIND == L2O_PROB_QUADRATIC ? 2.0f : 1.0f) * pp.inv_bg;
@@ -172,7 +178,21 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
     if (HIST && t == a.T) break;
 
     float in0, in1;
-    preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
+    if (PRE == L2O_PRE_FC_ELU) {
+      rnnprop_inputs(gv, mv, vv, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, 1.0f - p1h, 1.0f - p2h, in0, in1);
+      if (HIST && live && q == 0) { a.hist_m[(size_t)t * hist_n + idx] = mv; a.hist_v[(size_t)t * hist_n + idx] = vv; }
+      if (!live) { in0 = 0.0f; in1 = 0.0f; }
+      {
+        float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
+        float lo = __builtin_fmaf(p1l, a.np.beta1, er), sum = hi + lo;
+        p1l = lo - (sum - hi); p1h = sum;
+        hi = p2h * a.np.beta2; er = __builtin_fmaf(p2h, a.np.beta2, -hi);
+        lo = __builtin_fmaf(p2l, a.np.beta2, er); sum = hi + lo;
+        p2l = lo - (sum - hi); p2h = sum;
+      }
+    } else {
+      preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
+    }
     float d = core.template finish<!L2O_LDS_MFMA_ORDER>(s, acc1, acc2, in0, in1, q, pc);
     if (L2O_LDS_MFMA_ORDER) core.refresh(s);             // split h2 -> the L2B operand of the next step
     if (a.np.tanh_output) {
@@ -184,6 +204,9 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
     if (q == 0) xs[j] = live ? xv * sc : 0.0f;
   }
 
-  if (live && q == 0) a.x[idx] = xv;
+  if (live && q == 0) {
+    a.x[idx] = xv;
+    if (PRE == L2O_PRE_FC_ELU) { a.m[idx] = mv; a.v[idx] = vv; }
+  }
   store_tile_state(s, st_tile, lane);
 }

@@ -152,7 +152,7 @@ def bx_packed_default(pre):
 
 
 def bx_packed_words(pre):
-    return bx_nchunks(pre) * KNT * 4 * 256 if bx_packed_default(pre) else 0
+    return bx_nchunks(pre) * KNT * 4 * 256       # (round 4: RNNProp's wpack carries the packed section too, for k_unroll_lds)
 
 
 def bx_level_words(pre):
