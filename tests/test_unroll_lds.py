@@ -1,4 +1,4 @@
-"""The fused unroll for LARGE shards (round 4; DM nets, 5..8 tiles), both forms with the bf16x3 gate GEMM's fragments in LDS
+"""The fused unroll for LARGE shards (round 4; 5..8 tiles; DM nets, and RNNProp on k_unroll_lds), both forms with the bf16x3 gate GEMM's fragments in LDS
 and two waves per SIMD (L2O_OPT_ONE_LDS):
   2 / default 1 above #CU / 2 problems   k_unroll_lds   -- one problem per CU, two waves of the same problem per SIMD
   3                                      k_unroll_pair2 -- the two-CU kernel, TWO workgroups (halves of two different
