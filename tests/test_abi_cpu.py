@@ -164,8 +164,12 @@ def test_packed_weights_reproduce_oracle_under_mfma_layout(lib, name):
     # fp32 MFMA section (exact weights: float64 emulation agrees to 1e-9) and the bf16x3
     # section (weights and activations carried as three bf16 terms = 24 bits: fp32-level error)
     # (both forms of it: 4 packed MFMAs per M-tile -- the DM nets' default -- and one MFMA per product)
+    # (round 4: RNNProp's wpack carries the packed section too -- k_unroll_lds reads it from LDS -- so both forms are
+    #  emulated for every net, whatever its register-resident kernels default to)
     bx_levels = lambda *a: E.tile_step_bx3(*a, packed=False)
-    for step_fn, rtol, atol in ((E.tile_step, 1e-9, 1e-12), (E.tile_step_bx3, 2e-6, 2e-7), (bx_levels, 2e-6, 2e-7)):
+    bx_packed = lambda *a: E.tile_step_bx3(*a, packed=True)
+    for step_fn, rtol, atol in ((E.tile_step, 1e-9, 1e-12), (E.tile_step_bx3, 2e-6, 2e-7), (bx_levels, 2e-6, 2e-7),
+                                (bx_packed, 2e-6, 2e-7)):
         d, h1n, c1n, h2n, c2n = step_fn(wpack, spec.preprocess, h1, c1, h2, c2,
                                         np.asarray(in0, np.float64)[lanes & 15],
                                         np.asarray(in1, np.float64)[lanes & 15])
