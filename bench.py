@@ -388,8 +388,9 @@ def roofline_block(case, args, counters):
     whole timed region / steps (one event pair on the launch stream: the unroll kernel + its epilogue per step);
     kernel_ms_min = the shortest of a few individually bracketed launches made after the timed region.
 
-    bound == "hbm" (streaming / step-granular kernels): achieved = HBM bytes per launch (PMC: FETCH_SIZE x 2 on
-    gfx950 + WRITE_SIZE, committed under profiles/) / the kernel time measured live with HIP events.
+    bound == "hbm" (streaming / step-granular kernels): achieved = the bytes a kernel of this form must move per launch
+    (the matrices once per evaluation + x / state once each way) / the kernel time measured live with HIP events; traffic =
+    HBM bytes per launch from the PMC pass (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, committed under profiles/).
     bound == "valu_issue" (the LDS/register-resident fused kernels: ~20 MB of HBM traffic per launch, one wave per
     SIMD issuing in order): achieved = VALU-active SIMD-cycles per second = 4 x SQ_ACTIVE_INST_VALU per launch
     (quad-cycles -> cycles; MFMA issue slots included; PMC, committed) / live kernel time; peak = SIMDs in use x
@@ -423,12 +424,14 @@ def roofline_block(case, args, counters):
                      "insts_valu": c.get("per_launch", {}).get("SQ_INSTS_VALU"),        # (per DISPATCH, like `waves`)
                      "waves": c.get("per_launch", {}).get("SQ_WAVES")}
     if case["hbm_bound"]:
-        out.update(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, traffic=traffic)
+        # achieved = the bytes a kernel of this form MUST move per launch (the matrices once per evaluation + x / state once
+        # each way: hbm_model_bytes) / live time; traffic = what the PMC pass saw (FETCH_SIZE x 2 + WRITE_SIZE).  The two agree
+        # to 0.1 % for k_unroll_cu; a kernel that spills (k_unroll_cu8: 1.28 x) shows it in traffic, not in frac.
+        model = case["hbm_model_bytes"]
+        out.update(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, traffic=traffic, traffic_model_bytes=model,
+                   achieved=model / kern_s / 1e9, frac=model / kern_s / HBM_PEAK)
         if traffic is not None:
-            out.update(achieved=traffic / kern_s / 1e9, frac=traffic / kern_s / HBM_PEAK)
-        else:   # no PMC pass of this workload committed: the matrix-once-per-evaluation model of the streaming kernels
-            model = case["hbm_model_bytes"]
-            out.update(achieved=model / kern_s / 1e9, frac=model / kern_s / HBM_PEAK, traffic_model_bytes=model)
+            out.update(traffic_GBps=traffic / kern_s / 1e9, traffic_over_model=traffic / model if model else None)
         if issue is not None:
             out["valu_issue_frac"] = issue["valu_active_cycles"] / (issue["simds"] * issue["clock_hz"] * kern_s)
     else:
@@ -604,7 +607,10 @@ def run_case(args, eng, world, rank, Bg, B, label):
     if args.problem == "mnist":
         kernel = "l2o_mlp_unroll (persistent)" if graph.last_path == "mlp_unroll" else "l2o_mlp_fg + l2o_cwlstm_step_multi per step"
     elif streaming:
-        kernel = "k_unroll_cu"
+        from open_l2o_amd import _abi
+        form = _abi.get_option(_abi.OPT_UNROLL_CU)
+        cu8 = form in (3, 4)
+        kernel = "k_unroll_cu8 (eight waves, fragments in LDS, LSTM state in registers)" if cu8 else "k_unroll_cu"
     elif fused:
         # (the two-CU kernel; a shard of more than #CU / 2 = 128 problems runs it as consecutive chunk launches)
         from open_l2o_amd import _abi

@@ -851,6 +851,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 #include "l2o_unroll_pairh.h"
 
 #include "l2o_unroll_cu.h"
+#include "l2o_unroll_cu8.h"
 
 #include "l2o_mlp.h"
 
@@ -1280,8 +1281,31 @@ static bool unroll_cu_eligible(const l2o_problem* p) {
   if (p->D < 4 || p->D > 512 || (p->D & 3) || p->M <= 0) return false;   // (D <= 128: only when the rows do not fit the LDS forms)
   return unroll_cu_layout(p->D).lds + sizeof(float) * bx::kBiasWords <= 160 * 1024;   // (+ the static bias table)
 }
+// L2O_OPT_UNROLL_CU: 0 step-granular path, 1* (and 2) the four-wave form (k_unroll_cu), 3 the eight-wave form (k_unroll_cu8:
+// two waves per SIMD, fragments in LDS, LSTM state in registers), 4 k_unroll_cu8 with three register tiles + one LDS slot
+// per wave (A/B runs)
+template <int PRE, int KR>
+static int launch_unroll_cu8(const UnrollArgs& a, hipStream_t s) {
+  const UnrollCu8Layout L = unroll_cu8_layout(a.pp.D, PRE, KR);
+  const bool hist = a.hist_st != nullptr;
+  void (*fn)(UnrollArgs) = a.pp.D <= 256 ? (hist ? k_unroll_cu8<PRE, 1, KR, true> : k_unroll_cu8<PRE, 1, KR, false>)
+                                         : (hist ? k_unroll_cu8<PRE, 2, KR, true> : k_unroll_cu8<PRE, 2, KR, false>);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
+  hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(kCu8Threads), L.lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
+}
 template <int PRE>
 static int launch_unroll_cu(const UnrollArgs& a_in, hipStream_t s) {
+  const int form = (int)opt(L2O_OPT_UNROLL_CU);
+  // (the eight-wave form is opt-in: at the 256-register cap its RNNProp instantiation spills 109 registers -- config 3: -2.4 %
+  //  kernel time but 28 % more memory traffic than the matrix stream needs -- and the DM nets' spill 300 and run at half
+  //  the four-wave kernel's speed: DESIGN.md 3.1c)
+  if (form == 3 || form == 4) {
+    const int KR = form == 4 ? 3 : 4;
+    if (unroll_cu8_layout(a_in.pp.D, PRE, KR).lds + sizeof(float) * bx::kBiasWords <= 160 * 1024)
+      return KR == 4 ? launch_unroll_cu8<PRE, 4>(a_in, s) : launch_unroll_cu8<PRE, 3>(a_in, s);
+  }
   const UnrollCuLayout L = unroll_cu_layout(a_in.pp.D);
   const UnrollArgs& a = a_in;
   const bool hist = a.hist_st != nullptr;

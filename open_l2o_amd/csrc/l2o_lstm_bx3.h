@@ -190,6 +190,7 @@ struct NetWB {
   float fcw0[kNT], fcw1[kNT], fcb[kNT];   // RNNProp input projection (2 -> 20)
   const __attribute__((address_space(3))) f32x4* bias;   // LDS: this lane group's [layer][t] accumulator inits (set_bias)
   static constexpr bool kLdsFrags = false;               // (NetWBL: the A operands are read from LDS at issue time)
+  static constexpr int kFragFence = 0;
 };
 // The packed DM network with its weight FRAGMENTS IN LDS (round 4, k_unroll_lds): `a` is never loaded (no registers), an
 // MFMA's A operand is one ds_read_b128 from the workgroup's 60 KB fragment image -- what lets TWO waves share a SIMD
@@ -198,6 +199,7 @@ struct NetWB {
 template <int PRE>
 struct NetWBL : NetWB<PRE, true> {
   static constexpr bool kLdsFrags = true;
+  static constexpr int kFragFence = 0;
   const __attribute__((address_space(3))) u32x4* lfr;
 };
 
@@ -285,6 +287,11 @@ __device__ __forceinline__ void issue(const W& w, const BOp<PK>& b, f32x4 (&acc)
 #else
       acc[t] = mfma_bf(w.lfr[((CH * kNT + t) * kPack + p) * 64], b.m[p], acc[t]);
 #endif
+      // W::kFragFence > 0: a scheduling fence every kFragFence MFMAs -- left alone the scheduler issues ALL fragment reads of
+      // a chunk (20 x 4 registers) ahead of the first MFMA, which a kernel with several tiles' state in registers cannot hold
+      if constexpr (W::kFragFence > 0) {
+        if ((n - LO) % W::kFragFence == W::kFragFence - 1) __builtin_amdgcn_sched_barrier(0);
+      }
     } else if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], acc[t]);
     else acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.m[prod_x(p)], acc[t]);
   });
@@ -467,8 +474,9 @@ __device__ __forceinline__ float finish(const W& w, TileState& s, BOp<PK>& b1, B
 }
 
 // One optimizer-network evaluation for a 16-coordinate tile (step-granular kernel).
-template <int PRE, bool PK>
-__device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s, float in0, float in1, int q) {
+// (W: NetWB<PRE, PK> -- fragments in registers -- or NetWBL<PRE> -- packed fragments read from LDS at issue time)
+template <int PRE, bool PK, class W>
+__device__ __forceinline__ float tile_step_w(const W& w, TileState& s, float in0, float in1, int q) {
   const unsigned one = bias_one<PK>(q);
   constexpr int kN = chunk_mfmas(PK);
   BOp<PK> b1, b2;
@@ -481,8 +489,8 @@ __device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s
   // round 4: the ten bias reads go out first, UNPINNED (the pinning asm made the wave wait for them on the spot: one
   // exposed LDS round trip per tile-step, eight per step and wave in the streaming unroll), the split of h2 hides their
   // latency; the group barriers keep the scheduler from sinking the reads to the first MFMA that needs them
-  preload_bias<1, NetWB<PRE, PK>, false>(w, acc2);
-  preload_bias<0, NetWB<PRE, PK>, false>(w, acc1);
+  preload_bias<1, W, false>(w, acc2);
+  preload_bias<0, W, false>(w, acc1);
   split5<PK>(s.h2, one, b2);
   __builtin_amdgcn_sched_group_barrier(0x100, 2 * kNT, 0);
   __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
@@ -491,7 +499,11 @@ __device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s
   split5<PK>(s.h1, one, b1);
   issue<PRE, kChL1H, 0, kN, true>(w, b1, acc1);
   PhaseClock pc;
-  return finish<PRE, false, PK, NoShadow, false>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
+  return finish<PRE, false, PK, NoShadow, false, W>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc);
+}
+template <int PRE, bool PK>
+__device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s, float in0, float in1, int q) {
+  return tile_step_w<PRE, PK, NetWB<PRE, PK>>(w, s, in0, in1, q);
 }
 
 }  // namespace bx
@@ -597,12 +609,20 @@ struct LstmCore<PRE, true, PK> {
   __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<PK>(s.h2, one, b2); }
 };
 
-// BX packed form with the fragments in LDS (bx::NetWBL): the same interface as LstmCore, <= 256 registers per lane
+namespace bx {
+#ifndef L2O_CU8_FRAG_FENCE
+#define L2O_CU8_FRAG_FENCE 0
+#endif
 template <int PRE>
+struct NetWBLF : NetWBL<PRE> { static constexpr int kFragFence = L2O_CU8_FRAG_FENCE; };   // (k_unroll_cu8)
+}  // namespace bx
+
+// BX packed form with the fragments in LDS (bx::NetWBL): the same interface as LstmCore, <= 256 registers per lane
+template <int PRE, class WT = bx::NetWBL<PRE>>
 struct LstmCoreLds {
   static constexpr int kTotal = bx::chunk_mfmas(true), kHalf = kTotal / 2;
   static constexpr int kFragWords = bx::packed_words(PRE);            // 3 chunks x 5 M-tiles x 4 MFMAs x 256 words = 60 KB
-  bx::NetWBL<PRE> w;
+  WT w;                                                              // (bx::NetWBL<PRE>, or its fenced variant NetWBLF)
   bx::BOp<true> b1, b2;
   unsigned one;
   __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, false, true>(w, wpack, lane); }
@@ -630,8 +650,8 @@ struct LstmCoreLds {
     bx::preload_bias<1>(w, acc2);
   }
   __device__ __forceinline__ void preload_unpinned(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
-    bx::preload_bias<0, bx::NetWBL<PRE>, false>(w, acc1);
-    bx::preload_bias<1, bx::NetWBL<PRE>, false>(w, acc2);
+    bx::preload_bias<0, WT, false>(w, acc1);
+    bx::preload_bias<1, WT, false>(w, acc2);
   }
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {
@@ -644,7 +664,7 @@ struct LstmCoreLds {
   template <bool NEXT, class Shadow = bx::NoShadow, bool REARM = true>
   __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
                                           int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
-    return bx::finish<PRE, NEXT, true, Shadow, REARM>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, static_cast<Shadow&&>(shadow));
+    return bx::finish<PRE, NEXT, true, Shadow, REARM, WT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, static_cast<Shadow&&>(shadow));
   }
   __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<true>(s.h2, one, b2); }
 };

@@ -1,74 +1,63 @@
-// l2o_unroll_cu.h -- the fused persistent unroll for optimizees that do NOT fit a CU's LDS
-// (D <= 512 with D % 4 == 0, any M: BASELINE config 3 = Lasso 256 x 512 per problem).  Included by
-// l2o_kernels.hip after k_unroll; written for gfx950 only.
+// l2o_unroll_cu8.h -- the streaming fused unroll (l2o_unroll_cu.h: D <= 512, any M: BASELINE config 3) with EIGHT waves per
+// workgroup -- two per SIMD.  Included by l2o_kernels.hip after l2o_unroll_cu.h; written for gfx950 only.
 //
-// Replaces, for these sizes, the step-granular pair {l2o_problem_fg, l2o_cwlstm_step} x T
-// (DM/meta.py:338-359 time_step; RNNProp fork DM/meta_rnnprop_train.py:397-423) with ONE
-// launch: one workgroup (4 waves, one per SIMD, 512 registers per lane) per problem, T steps.
-//
-//   LDS   : the LSTM state of the problem's coordinates (5 KB per 16-coordinate tile, packed
-//           layout of l2o_common.h) for up to 7 tiles per wave -- 140 KB of the 160 KB for
-//           D = 512 -- plus x, x*s, s, m, v and the 4 partial gradients.  The state of a
-//           wave's EIGHTH tile (D > 448) lives in its registers (a second inlined copy of the
-//           tile body): 32 tiles x 5 KB is exactly the whole LDS.
-//   VGPR  : the bf16x3 optimizer weights (loop-invariant), the row groups of the matrix in flight
-//   HBM   : the matrix streamed ONCE per step (k_problem_fg1's scheme: a wave keeps the rows it
-//           visits in registers between r_i = <row, x> - y_i and g += r_i row), nothing else:
-//           x / state / m / v never leave the CU between steps (the step-granular path moves
-//           664 B per coordinate-step of them through HBM, and pays 2 launches per step).
-//           A wave keeps 2-3 row groups (16-24 KB) in flight while it reduces another; the first
-//           groups of step t+1 are requested at the end of the optimizer phase of step t, ahead of
-//           the barrier (which waits for LDS traffic only), so the stream's start-up latency
-//           overlaps the barrier and the GEMV prologue.
-// Per step:  GEMV phase (4 waves x M/4 rows) -> partial g, partial f -> barrier ->
-//            optimizer phase (wave w: tiles w, w+4, ...) -> x, x*s in LDS -> barrier.
+// Why (round 4, after k_unroll_lds): k_unroll_cu's step is an 11 us matrix stream followed by a 17 us optimizer phase in
+// which every SIMD runs ONE wave through eight tile steps, one after the other -- and a single wave is issue-bound
+// (one VALU instruction per ~5.3 cycles where the pipe takes one per ~2.7).  Unlike the waves of
+// k_unroll_lds, the tile steps of the optimizer phase are independent of each other (no barrier until all tiles are
+// done), so two free-running waves per SIMD fill each other's stalls.  Two waves per SIMD mean <= 256 registers per
+// wave, so -- as in k_unroll_lds -- the bf16x3 fragments live in LDS (the PACKED form for every net: 60 KB DM, 80 KB
+// RNNProp, i.e. 80 MFMAs per RNNProp tile step instead of the register form's 120), and the LSTM state that used to fill
+// the LDS moves into registers: a wave owns at most four tiles, KR of them register-resident (20 registers each), the
+// others in an LDS slot.
+//   LDS  : fragments | state slots of the tiles beyond KR per wave | part[8][D] | x, x*s, s, m, v | red[8]
+//   per step:  GEMV phase (8 waves x M/8 rows, a ring of 2 row groups per wave) -> partial g, partial f -> barrier B1 ->
+//              optimizer phase (wave w: tiles w, w + 8, ...) -> x, x*s in LDS -> barrier B2
 #pragma once
 
 namespace l2o {
 
-constexpr int kCuWaves = 4;
-constexpr int kCuThreads = 64 * kCuWaves;
-constexpr int kCuMaxLdsSlots = 7;            // tile slots per wave whose state is LDS-resident
-constexpr int kCuSlotF4 = 5 * 64;            // float4 per tile slot (packed tile state)
-// Row groups (4 rows each) per wave in the GEMV ring.  RNNProp with two chunks per lane (D > 256) has 240
-// fragment registers + a 32-register group: a fourth group spills (measured: 4.29 vs 4.70 G on config 3).
-constexpr int cu_ring(int pre, int nv) { return (pre == L2O_PRE_FC_ELU && nv == 2) ? 3 : 4; }
+constexpr int kCu8Waves = 8;
+constexpr int kCu8Threads = 64 * kCu8Waves;
 
-struct UnrollCuLayout { int tpp, nslots, nlds, DP; size_t lds; };
-static inline UnrollCuLayout unroll_cu_layout(int D) {
-  UnrollCuLayout L;
+struct UnrollCu8Layout { int tpp, nslots, nlds, DP; size_t frag_floats, lds; };
+// KR: register-resident tiles per wave
+static inline UnrollCu8Layout unroll_cu8_layout(int D, int pre, int KR) {
+  UnrollCu8Layout L;
   L.tpp = (D + kTile - 1) / kTile;
-  L.nslots = (L.tpp + kCuWaves - 1) / kCuWaves;
-  L.nlds = L.nslots < kCuMaxLdsSlots ? L.nslots : kCuMaxLdsSlots;
+  L.nslots = (L.tpp + kCu8Waves - 1) / kCu8Waves;
+  L.nlds = L.nslots > KR ? L.nslots - KR : 0;
   L.DP = L.tpp * kTile;
-  L.lds = (size_t)kCuWaves * L.nlds * kCuSlotF4 * 16 + sizeof(float) * ((size_t)kCuWaves * D + 5 * (size_t)L.DP + 8);
+  L.frag_floats = (size_t)bx::packed_words(pre);
+  L.lds = sizeof(float) * (L.frag_floats + (size_t)kCu8Waves * L.nlds * kCuSlotF4 * 4 + (size_t)kCu8Waves * D +
+                           5 * (size_t)L.DP + 8);
   return L;
 }
 
-// HIST: also record what back-propagation through time needs (l2o_unroll_record): the packed state BEFORE each
-// step, the gradient fed to the network, RNNProp's moments after the step, and the gradient at x_T.
-template <int PRE, int NV, bool HIST>
-__global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_unroll_cu(UnrollArgs a) {
-  constexpr int kCuRing = cu_ring(PRE, NV);
-  extern __shared__ float4 cu_smem[];
+template <int PRE, int NV, int KR, bool HIST>
+__global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
+  constexpr int kRing = 2;
+  extern __shared__ __attribute__((aligned(16))) float cu8_smem[];
   const ProbParams& pp = a.pp;
   const int D = pp.D, M = pp.M;
   const int tpp = (D + kTile - 1) / kTile;
-  const int nslots = (tpp + kCuWaves - 1) / kCuWaves;
-  const int nlds = nslots < kCuMaxLdsSlots ? nslots : kCuMaxLdsSlots;
+  const int nslots = (tpp + kCu8Waves - 1) / kCu8Waves;
+  const int nlds = nslots > KR ? nslots - KR : 0;
   const int DP = tpp * kTile;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
   const int b = blockIdx.x;
-  float4* stL = cu_smem + (size_t)wv * nlds * kCuSlotF4;                 // this wave's tile slots
-  float* part = reinterpret_cast<float*>(cu_smem + (size_t)kCuWaves * nlds * kCuSlotF4);   // [4][D]
-  float* xL = part + kCuWaves * D;       // [DP] x
+  using Core = LstmCoreLds<PRE, bx::NetWBLF<PRE>>;      // (fenced fragment reads: see NetWBLF)
+  float* frs = cu8_smem;                                                     // [Core::kFragWords] packed fragments
+  float4* stL = reinterpret_cast<float4*>(frs + Core::kFragWords) + (size_t)wv * nlds * kCuSlotF4;   // this wave's slots
+  float* part = frs + Core::kFragWords + (size_t)kCu8Waves * nlds * kCuSlotF4 * 4;                   // [8][D]
+  float* xL = part + kCu8Waves * D;      // [DP] x
   float* xsL = xL + DP;                  // [DP] x * s (what the optimizee sees)
   float* scL = xsL + DP;                 // [DP] s
   float* mL = scL + DP;                  // [DP] RNNProp moments
   float* vL = mL + DP;
-  float* red = vL + DP;                  // [4]
+  float* red = vL + DP;                  // [8]
 
   const int kind = pp.kind;
   const bool kCos = kind == L2O_PROB_RASTRIGIN || kind == L2O_PROB_SQUARE_COS;
@@ -79,10 +68,8 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   const l2o_cfp yb = (l2o_cfp)(pp.y + (size_t)b * M);
   const float* Cb = kCos ? pp.C + (size_t)b * D : nullptr;
 
-  // ---- the matrix stream: groups of four rows, wave w owns groups w, w + 4, ... ------------
-  constexpr int kRowStep = 4 * kCuWaves;
-  // lanes beyond the last column (D < 256 NV) read column 0 instead of branching around the load:
-  // their x chunk is zero and their partial gradient is never stored
+  // ---- the matrix stream: groups of four rows, wave w owns groups w, w + 8, ... ------------
+  constexpr int kRowStep = 4 * kCu8Waves;
   int jcol[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) jcol[v] = 4 * (64 * v + lane) < D ? 4 * (64 * v + lane) : 0;
@@ -90,29 +77,26 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k < M ? i0 + k : M - 1;             // clamped rows contribute r = 0 below
-      // the row offset is wave-uniform; passing it through an opaque scalar keeps the compiler from
-      // hoisting one 64-bit per-lane address per (row group, chunk) out of the step loop and spilling them
-      unsigned long long ro = (unsigned long long)i * (unsigned)D;
-      asm volatile("" : "+s"(ro));
+      // (opaque scalar row offset: see k_unroll_cu; the row index is wave-uniform by construction)
+      const unsigned long long ro0 = (unsigned long long)i * (unsigned)D;
+      unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ro0), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ro0 >> 32));
+      asm volatile("" : "+s"(rlo), "+s"(rhi));
+      const unsigned long long ro = ((unsigned long long)rhi << 32) | rlo;
       const float* rowp = Wb + ro;
 #pragma unroll
       for (int v = 0; v < NV; ++v) w4[k][v] = *reinterpret_cast<const float4*>(rowp + jcol[v]);
     }
   };
-  // the ring is live in the GEMV phase only (and across barrier B2), where the registers of the network's
-  // temporaries are free
-  float4 wa[4][NV], wb[4][NV], wc[4][NV], wd[4][NV];
+  float4 wa[4][NV], wb[4][NV];
   const int i_first = 4 * wv;
-  auto load_head = [&]() {                 // the ring's groups of a step's first trip
+  auto load_head = [&]() {
     if (i_first < M) load4(i_first, wa);
     if (i_first + kRowStep < M) load4(i_first + kRowStep, wb);
-    if (kCuRing >= 3 && i_first + 2 * kRowStep < M) load4(i_first + 2 * kRowStep, wc);
-    if (kCuRing >= 4 && i_first + 3 * kRowStep < M) load4(i_first + 3 * kRowStep, wd);
   };
   load_head();
 
-  // ---- problem vectors and LSTM state into LDS ----------------------------------------------
-  for (int j = tid; j < DP; j += kCuThreads) {
+  // ---- problem vectors into LDS, LSTM state into registers / slots ---------------------------
+  for (int j = tid; j < DP; j += kCu8Threads) {
     const bool live = j < D;
     const size_t idx = (size_t)b * D + (live ? j : D - 1);
     const float xv = live ? (a.x_in ? a.x_in : a.x)[idx] : 0.0f;
@@ -122,8 +106,16 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     vL[j] = (PRE == L2O_PRE_FC_ELU && live && !a.zero_state) ? a.v[idx] : 0.0f;
   }
   float* st_b = a.st + (size_t)b * tpp * kStateFloatsPerTile;
+  TileState sr[KR];                                           // tiles wv + 8 k, k < KR
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+#pragma unroll
+    for (int t5 = 0; t5 < kNT; ++t5) { sr[k].h1[t5] = 0.f; sr[k].c1[t5] = 0.f; sr[k].h2[t5] = 0.f; sr[k].c2[t5] = 0.f; }
+    const int tile = wv + kCu8Waves * k;
+    if (tile < tpp && !a.zero_state) load_tile_state(sr[k], st_b + (size_t)tile * kStateFloatsPerTile, lane);
+  }
   for (int k = 0; k < nlds; ++k) {
-    const int tile = wv + kCuWaves * k;
+    const int tile = wv + kCu8Waves * (KR + k);
     if (tile < tpp) {
       const float4* src = reinterpret_cast<const float4*>(st_b + (size_t)tile * kStateFloatsPerTile);
 #pragma unroll
@@ -131,44 +123,29 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         stL[k * kCuSlotF4 + jj * 64 + lane] = a.zero_state ? float4{0.f, 0.f, 0.f, 0.f} : src[jj * 64 + lane];
     }
   }
-  const int tile7 = wv + kCuWaves * kCuMaxLdsSlots;            // the register-resident eighth tile
-  const bool has7 = nslots > kCuMaxLdsSlots && tile7 < tpp;    // wave-uniform
-  TileState s7;
-#pragma unroll
-  for (int t5 = 0; t5 < kNT; ++t5) { s7.h1[t5] = 0.f; s7.c1[t5] = 0.f; s7.h2[t5] = 0.f; s7.c2[t5] = 0.f; }
-  if (has7 && !a.zero_state) load_tile_state(s7, st_b + (size_t)tile7 * kStateFloatsPerTile, lane);
 
-  // packed gate GEMM (80 fragment registers per chunk) only beside ONE column block of the problem: with two, or with
-  // RNNProp's four chunks, the fragments spill (config 3: 4.8 -> 2.8 G coordinate-steps/s)
-  constexpr bool PK = NV == 1 && bx::packed_default(PRE);
-  bx::NetWB<PRE, PK> w;
-  bx::load_netw<PRE, true, PK>(w, a.np.wpack, lane);
-  __shared__ __attribute__((aligned(16))) float bias_s[bx::kBiasWords];     // the gate biases = accumulator inits
-  bx::stage_bias(bias_s, a.np.wpack, PRE, tid, blockDim.x);               // (ordered by the __syncthreads() below)
-  bx::set_bias(w, bias_s, q);
-  // pin the 180-240 fragment registers to the accumulation half of the register file (MFMA reads its A
-  // operand from there directly): the architectural VGPRs stay free for the row ring and the gate math.
-  // Left to itself the allocator spreads the fragments over both halves and spills the ring.
-#pragma unroll
-  for (int ch = 0; ch < bx::NetWB<PRE, PK>::NCH; ++ch)
-#pragma unroll
-    for (int t5 = 0; t5 < kNT; ++t5)
-#pragma unroll
-      for (int s3 = 0; s3 < bx::frags(PK); ++s3) asm volatile("" : "+a"(w.a[ch][t5][s3]));
+  Core core;
+  core.load(a.np.wpack, lane);
+  core.stage_frags(frs, a.np.wpack, tid, kCu8Threads, lane);
+  __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];
+  core.stage_bias(bias_s, a.np.wpack, tid, kCu8Threads, q);
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   float om1 = 1.0f, om2 = 1.0f;
   __syncthreads();
 
-  int tcur = 0;                                             // the step being computed (history slots)
+  int tcur = 0;
   const size_t hist_n = (size_t)pp.B_local * D;
-  // the gradient of coordinate j = tile * 16 + c from the four waves' partial sums
-  auto grad_of = [&](int tile, float& xsv_out) {
-    const int j = tile * kTile + c;
+  // the lane's coordinate inside a tile, re-made opaque every step: with up to five inlined copies of the tile body LICM
+  // otherwise hoists a dozen per-lane LDS / global addresses PER COPY out of the step loop (~50 registers held for the
+  // whole unroll in a kernel that has 256)
+  int cc = c;
+  auto grad_of = [&](int tile, float& xsv_out) __attribute__((always_inline)) {
+    const int j = tile * kTile + cc;
     const bool live = j < D;
     const int jc = live ? j : D - 1;
-    float sum = part[jc];
-#pragma unroll
-    for (int p = 1; p < kCuWaves; ++p) sum += part[p * D + jc];
+    float s01 = part[jc] + part[D + jc], s23 = part[2 * D + jc] + part[3 * D + jc];
+    float s45 = part[4 * D + jc] + part[5 * D + jc], s67 = part[6 * D + jc] + part[7 * D + jc];
+    const float sum = (s01 + s23) + (s45 + s67);
     const float xsv = xsL[j], sc = scL[j];
     float gj = cg * sum;
     if (kind == L2O_PROB_LASSO) gj += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
@@ -176,9 +153,10 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     xsv_out = xsv;
     return live ? gj * pp.inv_bg * sc : 0.0f;
   };
-  // one optimizer step for a 16-coordinate tile whose state is in `s`
-  auto do_tile = [&](int tile, TileState& s) {
-    const int j = tile * kTile + c;
+  // (always_inline: with up to five call sites the inliner otherwise turns the tile body into a real function -- a stack
+  //  frame in scratch and the state passed through memory)
+  auto do_tile = [&](int tile, TileState& s) __attribute__((always_inline)) {
+    const int j = tile * kTile + cc;
     const bool live = j < D;
     float xsv;
     const float gv = grad_of(tile, xsv);
@@ -200,7 +178,7 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-    float d = bx::tile_step<PRE>(w, s, in0, in1, q);
+    float d = bx::tile_step_w<PRE, true, bx::NetWBLF<PRE>>(core.w, s, in0, in1, q);
     if (a.np.tanh_output) d = tanhf_(d);
     d *= a.np.scale;
     const float xn = xj + d;
@@ -218,8 +196,10 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int i = 0; i < L2O_CU_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   }
   for (int t = 0;; ++t) {
-    const bool want_g = t < a.T || HIST;                      // (history mode: the gradient at x_T is recorded too)
+    const bool want_g = t < a.T || HIST;
     tcur = t;
+    cc = c;
+    asm volatile("" : "+v"(cc));
     // ---- optimizee: f_b(x s) and the partial gradients of this wave's rows -------------------
     float4 xv[NV], ga[NV];
     float facc = 0.0f;
@@ -270,21 +250,15 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       }
     };
-    // kCuRing row groups in the ring, all but one in flight while that one is reduced; the first trip's
-    // were requested at the end of the previous optimizer phase, ahead of barrier B2
-    for (int i0 = i_first; i0 < M; i0 += kCuRing * kRowStep) {
+#ifdef L2O_CU8_ABL_NOGEMV
+    for (int i0 = i_first; i0 < 0; i0 += kRing * kRowStep) {
+#else
+    for (int i0 = i_first; i0 < M; i0 += kRing * kRowStep) {
+#endif
       use4(i0, wa);
-      if (i0 + kCuRing * kRowStep < M) load4(i0 + kCuRing * kRowStep, wa);
+      if (i0 + kRing * kRowStep < M) load4(i0 + kRing * kRowStep, wa);
       if (i0 + kRowStep < M) use4(i0 + kRowStep, wb);
-      if (i0 + (kCuRing + 1) * kRowStep < M) load4(i0 + (kCuRing + 1) * kRowStep, wb);
-      if (kCuRing >= 3) {
-        if (i0 + 2 * kRowStep < M) use4(i0 + 2 * kRowStep, wc);
-        if (i0 + (kCuRing + 2) * kRowStep < M) load4(i0 + (kCuRing + 2) * kRowStep, wc);
-      }
-      if (kCuRing >= 4) {
-        if (i0 + 3 * kRowStep < M) use4(i0 + 3 * kRowStep, wd);
-        if (i0 + (kCuRing + 3) * kRowStep < M) load4(i0 + (kCuRing + 3) * kRowStep, wd);
-      }
+      if (i0 + (kRing + 1) * kRowStep < M) load4(i0 + (kRing + 1) * kRowStep, wb);
     }
     if (want_g) {
 #pragma unroll
@@ -296,13 +270,14 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     const float fw = wave_sum64(facc);
     if (lane == 0) red[wv] = fw;
     lds_barrier();                                            // B1: partial gradients and partial f complete
-    if (tid == 0) a.fx_part[(size_t)t * pp.B_local + b] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (tid == 0)
+      a.fx_part[(size_t)t * pp.B_local + b] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
     if (!want_g) break;
     if (HIST && t == a.T) {                                   // the gradient at x_T, then done
-      for (int tile = wv; tile < tpp; tile += kCuWaves) {
+      for (int tile = wv; tile < tpp; tile += kCu8Waves) {
         float xsv;
         const float gv = grad_of(tile, xsv);
-        const int j = tile * kTile + c;
+        const int j = tile * kTile + cc;
         if (j < D && q == 0) a.hist_gfinal[(size_t)b * D + j] = gv;
       }
       break;
@@ -310,9 +285,16 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 
     // ---- optimizer network on this wave's tiles ------------------------------------------------
     if (PRE == L2O_PRE_FC_ELU) { om1 = 1.0f - p1h; om2 = 1.0f - p2h; }
+#ifndef L2O_CU8_ABL_NOOPT     // (timing ablations: -DL2O_CU8_ABL_NOOPT no optimizer phase, -DL2O_CU8_ABL_NOGEMV no matrix stream)
+    static_for<0, KR>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const int tile = wv + kCu8Waves * k;
+      if (tile < tpp) do_tile(tile, sr[k]);
+    });
+#endif
 #pragma unroll 1
     for (int k = 0; k < nlds; ++k) {
-      const int tile = wv + kCuWaves * k;
+      const int tile = wv + kCu8Waves * (KR + k);
       if (tile >= tpp) break;
       float4* slot = stL + k * kCuSlotF4 + lane;
       TileState s;
@@ -335,7 +317,6 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       }
     }
-    if (has7) do_tile(tile7, s7);
     if (PRE == L2O_PRE_FC_ELU) {                              // beta^k as a float-float running product
       float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
       float lo = __builtin_fmaf(p1l, a.np.beta1, er), sum = hi + lo;
@@ -344,25 +325,32 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       lo = __builtin_fmaf(p2l, a.np.beta2, er); sum = hi + lo;
       p2l = lo - (sum - hi); p2h = sum;
     }
-    load_head();                                              // (the network's temporaries are dead: registers for the ring)
+    __builtin_amdgcn_sched_barrier(0);                        // (the ring's loads must not be scheduled up into the last tile body)
+#ifndef L2O_CU8_ABL_NOGEMV
+    load_head();
+#endif                                              // (the network's temporaries are dead: registers for the ring)
     lds_barrier();                                            // B2: x s of the next step complete, `part` free
   }
 
   // ---- write back: x, moments, LSTM state ------------------------------------------------------
-  for (int j = tid; j < D; j += kCuThreads) {
+  for (int j = tid; j < D; j += kCu8Threads) {
     const size_t idx = (size_t)b * D + j;
     a.x[idx] = xL[j];
     if (PRE == L2O_PRE_FC_ELU) { a.m[idx] = mL[j]; a.v[idx] = vL[j]; }
   }
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int tile = wv + kCu8Waves * k;
+    if (tile < tpp) store_tile_state(sr[k], st_b + (size_t)tile * kStateFloatsPerTile, lane);
+  }
   for (int k = 0; k < nlds; ++k) {
-    const int tile = wv + kCuWaves * k;
+    const int tile = wv + kCu8Waves * (KR + k);
     if (tile < tpp) {
       float4* dst = reinterpret_cast<float4*>(st_b + (size_t)tile * kStateFloatsPerTile);
 #pragma unroll
       for (int jj = 0; jj < 5; ++jj) dst[jj * 64 + lane] = stL[k * kCuSlotF4 + jj * 64 + lane];
     }
   }
-  if (has7) store_tile_state(s7, st_b + (size_t)tile7 * kStateFloatsPerTile, lane);
 }
 
 }  // namespace l2o

@@ -41,7 +41,7 @@ workload_json() { # the `workload` key scripts/counters_to_json.py stores and be
     5) echo '["mnist", "rnnprop", 15910, 64, 200]' ;;
   esac
 }
-kernel_of() { case $1 in 2) echo 'k_unroll_pair<' ;; 4) echo 'k_unroll_lds<' ;; 3) echo 'k_unroll_cu<' ;; 5) echo 'k_mlp_unroll<' ;; esac; }
+kernel_of() { case $1 in 2) echo 'k_unroll_pair<' ;; 4) echo 'k_unroll_lds<' ;; 3) echo 'k_unroll_cu' ;; 5) echo 'k_mlp_unroll<' ;; esac; }
 train_cmd() { # NAME SECONDS -> command line (the ones recorded in tests/golden/trained/README.md)
   local S=$2
   case $1 in
