@@ -609,7 +609,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
     elif streaming:
         from open_l2o_amd import _abi
         form = _abi.get_option(_abi.OPT_UNROLL_CU)
-        cu8 = form in (3, 4)
+        cu8 = form in (3, 4) or (form == 1 and args.net == "rnnprop")
         kernel = "k_unroll_cu8 (eight waves, fragments in LDS, LSTM state in registers)" if cu8 else "k_unroll_cu"
     elif fused:
         # (the two-CU kernel; a shard of more than #CU / 2 = 128 problems runs it as consecutive chunk launches)

@@ -114,9 +114,10 @@ const char* l2o_last_error(void);
 #define L2O_OPT_PAIR 0               /* 1*: l2o_unroll may split every problem over two CUs; 0: one CU per problem        */
 #define L2O_OPT_PAIR_PLAIN_STORES 1  /* 1*: partners that CONFIRMED (XCC_ID handshake) they share an XCD publish their
                                         exchange granules with plain stores (L2-resident); 0: agent-scope stores always    */
-#define L2O_OPT_UNROLL_CU 2          /* the streaming fused unroll for D > 128: 1*: on (k_unroll_cu: four waves per workgroup);
-                                        0: such sizes run step-granular; 3 / 4: the eight-wave experiment k_unroll_cu8 (fragments
-                                        in LDS, LSTM state in registers: 4 / 3 register tiles per wave) -- A/B runs          */
+#define L2O_OPT_UNROLL_CU 2          /* the streaming fused unroll for D > 128: 1*: on -- RNNProp's plain unroll on eight waves
+                                        per workgroup with the fragments in LDS and the LSTM state in registers (k_unroll_cu8),
+                                        everything else on four waves (k_unroll_cu); 2: k_unroll_cu always; 3 / 4: k_unroll_cu8
+                                        always (4 / 3 register tiles per wave); 0: such sizes run step-granular               */
 #define L2O_OPT_FG_TWO_PASS 3        /* (l2o_problem.flags: L2O_PROB_FG_TWO_PASS)                                           */
 #define L2O_OPT_MLP_GENERIC 4        /* (l2o_mlp.flags: L2O_MLP_GENERIC)                                                    */
 #define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups (L2O_OPTW_BWD_BLOCKS) */

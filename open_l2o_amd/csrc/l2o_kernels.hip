@@ -1281,9 +1281,9 @@ static bool unroll_cu_eligible(const l2o_problem* p) {
   if (p->D < 4 || p->D > 512 || (p->D & 3) || p->M <= 0) return false;   // (D <= 128: only when the rows do not fit the LDS forms)
   return unroll_cu_layout(p->D).lds + sizeof(float) * bx::kBiasWords <= 160 * 1024;   // (+ the static bias table)
 }
-// L2O_OPT_UNROLL_CU: 0 step-granular path, 1* (and 2) the four-wave form (k_unroll_cu), 3 the eight-wave form (k_unroll_cu8:
-// two waves per SIMD, fragments in LDS, LSTM state in registers), 4 k_unroll_cu8 with three register tiles + one LDS slot
-// per wave (A/B runs)
+// L2O_OPT_UNROLL_CU: 0 step-granular path, 1* the eight-wave form (k_unroll_cu8: two waves per SIMD, fragments in LDS, LSTM
+// state in registers) for RNNProp's plain unroll and the four-wave form (k_unroll_cu) otherwise, 2 k_unroll_cu always,
+// 3 k_unroll_cu8 always, 4 k_unroll_cu8 with three register tiles + one LDS slot per wave (A/B runs)
 template <int PRE, int KR>
 static int launch_unroll_cu8(const UnrollArgs& a, hipStream_t s) {
   const UnrollCu8Layout L = unroll_cu8_layout(a.pp.D, PRE, KR);
@@ -1298,10 +1298,11 @@ static int launch_unroll_cu8(const UnrollArgs& a, hipStream_t s) {
 template <int PRE>
 static int launch_unroll_cu(const UnrollArgs& a_in, hipStream_t s) {
   const int form = (int)opt(L2O_OPT_UNROLL_CU);
-  // (the eight-wave form is opt-in: at the 256-register cap its RNNProp instantiation spills 109 registers -- config 3: -2.4 %
-  //  kernel time but 28 % more memory traffic than the matrix stream needs -- and the DM nets' spill 300 and run at half
-  //  the four-wave kernel's speed: DESIGN.md 3.1c)
-  if (form == 3 || form == 4) {
+  // (default: the eight-wave form for RNNProp's plain unroll -- config 3: kernel 5.55 -> 4.60 ms, 3 spilled registers; the
+  //  DM nets' and the recording instantiations spill 70-250 registers at the 256-register cap and stay on the four-wave
+  //  kernel: DESIGN.md 3.1c)
+  const bool hist0 = a_in.hist_st != nullptr;
+  if ((form == 1 && PRE == L2O_PRE_FC_ELU && !hist0) || form == 3 || form == 4) {
     const int KR = form == 4 ? 3 : 4;
     if (unroll_cu8_layout(a_in.pp.D, PRE, KR).lds + sizeof(float) * bx::kBiasWords <= 160 * 1024)
       return KR == 4 ? launch_unroll_cu8<PRE, 4>(a_in, s) : launch_unroll_cu8<PRE, 3>(a_in, s);

@@ -34,9 +34,13 @@ static inline UnrollCu8Layout unroll_cu8_layout(int D, int pre, int KR) {
   return L;
 }
 
+#ifndef L2O_CU8_RING
+#define L2O_CU8_RING 2    // row groups (4 rows each) per wave in flight: 8 waves x 2 x 8 KB = 128 KB per CU at D = 512
+                          // (config 3, RNNProp, four register tiles: ring 2 -> 3 spilled registers, 4.60 ms; 3 -> 60, 5.39; 4 -> 126, 6.02)
+#endif
 template <int PRE, int NV, int KR, bool HIST>
 __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
-  constexpr int kRing = 2;
+  constexpr int kRing = L2O_CU8_RING;
   extern __shared__ __attribute__((aligned(16))) float cu8_smem[];
   const ProbParams& pp = a.pp;
   const int D = pp.D, M = pp.M;
@@ -87,13 +91,20 @@ __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
       for (int v = 0; v < NV; ++v) w4[k][v] = *reinterpret_cast<const float4*>(rowp + jcol[v]);
     }
   };
-  float4 wa[4][NV], wb[4][NV];
-  const int i_first = 4 * wv;
-  auto load_head = [&]() {
-    if (i_first < M) load4(i_first, wa);
-    if (i_first + kRowStep < M) load4(i_first + kRowStep, wb);
+  // The ring lives INSIDE the GEMV phase (declared there, every conditional load paired with a zeroing else-branch): as
+  // loop-carried variables with conditional loads -- k_unroll_cu's form, where 512 registers make it harmless -- the 64
+  // ring registers stay live through the whole optimizer phase (a phi with the old values), which at 256 registers is
+  // the difference between 0 and 100 spilled registers.
+  auto zero4 = [&](float4 (&w4)[4][NV]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) w4[k][v] = float4{0.f, 0.f, 0.f, 0.f};
   };
-  load_head();
+  auto load4z = [&](int i0, float4 (&w4)[4][NV]) {
+    if (i0 < M) load4(i0, w4); else zero4(w4);
+  };
+  const int i_first = 4 * wv;
 
   // ---- problem vectors into LDS, LSTM state into registers / slots ---------------------------
   for (int j = tid; j < DP; j += kCu8Threads) {
@@ -220,6 +231,15 @@ __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
         }
       }
     }
+    float4 ring[kRing][4][NV];
+    static_for<0, kRing>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+#ifndef L2O_CU8_ABL_NOGEMV
+      load4z(i_first + r * kRowStep, ring[r]);
+#else
+      zero4(ring[r]);
+#endif
+    });
     auto use4 = [&](int i0, const float4 (&w4)[4][NV]) {
       float acc[4];
 #pragma unroll
@@ -255,10 +275,11 @@ __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
 #else
     for (int i0 = i_first; i0 < M; i0 += kRing * kRowStep) {
 #endif
-      use4(i0, wa);
-      if (i0 + kRing * kRowStep < M) load4(i0 + kRing * kRowStep, wa);
-      if (i0 + kRowStep < M) use4(i0 + kRowStep, wb);
-      if (i0 + (kRing + 1) * kRowStep < M) load4(i0 + (kRing + 1) * kRowStep, wb);
+      static_for<0, kRing>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if (i0 + r * kRowStep < M) use4(i0 + r * kRowStep, ring[r]);
+        load4z(i0 + (kRing + r) * kRowStep, ring[r]);
+      });
     }
     if (want_g) {
 #pragma unroll
@@ -325,10 +346,6 @@ __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
       lo = __builtin_fmaf(p2l, a.np.beta2, er); sum = hi + lo;
       p2l = lo - (sum - hi); p2h = sum;
     }
-    __builtin_amdgcn_sched_barrier(0);                        // (the ring's loads must not be scheduled up into the last tile body)
-#ifndef L2O_CU8_ABL_NOGEMV
-    load_head();
-#endif                                              // (the network's temporaries are dead: registers for the ring)
     lds_barrier();                                            // B2: x s of the next step complete, `part` free
   }
 
