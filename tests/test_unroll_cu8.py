@@ -22,7 +22,10 @@ def eng():
 @pytest.mark.parametrize("form", [3, 4])
 @pytest.mark.parametrize("name,kind,B,D,M", [("rnnprop", "lasso", 3, 512, 256), ("rnnprop", "lasso", 4, 300, 100),
                                              ("dm", "lasso", 3, 512, 64), ("dm_logsign", "quadratic", 2, 256, None),
-                                             ("rnnprop", "rastrigin", 2, 200, None)])
+                                             ("rnnprop", "rastrigin", 2, 200, None),
+                                             # few tiles, many rows (the LDS-resident forms cannot hold M > 16 tiles' rows):
+                                             # waves 4..7 own no tile, the stream still splits over all eight
+                                             ("rnnprop", "lasso", 5, 64, 200), ("rnnprop", "lasso", 3, 20, 90)])
 def test_cu8_vs_oracle_and_four_wave_kernel(eng, name, kind, B, D, M, form):
     cfg = ORACLE_CFGS[name]
     params = make_params(cfg, seed=6, trained_like=True)
