@@ -32,7 +32,10 @@ constexpr int kCuMaxLdsSlots = 7;            // tile slots per wave whose state 
 constexpr int kCuSlotF4 = 5 * 64;            // float4 per tile slot (packed tile state)
 // Row groups (4 rows each) per wave in the GEMV ring.  RNNProp with two chunks per lane (D > 256) has 240
 // fragment registers + a 32-register group: a fourth group spills (measured: 4.29 vs 4.70 G on config 3).
-constexpr int cu_ring(int pre, int nv) { return (pre == L2O_PRE_FC_ELU && nv == 2) ? 3 : 4; }
+#ifndef L2O_CU_RING_RNNPROP2
+#define L2O_CU_RING_RNNPROP2 3
+#endif
+constexpr int cu_ring(int pre, int nv) { return (pre == L2O_PRE_FC_ELU && nv == 2) ? L2O_CU_RING_RNNPROP2 : 4; }
 
 struct UnrollCuLayout { int tpp, nslots, nlds, DP; size_t lds; };
 static inline UnrollCuLayout unroll_cu_layout(int D) {
@@ -103,11 +106,27 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   // temporaries are free
   float4 wa[4][NV], wb[4][NV], wc[4][NV], wd[4][NV];
   const int i_first = 4 * wv;
+  // (round 4: every conditional refill has a zeroing else-branch.  Without it a ring array is a phi with its OLD values on
+  //  the not-taken path and stays live through the whole optimizer phase -- what made k_unroll_cu8 spill 100 registers,
+  //  DESIGN.md 3.1c; -DL2O_CU_RING_PHI restores the old form)
+  auto zero4 = [&](float4 (&w4)[4][NV]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) w4[k][v] = float4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto load4z = [&](int i0, float4 (&w4)[4][NV]) {
+#ifdef L2O_CU_RING_PHI
+    if (i0 < M) load4(i0, w4);
+#else
+    if (i0 < M) load4(i0, w4); else zero4(w4);
+#endif
+  };
   auto load_head = [&]() {                 // the ring's groups of a step's first trip
-    if (i_first < M) load4(i_first, wa);
-    if (i_first + kRowStep < M) load4(i_first + kRowStep, wb);
-    if (kCuRing >= 3 && i_first + 2 * kRowStep < M) load4(i_first + 2 * kRowStep, wc);
-    if (kCuRing >= 4 && i_first + 3 * kRowStep < M) load4(i_first + 3 * kRowStep, wd);
+    load4z(i_first, wa);
+    load4z(i_first + kRowStep, wb);
+    if (kCuRing >= 3) load4z(i_first + 2 * kRowStep, wc);
+    if (kCuRing >= 4) load4z(i_first + 3 * kRowStep, wd);
   };
   load_head();
 
@@ -274,16 +293,16 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     // were requested at the end of the previous optimizer phase, ahead of barrier B2
     for (int i0 = i_first; i0 < M; i0 += kCuRing * kRowStep) {
       use4(i0, wa);
-      if (i0 + kCuRing * kRowStep < M) load4(i0 + kCuRing * kRowStep, wa);
+      load4z(i0 + kCuRing * kRowStep, wa);
       if (i0 + kRowStep < M) use4(i0 + kRowStep, wb);
-      if (i0 + (kCuRing + 1) * kRowStep < M) load4(i0 + (kCuRing + 1) * kRowStep, wb);
+      load4z(i0 + (kCuRing + 1) * kRowStep, wb);
       if (kCuRing >= 3) {
         if (i0 + 2 * kRowStep < M) use4(i0 + 2 * kRowStep, wc);
-        if (i0 + (kCuRing + 2) * kRowStep < M) load4(i0 + (kCuRing + 2) * kRowStep, wc);
+        load4z(i0 + (kCuRing + 2) * kRowStep, wc);
       }
       if (kCuRing >= 4) {
         if (i0 + 3 * kRowStep < M) use4(i0 + 3 * kRowStep, wd);
-        if (i0 + (kCuRing + 3) * kRowStep < M) load4(i0 + (kCuRing + 3) * kRowStep, wd);
+        load4z(i0 + (kCuRing + 3) * kRowStep, wd);
       }
     }
     if (want_g) {
