@@ -17,7 +17,7 @@
 // RNNProp (fc + ELU: four chunks, 80 KB).
 #pragma once
 
-// (timing ablations, scripts/ablate_lds.sh: L2O_LDS_ABL_NOBAR drops the two barriers, _NOGEMV the xs / rs reads,
+// (timing ablations, scripts/ab.sh ablate_lds: L2O_LDS_ABL_NOBAR drops the two barriers, _NOGEMV the xs / rs reads,
 //  _NOFRAG (l2o_lstm_bx3.h) the fragment reads -- each gives wrong numerics and is never shipped)
 #ifdef L2O_LDS_ABL_NOBAR
 #define L2O_LDS_BARRIER() __builtin_amdgcn_sched_barrier(0)
