@@ -12,8 +12,7 @@ Without a trained file for the workload (config 5, --net dm_logsign) the weights
 draws with the output Linear x0.1 and the line says "untrained" (that trajectory diverges).
 
 One UNROLL = what the reference does between `reset` and the last `fx`: a FRESH problem instance
-(one of a ring of --instances pre-sampled instances already resident in HBM) -> its per-problem preparation
-(l2o_unroll_prepare: H = W^T W, q = W^T y for the two-CU form) -> rewind x / LSTM state -> T x {f(x), grad f,
+(one of a ring of --instances pre-sampled instances already resident in HBM) -> rewind x / LSTM state -> T x {f(x), grad f,
 LSTM optimizer step, x += delta} -> f(x_T) -> per-step loss reduction (-> all-reduce of the T+1 partial losses
 over ranks when N > 1).  One bench "step" = --unrolls-per-step consecutive unrolls (default per config, so that
 --steps 20 times >= 50 ms of GPU work); value counts every one of them.  Inputs are resident in HBM when the
@@ -31,7 +30,11 @@ Prints ONE JSON line (rank 0).  value = coordinate-steps per second, whole job:
 loss mean is over the global batch (DM/problems.py:99) and the only collective is the all-reduce
 of T+1 floats per unroll.  For N > 1 the line also carries, under "also", the config-2 strong-scaling
 run (global batch 128) and the config-4 run (Rastrigin d=100, global batch 1024 sharded over the N
-GPUs) measured in the same job.  The oracle is imported by the cpu_baseline leg only.
+GPUs) measured in the same job.  For N = 1 (the default run) "also" carries compact lines of the OTHER
+BASELINE configurations measured in the same process right after the primary one: config 3, config 4 on
+one GPU, config 4's shard of 8 (128 of the 1024 problems, 1/B_global = 1/1024, no communication:
+--emulate-world 8 on its own) and config 5 -- each with value, kernel_ms, roofline.frac and a bounded
+cpu_baseline (--no-also skips them; budget <= 90 s).  The oracle is imported by the cpu_baseline legs only.
 """
 import argparse
 import glob
@@ -121,57 +124,48 @@ def work_model(problem, net, D, M):
     return {"valu_plain": plain, "transcendental": trans, "mfma": mfma}
 
 
-def work_block(case, issue, args):
-    """cycles_per_tile_step (measured), valu_insts_per_tile_step (PMC), the stated issue-port floor of the tile-step and
-    frac_work = floor / measured -- next to the utilisation-type `frac`."""
-    # one tile per wave, one wave per SIMD by construction (464 / 512 registers per lane; amdgpu_waves_per_eu(1, 1)): the
-    # two-CU fused unroll and the persistent MLP unroll.  (rocprofv3's kernels view reports the architectural VGPR count
-    # only, so the counters file cannot tell.)  The streaming kernels run several tiles per wave and are HBM-bound.
-    one_tile_per_wave = ((case["fused"] and not case["hbm_bound"] and case["D"] > 16) or "l2o_mlp_unroll" in case["kernel"]) \
-        and "k_unroll_lds" not in case["kernel"] and "k_unroll_pair2" not in case["kernel"]   # (two waves per SIMD: not this model)
-    two_waves = "k_unroll_lds" in case["kernel"] or "k_unroll_pair2" in case["kernel"]
-    if issue is not None and two_waves:
-        # two waves (tiles) per SIMD: the floor is the SIMD's pipe time for TWO tile-steps per step
-        T, dispatches = case["T"], float(case.get("dispatches", 1))
-        wm = work_model(args.problem, args.net, case["D"], case["Mrows"])
-        per_tile = wm["valu_plain"] * PIPE_COST["valu"] + wm["transcendental"] * PIPE_COST["trans"]
-        # k_unroll_lds: one launch, ceil(B / #CU) problems per CU one after the other; pair2: `dispatches` chunk launches
-        rounds = -(-case["B"] // max(1, case.get("n_cus", 256))) if "k_unroll_lds" in case["kernel"] else 1
-        cyc = case["kern_ms"] * 1e-3 * issue["clock_hz"] / (dispatches * rounds * (T + 0.3))
-        return {"cycles_per_step": cyc, "tiles_per_simd": 2, "work_model_instructions_per_tile_step": wm,
-                "pipe_cost_cycles": dict(PIPE_COST), "pipe_floor_cycles_per_step": 2 * per_tile,
-                "mfma_pipe_cycles_per_step": 2 * wm["mfma"] * PIPE_COST["mfma"],
-                "frac_work": 2 * per_tile / cyc,
-                "frac_work_note": "two tile-steps per SIMD and step: stated minimal VALU + transcendental counts (bench.py: "
-                                  "work_model) x the measured PIPE time per instruction with two waves per SIMD "
-                                  "(profiles/r04w_two_wave_issue.txt) / measured cycles per step (kernel time / rounds of "
-                                  "problems per CU / T).  The timing-only build of the kernel without barriers and LDS operand "
-                                  "reads runs at 0.78 of the shipped one's step time (profiles/r04u_ablate_k_unroll_lds.txt): "
-                                  "the ISA executes ~30 % more VALU instructions than the stated minimum and its dependency "
-                                  "chains keep two waves from filling the pipe"}
-    if issue is None or not one_tile_per_wave:
+def work_block(case, issue, args, clock_hz):
+    """The work-based figures of a VALU-bound fused kernel.
+    cycles_per_step: shader-clock cycles one SIMD spends per optimizer step -- MEASURED inside the kernel (s_memtime
+        around the step loop of workgroup 0, workspace bytes 16..23, / (T + 0.3): the T + 1-st loss evaluation is ~1/3 of
+        a step); without that word: live kernel time x clock / (chunk launches x rounds of problems per CU x (T + 0.3)).
+    pipe_floor_cycles_per_step: the STATED minimal instruction counts of the tile-steps that SIMD does per step
+        (bench.py: work_model; 1 tile per SIMD for the one-wave kernels, 2 for k_unroll_lds) x the PIPE time per
+        instruction class (plain VALU 2.93, transcendental 8.39 cycles: two_wave_issue.hip) -- what the SIMD's VALU pipe
+        could retire them in.  frac = floor / measured: the roofline fraction of the line.
+    issue_cost_frac (one-wave kernels): the same counts x the SINGLE-WAVE issue costs (5.26 / 8.51 / 5.26 for the MFMA
+        slot) / measured -- the share of the step ONE wave's issue port needs; named secondary."""
+    name = case["kernel"]
+    T = case["T"]
+    if not case["fused"] and "k_mlp_unroll" not in name:
         return None
-    T, dispatches = case["T"], float(case.get("dispatches", 1))
-    net = args.net
-    wm = work_model(args.problem, net, case["D"], case["Mrows"])
-    floor = (wm["valu_plain"] * ISSUE_COST["valu"] + wm["transcendental"] * ISSUE_COST["trans"] + wm["mfma"] * ISSUE_COST["mfma"])
-    # one launch = T tile-steps per wave (the T + 1-st loss evaluation is ~1/3 of a step); chunk launches run back to back
-    cyc = case["kern_ms"] * 1e-3 * issue["clock_hz"] / (dispatches * (T + 0.3))
-    out = {"cycles_per_tile_step": cyc, "work_model_instructions_per_tile_step": wm,
-           "issue_cost_cycles": dict(ISSUE_COST), "issue_floor_cycles_per_tile_step": floor,
-           "mfma_pipe_floor_cycles_per_tile_step": wm["mfma"] * MFMA_PIPE_CYCLES,
-           "frac_work": floor / cyc,
-           "frac_work_note": "stated minimal instruction counts of one tile-step (bench.py: work_model) x measured per-class "
-                             "issue cost (profiles/r04c_valu_issue_cost.txt) / measured cycles per tile-step: the share of "
-                             "the step the wave's issue port NEEDS; the rest is dependency / LDS / exchange latency that one "
-                             "wave per SIMD cannot hide (profiles/r04b_coresident_split_bench.txt: a second wave per SIMD "
-                             "makes the step 24 % slower)"}
-    if issue.get("insts_valu") and issue.get("waves"):
-        out["valu_insts_per_tile_step"] = issue["insts_valu"] / issue["waves"] / (T + 0.3)
+    if case["hbm_bound"]:
+        return None
+    two_waves = "k_unroll_lds" in name
+    tiles_per_simd = 2 if two_waves else 1
+    wm = work_model(args.problem, args.net, case["D"], case["Mrows"])
+    per_tile_pipe = wm["valu_plain"] * PIPE_COST["valu"] + wm["transcendental"] * PIPE_COST["trans"]
+    dispatches = float(case.get("dispatches", 1))
+    rounds = -(-case["B"] // max(1, case.get("n_cus", 256))) if two_waves else 1
+    cyc_time = case["kern_ms"] * 1e-3 * clock_hz / (dispatches * rounds * (T + 0.3))
+    ticks = case.get("loop_ticks")
+    cyc = ticks / (T + 0.3) if ticks else cyc_time
+    floor = tiles_per_simd * per_tile_pipe
+    out = {"cycles_per_step": cyc, "cycles_source": "s_memtime around the step loop of workgroup 0 (workspace bytes 16..23)" if ticks
+           else "kernel_ms_avg x clock_hz", "cycles_per_step_from_kernel_time": cyc_time, "clock_hz": clock_hz,
+           "tiles_per_simd": tiles_per_simd, "work_model_instructions_per_tile_step": wm,
+           "pipe_cost_cycles": dict(PIPE_COST), "pipe_floor_cycles_per_step": floor,
+           "mfma_pipe_cycles_per_step": tiles_per_simd * wm["mfma"] * PIPE_COST["mfma"],
+           "frac_work": floor / cyc}
+    if not two_waves:
+        issue_floor = (wm["valu_plain"] * ISSUE_COST["valu"] + wm["transcendental"] * ISSUE_COST["trans"] + wm["mfma"] * ISSUE_COST["mfma"])
+        out.update(issue_cost_cycles=dict(ISSUE_COST), issue_floor_cycles_per_step=issue_floor, issue_cost_frac=issue_floor / cyc)
+    if issue is not None and issue.get("insts_valu") and issue.get("waves"):
+        out["valu_insts_per_tile_step"] = issue["insts_valu"] / issue["waves"] / (T + 0.3) / max(1, rounds)
     return out
 
 
-def cpu_baseline(problem, net, arrays, weights, x0, T, max_seconds=20.0):
+def cpu_baseline(problem, net, arrays, weights, x0, T, max_seconds=20.0, B_global=None, numpy_leg=True):
     """The reference path restated for the CPU (oracle/, test infrastructure), timed on this
     host's cores on the SAME inputs (whole unrolls, bounded to ~max_seconds): the plain-C +
     OpenMP port (oracle/l2o_oracle.c, one problem per thread) is the reported baseline; the
@@ -180,11 +174,12 @@ def cpu_baseline(problem, net, arrays, weights, x0, T, max_seconds=20.0):
     from oracle.c_oracle import c_unroll
     cfg = {"dm": O.DM_IDENTITY, "dm_logsign": O.DM_LOGSIGN, "rnnprop": O.RNNPROP}[net]
     B, M, D = arrays["W"].shape
-    c_unroll(problem, cfg, weights, arrays, x0, 2)                # warm-up (thread pool, page faults)
+    kw = {} if B_global in (None, B) else {"B_global": int(B_global)}
+    c_unroll(problem, cfg, weights, arrays, x0, 2, **kw)          # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
     n = 0
     while True:
-        fx, _, _, _, _, threads = c_unroll(problem, cfg, weights, arrays, x0, T)
+        fx, _, _, _, _, threads = c_unroll(problem, cfg, weights, arrays, x0, T, **kw)
         n += 1
         if time.perf_counter() - t0 > max_seconds or n >= 20:
             break
@@ -193,7 +188,7 @@ def cpu_baseline(problem, net, arrays, weights, x0, T, max_seconds=20.0):
            "host_cpus": os.cpu_count(), "kind": "port",
            "sample": "%d full unroll(s) of the same workload and inputs (C99+OpenMP port oracle/l2o_oracle.c, "
                      "%s/%s B=%d D=%d T=%d), %.1f s" % (n, net, problem, B, D, T, dt), "fx_T": float(fx[-1])}
-    if problem == "quadratic" and B * D * T <= 2_000_000:
+    if numpy_leg and problem == "quadratic" and B * D * T <= 2_000_000:
         prob = O.Quadratic(arrays["W"], arrays["y"])
         t0 = time.perf_counter()
         res = O.unroll(prob, cfg, weights, x0, O.net_initial_state(cfg, B * D), T)
@@ -326,7 +321,14 @@ def parse_args(argv=None):
                     help="complete unrolls (each on a fresh problem instance) per bench step; default per config so "
                          "that 20 steps are >= 50 ms of GPU work")
     ap.add_argument("--instances", type=int, default=4, help="ring of pre-sampled problem instances resident in HBM")
-    ap.add_argument("--no-also", action="store_true", help="N > 1: skip the extra strong-scaling / config-4 runs")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra runs of the `also` block (N > 1: strong scaling / "
+                                                           "config 4; N = 1: configs 3, 4, 4's shard of 8, 5)")
+    ap.add_argument("--also-budget", dest="also_budget", type=float, default=75.0, help="seconds after which no further also-run starts")
+    ap.add_argument("--also-cpu-seconds", dest="also_cpu_seconds", type=float, default=4.0,
+                    help="bound of each also-run's cpu_baseline sample")
+    ap.add_argument("--emulate-world", dest="emulate_world", type=int, default=0,
+                    help="run ONE shard (rank 0) of a job sharded over this many GPUs in this single process: batch / N "
+                         "problems, 1/B_global = 1/batch, no collective (with --config 4: the per-rank work of BASELINE configs[3])")
     ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin", "mnist"])
     ap.add_argument("--rows", type=int, default=None, help="lasso rows M (default: dims)")
     ap.add_argument("--shared-matrix", dest="shared_matrix", action="store_true",
@@ -364,94 +366,101 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def counters_for(workload, kernel_hint):
-    """The newest committed PMC summary of exactly this workload (profiles/r*_counters_*.json, written by
-    scripts/counters_to_json.py from rocprofv3 --pmc passes of this command), or None."""
-    best = None
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters_*.json")))
+def counters_for(workload, kernel_hint, build_id):
+    """The PMC summary of exactly this workload (profiles/*_counters_*.json + $L2O_COUNTERS_DIR/counters_*.json, written
+    by scripts/counters_to_json.py from rocprofv3 --pmc passes of this command) -> (path, dict, status) or None.
+    Chosen by what the file SAYS about itself, never by its name (a lexicographic "newest" picked r04z over
+    r04av): a file collected on the build being timed (build_id == l2o_build_id() of the loaded library) wins and is
+    "same_build"; otherwise the most recently collected one (collected_unix inside the file; files from before round 5
+    carry neither and rank oldest) is returned as "stale" -- its instruction counts belong to another build."""
+    paths = glob.glob(os.path.join(ROOT, "profiles", "*_counters_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "*", "*_counters_*.json"))
     if os.environ.get("L2O_COUNTERS_DIR"):
-        # counters collected in THIS lease, on THIS build, ahead of the bench line (scripts/gpu_lease.sh `final:N`):
-        # they take precedence over every committed file (sorted last)
-        paths += sorted(glob.glob(os.path.join(os.environ["L2O_COUNTERS_DIR"], "counters_*.json")))
+        paths += glob.glob(os.path.join(os.environ["L2O_COUNTERS_DIR"], "counters_*.json"))
+    best = None
     for path in paths:
         try:
             c = json.load(open(path))
         except Exception:
             continue
-        if c.get("workload") == list(workload) and (not kernel_hint or kernel_hint in c.get("kernel", "")):
-            best = (path, c)
-    return best
+        if c.get("workload") != list(workload) or (kernel_hint and kernel_hint not in c.get("kernel", "")):
+            continue
+        rank = (1 if (build_id and c.get("build_id") == build_id) else 0, float(c.get("collected_unix") or 0.0))
+        if best is None or rank > best[0]:
+            best = (rank, path, c)
+    if best is None:
+        return None
+    return best[1], best[2], "same_build" if best[0][0] else "stale"
 
 
 def roofline_block(case, args, counters):
-    """The binding roofline of the dominant kernel of this workload.  Time base: kernel_ms_avg = HIP-event time of the
-    whole timed region / steps (one event pair on the launch stream: the unroll kernel + its epilogue per step);
-    kernel_ms_min = the shortest of a few individually bracketed launches made after the timed region.
+    """The binding roofline of the dominant kernel of this workload.  Time base: kernel_ms_avg = HIP-event time around
+    replays of one problem instance on the launch stream (the unroll kernel + its epilogue), measured live in THIS run.
 
-    bound == "hbm" (streaming / step-granular kernels): achieved = the bytes a kernel of this form must move per launch
-    (the matrices once per evaluation + x / state once each way) / the kernel time measured live with HIP events; traffic =
-    HBM bytes per launch from the PMC pass (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, committed under profiles/).
-    bound == "valu_issue" (the LDS/register-resident fused kernels: ~20 MB of HBM traffic per launch, one wave per
-    SIMD issuing in order): achieved = VALU-active SIMD-cycles per second = 4 x SQ_ACTIVE_INST_VALU per launch
-    (quad-cycles -> cycles; MFMA issue slots included; PMC, committed) / live kernel time; peak = SIMDs in use x
-    the clock the profiled run sustained.  frac is the share of the SIMDs' cycles in which the VALU issued; the
-    matrix-pipe share (SQ_VALU_MFMA_BUSY_CYCLES) and the sum of the two (an upper bound: they overlap) ride along.
-    The step-granular algorithmic-bytes figure of SURVEY.md 8(d) is kept as alg_bytes_frac (it exceeds 1 for a
-    fused kernel: those bytes never move) and the fp32-equivalent FLOP fraction as fp32_frac."""
+    bound == "hbm" (the streaming kernels): achieved = the bytes a kernel of this form must move per launch (the
+        matrices once per evaluation + x / state once each way) / kernel_ms_avg; peak 8 TB/s; traffic = HBM bytes per
+        launch from the PMC pass (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), when one exists for this workload.
+    bound == "valu_pipe" (the register / LDS-resident fused kernels: ~20 MB of HBM traffic per launch): a WORK / PEAK
+        figure -- achieved = tile-steps per second a SIMD completes (measured cycles per step: work_block), peak = the
+        tile-steps per second its VALU pipe could retire from the stated minimal instruction counts at the measured
+        pipe rates; frac = achieved / peak = pipe_floor_cycles / measured cycles.  Independent of what the compiler
+        emitted and -- with the in-kernel cycle count -- of any clock assumption.
+    Named secondaries: valu_active_frac (the UTILISATION round 4 reported as frac: 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles;
+    needs counters), issue_cost_frac (single-wave issue costs), alg_bytes_frac (SURVEY.md 8(d)'s step-granular contract
+    figure: exceeds 1 for a fused kernel, those bytes never move), fp32_frac.  counters = "same_build" | "stale" | "none"
+    says whether the PMC file quoted belongs to the build being timed."""
     kern_s = case["kern_ms"] * 1e-3
     out = {"kernel": case["kernel"], "kernel_ms_avg": case["kern_ms"], "kernel_ms_min": case["kern_ms_min"],
            "algorithmic_bytes_per_launch": case["alg_bytes"], "alg_bytes_per_coord_step": case["bpc"],
            "alg_bytes_GBps": case["alg_bytes"] / kern_s / 1e9, "alg_bytes_frac": case["alg_bytes"] / kern_s / HBM_PEAK,
            "fp32_tflops": case["flops"] / kern_s / 1e12, "fp32_frac": case["flops"] / kern_s / FP32_PEAK}
-    src, traffic, issue = None, None, None
+    src, traffic, issue, status, clock_hz, clock_src = None, None, None, "none", 2.4e9, "nominal 2.4 GHz"
     if counters is not None:
-        path, c = counters
+        path, c, status = counters
         src = os.path.relpath(path, ROOT)
         # (the counters are per kernel DISPATCH; a shard beyond the co-resident capacity is several dispatches per unroll)
         nd = float(case.get("dispatches", 1))
         pl = {k: (v * nd if isinstance(v, (int, float)) and k != "SQ_WAVES" else v) for k, v in c.get("per_launch", {}).items()}
         if "FETCH_SIZE_KiB" in pl and "WRITE_SIZE_KiB" in pl:
             traffic = (2.0 * pl["FETCH_SIZE_KiB"] + pl["WRITE_SIZE_KiB"]) * 1024.0
+        if c.get("clock_hz_profiled"):
+            clock_hz, clock_src = float(c["clock_hz_profiled"]), "GRBM_GUI_ACTIVE / kernel time of the PMC pass (%s counters)" % status
         if all(k in pl for k in ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVES")):
             simds = min(N_SIMD, pl["SQ_WAVES"]) if c.get("one_wave_per_simd") else N_SIMD
-            issue = {"simds": simds, "clock_hz": c.get("clock_hz_profiled") or 2.4e9,
-                     "valu_active_cycles": 4.0 * pl["SQ_ACTIVE_INST_VALU"],
+            issue = {"simds": simds, "valu_active_cycles": 4.0 * pl["SQ_ACTIVE_INST_VALU"],
                      "mfma_busy_cycles": pl["SQ_VALU_MFMA_BUSY_CYCLES"],
-                     "mfma_issue_cycles": 4.0 * pl.get("SQ_INSTS_MFMA", 0.0),
                      "kernel_us_profiled": (sum(c["kernel_ns_profiled"].values()) / max(1, len(c["kernel_ns_profiled"])) / 1e3
                                             if c.get("kernel_ns_profiled") else None),
-                     "one_wave_per_simd": bool(c.get("one_wave_per_simd")),
                      "insts_valu": c.get("per_launch", {}).get("SQ_INSTS_VALU"),        # (per DISPATCH, like `waves`)
                      "waves": c.get("per_launch", {}).get("SQ_WAVES")}
+    out.update(counters=status, counters_source=src, counters_build_id=None if counters is None else counters[1].get("build_id"))
     if case["hbm_bound"]:
-        # achieved = the bytes a kernel of this form MUST move per launch (the matrices once per evaluation + x / state once
-        # each way: hbm_model_bytes) / live time; traffic = what the PMC pass saw (FETCH_SIZE x 2 + WRITE_SIZE).  The two agree
-        # to 0.1 % for k_unroll_cu; a kernel that spills (k_unroll_cu8: 1.28 x) shows it in traffic, not in frac.
         model = case["hbm_model_bytes"]
         out.update(bound="hbm", unit="GB/s", peak=HBM_PEAK / 1e9, traffic=traffic, traffic_model_bytes=model,
                    achieved=model / kern_s / 1e9, frac=model / kern_s / HBM_PEAK)
         if traffic is not None:
             out.update(traffic_GBps=traffic / kern_s / 1e9, traffic_over_model=traffic / model if model else None)
-        if issue is not None:
-            out["valu_issue_frac"] = issue["valu_active_cycles"] / (issue["simds"] * issue["clock_hz"] * kern_s)
     else:
-        out.update(bound="valu_issue", unit="VALU-active SIMD-cycles/s", traffic=traffic)
-        if issue is not None:
-            peak = issue["simds"] * issue["clock_hz"]
-            ach = issue["valu_active_cycles"] / kern_s
-            both = (issue["valu_active_cycles"] + issue["mfma_busy_cycles"] - issue["mfma_issue_cycles"]) / kern_s
-            out.update(achieved=ach, peak=peak, frac=min(ach / peak, 1.0),
-                       mfma_busy_frac=issue["mfma_busy_cycles"] / kern_s / peak,
-                       valu_plus_mfma_frac=min(both / peak, 1.0), issue=issue)
-        else:   # no SQ pass committed for this workload: the fp32-equivalent FLOP fraction stands in
+        wb = work_block(case, issue, args, clock_hz)
+        if wb is not None:
+            cyc, floor = wb["cycles_per_step"], wb["pipe_floor_cycles_per_step"]
+            per_tile = floor / wb["tiles_per_simd"]
+            out.update(bound="valu_pipe", unit="tile-steps/s per SIMD",
+                       achieved=wb["tiles_per_simd"] * clock_hz / cyc, peak=clock_hz / per_tile, frac=floor / cyc,
+                       traffic=traffic, clock_source=clock_src if not case.get("loop_ticks") else
+                       "cycles counted in the kernel (s_memtime); clock_hz (%s) only scales achieved / peak alike" % clock_src)
+            out.update(wb)
+        else:   # the step-granular launches: the fp32-equivalent FLOP fraction stands in
             out.update(bound="fp32_flops", unit="TFLOP/s", achieved=out["fp32_tflops"], peak=FP32_PEAK / 1e12,
-                       frac=out["fp32_frac"])
+                       frac=out["fp32_frac"], traffic=traffic)
         if traffic is not None:
             out["hbm_frac_measured"] = traffic / kern_s / HBM_PEAK
-    out["counters_source"] = src
-    wb = work_block(case, issue, args)
-    if wb is not None:
-        out.update(wb)
+    if issue is not None:                                    # the utilisation figures (PMC; round 4's `frac`)
+        prof_s = (issue["kernel_us_profiled"] or case["kern_ms"] * 1e3) * 1e-6
+        peak_cyc = issue["simds"] * clock_hz * prof_s
+        out.update(valu_active_frac=min(issue["valu_active_cycles"] / peak_cyc, 1.0),
+                   mfma_busy_frac=issue["mfma_busy_cycles"] / peak_cyc,
+                   utilisation_note="share of the profiled run's SIMD-cycles in which the VALU issued / the matrix pipe was "
+                                    "busy (PMC, %s counters)" % status)
     return out
 
 
@@ -468,8 +477,8 @@ def run_case(args, eng, world, rank, Bg, B, label):
     graph.reset()                                           # (first call: allocator / context warm-up)
     torch.cuda.synchronize()
     # ---- a ring of problem instances, sampled and uploaded BEFORE the timed region (H2D excluded):
-    # every timed unroll runs on the next instance, so whatever a new instance costs on the device (the two-CU
-    # form's l2o_unroll_prepare) is inside the timed region.  The iterate lives in its own working buffer.
+    # every timed unroll runs on the next instance, so whatever a new instance costs on the device is inside the timed
+    # region.  The iterate lives in its own working buffer.
     graph.launch(feed, commit=True, use_graph=True, restart=[v.value.clone() for v in graph.x])   # which path?
     torch.cuda.synchronize()
     # (only the single-launch fused forms take a new instance per unroll: the step-granular path replays a captured
@@ -584,57 +593,28 @@ def run_case(args, eng, world, rank, Bg, B, label):
     torch.cuda.synchronize()
     kt = [a.elapsed_time(b) for a, b in ev]
     kern_all = ev_rep[0].elapsed_time(ev_rep[1]) / max(10, reps)
-    # the per-problem preparation of the two-CU form (H = W^T W, q = W^T y; l2o_unroll_prepare): runs once per problem
-    # instance -- INSIDE every timed unroll above; timed on its own here for the breakdown
-    prepare_ms = None
-    again = getattr(eng, "_prepare_again", None)
-    if again is not None and graph.last_path == "fused":
-        pe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        again(); torch.cuda.synchronize()
-        pe[0].record()
-        for _ in range(3):
-            again()
-        pe[1].record(); torch.cuda.synchronize()
-        prepare_ms = pe[0].elapsed_time(pe[1]) / 3.0
     coord_steps = (1 if args.problem == "mnist" else B) * D * T     # per GPU per unroll
     Mrows = B if args.problem == "mnist" else (args.rows or D)
     shared = args.problem == "lasso" and args.shared_matrix
     bpc = (alg_bytes_lasso_shared(args.net, B, D, Mrows) if shared
            else alg_bytes_per_coord_step(args.problem, args.net, D, Mrows))
     fused = graph.last_path == "fused"
-    streaming = fused and D > 128
-    dispatches = 1
-    if args.problem == "mnist":
-        kernel = "l2o_mlp_unroll (persistent)" if graph.last_path == "mlp_unroll" else "l2o_mlp_fg + l2o_cwlstm_step_multi per step"
-    elif streaming:
+    # which kernel ran: what the LIBRARY says it launched for the last unroll of this thread (l2o_last_unroll_form, ABI v12:
+    # no mirror of the selection logic here), and the step-loop cycle count that kernel left in the workspace header
+    form, dispatches = eng.last_unroll_form() if graph.last_path in ("fused", "mlp_unroll") else (None, 1)
+    dispatches = max(1, dispatches)
+    loop_ticks = eng.last_loop_ticks() if form in ("k_unroll_pair", "k_unroll_lds") or (form or "").startswith("k_mlp_unroll") else None
+    streaming = form in ("k_unroll_cu", "k_unroll_cu8")
+    notes = {"k_unroll_pair": "every problem on two CUs, one wave per SIMD", "k_unroll_lds": "one problem per CU, two waves per "
+             "SIMD, fragments in LDS", "k_unroll_cu8": "streaming, eight waves, fragments in LDS, LSTM state in registers",
+             "k_unroll_cu": "streaming, four waves", "k_unroll": "one workgroup per problem, W in LDS"}
+    if form is not None:
+        kernel = form + (" (%s)" % notes[form] if form in notes else "") + (" x %d chunk launches" % dispatches if dispatches > 1 else "")
         from open_l2o_amd import _abi
-        form = _abi.get_option(_abi.OPT_UNROLL_CU)
-        cu8 = form in (3, 4) or (form == 1 and args.net == "rnnprop")
-        kernel = "k_unroll_cu8 (eight waves, fragments in LDS, LSTM state in registers)" if cu8 else "k_unroll_cu"
-    elif fused:
-        # (the two-CU kernel; a shard of more than #CU / 2 = 128 problems runs it as consecutive chunk launches)
-        from open_l2o_amd import _abi
-        two_cu = "k_unroll_pairh" if _abi.get_option(_abi.OPT_PAIR_NORMAL) and not _abi.get_option(_abi.OPT_EXACT_GATES) \
-            else "k_unroll_pair"
-        if _abi.get_option(_abi.OPT_EXACT_GATES):
-            two_cu += " (exact gates)"
-        cap = max(8, eng.coresident_cus // 2)
-        # (round 4) a shard of more than #CU / 2 problems of a DM net with 5..8 tiles: the gate-GEMM fragments move to LDS and
-        # every SIMD runs two waves -- k_unroll_lds (one problem per CU; the default) or k_unroll_pair2 (the two-CU kernel,
-        # two workgroups per CU, chunks of #CU problems; L2O_ONE_LDS=3) -- instead of chunk launches of the two-CU kernel
-        one_lds = _abi.get_option(_abi.OPT_ONE_LDS)
-        lds_shape = 64 < D <= 128 and not _abi.get_option(_abi.OPT_EXACT_GATES)            # (5..8 tiles)
-        pair_on = bool(_abi.get_option(_abi.OPT_PAIR))
-        if lds_shape and (one_lds == 2 or (one_lds == 1 and (B > cap or not pair_on))):
-            kernel = "k_unroll_lds (one problem per CU, two waves per SIMD, fragments in LDS)"
-        elif lds_shape and args.net != "rnnprop" and pair_on and not _abi.get_option(_abi.OPT_PAIR_NORMAL) and one_lds == 3:
-            dispatches = (B + 2 * cap - 1) // (2 * cap)
-            kernel = "k_unroll_pair2 (two-CU kernel, fragments in LDS, two workgroups per CU)" + (
-                " x %d chunk launches" % dispatches if dispatches > 1 else "")
-        else:
-            kernel = "k_unroll" if (D <= 16 or not _abi.get_option(_abi.OPT_PAIR)) else (
-                two_cu if B <= cap else "%s x %d chunk launches" % (two_cu, (B + cap - 1) // cap))
-            dispatches = 1 if (D <= 16 or not _abi.get_option(_abi.OPT_PAIR) or B <= cap) else (B + cap - 1) // cap
+        if fused and _abi.get_option(_abi.OPT_EXACT_GATES):
+            kernel += " (exact gates)"
+    elif args.problem == "mnist":
+        kernel = "l2o_mlp_fg + l2o_cwlstm_step_multi per step"
     else:
         kernel = "k_problem_fg1 + k_cwlstm_step per step"
     # HBM bytes per launch that a kernel of this form MUST move (used only when no PMC pass is committed):
@@ -650,8 +630,9 @@ def run_case(args, eng, world, rank, Bg, B, label):
             "kern_ms": float(kern_all), "kern_ms_min": float(np.min(kt)), "coord_steps": coord_steps,
             "bpc": bpc, "alg_bytes": bpc * coord_steps,
             "flops": alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps,
-            "fused": fused, "kernel": kernel, "dispatches": dispatches, "n_cus": int(getattr(eng, "coresident_cus", 256)), "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
-            "hbm_model_bytes": hbm_model, "t_reset": t_reset, "prepare_ms": prepare_ms, "D": D, "B": B, "Bg": Bg, "T": T, "Mrows": Mrows,
+            "fused": fused, "kernel": kernel, "dispatches": dispatches, "loop_ticks": loop_ticks,
+            "n_cus": int(getattr(eng, "coresident_cus", 256)), "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
+            "hbm_model_bytes": hbm_model, "t_reset": t_reset, "D": D, "B": B, "Bg": Bg, "T": T, "Mrows": Mrows,
             "shared": shared}
 
 
@@ -673,7 +654,7 @@ def main(argv=None):
 
     import torch
     import torch.distributed as dist
-    from open_l2o_amd import _engine
+    from open_l2o_amd import _abi, _engine, _graph_core
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -709,7 +690,15 @@ def main(argv=None):
     if sz is None:
         raise SystemExit("bench.py: --scaling strong needs --batch divisible by --gpus")
     Bg, B = sz
+    if args.emulate_world > 1:
+        # ONE shard of a job defined on more GPUs than this box has: this process is rank 0 of `emulate_world` (contiguous
+        # batch slice, 1/B_global everywhere, no collective) -- the per-rank rate of BASELINE configs[3] on one GPU
+        if world != 1 or args.problem == "mnist" or args.batch % args.emulate_world:
+            raise SystemExit("bench.py: --emulate-world needs --gpus 1, a batched optimizee and a divisible batch")
+        _graph_core.emulate_world(0, args.emulate_world)
+        Bg, B = args.batch, args.batch // args.emulate_world
     case = run_case(args, eng, world, rank, Bg, B, "primary")
+    _graph_core.emulate_world()
 
     also = {}
     if world > 1 and not args.no_also and args.problem == "quadratic" and args.config in (None, 2):
@@ -742,97 +731,141 @@ def main(argv=None):
         copy_gbps = 5 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
 
-    if rank == 0:
-        D, T, Mrows, shared = case["D"], case["T"], case["Mrows"], case["shared"]
-        netname, probname = workload_names(args, D, B, Bg, T, Mrows, shared)
-        is_c2 = (args.problem, args.net, D, B, T) == ("quadratic", "dm", 128, 128, 100)
+    build_id = _abi.build_id()
+
+    def describe(a, c, Bg_, B_, full):
+        """The measurement of one workload as a dict: the whole contract line (full) or its compact form (also)."""
+        D, T, Mrows, shared = c["D"], c["T"], c["Mrows"], c["shared"]
+        netname, probname = workload_names(a, D, B_, Bg_, T, Mrows, shared)
+        is_c2 = (a.problem, a.net, D, B_, Bg_, T) == ("quadratic", "dm", 128, 128, 128 * world, 100)
         baseline_config = None
         if is_c2:
             baseline_config = "BASELINE.json configs[1]"
-        elif (args.problem, args.net, D, Bg, T, Mrows) == ("lasso", "rnnprop", 512, 256, 200, 256) and world == 1:
+        elif (a.problem, a.net, D, Bg_, T, Mrows) == ("lasso", "rnnprop", 512, 256, 200, 256) and world == 1:
             baseline_config = "BASELINE.json configs[2]"
-        elif (args.problem, args.net, D, Bg, T) == ("rastrigin", "dm", 100, 1024, 100):
-            baseline_config = "BASELINE.json configs[3]"      # (defined on 8 GPUs: --gpus 8 --config 4 is that line)
-        elif (args.problem, args.net, B, T) == ("mnist", "rnnprop", 64, 200):
+        elif (a.problem, a.net, D, Bg_, T) == ("rastrigin", "dm", 100, 1024, 100):
+            baseline_config = "BASELINE.json configs[3]" + (        # (defined on 8 GPUs: --gpus 8 --config 4 is that line)
+                " -- ONE shard of %d (rank 0's %d problems, 1/B_global = 1/1024, no communication)" % (a.emulate_world, B_)
+                if a.emulate_world > 1 else (" -- all 1024 problems on ONE GPU" if world == 1 else ""))
+        elif (a.problem, a.net, B_, T) == ("mnist", "rnnprop", 64, 200):
             baseline_config = "BASELINE.json configs[4] (forward unroll, one replica per GPU)"
         counters = None
         if world == 1 and not shared:
-            counters = counters_for([args.problem, args.net, D, B, T] + ([Mrows] if args.problem == "lasso" else []),
-                                    case["kernel"].split(" ")[0] if case["fused"] else "")
-        roof = roofline_block(case, args, counters)
-        roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms=case["t_reset"] * 1e3)   # MetaLoss.reset: the problem re-sampled on the device (4 ms with the host draw + upload of round 2)
-        same_lease = bool(os.environ.get("L2O_COUNTERS_DIR")) and roof.get("counters_source") and \
-            not str(roof["counters_source"]).startswith("profiles")
-        roof.update(time_base="kernel_ms_avg: HIP events on the launch stream of THIS run around replays of one problem "
-                              "instance (the unroll kernel + its epilogue, no preparation); counters (traffic, issue): the "
-                              "rocprofv3 --pmc passes named in counters_source, " +
-                              ("collected in THIS lease on THIS build by the same bench command (scripts/gpu_lease.sh final:N; "
-                               "committed as profiles/<tag>_counters_cN.json)" if same_lease else
-                               "collected on an earlier lease of the same bench command"),
-                    counters_same_lease=bool(same_lease))
-        if case.get("prepare_ms") is not None:
-            roof.update(problem_prepare_ms=case["prepare_ms"],
-                        problem_prepare_note="l2o_unroll_prepare (H = W^T W, q = W^T y of the sampled problems): once per "
-                                             "problem instance, INSIDE every timed unroll (each runs on a fresh instance)")
-        scaling_note = None
-        if world > 1 or args.scaling == "strong":
-            scaling_note = ("weak: %d problems per GPU, global batch %d (config 2 cannot strong-scale: a T-step unroll "
-                            "is a serial chain of T x ~2.4 us per problem whatever the number of problems per GPU -- "
-                            "see also.config2_strong; config 4's 1024 problems do, see also.config4)" % (B, Bg)
-                            if args.scaling == "weak" else "strong: global batch %d, %d per GPU" % (Bg, B))
-        out = {
-            "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
-            "value": case["value"], "unit": "coordinate-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": case["ms_per_step"], "unrolls_per_step": case["reps"],
-            "ms_per_unroll": case["ms_per_unroll"], "host_enqueue_ms_per_unroll": case["host_enqueue_ms_per_unroll"],
-            "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s on %s, batch=%d per GPU (global %d), T=%d%s"
-                                   % (netname, probname, B, Bg, T, ", BASELINE.json configs[1]" if is_c2 else ""),
-                       "baseline_config": baseline_config,
-                       "kernel": case["kernel"],
-                       "optimizer_weights": getattr(args, "weights_source", None),
-                       "step_definition": "one bench step = %d complete unrolls, each on the next of %d pre-uploaded problem "
-                                          "instances: per-problem preparation + rewind + T optimizer steps + f(x_T) + loss "
-                                          "reduction; value counts all steps x unrolls" % (case["reps"], case["n_inst"]),
-                       "arithmetic": "fp32 state, inputs and outputs; optimizee gradient in the reference's form (r = Wx - y, "
-                                     "g = W^T r); the LSTM gate GEMM is a 3-way bf16 split (the six exact products per term, "
-                                     "packed into 4 MFMAs per tile for the DM nets) on v_mfma_f32_16x16x32_bf16 with fp32 "
-                                     "accumulation (fp32-level error per step; its in-group truncation shows as ~1e-5 "
-                                     "drift at T = 1000 -- L2O_EXACT_GATES=1 selects the fmaf-chain-equal fp32 MFMA, "
-                                     "DESIGN.md 4); everything else fp32 VALU",
-                       "api": "open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> UnrollGraph.launch",
-                       "parallelism": "problem-batch sharding x%d, one all-reduce of T+1 floats per unroll" % world,
-                       "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
-                       "backend": (dist.get_backend() if world > 1 else None),
-                       "scaling_note": scaling_note},
-            "final_loss_fx_T": float(case["fx_host"][-1]), "fx_0": float(case["fx_host"][0]),
-            "final_loss_fx_T_per_rank": case["fx_ranks"],
-            "value_replayed_problem": case["value_replayed"],
-            "value_replayed_note": "the round-1/2 figure: the same instance replayed (no per-problem preparation in the "
-                                   "timed launches); not the headline",
-            "parity_pin": PARITY_PIN,
-            "roofline": roof,
-        }
+            counters = counters_for([a.problem, a.net, D, B_, T] + ([Mrows] if a.problem == "lasso" else []),
+                                    c["kernel"].split(" ")[0] if c["fused"] or "k_mlp_unroll" in c["kernel"] else "", build_id)
+        roof = roofline_block(c, a, counters)
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline and not shared:
+            secs = 20.0 if full else args.also_cpu_seconds
+            if a.problem == "mnist":
+                cpu = cpu_baseline_mnist(c["weights"], B_, T, max_seconds=min(secs, 15.0))
+            else:
+                names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None), "rastrigin": ("A", "B", "C")}[a.problem]
+                g = c["graph"]._by_name
+                arrays = {"W": g[names[0]].eval(), "y": g[names[1]].eval().reshape(B_, -1)}
+                if names[2]:
+                    arrays["C"] = g[names[2]].eval().reshape(B_, -1)
+                arrays["l1"], arrays["alpha"] = 0.1, 10.0
+                cpu = cpu_baseline(a.problem, a.net, arrays, c["weights"], eng.to_numpy(c["x0"][0]).reshape(B_, D), T,
+                                   max_seconds=secs, B_global=Bg_, numpy_leg=full)
+        workload = "%s on %s, batch=%d per GPU (global %d), T=%d%s" % (netname, probname, B_, Bg_, T,
+                                                                       ", BASELINE.json configs[1]" if is_c2 else "")
+        if not full:
+            keep = ("kernel", "kernel_ms_avg", "bound", "frac", "achieved", "peak", "unit", "traffic", "traffic_over_model",
+                    "cycles_per_step", "cycles_source", "pipe_floor_cycles_per_step", "tiles_per_simd", "valu_active_frac",
+                    "alg_bytes_frac", "fp32_frac", "counters", "counters_source")
+            out = {"workload": workload, "baseline_config": baseline_config, "value": c["value"], "unit": "coordinate-steps/s",
+                   "steps": a.steps, "unrolls_per_step": c["reps"], "ms_per_unroll": c["ms_per_unroll"],
+                   "optimizer_weights": getattr(a, "weights_source", None),
+                   "final_loss_fx_T": float(c["fx_host"][-1]), "fx_0": float(c["fx_host"][0]),
+                   "roofline": {k: roof[k] for k in keep if k in roof}}
+            if a.emulate_world > 1:
+                out["loss_note"] = "fx are the SHARD's partial sums / B_global (no all-reduce under --emulate-world)"
+        else:
+            roof.update(hbm_copy_measured_GBps=copy_gbps, reset_ms=c["t_reset"] * 1e3)   # MetaLoss.reset: the problem re-sampled on the device
+            roof.update(time_base="kernel_ms_avg: HIP events on the launch stream of THIS run around replays of one problem "
+                                  "instance (the unroll kernel + its epilogue); cycles_per_step: counted inside the kernel; "
+                                  "counters (traffic, valu_active_frac): the rocprofv3 --pmc passes named in counters_source, "
+                                  "matched to this library by build id (counters = same_build) or not (stale)",
+                        build_id=build_id)
+            scaling_note = None
+            if world > 1 or a.scaling == "strong":
+                scaling_note = ("weak: %d problems per GPU, global batch %d (config 2 cannot strong-scale: a T-step unroll "
+                                "is a serial chain of T x ~1.8 us per problem whatever the number of problems per GPU -- "
+                                "see also.config2_strong; config 4's 1024 problems do, see also.config4)" % (B_, Bg_)
+                                if a.scaling == "weak" else "strong: global batch %d, %d per GPU" % (Bg_, B_))
+            out = {
+                "metric": "unroll-steps/sec (batch x params x T), %s on %s" % (netname.split(" ")[0], probname),
+                "value": c["value"], "unit": "coordinate-steps/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": c["ms_per_step"], "unrolls_per_step": c["reps"],
+                "ms_per_unroll": c["ms_per_unroll"], "host_enqueue_ms_per_unroll": c["host_enqueue_ms_per_unroll"],
+                "higher_is_better": True,
+                "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": workload,
+                           "baseline_config": baseline_config,
+                           "kernel": c["kernel"],
+                           "optimizer_weights": getattr(a, "weights_source", None),
+                           "step_definition": "one bench step = %d complete unrolls, each on the next of %d pre-uploaded problem "
+                                              "instances: rewind + T optimizer steps + f(x_T) + loss reduction; value counts "
+                                              "all steps x unrolls" % (c["reps"], c["n_inst"]),
+                           "arithmetic": "fp32 state, inputs and outputs; optimizee gradient in the reference's form (r = Wx - y, "
+                                         "g = W^T r); the LSTM gate GEMM is a 3-way bf16 split (the six exact products per term, "
+                                         "packed into 4 MFMAs per tile for the DM nets) on v_mfma_f32_16x16x32_bf16 with fp32 "
+                                         "accumulation (fp32-level error per step; its in-group truncation shows as ~1e-5 "
+                                         "drift at T = 1000 -- L2O_EXACT_GATES=1 selects the fmaf-chain-equal fp32 MFMA, "
+                                         "DESIGN.md 4); everything else fp32 VALU",
+                           "api": "open_l2o_amd.util.get_config -> MetaOptimizer.meta_loss -> UnrollGraph.launch",
+                           "parallelism": "problem-batch sharding x%d, one all-reduce of T+1 floats per unroll" % world,
+                           "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                           "backend": (dist.get_backend() if world > 1 else None),
+                           "scaling_note": scaling_note},
+                "final_loss_fx_T": float(c["fx_host"][-1]), "fx_0": float(c["fx_host"][0]),
+                "final_loss_fx_T_per_rank": c["fx_ranks"],
+                "value_replayed_problem": c["value_replayed"],
+                "value_replayed_note": "the same instance replayed (the round-1/2 figure); not the headline",
+                "parity_pin": PARITY_PIN,
+                "roofline": roof,
+            }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_baseline"] = c["value"] / cpu["value"]
+            if "fx_T" in cpu:
+                ref = cpu["fx_T"]
+                out["final_loss_rel_diff_vs_cpu_port"] = abs(float(c["fx_host"][-1]) - ref) / max(abs(ref), 1e-30)
+        return out
+
+    out = describe(args, case, Bg, B, True) if rank == 0 else None
+    # ---- N = 1, the default run: the other BASELINE configurations, driver-timed in the same process (VERDICT r04 1c)
+    if world == 1 and not args.no_also and args.config in (None, 2) and args.problem == "quadratic" and args.emulate_world <= 1 \
+            and (args.dims, args.batch, args.unroll, args.net) == (128, 128, 100, "dm"):
+        del case
+        torch.cuda.empty_cache()
+        t_also = time.perf_counter()
+        for name, extra_argv in (("config3", ["--config", "3", "--steps", "3"]),
+                                 ("config4_one_gpu", ["--config", "4", "--steps", "5"]),
+                                 ("config4_shard_of_8", ["--config", "4", "--emulate-world", "8", "--steps", "10", "--unrolls-per-step", "8"]),
+                                 ("config5", ["--config", "5", "--steps", "5"])):
+            if time.perf_counter() - t_also > args.also_budget:
+                also[name] = {"skipped": "the also-block's time budget (%g s) was spent" % args.also_budget}
+                continue
+            a2 = parse_args(extra_argv + ["--warmup", "2"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+            a2.also_cpu_seconds = args.also_cpu_seconds
+            if a2.emulate_world > 1:
+                _graph_core.emulate_world(0, a2.emulate_world)
+                Bg2, B2 = a2.batch, a2.batch // a2.emulate_world
+            else:
+                Bg2, B2 = sizes(a2)
+            try:
+                c2 = run_case(a2, eng, 1, 0, Bg2, B2, name)
+            finally:
+                _graph_core.emulate_world()
+            also[name] = describe(a2, c2, Bg2, B2, False)
+            del c2
+            torch.cuda.empty_cache()
+        also["seconds"] = time.perf_counter() - t_also
+    if rank == 0:
         if also:
             out["also"] = also
-        if world == 1 and not args.no_cpu_baseline and not shared:
-            if args.problem == "mnist":
-                out["cpu_baseline"] = cpu_baseline_mnist(case["weights"], B, T)
-            else:
-                names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None),
-                         "rastrigin": ("A", "B", "C")}[args.problem]
-                g = case["graph"]._by_name
-                arrays = {"W": g[names[0]].eval(), "y": g[names[1]].eval().reshape(B, -1)}
-                if names[2]:
-                    arrays["C"] = g[names[2]].eval().reshape(B, -1)
-                arrays["l1"], arrays["alpha"] = 0.1, 10.0
-                out["cpu_baseline"] = cpu_baseline(args.problem, args.net, arrays, case["weights"],
-                                                   eng.to_numpy(case["x0"][0]).reshape(B, D), T)
-            out["speedup_vs_cpu_baseline"] = case["value"] / out["cpu_baseline"]["value"]
-            if "fx_T" in out["cpu_baseline"]:
-                ref = out["cpu_baseline"]["fx_T"]
-                out["final_loss_rel_diff_vs_cpu_port"] = abs(out["final_loss_fx_T"] - ref) / max(abs(ref), 1e-30)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -17,7 +17,8 @@
  *   - return value: 0 = OK, L2O_ERR_ARG (-1) bad argument, L2O_ERR_UNSUPPORTED
  *     (-2) shape / configuration not implemented by the fused kernels (callers
  *     fall back to the step-granular entry points), L2O_ERR_HIP (-3) HIP runtime
- *     error; l2o_last_error() returns a thread-local message;
+ *     error, L2O_ERR_TIMEOUT (-4) a recoverable partner timeout reported by
+ *     l2o_unroll_status; l2o_last_error() returns a thread-local message;
  *   - no C++ exception crosses the ABI; plain pointers and sizes only.
  */
 #ifndef L2O_ABI_H_
@@ -30,12 +31,16 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 11
+#define L2O_ABI_VERSION 12
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
 #define L2O_ERR_UNSUPPORTED (-2)
 #define L2O_ERR_HIP (-3)
+#define L2O_ERR_TIMEOUT (-4)   /* ABI v12, l2o_unroll_status only: a workgroup of a kernel that exchanges data with a partner
+                                  workgroup gave up waiting (bounded spin): that launch's outputs are invalid, the inputs
+                                  the caller kept are not -- re-run it on an exchange-free form (L2O_OPT_PAIR = 0 /
+                                  L2O_OPT_MLP_UNROLL = 0), which is what the Python host does */
 
 /* optimizer-network kinds: networks.CoordinateWiseDeepLSTM (DM/networks.py:239-276),
  * networks.RNNprop (DM/networks.py:279-300) */
@@ -102,6 +107,23 @@ typedef struct l2o_problem {
 /* ---- library info ------------------------------------------------------ */
 int l2o_abi_version(void);
 const char* l2o_last_error(void);
+/* ABI v12.  l2o_build_id: 16 hex digits = sha256 over the sources the library was built from (csrc/Makefile passes it
+ * in): measurements (rocprofv3 counter summaries under profiles/) carry it, so that bench.py can tell whether the
+ * counters it quotes belong to the build it is timing.
+ * l2o_last_unroll_form: which kernel the last l2o_unroll / l2o_unroll_record / l2o_unroll_reduce / l2o_mlp_unroll(_record)
+ * call of THIS thread launched: L2O_FORM_* | (number of consecutive chunk launches << 8); 0 before the first call.
+ * Diagnostic (thread-local, like l2o_last_error): the host labels its measurements with it and uses it to know whether a
+ * launch exchanged data between workgroups (forms marked +: they can report L2O_ERR_TIMEOUT through l2o_unroll_status). */
+const char* l2o_build_id(void);
+int l2o_last_unroll_form(void);
+#define L2O_FORM_UNROLL 1              /* k_unroll: one workgroup per problem, W in LDS                                  */
+#define L2O_FORM_UNROLL_PAIR 2         /* + k_unroll_pair: every problem on two workgroups / CUs                         */
+#define L2O_FORM_UNROLL_LDS 5          /* k_unroll_lds: one problem per CU, two waves per SIMD, fragments in LDS         */
+#define L2O_FORM_UNROLL_CU 6           /* k_unroll_cu: the streaming form, four waves                                    */
+#define L2O_FORM_UNROLL_CU8 7          /* k_unroll_cu8: the streaming form, eight waves                                  */
+#define L2O_FORM_MLP_UNROLL 8          /* + k_mlp_unroll, fast instantiation, flat all-reduce                            */
+#define L2O_FORM_MLP_UNROLL_HIER 9     /* + k_mlp_unroll, fast instantiation, XCD-hierarchical all-reduce                */
+#define L2O_FORM_MLP_UNROLL_GENERIC 10 /* + k_mlp_unroll, generic loops                                                  */
 
 /* ---- options (ABI v9: per call, caller-owned) -------------------------------
  * A/B switches between kernels that compute the same thing (all results stay within the parity tolerance).  The
@@ -123,11 +145,9 @@ const char* l2o_last_error(void);
 #define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups (L2O_OPTW_BWD_BLOCKS) */
 #define L2O_OPT_BWD_KERNEL 6         /* 0*: matrix-core BPTT step (needs wpack); 1: fp32 tile kernel; 2: generic kernel     */
 #define L2O_OPT_MLP_UNROLL 7         /* 1*: l2o_mlp_unroll available to the host layer (0: it reports "unsupported")       */
-#define L2O_OPT_PAIR_NORMAL 8        /* 0*: the two-CU unroll uses the reference's arithmetic, r = W x - y then g = W^T r
-                                        (exchange of the partial residuals); 1: g = H x - q from the PREPARED normal matrix
-                                        H = W^T W (l2o_unroll_prepare; one GEMV and an exchange of the iterate per step):
-                                        faster when ONE problem instance is unrolled many times, but its gradient error no
-                                        longer shrinks with the residual                                       */
+/* (option 8 was L2O_OPT_PAIR_NORMAL -- the two-CU unroll on a prepared normal matrix H = W^T W, l2o_unroll_prepare, ABI
+ *  v7..v11: 14 % less kernel time on a replayed instance, but a gradient error that no longer shrinks with the residual and
+ *  a preparation pass per fresh instance; removed in ABI v12, docs/DESIGN_history_r04.md.  Its field is ignored.) */
 #define L2O_OPT_EXACT_GATES 9        /* 0*: LSTM gate GEMM as a 3-way bf16 split on v_mfma_f32_16x16x32_bf16 (fp32-level error,
                                         but the matrix pipe TRUNCATES small products inside an 8-slot group: a deterministic
                                         bias that shows as ~1e-5 drift at T = 1000); 1: v_mfma_f32_16x16x4_f32 (bit-equal to
@@ -142,8 +162,7 @@ const char* l2o_last_error(void);
                                         the #CU / 2 that one launch of the two-CU kernel holds: 0: consecutive chunk launches of
                                         that kernel (one workgroup per CU, fragments in registers); 1*: one problem per CU, two
                                         waves per SIMD, the gate-GEMM fragments in LDS (k_unroll_lds); 2: k_unroll_lds for every
-                                        shard; 3: the two-CU kernel with the fragments in LDS and TWO workgroups per CU
-                                        (k_unroll_pair2; chunks of #CU problems; DM nets only) for every shard -- measures like 1 */
+                                        shard.  (3 was k_unroll_pair2, removed in ABI v12: it measured like 1)                  */
 #define L2O_OPT_COUNT_ 13            /* (* = default) */
 /* an option's 4-bit field in l2o_net_cfg.options: bit 3 = "set", bits 0-2 = the value.  Fields 0..11 sit at 4 * option;
  * bits 48-63 are the L2O_OPT_BWD_BLOCKS count, so option 12 uses the field that option 5 (that count) leaves unused */
@@ -501,7 +520,7 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
  *
  * workspace: caller-owned device scratch of l2o_unroll_workspace_bytes() bytes, or NULL.
  * With a workspace every problem is split over TWO workgroups (two CUs) that exchange their partial
- * residuals (L2O_OPT_PAIR_NORMAL: the iterate) once per step through tagged 8-byte granules in the
+ * residuals once per step through tagged 8-byte granules in the
  * workspace; a launch holds at most (CUs usable by the stream) / 2 problems -- both halves of each
  * co-resident, see l2o_coresident_workgroups -- and a larger shard runs as consecutive launches of
  * equal chunks.  Without a workspace: one workgroup per problem.
@@ -509,7 +528,13 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
  * never showed up (bounded spin, no hang; the results of that launch are then invalid): after
  * synchronising, copy them to the host and pass them to l2o_unroll_status(); the caller clears
  * the word (writes 0) once it has handled the error.  The next 4 bytes are a launch sequence
- * number the kernels maintain (the salt of the exchange tags).  A workspace must start zeroed
+ * number the kernels maintain (the salt of the exchange tags).  Bytes 8..11 are a FAULT-INJECTION word for
+ * tests (ABI v12; 0 in production and after l2o_unroll_workspace_init): while it is non-zero every launch of
+ * a kernel that exchanges data behaves as if its partners never showed up -- it raises the status at once
+ * and its results are invalid; the exchange-free forms ignore it.  Bytes 16..23 (ABI v12, int64): the shader-clock
+ * cycles (s_memtime) wave 0 of workgroup 0 spent in the step loop of the LAST launch on this workspace (the two-CU
+ * kernel, k_unroll_lds, l2o_mlp_unroll) -- T steps + the final loss evaluation -- a measurement in cycles that needs
+ * no clock-frequency assumption (bench.py's roofline block).  A workspace must start zeroed
  * (see l2o_unroll_workspace_init / _layout below) and must not be shared by two streams at the same time.
  * Problems beyond the LDS-resident sizes (D <= 512, D % 4 == 0, any M) run the streaming
  * form: one workgroup per problem, the matrix streamed once per step, x / state / moments on-chip
@@ -542,11 +567,8 @@ int l2o_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device */,
  *          iterate (DM/meta.py:379-383 re-runs the x initializer; a driver that restarts the SAME instance keeps x0);
  *   flags  L2O_UNROLL_ZERO_STATE: start from the zero LSTM state and zero RNNProp moments (what `reset` leaves,
  *          DM/meta.py:381, DM/meta_rnnprop_train.py:559-566) instead of reading st, m, v; they are still written.
- *          L2O_UNROLL_PREPARED (ABI v7): the workspace holds what l2o_unroll_prepare left for THIS prob (same W, y
- *          contents, same layout) -- the launch skips its own preparation pass.
  * i.e. `reset` + the first unroll of an epoch + fx_array.stack() in one call, without memset / copy passes. */
 #define L2O_UNROLL_ZERO_STATE 1
-#define L2O_UNROLL_PREPARED 2
 int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_problem* prob,
                       const float* x0 /* device or NULL */, float* x, float* st, float* m, float* v, int32_t T,
                       int32_t step0, int32_t flags, float* fx_part, float* fx /* device [T+1] */, void* workspace,
@@ -557,16 +579,6 @@ int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack /* device */, c
  * Between launches of one layout the library keeps the granule area clean itself (the epilogue kernel of a launch
  * re-zeroes it), so there is no memset per unroll.  layout == 0: the pair has no workspace-using kernel. */
 int l2o_unroll_workspace_init(void* workspace, size_t bytes, void* stream);
-/* Problem preparation of the NORMAL-MATRIX two-CU form (ABI v7; since ABI v9 only with L2O_OPT_PAIR_NORMAL = 1 in
- * cfg->options -- the default two-CU form needs none and this call is then a no-op).  The optimizees of the fused forms
- * are  coef |W x - y|^2 + separable terms (DM/problems.py:73-213, 959-994); that form takes the gradient of the first
- * term as  H x - q  with H = W^T W, q = W^T y (float64 accumulation, rounded once) kept in the workspace -- the problem
- * is constant over an unroll and over every unroll until the caller re-samples it (MetaLoss.reset).  l2o_unroll / l2o_unroll_record and
- * l2o_unroll_reduce without L2O_UNROLL_PREPARED run this pass themselves ahead of the unroll (two small kernels);
- * a caller that launches many unrolls on one problem calls it once after (re)sampling W, y -- and after every
- * l2o_unroll_workspace_init -- and passes L2O_UNROLL_PREPARED.  The loss itself is still |W x - y|^2 from W.
- * A no-op (L2O_OK) for pairs whose unroll has no workspace-using kernel. */
-int l2o_unroll_prepare(const l2o_net_cfg* cfg, const l2o_problem* prob, void* workspace, void* stream);
 int64_t l2o_unroll_workspace_layout(const l2o_net_cfg* cfg, const l2o_problem* prob);
 int l2o_unroll_status(const void* workspace_header_host /* host copy of the first 4 bytes */);
 /* 1 if l2o_unroll has a fused kernel for this (cfg, prob) pair, else 0: the LDS-resident forms

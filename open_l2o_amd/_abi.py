@@ -14,8 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # L2O_HIP_LIB: alternative build of the SAME library (timing ablations, scripts/ablate.sh)
 LIB_PATH = os.environ.get("L2O_HIP_LIB") or os.path.join(_HERE, "libl2o_hip.so")
 
-L2O_ABI_VERSION = 11
-L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP = 0, -1, -2, -3
+L2O_ABI_VERSION = 12
+L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP, L2O_ERR_TIMEOUT = 0, -1, -2, -3, -4
 
 NET_CW, NET_RNNPROP = 0, 1
 PRE_IDENTITY, PRE_LOGSIGN, PRE_FC_ELU = 0, 1, 2
@@ -23,10 +23,10 @@ PROB_SIMPLE, PROB_QUADRATIC, PROB_LASSO, PROB_RASTRIGIN, PROB_SQUARE_COS, PROB_M
 
 # every symbol include/l2o_abi.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "l2o_abi_version", "l2o_last_error", "l2o_coresident_workgroups", "l2o_wpack_floats", "l2o_wpack_host",
+    "l2o_abi_version", "l2o_last_error", "l2o_build_id", "l2o_last_unroll_form", "l2o_coresident_workgroups", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_record", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
-    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_unroll_prepare", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_adam_step_gather", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_adam_step_gather", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
     "l2o_suffix_sums", "l2o_colsum", "l2o_colsum_scratch_floats", "l2o_lincomb", "l2o_rnnprop_input_adjoint",
 )
@@ -36,11 +36,16 @@ SYMBOLS = (
 # This binding keeps the caller's side of it: one process-wide dict of non-default values (applied from the L2O_*
 # environment variables once at import, changed by set_option) that NetSpec.to_c() / the problem and MLP descriptors
 # encode into every struct they hand to the library.
+# (id 8 was OPT_PAIR_NORMAL -- the normal-matrix two-CU form, removed with ABI v12)
 OPT_PAIR, OPT_PAIR_PLAIN_STORES, OPT_UNROLL_CU, OPT_FG_TWO_PASS, OPT_MLP_GENERIC, OPT_BWD_BLOCKS, OPT_BWD_KERNEL, \
-    OPT_MLP_UNROLL, OPT_PAIR_NORMAL, OPT_EXACT_GATES, OPT_WPACK_NO_CLEAR, OPT_MLP_HIER, OPT_ONE_LDS = range(13)
+    OPT_MLP_UNROLL, _OPT_REMOVED_8, OPT_EXACT_GATES, OPT_WPACK_NO_CLEAR, OPT_MLP_HIER, OPT_ONE_LDS = range(13)
 OPT_DEFAULTS = {OPT_PAIR: 1, OPT_PAIR_PLAIN_STORES: 1, OPT_UNROLL_CU: 1, OPT_FG_TWO_PASS: 0, OPT_MLP_GENERIC: 0,
-                OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_PAIR_NORMAL: 0, OPT_EXACT_GATES: 0,
+                OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_EXACT_GATES: 0,
                 OPT_WPACK_NO_CLEAR: 0, OPT_MLP_HIER: 1, OPT_ONE_LDS: 1}
+# l2o_last_unroll_form(): which kernel a fused launch ran (include/l2o_abi.h L2O_FORM_*)
+FORM_NAMES = {1: "k_unroll", 2: "k_unroll_pair", 5: "k_unroll_lds", 6: "k_unroll_cu", 7: "k_unroll_cu8",
+              8: "k_mlp_unroll (flat all-reduce)", 9: "k_mlp_unroll (XCD-hierarchical all-reduce)", 10: "k_mlp_unroll (generic loops)"}
+FORMS_WITH_EXCHANGE = (2, 8, 9, 10)    # workgroups wait for partner workgroups: can end in L2OPartnerTimeout
 PROB_FG_TWO_PASS = 2      # l2o_problem.flags
 MLP_GENERIC = 1           # l2o_mlp.flags
 _options = {}
@@ -56,8 +61,6 @@ _ENV_OPTIONS = (
     ("L2O_BWD_TILE", OPT_BWD_KERNEL, lambda v: 1),
     ("L2O_BWD_GENERIC", OPT_BWD_KERNEL, lambda v: 2),
     ("L2O_NO_MLP_UNROLL", OPT_MLP_UNROLL, lambda v: 0),
-    ("L2O_PAIR_TWO_PASS", OPT_PAIR_NORMAL, lambda v: 0),
-    ("L2O_PAIR_NORMAL", OPT_PAIR_NORMAL, lambda v: 1),
     ("L2O_EXACT_GATES", OPT_EXACT_GATES, lambda v: 1),
     ("L2O_NO_MLP_HIER", OPT_MLP_HIER, lambda v: 0),
     ("L2O_ONE_LDS", OPT_ONE_LDS, lambda v: int(v)),
@@ -80,6 +83,22 @@ def set_option(opt, value):
             raise ValueError("option %d: value %d out of range" % (opt, value))
         _options[opt] = value
     return old
+
+
+class option_scope(object):
+    """with option_scope({OPT_PAIR: 0}): ... -- the settings for the calls inside, restored afterwards."""
+
+    def __init__(self, settings):
+        self.settings = dict(settings)
+
+    def __enter__(self):
+        self.old = {o: set_option(o, v) for o, v in self.settings.items()}
+        return self
+
+    def __exit__(self, *exc):
+        for o, v in self.old.items():
+            set_option(o, v)
+        return False
 
 
 def get_option(opt):
@@ -161,7 +180,6 @@ class BwdIO(C.Structure):
 
 
 UNROLL_ZERO_STATE = 1     # l2o_unroll_reduce flags
-UNROLL_PREPARED = 2
 PROB_W_SHARED = 1     # l2o_problem.flags: W is one [M, D] matrix for every problem
 
 
@@ -196,7 +214,40 @@ class L2OUnsupported(L2OError):
     """L2O_ERR_UNSUPPORTED: no fused kernel for this configuration."""
 
 
+class L2OPartnerTimeout(L2OError):
+    """L2O_ERR_TIMEOUT (l2o_unroll_status): a workgroup of a kernel that exchanges data with partner workgroups gave up
+    waiting -- that launch's outputs are invalid.  Recoverable: the host re-runs the unroll on an exchange-free form."""
+
+
+def source_build_id():
+    """What l2o_build_id() of a library built from the sources in this tree returns (csrc/Makefile: sha256 over
+    l2o_kernels.hip, the headers and the Makefile in make's $(sort) order), or None without the sources."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    names = ["l2o_kernels.hip", "Makefile", "../../include/l2o_abi.h"] + [os.path.basename(p) for p in glob.glob(os.path.join(csrc, "*.h"))]
+    h = hashlib.sha256()
+    try:
+        for n in sorted(set(names)):
+            with open(os.path.join(csrc, n), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
 _lib = None
+
+
+def build_id():
+    """l2o_build_id() of the loaded library (16 hex digits)."""
+    return lib().l2o_build_id().decode("ascii", "replace")
+
+
+def last_unroll_form():
+    """(name, dispatches) of the kernel the last fused unroll call of this thread launched, or (None, 0)."""
+    w = int(lib().l2o_last_unroll_form())
+    return FORM_NAMES.get(w & 0xff), w >> 8
 
 
 def lib():
@@ -214,6 +265,10 @@ def lib():
     L.l2o_abi_version.argtypes = []
     L.l2o_last_error.restype = C.c_char_p
     L.l2o_last_error.argtypes = []
+    L.l2o_build_id.restype = C.c_char_p
+    L.l2o_build_id.argtypes = []
+    L.l2o_last_unroll_form.restype = C.c_int
+    L.l2o_last_unroll_form.argtypes = []
     L.l2o_coresident_workgroups.restype = C.c_int32
     L.l2o_coresident_workgroups.argtypes = [C.c_void_p, C.c_void_p]
     L.l2o_wpack_floats.restype = C.c_size_t
@@ -284,8 +339,6 @@ def lib():
     L.l2o_cwlstm_wgrad_dims.argtypes = [C.POINTER(NetCfg), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.l2o_cwlstm_wgrad.restype = C.c_int
     L.l2o_cwlstm_wgrad.argtypes = [C.POINTER(NetCfg), vp, vp, C.c_int64, vp, vp, vp]
-    L.l2o_unroll_prepare.restype = C.c_int
-    L.l2o_unroll_prepare.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem), vp, vp]
     L.l2o_unroll_workspace_layout.restype = C.c_int64
     L.l2o_unroll_workspace_layout.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem)]
     L.l2o_unroll_workspace_bytes.restype = C.c_size_t
@@ -326,6 +379,8 @@ def check(rc):
     msg = lib().l2o_last_error().decode("utf-8", "replace")
     if rc == L2O_ERR_UNSUPPORTED:
         raise L2OUnsupported(rc, msg)
+    if rc == L2O_ERR_TIMEOUT:
+        raise L2OPartnerTimeout(rc, msg)
     if rc == L2O_ERR_ARG:
         raise ValueError("libl2o_hip: " + msg)
     raise L2OError(rc, msg)

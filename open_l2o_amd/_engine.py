@@ -563,33 +563,13 @@ class HipEngine(object):
             layout = int(self.lib.l2o_unroll_workspace_layout(C.byref(cc), C.byref(cp)))
             if ws is None or ws.numel() < nbytes:
                 ws = self._workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-                self._ws_prepared = None
             elif layout != self.__dict__.get("_ws_layout"):
                 # the granule area moved: zero the workspace once (the library keeps it clean between launches)
                 _abi.check(self.lib.l2o_unroll_workspace_init(C.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
-                self._ws_prepared = None
             self._ws_layout = layout
         self._last_ws = ws
         wsp = None if ws is None else C.c_void_p(ws.data_ptr())
         flags = _abi.UNROLL_ZERO_STATE if zero_state else 0
-        if ws is not None and fx is not None and p.W is not None and p.y is not None \
-                and _abi.get_option(_abi.OPT_PAIR_NORMAL) and not _abi.get_option(_abi.OPT_EXACT_GATES):
-            # problem preparation of the two-CU form (l2o_unroll_prepare: H = W^T W, q = W^T y in the workspace) once
-            # per problem INSTANCE: the same W / y tensors, unmodified (torch bumps ._version on every in-place write;
-            # the tensors are kept referenced here, so their addresses cannot be recycled behind the key)
-            key = (p.W._version, p.y._version, p.B_local, p.D, p.M, p.w_shared, layout)
-            prep = self.__dict__.get("_ws_prepared")
-            if prep is None or prep[0] != key or prep[1] is not p.W or prep[2] is not p.y:
-                _abi.check(self.lib.l2o_unroll_prepare(C.byref(cc), C.byref(cp), wsp, self._stream()))
-                self._ws_prepared = (key, p.W, p.y)
-                # (bench.py times this pass on its own: it is outside the timed unrolls, once per problem instance)
-                self._prepare_again = lambda: _abi.check(self.lib.l2o_unroll_prepare(C.byref(cc), C.byref(cp), wsp,
-                                                                                    self._stream()))
-            flags |= _abi.UNROLL_PREPARED
-        elif ws is not None:
-            # a launch WITHOUT the PREPARED flag re-prepares H / q of THIS problem in the shared workspace: whatever
-            # the fx= path cached there for another problem is gone (stale H / q -> silently wrong iterates)
-            self._ws_prepared = None
         h = None
         if hist is not None:
             h = _abi.UnrollHist()
@@ -611,12 +591,10 @@ class HipEngine(object):
         """l2o_unroll_reduce with every argument object built ONCE: returns call(fx, step0) for launches that repeat with
         the same buffers (an evaluation loop that re-runs one problem instance from x0; bench.py's ring of instances) --
         per call the host does one ctypes call (~10 us) instead of rebuilding the structs (~0.2 ms, which is a whole
-        config-2 unroll).  Returns None when the launch needs the general path (a workspace that must be (re)initialised,
-        the normal-matrix form's preparation cache).  The closure is valid while the engine's workspace AND its layout
+        config-2 unroll).  Returns None when the launch needs the general path (a workspace that must be (re)initialised).
+        The closure is valid while the engine's workspace AND its layout
         are unchanged (it checks both and returns False otherwise) and the option settings are the ones it was built
         under (the caller keys its cache on them)."""
-        if _abi.get_option(_abi.OPT_PAIR_NORMAL) and not _abi.get_option(_abi.OPT_EXACT_GATES):
-            return None                                      # (per-instance preparation: unroll() keeps that cache)
         cc, cp = spec.to_c(), self._cprob(p)
         nbytes = int(self.lib.l2o_unroll_workspace_bytes(C.byref(cc), C.byref(cp), int(T)))
         ws, layout = None, None
@@ -643,8 +621,6 @@ class HipEngine(object):
             if rc:
                 check(rc)
             eng._last_ws = ws
-            if ws is not None:
-                eng._ws_prepared = None                      # (an unprepared launch owns the workspace's H / q area)
             return True
         return call
 
@@ -661,8 +637,41 @@ class HipEngine(object):
         pin.copy_(ws[:4], non_blocking=True)
         self._status_pending = ws
 
+    def last_unroll_form(self):
+        """(kernel name, dispatches) of the last fused unroll this thread launched (l2o_last_unroll_form)."""
+        return _abi.last_unroll_form()
+
+    def last_unroll_exchanges(self):
+        """The last fused launch ran a kernel whose workgroups wait for partner workgroups (the two-CU unroll, the
+        persistent MLP unroll): the only launches that can end in L2OPartnerTimeout."""
+        return (int(self.lib.l2o_last_unroll_form()) & 0xff) in _abi.FORMS_WITH_EXCHANGE
+
+    def last_loop_ticks(self):
+        """Shader-clock cycles workgroup 0 spent in the step loop of the last fused launch (workspace bytes 16..23; the
+        two-CU kernel, k_unroll_lds, l2o_mlp_unroll), or None.  Synchronises the host."""
+        ws = self._last_ws
+        if ws is None:
+            return None
+        v = int(ws[16:24].view(torch.int64).item())
+        return v if v > 0 else None
+
+    def unroll_status_tensor(self):
+        """The sticky status word of the last fused launch's workspace as a device int32 [1] view (None without a
+        workspace): what a sharded training step all-reduces (MAX) ahead of its guarded meta-step, so that every rank
+        skips the update when any rank's unroll failed."""
+        ws = self._last_ws
+        return None if ws is None else ws[:4].view(torch.int32)
+
+    def inject_unroll_fault(self, on=True):
+        """TEST HOOK (include/l2o_abi.h: workspace bytes 8..11): while set, every launch of an exchanging kernel on the
+        engine's workspaces behaves as if its partners never showed up.  Cleared by check_unroll_status / by hand."""
+        for ws in (self._workspace, self.__dict__.get("_mlp_ws")):
+            if ws is not None:
+                ws[8:12].view(torch.int32).fill_(1 if on else 0)
+
     def check_unroll_status(self):
-        """After a host sync: raise if the split-problem kernel reported a partner timeout."""
+        """After a host sync: raise if the split-problem kernel reported a partner timeout (_abi.L2OPartnerTimeout;
+        the status word -- and the test hook's fault word -- are cleared: the caller handles it)."""
         ws = self._last_ws
         if ws is not None:
             if self.__dict__.pop("_status_pending", None) is ws:
@@ -671,6 +680,7 @@ class HipEngine(object):
                 hdr = ws[:4].cpu().numpy().tobytes()
             if hdr != b"\0\0\0\0":
                 ws[:4].zero_()                               # the status word is sticky: handled here, cleared here
+                ws[8:12].zero_()                             # (an injected fault is one-shot)
             _abi.check(self.lib.l2o_unroll_status(hdr))
 
     def atb(self, A, B):
@@ -709,9 +719,21 @@ class HipEngine(object):
         T, n = len(gs), g_final.numel()
         if T == 0:
             return out
-        table = torch.tensor([g.data_ptr() for g in gs], dtype=torch.int64).to(self.device)
+        # the pointer table: cached on the addresses it holds (a planned unroll records into the same history buffers
+        # every step -- one upload for the whole training run), uploaded from a pinned staging buffer otherwise: a
+        # pageable H2D copy synchronises the host with the stream on every BPTT
+        ptrs = tuple(g.data_ptr() for g in gs)
+        cache = self.__dict__.setdefault("_suffix_tables", {})
+        table = cache.get(ptrs)
+        if table is None:
+            if len(cache) >= 16:
+                cache.clear()
+            pin = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+            table = torch.empty(T, dtype=torch.int64, device=self.device)
+            table.copy_(pin, non_blocking=True)
+            cache[ptrs] = table
+            self._suffix_pin = pin                       # (the staging buffer outlives the asynchronous copy)
         _abi.check(self.lib.l2o_suffix_sums(C.c_void_p(table.data_ptr()), _ptr(g_final), _ptr(out), n, T, self._stream()))
-        self._keep_table = table                         # (alive until the next call: the launch is asynchronous)
         return out
 
     def colsum(self, A, out=None, accumulate=False):

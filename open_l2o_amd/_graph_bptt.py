@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _abi, networks
-from ._graph_core import PackedState, _DevGrad, _LazyHost, _term_vars, _world, rng  # noqa: F401
+from ._graph_core import PackedState, _DevGrad, _LazyHost, _term_vars, _world, _all_reduce, rng  # noqa: F401
 
 
 class BpttMixin(object):
@@ -36,8 +36,15 @@ class BpttMixin(object):
             k = (mod, var)
             if k not in acc:
                 acc[k] = val
-            else:
-                eng.lincomb(acc[k], acc[k], 1.0, val.reshape(acc[k].shape), 1.0)       # acc += val (l2o_lincomb)
+                return
+            # acc += val (l2o_lincomb takes raw pointers: dense operands only).  The first `val` of a key is a column
+            # block of a [KA, KB] contraction result -- a STRIDED view -- so the running sum moves into a
+            # buffer of its own the first time something is added to it, and every later block is densified.
+            a = acc[k]
+            if not a.is_contiguous():
+                a = acc[k] = a.contiguous()
+            v = val.reshape(a.shape)
+            eng.lincomb(a, a, 1.0, v if v.is_contiguous() else v.contiguous(), 1.0)
 
         second = any(pn.get("second") for pn in panels)
 
@@ -253,11 +260,10 @@ class BpttMixin(object):
             # sum of the shards' weight gradients (1/B_global is already in every gradient): ONE collective
             # per network on a contiguous buffer -- the entries of `acc` are column blocks of A^T Bm, i.e.
             # NON-contiguous views, which RCCL rejects and gloo silently mis-reduces
-            import torch.distributed as dist
             for acc in out.values():
                 keys = sorted(acc)
                 flat = torch.cat([acc[k].reshape(-1) for k in keys])
-                dist.all_reduce(flat)
+                _all_reduce(flat)
                 off = 0
                 for k in keys:
                     n = acc[k].numel()

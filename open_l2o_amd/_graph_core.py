@@ -255,18 +255,49 @@ def _term_vars(term):
     return (term.var,) if hasattr(term.var, "initializer") else tuple(term.var)
 
 
+_EMULATED_WORLD = None
+
+
+def emulate_world(rank=None, world=None):
+    """Run ONE shard of a sharded job in a single process, without a process group: graphs built afterwards behave as
+    rank ``rank`` of ``world`` (contiguous batch slice, 1/B_global in every gradient) and skip the collectives -- the losses
+    they report are the SHARD's partial sums / B_global.  For measuring the per-rank rate of a configuration that is defined
+    on more GPUs than the box has (bench.py --emulate-world: BASELINE config 4's shard of 8).  emulate_world() ends it."""
+    global _EMULATED_WORLD
+    if rank is None or world is None or int(world) <= 1:
+        _EMULATED_WORLD = None
+    else:
+        if not 0 <= int(rank) < int(world):
+            raise ValueError("emulate_world: rank %r outside world %r" % (rank, world))
+        _EMULATED_WORLD = (int(rank), int(world))
+
+
 def _world():
+    if _EMULATED_WORLD is not None:
+        return _EMULATED_WORLD
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
 
+def _all_reduce(t, async_op=False, op=None):
+    """torch.distributed.all_reduce(t) over the job's ranks -- the ONLY collective of the data path (the
+    T + 1 partial losses per unroll; the flat weight gradient and the unroll status word per training step).  A no-op
+    under emulate_world (one shard measured on its own)."""
+    if _EMULATED_WORLD is not None:
+        return None
+    import torch.distributed as dist
+    if op is None:
+        return dist.all_reduce(t, async_op=async_op)
+    return dist.all_reduce(t, op=getattr(dist.ReduceOp, op), async_op=async_op)
+
+
 def synced_scale(shape, bound):
     """exp(U[-bound, bound]) of the given (GLOBAL) shape from ``np.random`` (DM/util.py:44), identical on
     every rank: drawn on rank 0 and broadcast when torch.distributed is initialised."""
     arr = np.exp(np.random.uniform(-bound, bound, size=tuple(shape)))
-    if _world()[1] > 1:
+    if _world()[1] > 1 and _EMULATED_WORLD is None:
         import torch.distributed as dist
         box = [arr]
         dist.broadcast_object_list(box, src=0)

@@ -140,6 +140,8 @@ class StepPlanMixin(object):
         previous unroll); a `sampler` of the problem (parity tests) or L2O_HOST_SAMPLING=1: the host draw + upload."""
         bufs = self.__dict__.setdefault("_mlp_idx", {})
         eng = self.engine
+        if self.__dict__.get("_reuse_minibatches") and bufs:
+            return                                          # (recovery re-run of an unroll: the minibatches it drew)
         for k, term in enumerate(self.terms):
             if term.kind != _abi.PROB_MLP:
                 continue

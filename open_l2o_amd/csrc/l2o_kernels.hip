@@ -25,6 +25,10 @@ using namespace l2o;
 // error plumbing
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+// which kernel form the last l2o_unroll* / l2o_mlp_unroll* call of this thread launched (l2o_last_unroll_form, ABI v12):
+// L2O_FORM_* | dispatches << 8.  Diagnostic only, like g_err -- no launch depends on it.
+static thread_local int g_last_form = 0;
+static inline void note_form(int form, int dispatches = 1) { g_last_form = form | (dispatches << 8); }
 
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -656,7 +660,7 @@ struct UnrollArgs {
   // zero moments instead of reading st, m, v -- `reset` + the first unroll in one launch, no memset / copy pass
   const float* x_in;
   int zero_state;
-  int prepared;      // host side only: the workspace already holds this problem's H / q (l2o_unroll_prepare)
+  long long* ticks;   // where k_unroll_lds leaves the step-loop cycle count of problem 0 (PairWs::ticks), or NULL
 };
 
 #ifdef L2O_ABLATE_BARRIER
@@ -848,7 +852,6 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_unroll_pair.h"
 #include "l2o_unroll_lds.h"
-#include "l2o_unroll_pairh.h"
 
 #include "l2o_unroll_cu.h"
 #include "l2o_unroll_cu8.h"
@@ -997,7 +1000,7 @@ static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
 static const int64_t kOptDefault[L2O_OPT_COUNT_] = {
     /* L2O_OPT_PAIR */ 1, /* L2O_OPT_PAIR_PLAIN_STORES */ 1, /* L2O_OPT_UNROLL_CU */ 1,
     /* L2O_OPT_FG_TWO_PASS */ 0, /* L2O_OPT_MLP_GENERIC */ 0, /* L2O_OPT_BWD_BLOCKS */ 0,
-    /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* L2O_OPT_PAIR_NORMAL */ 0, /* L2O_OPT_EXACT_GATES */ 0,
+    /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* (8: was L2O_OPT_PAIR_NORMAL, removed in ABI v12) */ 0, /* L2O_OPT_EXACT_GATES */ 0,
     /* L2O_OPT_WPACK_NO_CLEAR */ 0, /* L2O_OPT_MLP_HIER */ 1, /* L2O_OPT_ONE_LDS */ 1};
 static thread_local uint64_t t_optw = 0;
 struct OptScope {
@@ -1084,54 +1087,26 @@ __global__ __launch_bounds__(256) void k_coresident_probe(unsigned* ctr, unsigne
 // partner: at most #CU / 2 per launch.  A larger batch shard runs as consecutive launches of equal chunks (a multiple
 // of the 8-problem launch groups) -- normal-matrix kernel only; a chunk launch with every tile on its own SIMD beats
 // one round of the one-CU form (config 4, 1024 problems on one GPU: 5.3 -> 6.0 G coordinate-steps/s).
-// per_cu: workgroups of the kernel that share a CU (k_unroll_pair2: 2 -- its 60 KB of LDS and 256 registers per lane
-// leave room for exactly two)
-static int pair_chunk(const l2o_problem* p, const UnrollGeom& g, hipStream_t s, int per_cu = 1) {
+static int pair_chunk(const l2o_problem* p, const UnrollGeom& g, hipStream_t s) {
   if (!opt(L2O_OPT_PAIR) || g.CH < 2) return 0;
-  const int cap = coresident_cus(s) * per_cu / 2;
+  const int cap = coresident_cus(s) / 2;
   if (p->B_local <= cap) return p->B_local;
   if (cap < 8) return 0;
   const int n = (p->B_local + cap - 1) / cap;               // launches
   const int chunk = (((p->B_local + n - 1) / n) + 7) & ~7;  // balanced, whole launch groups
   return chunk <= cap ? chunk : (cap & ~7);
 }
-struct PairLayout { size_t xbuf_off, xbuf_bytes, h_off, q_off, fxh_off, total; int npg, nW; size_t lds; };
+struct PairLayout { size_t xbuf_off, xbuf_bytes, fxh_off, total; int npg; size_t lds; };
 static PairLayout pair_layout(const l2o_problem* p, const UnrollGeom& g, int T) {
   PairLayout L;
   const int SQ = 16 * g.CH;
   L.npg = SQ;                         // granules per (half, parity): one per residual row
   L.xbuf_off = sizeof(PairWs);
   L.xbuf_bytes = (size_t)p->B_local * 2 * 2 * L.npg * sizeof(unsigned long long);
-  // the prepared normal matrices H = W^T W [nW][SQ][SQ] and q = W^T y [B][SQ] (l2o_unroll_pairh.h); T-independent
-  L.nW = (p->flags & L2O_PROB_W_SHARED) ? 1 : p->B_local;
-  L.h_off = L.xbuf_off + L.xbuf_bytes;
-  L.q_off = L.h_off + sizeof(float) * (size_t)L.nW * SQ * SQ;
-  L.fxh_off = L.q_off + sizeof(float) * (size_t)p->B_local * SQ;
+  L.fxh_off = L.xbuf_off + L.xbuf_bytes;
   L.total = L.fxh_off + sizeof(float) * (size_t)(T + 1) * g.CH * p->B_local;   // one partial per (step, problem, wave)
   L.lds = 0;                          // static LDS only (xs, rs, fpart)
   return L;
-}
-
-// H = W^T W and q = W^T y of every problem into the workspace (l2o_unroll_pairh.h)
-static int launch_pair_prepare(const l2o_problem* prob, const UnrollGeom& g, void* workspace, hipStream_t s) {
-  const PairLayout L = pair_layout(prob, g, 0);
-  float* H = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.h_off);
-  float* qv = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.q_off);
-  const int SQ = 16 * g.CH;
-  const bool shared = (prob->flags & L2O_PROB_W_SHARED) != 0;
-  const dim3 grid(L.nW, 2);
-  const size_t lds = sizeof(float) * (size_t)prob->M * SQ;
-  float* qh = shared ? nullptr : qv;                       // a per-problem W: q comes out of the same blocks
-  void (*fn)(const float*, const float*, int, int, float*, float*) =
-      g.CH == 2 ? k_pair_prepare_h<2> : (g.CH == 4 ? k_pair_prepare_h<4> : k_pair_prepare_h<8>);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, prob->W, prob->y, prob->M, prob->D, H, qh);
-  HIP_TRY(hipGetLastError());
-  if (shared) {
-    hipLaunchKernelGGL(k_pair_prepare_q, dim3(prob->B_local), dim3(SQ), 0, s, prob->W, prob->y, prob->M, prob->D, SQ, qv);
-    HIP_TRY(hipGetLastError());
-  }
-  return L2O_OK;
 }
 
 template <int PRE, int KIND>
@@ -1139,16 +1114,14 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
                             void* workspace, float* fx, bool* fx_done) {
   const bool hist = a.hist_st != nullptr;
   int chunk = workspace ? pair_chunk(prob, g, s) : 0;
-  // Large shards (round 4) -- more problems than the #CU / 2 one launch of the two-CU kernel holds.  Both new forms keep the
-  // gate-GEMM fragments in LDS and run two waves per SIMD; they measure the same (config 4: 1.28 / 1.30 ms).  L2O_OPT_ONE_LDS:
-  //   0  consecutive chunk launches of the two-CU kernel (one workgroup per CU, fragments in registers: rounds 2-3)
-  //   1  (default) k_unroll_lds for large shards: one problem per CU, two waves of the SAME problem per SIMD, one launch,
-  //      no cross-CU protocol
-  //   2  k_unroll_lds for every shard (A/B runs)
-  //   3  k_unroll_pair2: the two-CU kernel with the fragments in LDS, TWO workgroups (halves of different problems) per CU,
-  //      chunks of #CU problems (A/B runs; <= #CU / 2 problems leave it one workgroup per CU)
-  // DM nets, 5..8 tiles, no exact-gates / normal-matrix request.
-  bool pair2 = false;
+  // Large shards (round 4) -- more problems than the #CU / 2 one launch of the two-CU kernel holds -- run k_unroll_lds: one
+  // problem per CU, the gate-GEMM fragments in LDS, two waves of the SAME problem per SIMD, one launch, no cross-CU
+  // protocol.  L2O_OPT_ONE_LDS: 0 = consecutive chunk launches of the two-CU kernel instead (rounds 2-3; A/B runs), 1 = the
+  // default, 2 = k_unroll_lds for every shard (A/B runs).  5..8 tiles, no exact-gates request.  Also the exchange-free
+  // fallback of those shapes when the two-CU form is not available (no workspace, L2O_OPT_PAIR = 0; the host's recovery
+  // from a partner timeout): the alternative there is k_unroll's fp32-MFMA form, 11 200 cycles per step against 7 200.
+  // (k_unroll_pair2 -- the two-CU kernel with fragments in LDS, two workgroups per CU -- measured the same as k_unroll_lds
+  //  in round 4 and was removed in round 5: docs/DESIGN_history_r04.md.)
   {
     const int one_lds = (int)opt(L2O_OPT_ONE_LDS);
 #ifdef L2O_LDS_ABL_ANYNW   // (timing ablation: also 1..4 tiles, i.e. ONE wave per SIMD in this kernel; needs M <= 16 nw)
@@ -1157,20 +1130,16 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     const bool shape_ok = g.CH == 8 && g.nw >= 5;
 #endif
     const bool plain = !(opt(L2O_OPT_EXACT_GATES) && !hist);
-    // (also when the two-CU form is not available at all -- no workspace, L2O_OPT_PAIR = 0: the alternative there is k_unroll's
-    //  fp32-MFMA form for 5..8 tiles, 11 200 cycles per step against 7 200)
     if ((one_lds == 2 || (one_lds == 1 && (chunk == 0 || a.pp.B_local > chunk))) && shape_ok && plain) {
+      UnrollArgs al = a;
+      al.ticks = workspace ? &reinterpret_cast<PairWs*>(workspace)->ticks : nullptr;
       void (*fl)(UnrollArgs) = hist ? k_unroll_lds<PRE, KIND, true> : k_unroll_lds<PRE, KIND, false>;
       const size_t lds = sizeof(float) * ((size_t)LstmCoreLds<PRE>::kFragWords + 2 * 128 + 8);
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(fl, dim3(a.pp.B_local), dim3(64 * g.nw), lds, s, a);
+      hipLaunchKernelGGL(fl, dim3(a.pp.B_local), dim3(64 * g.nw), lds, s, al);
       HIP_TRY(hipGetLastError());
+      note_form(L2O_FORM_UNROLL_LDS);
       return L2O_OK;
-    }
-    // (k_unroll_pair2: DM nets only -- two workgroups with RNNProp's 80 KB of fragments each do not fit a CU's LDS)
-    if (PRE != L2O_PRE_FC_ELU && chunk > 0 && g.CH == 8 && g.nw >= 5 && plain && !opt(L2O_OPT_PAIR_NORMAL) && one_lds == 3) {
-      pair2 = true;
-      chunk = pair_chunk(prob, g, s, 2);
     }
   }
   if (chunk > 0) {
@@ -1192,44 +1161,10 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
     const int B = a.pp.B_local;
     const bool one_launch = chunk >= B;
     const bool exact = opt(L2O_OPT_EXACT_GATES) != 0 && !hist;   // (the recording unroll keeps the bf16x3 core)
-    if (opt(L2O_OPT_PAIR_NORMAL) && !exact) {
-      // the gradient from the prepared normal matrix (l2o_unroll_pairh.h); prepared here unless the caller did
-      if (!a.prepared) {
-        const int rc = launch_pair_prepare(prob, g, workspace, s);
-        if (rc) return rc;
-      }
-      UnrollPairHArgs ha;
-      ha.p = pa;
-      ha.H = reinterpret_cast<const float*>(static_cast<char*>(workspace) + L.h_off);
-      ha.qv = reinterpret_cast<const float*>(static_cast<char*>(workspace) + L.q_off);
-      void (*fh)(UnrollPairHArgs) = nullptr;
-      switch (g.CH) {
-        case 2: fh = hist ? k_unroll_pairh<PRE, KIND, 2, true> : k_unroll_pairh<PRE, KIND, 2, false>; break;
-        case 4: fh = hist ? k_unroll_pairh<PRE, KIND, 4, true> : k_unroll_pairh<PRE, KIND, 4, false>; break;
-        default: fh = hist ? k_unroll_pairh<PRE, KIND, 8, true> : k_unroll_pairh<PRE, KIND, 8, false>; break;
-      }
-      for (int b0 = 0; b0 < B; b0 += chunk) {
-        ha.b0 = b0;
-        ha.nb = B - b0 < chunk ? B - b0 : chunk;
-        hipLaunchKernelGGL(fh, dim3((ha.nb + 7) / 8 * 16), dim3(64 * (g.CH / 2)), L.lds, s, ha);
-        HIP_TRY(hipGetLastError());
-        // (the epilogue of a chunk: its loss partials -> fx_part columns [b0, b0 + nb), its granules zeroed, the launch
-        //  sequence advanced -- the next chunk salts its tags with the new value)
-        hipLaunchKernelGGL(k_combine_halves, dim3(a.T + 1), dim3(256), 0, s, pa.fx_half, a.fx_part, ha.nb, g.CH,
-                           a.pp.inv_bg, one_launch ? fx : nullptr, pa.xbuf, (long)ha.nb * 2 * 2 * L.npg, pa.ws, b0, B);
-        HIP_TRY(hipGetLastError());
-      }
-    } else {
+    {
       void (*fn)(UnrollPairArgs) = nullptr;
-      size_t dyn_lds = L.lds;
-      if constexpr (PRE != L2O_PRE_FC_ELU) {
-        if (pair2) {
-          fn = hist ? k_unroll_pair2<PRE, KIND, true> : k_unroll_pair2<PRE, KIND, false>;
-          dyn_lds = sizeof(float) * (size_t)LstmCoreLds<PRE>::kFragWords;
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-        }
-      }
-      if (!fn) switch (g.CH) {
+      const size_t dyn_lds = L.lds;
+      switch (g.CH) {
         case 2: fn = hist ? k_unroll_pair<PRE, KIND, 2, true> : (exact ? k_unroll_pair<PRE, KIND, 2, false, true> : k_unroll_pair<PRE, KIND, 2, false>); break;
         case 4: fn = hist ? k_unroll_pair<PRE, KIND, 4, true> : (exact ? k_unroll_pair<PRE, KIND, 4, false, true> : k_unroll_pair<PRE, KIND, 4, false>); break;
         default: fn = hist ? k_unroll_pair<PRE, KIND, 8, true> : (exact ? k_unroll_pair<PRE, KIND, 8, false, true> : k_unroll_pair<PRE, KIND, 8, false>); break;
@@ -1244,6 +1179,7 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
         HIP_TRY(hipGetLastError());
       }
     }
+    note_form(L2O_FORM_UNROLL_PAIR, (B + chunk - 1) / chunk);
     if (fx_done) *fx_done = fx != nullptr && one_launch;
     return L2O_OK;
   }
@@ -1259,6 +1195,7 @@ static int launch_unroll_ch(const UnrollArgs& a, const UnrollGeom& g, hipStream_
                               (int)g.lds));
   hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(64 * g.nw), g.lds, s, a);
   HIP_TRY(hipGetLastError());
+  note_form(L2O_FORM_UNROLL);
   return L2O_OK;
 }
 
@@ -1292,6 +1229,7 @@ static int launch_unroll_cu8(const UnrollArgs& a, hipStream_t s) {
                                          : (hist ? k_unroll_cu8<PRE, 2, KR, true> : k_unroll_cu8<PRE, 2, KR, false>);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(kCu8Threads), L.lds, s, a);
+  note_form(L2O_FORM_UNROLL_CU8);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
 }
@@ -1315,6 +1253,7 @@ static int launch_unroll_cu(const UnrollArgs& a_in, hipStream_t s) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)L.lds));
   hipLaunchKernelGGL(fn, dim3(a.pp.B_local), dim3(kCuThreads), L.lds, s, a);
+  note_form(L2O_FORM_UNROLL_CU);
   HIP_TRY(hipGetLastError());
   return L2O_OK;
 }
@@ -1323,6 +1262,11 @@ extern "C" {
 
 int l2o_abi_version(void) { return L2O_ABI_VERSION; }
 const char* l2o_last_error(void) { return g_err; }
+#ifndef L2O_BUILD_ID
+#define L2O_BUILD_ID "unknown"
+#endif
+const char* l2o_build_id(void) { return L2O_BUILD_ID; }
+int l2o_last_unroll_form(void) { return g_last_form; }
 
 size_t l2o_wpack_floats(const l2o_net_cfg* cfg) {
   if (!cfg) return 0;
@@ -2006,6 +1950,7 @@ static int mlp_unroll_launch(const l2o_net_cfg* cfg, const float* wpack, const l
   }
   hipLaunchKernelGGL(fn, grid, block, 0, s, a);
   HIP_TRY(hipGetLastError());
+  note_form(!L.fast ? L2O_FORM_MLP_UNROLL_GENERIC : (a.hier_R1 ? L2O_FORM_MLP_UNROLL_HIER : L2O_FORM_MLP_UNROLL));
   return L2O_OK;
 }
 
@@ -2315,12 +2260,12 @@ int l2o_unroll_status(const void* workspace_header_host) {
   const unsigned st = *static_cast<const unsigned*>(workspace_header_host);
   if (st == 0) return L2O_OK;
   if (st == 2)
-    return fail(L2O_ERR_HIP, "l2o_mlp_unroll: a workgroup's all-reduce inputs never arrived (status 2): the persistent "
+    return fail(L2O_ERR_TIMEOUT, "l2o_mlp_unroll: a workgroup's all-reduce inputs never arrived (status 2): the persistent "
                              "launch was not fully co-resident (a shared / masked device?); the iterate and LSTM state "
                              "of that launch are invalid.  Run l2o_coresident_workgroups once so that the library "
                              "sizes against what is really available, or switch the fused form off "
                              "(L2O_OPT_MLP_UNROLL = 0 / L2O_NO_MLP_UNROLL=1)");
-  return fail(L2O_ERR_HIP, "l2o_unroll: partner workgroup timed out (status %u): the two halves of a problem were not "
+  return fail(L2O_ERR_TIMEOUT, "l2o_unroll: partner workgroup timed out (status %u): the two halves of a problem were not "
                            "co-resident (a shared / masked device?); the iterate and LSTM state of that launch are "
                            "invalid.  Run l2o_coresident_workgroups once so that the library sizes against what is "
                            "really available, or use one CU per problem (L2O_OPT_PAIR = 0 / L2O_NO_PAIR=1)", st);
@@ -2348,21 +2293,9 @@ int l2o_unroll_reduce(const l2o_net_cfg* cfg, const float* wpack, const l2o_prob
                       void* workspace, const l2o_unroll_hist* hist, void* stream) {
   OptScope opt_scope(cfg_optw(cfg));
   if (!fx) return fail(L2O_ERR_ARG, "l2o_unroll_reduce: NULL fx");
-  if (flags & ~(L2O_UNROLL_ZERO_STATE | L2O_UNROLL_PREPARED))
+  if (flags & ~L2O_UNROLL_ZERO_STATE)
     return fail(L2O_ERR_ARG, "l2o_unroll_reduce: unknown flags %d", flags);
   return unroll_impl(cfg, wpack, prob, x, st, m, v, T, step0, fx_part, workspace, hist, fx, stream, x0, flags);
-}
-
-int l2o_unroll_prepare(const l2o_net_cfg* cfg, const l2o_problem* prob, void* workspace, void* stream) {
-  OptScope opt_scope(cfg_optw(cfg));
-  int rc = check_problem(prob);
-  if (rc) return rc;
-  UnrollGeom g;
-  if (!cfg || !l2o_unroll_supported(cfg, prob) || !unroll_geom(prob, &g) || g.CH < 2 || !opt(L2O_OPT_PAIR_NORMAL) ||
-      opt(L2O_OPT_EXACT_GATES))
-    return L2O_OK;   // nothing to prepare (only the normal-matrix two-CU form has a per-problem pass)
-  if (!workspace) return fail(L2O_ERR_ARG, "l2o_unroll_prepare: NULL workspace");
-  return launch_pair_prepare(prob, g, workspace, (hipStream_t)stream);
 }
 
 int32_t l2o_coresident_workgroups(void* scratch, void* stream) {
@@ -2430,7 +2363,7 @@ static int unroll_impl(const l2o_net_cfg* cfg, const float* wpack, const l2o_pro
   a.pp = make_prob_params(prob);
   a.x = x; a.st = st; a.m = m; a.v = v; a.fx_part = fx_part;
   a.x_in = x0; a.zero_state = (flags & L2O_UNROLL_ZERO_STATE) ? 1 : 0;
-  a.prepared = (flags & L2O_UNROLL_PREPARED) ? 1 : 0;
+  a.ticks = nullptr;
   a.T = T;
   a.hist_st = hist ? hist->st : nullptr;
   a.hist_g = hist ? hist->g : nullptr;

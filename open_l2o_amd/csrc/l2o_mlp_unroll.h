@@ -57,7 +57,12 @@ constexpr int kMuHierS = kMuHierM * kMuHierR1Max;
 struct MlpWs {                 // header of the caller-owned workspace (never cleared by the library)
   unsigned status;             // STICKY: 1 = a publisher never showed up
   unsigned seq;                // launch sequence number (tag salt), advanced by workgroup 0 at the end of a launch
-  unsigned pad[14];
+  unsigned fault;              // TEST HOOK (ABI v12; 0 in production): non-zero = no workgroup waits for anybody -- the status
+                               // is raised at once (the injected timeout; see PairWs in l2o_unroll_pair.h)
+  unsigned pad0;
+  long long ticks;             // ABI v12 (bytes 16..23): shader-clock cycles wave 0 of workgroup 0 spent in the step loop of
+                               // the last launch (see PairWs)
+  unsigned pad[10];
   long long phases[16];        // phase clock dump of the -DL2O_PROFILE_PHASES build (else unused)
 };
 
@@ -237,6 +242,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   const int sm_off = var == 1 ? 0 : (var == 2 ? H : H + H * O);        // slot of a small-parameter coordinate
   bool dead = false;
+  if (a.ws->fault != 0) {                              // (test hook: the injected timeout, see MlpWs)
+    dead = true;
+    if (tid == 0) atomicExch(status, 2u);
+  }
 
   // image columns + labels of evaluation `t` into the parity buffer (synchronous form: prologue)
   auto load_eval = [&](int t, int par) {
@@ -312,6 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   core.preload(acc1, acc2);                                 // accumulator inits of the first step (the biases)
   PhaseClock pc;
   pc.start();
+  const long long loop_t0 = __builtin_readcyclecounter();
   for (int t = 0;; ++t) {
     const int par = t & 1;
     const unsigned tag = salt | ((unsigned)t + 1u);
@@ -890,6 +900,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
   if (wg == L2O_PROFILE_WG && tid == 0) pc.dump(a.ws->phases);
 #endif
+  if (wg == 0 && tid == 0) a.ws->ticks = __builtin_readcyclecounter() - loop_t0;
 
   if (live && q == 0) {
     a.x[var][jl] = xv;

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
 
   const size_t hist_n = (size_t)pp.B_local * D;
   PhaseClock pc;
+  const long long loop_t0 = __builtin_readcyclecounter();
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     if (HIST && t < a.T)
@@ -203,6 +204,8 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
     // the next step's scaled iterate -> LDS now (this step's readers of xs all passed barrier B2)
     if (q == 0) xs[j] = live ? xv * sc : 0.0f;
   }
+  // (the step loop of problem 0 in shader-clock cycles -> the workspace header, see PairWs::ticks; NULL without a workspace)
+  if (a.ticks && blockIdx.x == 0 && threadIdx.x == 0) *a.ticks = __builtin_readcyclecounter() - loop_t0;
 
   if (live && q == 0) {
     a.x[idx] = xv;

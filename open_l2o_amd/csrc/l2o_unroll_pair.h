@@ -31,9 +31,17 @@ struct PairWs {               // header of the caller-owned workspace (never cle
   unsigned status;            // 0 ok, 1 = partner timeout.  STICKY: raised by the kernel, cleared by the caller
   unsigned seq;               // launch sequence number: read by every workgroup of a launch (tag salt), advanced
                               // by k_combine_halves after it -- the library keeps no host-side launch state
-  unsigned pad[14];
+  unsigned fault;             // TEST HOOK (ABI v12; 0 in production): non-zero = every workgroup behaves as if its partner
+                              // never showed up -- raises `status` at once and stops polling.  Lets a test force the
+                              // timeout path (and the host's recovery from it) deterministically; the caller clears it.
+  unsigned pad0;
+  long long ticks;            // ABI v12 (bytes 16..23): shader-clock cycles (s_memtime) wave 0 of workgroup 0 spent in the step
+                              // loop of the LAST launch on this workspace -- T steps + the final loss evaluation.  What
+                              // bench.py's roofline block divides its work model by: measured cycles, no clock assumption
+  unsigned pad[10];
   long long phases[16];       // phase clock dump of the -DL2O_PROFILE_PHASES build (else unused)
 };
+static_assert(sizeof(PairWs) == 64 + 128, "workspace header layout (include/l2o_abi.h)");
 
 struct UnrollPairArgs {
   UnrollArgs u;
@@ -102,7 +110,7 @@ __device__ __forceinline__ void dot4v(const float4 a, const l2o::f32x4 b, float4
 // quads (W packed once in the prologue, x / r straight from ds_read_b128), so the halves are sub-registers, no copies.
 // hsum4pk adds in hsum4's order: bit-identical to dot4v + hsum4.  (L2O_GEMV_PK=0 restores the scalar FMAs.)
 // Measured (profiles/r04aa_*): config 2, ONE wave per SIMD -- the wave is issue-bound and 32 fewer instructions per step are
-// worth 4 % (8.78 -> 9.15 G); with TWO waves per SIMD (k_unroll_pair2, k_unroll_lds) the VALU pipe is the limit, a packed FMA
+// worth 4 % (8.78 -> 9.15 G); with TWO waves per SIMD (k_unroll_lds) the VALU pipe is the limit, a packed FMA
 // occupies it twice as long, and the packed form is 1.5-3 % SLOWER: those keep the scalar FMAs.
 #ifndef L2O_GEMV_PK
 #define L2O_GEMV_PK 1
@@ -127,10 +135,9 @@ __device__ __forceinline__ void dot4q(const l2o::f32x4 a, const l2o::f32x4 b, fl
 #ifndef L2O_PAIR_LDS_BARRIERS
 #define L2O_PAIR_LDS_BARRIERS 0
 #endif
-// LDSF (round 4, k_unroll_pair2): the packed bf16x3 fragments live in LDS (60 KB, LstmCoreLds) instead of 240 AGPRs, the
-// wave fits 256 registers and TWO workgroups -- halves of two DIFFERENT problems -- share a CU: two waves per SIMD that
-// synchronise independently, so one computes while the other waits for its partner CU / a barrier / LDS.
-template <int PRE, int KIND, int CH, bool HIST, bool EXACT, bool LDSF>
+// (round 4 also ran this body with the fragments in LDS and two workgroups per CU -- k_unroll_pair2; it measured like
+//  k_unroll_lds and was removed in round 5)
+template <int PRE, int KIND, int CH, bool HIST, bool EXACT>
 __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
   constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
   constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
@@ -189,7 +196,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
       wt[m] = make_float4(e[0], e[1], e[2], e[3]);
     }
   }
-  constexpr bool kPk = L2O_GEMV_PK && !LDSF;                // packed GEMV FMAs: one wave per SIMD only (see dot4pk)
+  constexpr bool kPk = L2O_GEMV_PK != 0;                    // packed GEMV FMAs: one wave per SIMD (see dot4pk)
   l2o::f32x4 wrq[2][NWH], wtq[CH];                          // (the same values as register quads for the packed FMAs)
 #pragma unroll
   for (int m = 0; m < NWH; ++m) { wrq[0][m] = as_quad(wr[0][m]); wrq[1][m] = as_quad(wr[1][m]); }
@@ -201,16 +208,10 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
   const bool row_counted = gq < 2 && (half == 0 ? (myrow < NC) : (myrow >= NC));   // every row once per pair
 
   // ---- per-lane persistent registers -------------------------------------
-  // <= 4 waves per workgroup: bf16x3 gate GEMM, weights in VGPR + AGPR (LDSF: fragments in LDS)
-  using Core = typename std::conditional<LDSF, LstmCoreLds<PRE>, LstmCore<PRE, !EXACT>>::type;
+  // <= 4 waves per workgroup: bf16x3 gate GEMM, weights in VGPR + AGPR
+  using Core = LstmCore<PRE, !EXACT>;
   Core core;
   core.load(a.np.wpack, lane);
-  if constexpr (LDSF) {
-    // [Core::kFragWords]; 16-byte aligned (the static arrays in front of it end on a 4-byte word: misaligned ds_read_b128
-    // run at a quarter of the speed); the handshake's __syncthreads() orders the staging
-    extern __shared__ __attribute__((aligned(16))) float pair_frags[];
-    core.stage_frags(pair_frags, a.np.wpack, tid, blockDim.x, lane);
-  }
   core.pin();   // fragments -> AGPRs (MFMA reads them there): the VGPRs hold W, the state and the gate math
   __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];   // the gate biases = accumulator inits
   core.stage_bias(bias_s, a.np.wpack, tid, blockDim.x, q);   // (the handshake's __syncthreads() below orders it)
@@ -243,6 +244,10 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
   unsigned long long* mine = pa.xbuf + ((size_t)bl * 2 + half) * 2 * SQ;
   const unsigned long long* theirs = pa.xbuf + ((size_t)bl * 2 + (half ^ 1)) * 2 * SQ;
   bool dead = false;                                             // partner timed out
+  if (pa.ws->fault != 0) {                                       // (test hook: the injected timeout, see PairWs)
+    dead = true;
+    if (tid == 0) atomicExch(&pa.ws->status, 1u);
+  }
   // ---- handshake: do the two halves of this problem run on the same XCD?  HIP promises nothing about
   // placement (observed: block b on XCD b % 8, hence the b / b + 8 pairing above), so the halves tell each
   // other their XCC_ID once, through the coherent (agent-scope) path, in a granule slot that the step loop
@@ -262,7 +267,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     for (;;) {
       g = __hip_atomic_load(theirs + SQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((unsigned)(g >> 32) == kHsTag) break;
-      if (++spins > (1 << 20)) { ok = false; break; }       // (the step loop reports a missing partner)
+      if (dead || ++spins > (1 << 20)) { ok = false; break; }       // (the step loop reports a missing partner)
       __builtin_amdgcn_s_sleep(1);
     }
     same_xcd_s = ok && pa.plain_stores && ((unsigned)g & 0xfu) == my_xcc;
@@ -295,6 +300,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
   constexpr bool kR4 = false;
 #endif
   const size_t hist_n = (size_t)pp.B_local * D;
+  const long long loop_t0 = __builtin_readcyclecounter();
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     const unsigned tag = salt | ((unsigned)t + 1u);     // (T + 1 < 65 535 when salt != 0; the handshake tag ends in 0xffff)
@@ -504,6 +510,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
 #ifdef L2O_PROFILE_PHASES
   if (blockIdx.x == 0 && tid == 0) pc.dump(pa.ws->phases);
 #endif
+  if (bid == 0 && tid == 0) pa.ws->ticks = __builtin_readcyclecounter() - loop_t0;
 
   if (live && q == 0) {
     a.x[idx] = xv;
@@ -514,12 +521,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
 
 template <int PRE, int KIND, int CH, bool HIST, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
-  unroll_pair_body<PRE, KIND, CH, HIST, EXACT, false>(pa);
-}
-// two workgroups per CU (<= 256 registers per lane, 60 KB of dynamic LDS each): DM nets, 5..8 tiles (CH = 8)
-template <int PRE, int KIND, bool HIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_unroll_pair2(UnrollPairArgs pa) {
-  unroll_pair_body<PRE, KIND, 8, HIST, false, true>(pa);
+  unroll_pair_body<PRE, KIND, CH, HIST, EXACT>(pa);
 }
 
 // The epilogue of a two-CU unroll, one workgroup (64 threads) per step t; runs after every workgroup of the unroll

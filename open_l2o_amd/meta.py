@@ -37,7 +37,7 @@ from ._engine import ProblemDesc
 from ._graph_adam import AdamMixin
 from ._graph_bptt import BpttMixin
 from ._graph_core import (Fetch, Placeholder, Variable, PackedState, _make_nets, _DEFAULT_CONFIG, _DevGrad, _LazyHost,  # noqa: F401
-                          _term_vars, _world, synced_scale, local_slice, _Slot, set_random_seed, rng, _RngBox)
+                          _term_vars, _world, _all_reduce, synced_scale, local_slice, _Slot, set_random_seed, rng, _RngBox)
 from ._graph_steps import StepPlanMixin
 
 MetaLoss = collections.namedtuple("MetaLoss", "loss, update, reset, fx, x")     # DM/meta.py:158
@@ -188,17 +188,82 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         fx, xs = self.launch(feed, commit)
         eng = self.engine
         T = self.len_unroll
+        fx_host, fx, xs = self._sync_or_recover(fx, xs, feed, commit)
+        x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
+        # (host NumPy on the T + 1 losses already copied back: loss = tf.reduce_sum(fx_array), DM/meta.py:376)
+        return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
+                "x": x_out, "fx_array": fx_host}
+
+    # -- recovery from a partner timeout (round 5) -----------------------------------------
+    # The two-CU unroll and the persistent MLP unroll exchange data between workgroups with bounded spins; a timeout (a
+    # transient loss of co-residency: another process's kernels holding CUs) invalidates that launch's x_T / state, not its
+    # inputs.  An EVALUATION unroll is re-run from what it started from on the exchange-free kernels of the same shapes
+    # (k_unroll_lds / k_unroll: L2O_OPT_PAIR = 0; the step-granular MLP path: L2O_OPT_MLP_UNROLL = 0) and logged.  What it
+    # started from is either the caller's x0 + the zero state (`restart=`: nothing to keep) or the live buffers, which an
+    # in-place launch of an exchanging kernel snapshots first (one multi-tensor copy).  L2O_NO_RECOVERY=1: raise instead.
+    def _snapshot(self, slots):
+        """Copy x, packed LSTM states and moments aside ahead of an IN-PLACE launch that may time out."""
+        live = [v.value for v in self.x]
+        for s in slots:
+            if isinstance(s.state, PackedState) and s.state.packed is not None:
+                live.append(s.state.packed)
+            if s.m is not None:
+                live += [s.m, s.v]
+        snap = self.__dict__.get("_snap")
+        if snap is None or len(snap["bak"]) != len(live) or any(b.shape != t.shape for b, t in zip(snap["bak"], live)):
+            snap = self._snap = {"bak": [torch.empty_like(t) for t in live]}
+        if hasattr(torch, "_foreach_copy_") and len(live) > 1:
+            torch._foreach_copy_(snap["bak"], live)
+        else:
+            for b, t in zip(snap["bak"], live):
+                b.copy_(t)
+        snap["live"] = live
+        self._last_launch["snapshot"] = True
+
+    def _wants_snapshot(self, restart_fused):
+        """An in-place committed launch of a kernel that can time out: unknown before the first launch of a shape (then:
+        yes), afterwards what the library reported for it (l2o_last_unroll_form)."""
+        if restart_fused or os.environ.get("L2O_NO_RECOVERY") or not hasattr(self.engine, "last_unroll_exchanges"):
+            return False
+        return self.__dict__.get("_exchanges", True)
+
+    def _sync_or_recover(self, fx, xs, feed, commit):
+        """The host sync of an evaluation unroll + the status check; on a partner timeout the unroll is re-run on the
+        exchange-free kernels.  Returns (fx on the host, fx, xs)."""
+        eng = self.engine
         self.wait_fx()
         fused = self.last_path in ("fused", "mlp_unroll") and hasattr(eng, "check_unroll_status")
         if fused and hasattr(eng, "prefetch_unroll_status"):
             eng.prefetch_unroll_status()                 # (rides on the sync below)
         fx_host = eng.to_numpy(fx)                       # host sync
-        if fused:
+        if not fused:
+            return fx_host, fx, xs
+        if hasattr(eng, "last_unroll_exchanges"):
+            self._exchanges = bool(eng.last_unroll_exchanges())
+        try:
             self._check_unroll_status()
-        x_out = _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])   # copied to the host only if fetched
-        # (host NumPy on the T + 1 losses already copied back: loss = tf.reduce_sum(fx_array), DM/meta.py:376)
-        return {"loss": np.float32(fx_host.sum(dtype=np.float32)), "fx": np.float32(fx_host[T]),
-                "x": x_out, "fx_array": fx_host}
+        except _abi.L2OPartnerTimeout as err:
+            info = self.__dict__.get("_last_launch", {})
+            if os.environ.get("L2O_NO_RECOVERY") or not (info.get("restart") is not None or info.get("snapshot")
+                                                         or not info.get("commit", True)):
+                raise
+            import warnings
+            warnings.warn("open_l2o_amd: %s -- re-running this unroll on the exchange-free kernels" % (err,), RuntimeWarning)
+            self.recoveries = self.__dict__.get("recoveries", 0) + 1
+            if info.get("restart") is None and info.get("snapshot"):    # the in-place launch: its inputs come back
+                snap = self._snap
+                for t, b in zip(snap["live"], snap["bak"]):
+                    t.copy_(b)
+            self._reuse_minibatches = True               # (the MLP optimizee: the SAME minibatches, not a fresh draw)
+            try:
+                with _abi.option_scope({_abi.OPT_PAIR: 0, _abi.OPT_MLP_UNROLL: 0}):
+                    fx, xs = self.launch(feed, commit, restart=info.get("restart"), _recovering=True)
+                    self.wait_fx()
+                    fx_host = eng.to_numpy(fx)
+                    self._check_unroll_status()          # (an exchange-free kernel raises nothing)
+            finally:
+                self._reuse_minibatches = False
+        return fx_host, fx, xs
 
     def deterministic(self):
         """True when an unroll draws nothing at random (no minibatch sampling): then n committed unrolls
@@ -219,14 +284,11 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         L = self.len_unroll
         self.len_unroll = n * L
         try:
-            fx, _ = self.launch({self.step: 1} if self.rnnprop else {}, commit=True)
+            feed = {self.step: 1} if self.rnnprop else {}
+            fx, xs = self.launch(feed, commit=True)
+            fx_host, _, _ = self._sync_or_recover(fx, xs, feed, True)
         finally:
             self.len_unroll = L
-        eng = self.engine
-        self.wait_fx()
-        fx_host = eng.to_numpy(fx)
-        if self.last_path == "fused" and hasattr(eng, "check_unroll_status"):
-            self._check_unroll_status()
         return [np.float32(fx_host[(k + 1) * L]) for k in range(n)]
 
     def many_ok(self):
@@ -241,7 +303,7 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         states = [s.state for s in self.slots]
         return self._plan_ok(self.slots, states, len(self.x))
 
-    def launch(self, feed=None, commit=True, events=None, use_graph=False, record=None, restart=None):
+    def launch(self, feed=None, commit=True, events=None, use_graph=False, record=None, restart=None, _recovering=False):
         """Enqueue one unroll on the current stream WITHOUT synchronising the host; returns
         (device tensor fx[0..T] -- already all-reduced when sharded --, list of device x_T).
         ``events`` = (start, end) torch.cuda.Event pair recorded around the unroll kernels.
@@ -252,6 +314,9 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         eng = self.engine
         T = self.len_unroll
         feed = feed or {}
+        if not _recovering:
+            self._last_launch = {"restart": restart if (restart is not None and commit and record is None) else None,
+                                 "snapshot": False, "commit": bool(commit)}
         # ---- fast path: the SAME fused launch as before (same buffers / problem tensors / options) replays a
         # prepared call -- one ctypes call instead of ~0.2 ms of argument building, which is a whole config-2 unroll.
         # Both the committed launch of Session.run([fx, update]) (the product path: evaluate_*.py, util.run_eval_epoch)
@@ -269,6 +334,8 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
             fast_key = (T, restart is not None, _abi.options_word()) + tuple(id(o) for o in fast_objs)
             ent = self.__dict__.setdefault("_fast_unrolls", {}).get(fast_key)
             if ent is not None:
+                if commit and restart is None and not _recovering and self._wants_snapshot(False):
+                    self._snapshot(self.slots)
                 ring = self._fx_cache[T]
                 i = ring["i"]
                 ring["i"] = (i + 1) % len(ring["bufs"])
@@ -279,8 +346,7 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
                 if ent["call"](fx, int(feed[self.step]) if self.rnnprop else 1):
                     self.last_path = "fused"
                     if self.sharded:
-                        import torch.distributed as dist
-                        ring["work"][i] = dist.all_reduce(fx, async_op=True)
+                        ring["work"][i] = _all_reduce(fx, async_op=True)
                     return fx, [self.x[0].value]
                 self._fast_unrolls.pop(fast_key, None)      # stale (the engine's workspace / layout changed): general path
         # restart = list of device tensors x0: run this unroll from x0 and the zero LSTM state / moments on the SAME
@@ -420,6 +486,8 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
             s, d = slots[0], descs[0]
             fx_part = self._scratch("fx_part", (T + 1) * d.B_local)
             x0v = restart[0].view(panels[0].shape) if restart_fused else None
+            if commit and not _recovering and self._wants_snapshot(restart_fused):
+                self._snapshot(slots)
             eng.unroll(s.net.spec, s.net.wpack(eng), d, panels[0], states[0].packed, ms[0], vs[0], T, step0,
                        fx_part, fx=fx, x0=x0v, zero_state=restart_fused)   # (the batch-mean reduction rides in the epilogue)
             if fast_key is not None and (restart is None or restart_fused) and d.x_scale is None:
@@ -436,6 +504,8 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
             # the neural optimizee, all four variables stepped by one LSTM net: T steps in ONE persistent launch
             self.last_path = "mlp_unroll"
             self._draw_minibatches(T)
+            if commit and not _recovering and self._wants_snapshot(False):
+                self._snapshot(slots)
             term = self.terms[0]
             index_of = {v.decl.name: j for j, v in enumerate(self.x)}
             js = [index_of[tv.name] for tv in _term_vars(term)]
@@ -472,8 +542,7 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
                 events[1].record()
 
         if self.sharded:
-            import torch.distributed as dist
-            ring["work"][i] = dist.all_reduce(fx, async_op=True)
+            ring["work"][i] = _all_reduce(fx, async_op=True)
         if commit:
             for s, st in zip(slots, states):
                 s.state = st
@@ -508,6 +577,13 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         # device-side update is GUARDED by that unroll's status word (l2o_adam_step_guarded) and does not run; the host
         # learns of it at the sync below, takes the Adam step count back and raises.
         early = all(self._device_adam(self.nets[k]) for k in grads)
+        if fused and self.sharded and hasattr(eng, "unroll_status_tensor"):
+            # every rank must take the SAME decision about this meta-step: the status words of the ranks'
+            # unrolls are MAX-reduced in place, on the device, ahead of the guarded update -- one rank's partner timeout
+            # skips the update (and raises at the next host check) on all of them
+            stw = eng.unroll_status_tensor()
+            if stw is not None:
+                _all_reduce(stw, op="MAX")
         if early:
             self._adam_apply(grads, learning_rate, guarded=fused)
         pend = self.__dict__.setdefault("_guarded_pending", 0)
@@ -534,9 +610,10 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         """engine.check_unroll_status() after a host sync; when it raises, guarded meta-steps enqueued since the last
         check did not run on the device (l2o_adam_step_guarded): the Adam step counts of ALL of them are taken back (those
         enqueued before the failing unroll did run -- the count errs on the low side).  The exception is FATAL for the
-        optimizer state: Adam's step count no longer matches m / v, and in a sharded run only the failing rank
-        skipped its update -- a caller that wants to continue must `restore` the last checkpoint (the training drivers do
-        not catch it)."""
+        optimizer state of a TRAINING step: Adam's step count no longer matches m / v -- a caller that wants
+        to continue must `restore` the last checkpoint (the training drivers do not catch it); in a sharded run the status
+        word was MAX-reduced over the ranks ahead of the guarded update (train_step), so every rank skipped it and every
+        rank raises here.  Evaluation unrolls recover instead (_sync_or_recover)."""
         try:
             self.engine.check_unroll_status()
         except Exception:

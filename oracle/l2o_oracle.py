@@ -20,7 +20,7 @@ __all__ = [
     "NetConfig", "init_net_params", "net_initial_state", "net_apply",
     "Simple", "SimpleMulti", "Quadratic", "Lasso", "Rastrigin", "SquareCos",
     "unroll", "UnrollResult", "sgd_net", "adam_net", "truncated_normal", "MnistMLP", "unroll_multi", "rnnprop_inputs",
-    "net_bwd_step", "tf_adam_step",
+    "net_bwd_step", "preprocess_bwd", "tf_adam_step",
     "DM_IDENTITY", "DM_LOGSIGN", "RNNPROP",
 ]
 
@@ -577,7 +577,7 @@ def net_bwd_step(cfg, params, inputs, state_prev, dx_next, carry_in):
         dd = dx_next.reshape(-1, 1) * dt(cfg.scale)
         if cfg.tanh_output:
             dd = dd * (dt(1) - np.tanh(d) ** 2)
-        rows.update(act1=a, dd=dd[:, 0])
+        rows.update(act1=a, dd=dd[:, 0], da=dd @ lin["w"].T)
         return None, rows
     (h1p, c1p), (h2p, c2p) = state_prev
     H = h1p.shape[1]
@@ -614,7 +614,26 @@ def net_bwd_step(cfg, params, inputs, state_prev, dx_next, carry_in):
                 dd=dd[:, 0])
     if cfg.kind == "rnnprop":
         rows["du"] = da * np.where(pre > 0, dt(1), np.exp(np.minimum(pre, dt(0))))
+    rows["da"] = da            # adjoint of the network's (preprocessed) input: second_derivatives (preprocess_bwd)
     return (dh1_out, dc1_out, dh2_out, dc2_out), rows
+
+
+def preprocess_bwd(cfg, g, da):
+    """dL/dg [N] of a DM net from the adjoint ``da`` [N, P] of its preprocessed input (what flows back into the optimizee
+    gradient when MetaOptimizer.meta_loss(second_derivatives=True) drops the stop_gradient, DM/meta.py:328-329):
+    identity: da itself; LogAndSign (DM/preprocess.py:63-70): the log column has slope sign(g) / (k (|g| + eps)) where
+    it is not clamped at -1, the sign column slope e^k where |g e^k| < 1."""
+    g = g.reshape(-1)
+    dt = g.dtype.type
+    if cfg.preprocess_name != "LogAndSign":
+        return da[:, 0]
+    k = dt(cfg.preprocess_options["k"])
+    eps = dt(np.finfo(np.float32).eps)
+    mag = np.abs(g) + eps
+    d_log = np.where(np.log(mag) / k > dt(-1), np.sign(g) / (k * mag), dt(0))
+    ek = dt(np.exp(k))
+    d_sign = np.where(np.abs(g * ek) < dt(1), ek, dt(0))
+    return da[:, 0] * d_log + da[:, 1] * d_sign
 
 
 def tf_adam_step(var, g, m, v, t, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -5,7 +5,7 @@
 #
 # A "library variant" is every build/var/lib_*.so (scripts/build_variants.sh name:-DFLAG ...; lib_a_base.so = the in-tree
 # build); options are the binding's environment switches (open_l2o_amd/_abi.py).  NAMEs and what they were used for:
-#   large_shard_forms   L2O_ONE_LDS = 0 chunked two-CU | 2 k_unroll_lds | 3 k_unroll_pair2, config 4 and config-2 shape x 256..1024
+#   large_shard_forms   L2O_ONE_LDS = 0 chunked two-CU | 2 k_unroll_lds, config 4 and config-2 shape x 256..1024
 #   rnnprop_large       RNNProp on large shards: chunked two-CU form vs k_unroll_lds
 #   lds_variants        build variants of k_unroll_lds (unpinned re-arm, MFMA order, s_setprio): config-2 shape x 256, config 4
 #   ablate_lds          timing-only ablations of k_unroll_lds (-DL2O_LDS_ABL_NOBAR / _NOFRAG / _NOGEMV / _ANYNW builds)
@@ -20,7 +20,7 @@ cd "$(dirname "$0")/.."
 # run LABEL <bench.py arguments>: one bench line -> one summary line (options in effect are part of the label)
 run() {
   local lbl=$1; shift
-  python bench.py --warmup 3 --no-cpu-baseline "$@" 2>>$O/err.txt | LBL="$lbl" ARGS="$*" python -c "
+  python bench.py --warmup 3 --no-cpu-baseline --no-also "$@" 2>>$O/err.txt | LBL="$lbl" ARGS="$*" python -c "
 import json,os,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']; T=d['config'].get('T',100) if isinstance(d.get('config'),dict) else 100
 print('%-34s %-44s kernel_ms=%.4f  value=%.4g G  fx_T=%r  [%s]' % (os.environ['LBL'], os.environ['ARGS'], r['kernel_ms_avg'], d['value']/1e9, d['final_loss_fx_T'], r['kernel'][:36]))" | tee -a $O/$NAME.txt
@@ -29,11 +29,11 @@ libs() { ls build/var/lib_*.so 2>/dev/null; }
 case $NAME in
   large_shard_forms)
     for rep in 1 2; do
-      for f in 0 2 3; do export L2O_ONE_LDS=$f
+      for f in 0 2; do export L2O_ONE_LDS=$f
         run "ONE_LDS=$f" --config 4 --steps 6; run "ONE_LDS=$f" --batch 256 --steps 10
         run "ONE_LDS=$f" --batch 512 --steps 6 --unrolls-per-step 8; run "ONE_LDS=$f" --batch 1024 --steps 4 --unrolls-per-step 4
       done
-      L2O_ONE_LDS=3 run "ONE_LDS=3" --batch 128 --steps 10; L2O_ONE_LDS=0 run "ONE_LDS=0" --batch 128 --steps 10
+      L2O_ONE_LDS=0 run "ONE_LDS=0" --batch 128 --steps 10
     done ;;
   rnnprop_large)
     for rep in 1 2; do for f in 0 1; do export L2O_ONE_LDS=$f
@@ -54,7 +54,6 @@ case $NAME in
   pk)
     for rep in 1 2; do for v in $(libs); do export L2O_HIP_LIB=$PWD/$v; l=$(basename $v .so); unset L2O_ONE_LDS
       run "$l" --steps 20; run "$l" --config 4 --steps 6; run "$l" --batch 256 --steps 10
-      L2O_ONE_LDS=3 run "$l ONE_LDS=3" --config 4 --steps 6; L2O_ONE_LDS=3 run "$l ONE_LDS=3" --batch 256 --steps 10
     done; done ;;
   cu_forms)
     for rep in 1 2; do for f in 2 3 4; do L2O_UNROLL_CU=$f run "UNROLL_CU=$f" --config 3 --steps 4; done; done

@@ -16,6 +16,6 @@ if [ "$1" = build ]; then
 else
   for v in $VARS; do
     echo -n "$v: "
-    L2O_HIP_LIB=$PWD/build/ablate/lib_$v.so python bench.py --steps 10 --warmup 2 --no-cpu-baseline "${@:2}" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('kernel_ms_avg=%.4f min=%.4f' % (d['roofline']['kernel_ms_avg'], d['roofline']['kernel_ms_min']))"
+    L2O_HIP_LIB=$PWD/build/ablate/lib_$v.so python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also "${@:2}" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('kernel_ms_avg=%.4f min=%.4f' % (d['roofline']['kernel_ms_avg'], d['roofline']['kernel_ms_min']))"
   done
 fi

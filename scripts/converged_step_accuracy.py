@@ -62,7 +62,7 @@ def main():
             rows = {}
             d32, s32 = O.net_apply(cfg, params, pr32.grad(x32), st32)
             rows["numpy fp32 oracle"] = ([s32[0][0], s32[0][1], s32[1][0], s32[1][1]], d32)
-            forms = (("two-CU normal (bf16x3)", {_abi.OPT_PAIR_NORMAL: 1}), ("two-CU two-pass (bf16x3)", {_abi.OPT_PAIR_NORMAL: 0}),
+            forms = (("two-CU two-pass (bf16x3)", {}),
                      ("one-CU k_unroll (fp32 MFMA)", {_abi.OPT_PAIR: 0}))
             for label, opts in forms:
                 import contextlib

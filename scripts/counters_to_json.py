@@ -15,6 +15,9 @@ import json
 import os
 import sqlite3
 import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main(out, kernel, workload, dbs):
@@ -47,7 +50,15 @@ def main(out, kernel, workload, dbs):
             except Exception as e:
                 print("no kernels view in %s: %s" % (db, e))
             meta["dbs"].append(os.path.relpath(db))
+    # which build these counters belong to (bench.py matches it against the library it times) and when they were taken
+    try:
+        from open_l2o_amd import _abi
+        build_id = _abi.build_id()
+    except Exception as e:
+        print("no build id: %s" % e)
+        build_id = None
     res = {"workload": json.loads(workload), "kernel": meta.get("kernel", kernel), "per_launch": per,
+           "build_id": build_id, "collected_unix": time.time(),
            "kernel_ns_profiled": dur, "launch": {k: meta.get(k) for k in ("vgpr", "agpr", "sgpr", "workgroup_x", "grid_x")},
            "dispatches": meta.get("dispatches", {}), "instances_per_dispatch": meta.get("instances", {}),
            "source": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py ... (one pass per counter group; "

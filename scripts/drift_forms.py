@@ -40,10 +40,10 @@ for D, Bt, Bg in ((128, 16, 128), (64, 16, 128), (128, 16, 128)):
         print("%-34s drift vs float64 %.3g | first 101 %.3g | reported fx[T] vs float64 f(own x_T): %.3g" %
               (label, rel_err(fx, r64.fx), rel_err(fx[:101], r64.fx[:101]), abs(fx[-1] - f_at_x) / f_at_x), flush=True)
 
-    for label, opts in (("two-CU two-pass", {_abi.OPT_PAIR_NORMAL: 0}), ("two-CU normal", {_abi.OPT_PAIR_NORMAL: 1}),
-                        ("two-CU two-pass, agent stores", {_abi.OPT_PAIR_NORMAL: 0, _abi.OPT_PAIR_PLAIN_STORES: 0}),
+    for label, opts in (("two-CU two-pass", {}),
+                        ("two-CU two-pass, agent stores", {_abi.OPT_PAIR_PLAIN_STORES: 0}),
                         ("one-CU k_unroll (%s core)" % ("fp32" if D > 64 else "bf16x3"), {_abi.OPT_PAIR: 0}),
-                        ("two-CU two-pass, EXACT gates (fp32 MFMA)", {_abi.OPT_PAIR_NORMAL: 0, _abi.OPT_EXACT_GATES: 1}),
+                        ("two-CU two-pass, EXACT gates (fp32 MFMA)", {_abi.OPT_EXACT_GATES: 1}),
                         ("one-CU k_unroll, EXACT gates", {_abi.OPT_PAIR: 0, _abi.OPT_EXACT_GATES: 1})):
         with contextlib.ExitStack() as es:
             for o, v in opts.items():

@@ -8,10 +8,10 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_${TAG}_$name -o p -- python $R/bench.py --no-cpu-baseline "${BENCH_ARGS[@]}" > $O/pmc_${TAG}_$name.json 2> $O/pmc_${TAG}_$name.err || echo "pass $name failed (see $O/pmc_${TAG}_$name.err)"
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_${TAG}_$name -o p -- python $R/bench.py --no-cpu-baseline --no-also "${BENCH_ARGS[@]}" > $O/pmc_${TAG}_$name.json 2> $O/pmc_${TAG}_$name.err || echo "pass $name failed (see $O/pmc_${TAG}_$name.err)"
 }
 BENCH_ARGS=("$@")
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$TAG -o t -- python $R/bench.py --no-cpu-baseline "${BENCH_ARGS[@]}" > $O/trace_$TAG.json 2> $O/trace_$TAG.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$TAG -o t -- python $R/bench.py --no-cpu-baseline --no-also "${BENCH_ARGS[@]}" > $O/trace_$TAG.json 2> $O/trace_$TAG.err
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sq2 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM
 run sq3 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA

@@ -41,7 +41,7 @@ workload_json() { # the `workload` key scripts/counters_to_json.py stores and be
     5) echo '["mnist", "rnnprop", 15910, 64, 200]' ;;
   esac
 }
-kernel_of() { case $1 in 2) echo 'k_unroll_pair<' ;; 4) echo 'k_unroll_lds<' ;; 3) echo 'k_unroll_cu' ;; 5) echo 'k_mlp_unroll<' ;; esac; }
+kernel_of() { case $1 in 2) echo 'k_unroll_pair<' ;; 4) echo 'k_unroll_lds<' ;; 3) echo 'k_unroll_cu' ;; 5) echo 'k_mlp_unroll' ;; esac; }
 train_cmd() { # NAME SECONDS -> command line (the ones recorded in tests/golden/trained/README.md)
   local S=$2
   case $1 in
@@ -71,7 +71,7 @@ for job in "$@"; do
       timeout 600 python bench.py $(bench_args $a1) $extra $(words "$a2") 2>>$O/bench.err | tee $out | cut -c1-300 ;;
     trace)
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_c$a1 -o t -- \
-         python $R/bench.py $(bench_args $a1) --no-cpu-baseline $(words "$a2") > $O/trace_c$a1.json 2> $O/trace_c$a1.err)
+         python $R/bench.py $(bench_args $a1) --no-cpu-baseline --no-also $(words "$a2") > $O/trace_c$a1.json 2> $O/trace_c$a1.err)
       db=$(ls $O/trace_c$a1/*.db $O/trace_c$a1/*/*.db 2>/dev/null | head -1)
       [ -n "$db" ] && python scripts/rocprof_summary.py $db $O/kernel_trace_c$a1.txt | head -8
       rm -rf $O/trace_c$a1 ;;

@@ -29,15 +29,12 @@ for it in range(3):
 ws = eng._last_ws
 # workspace header: 64 B status block, then long long phases[16]
 raw = ws[64:64 + 12 * 8].cpu().numpy().view(np.int64)
-names = ["x(t) -> LDS + publish", "chunk L1H + partner poll -> LDS", "barrier B1", "own-half GEMV under chunk L2B",
-         "barrier B2", "partner-half GEMV + g + preprocess + input FMAs + L1 MFMA drain", "layer-1 gates",
-         "split h1 + chunk L2A + loss (shadow)", "layer-2 gates", "split h2 + linear + x update", "L2 MFMA drain", "-"]
-if not _abi.get_option(_abi.OPT_PAIR_NORMAL):
+if True:
     names = ["xs -> LDS", "MFMA (L2B + L1H) + partner poll + r", "barrier B1", "partial r + publish", "wave_sum + barrier B2",
              "g pass + preprocess + input FMAs + L1 MFMA drain", "layer-1 gates", "split h1 + issue MFMA (L2A)",
              "layer-2 gates", "split h2 + linear + x update", "L2 MFMA drain", "-"]
 tot = raw.sum()
-print("k_unroll_pair%s phase clock (s_memtime ticks, wave 0 of workgroup 0, %d steps)" % ("h" if _abi.get_option(_abi.OPT_PAIR_NORMAL) else "", T))
+print("k_unroll_pair phase clock (s_memtime ticks, wave 0 of workgroup 0, %d steps)" % T)
 for n, v in zip(names, raw):
     if n != "-":
         print("  %-40s %10d  %5.1f%%  (%.0f per step)" % (n, v, 100.0 * v / tot, v / T))

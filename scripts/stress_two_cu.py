@@ -27,7 +27,7 @@ for case in range(int(os.environ.get("N", "60"))):
     pd = device_problem(eng, arrays, B, D)
     outs = []
     import contextlib
-    for opts in ({_abi.OPT_PAIR_NORMAL: 0}, {_abi.OPT_PAIR_NORMAL: 1}, {_abi.OPT_EXACT_GATES: 1}):
+    for opts in ({}, {_abi.OPT_EXACT_GATES: 1}):
         with contextlib.ExitStack() as es:
             for o_, v_ in opts.items():
                 es.enter_context(lib_option(o_, v_))

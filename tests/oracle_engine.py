@@ -48,6 +48,27 @@ class OracleEngine(object):
         self.device = torch.device("cpu")
         self.lib = _abi.lib()
         self.calls = []
+        # the product engine's status-word protocol, emulated: `fused` unrolls of this engine "exchange" (so the host's
+        # snapshot / recovery / status all-reduce logic runs in the CPU suite); an injected fault makes the next such
+        # unroll leave garbage and raise the sticky status, exactly once
+        self._status = torch.zeros(1, dtype=torch.int32)
+        self._fault = False
+        self._exchanged = False
+
+    def inject_unroll_fault(self, on=True):
+        self._fault = bool(on)
+
+    def last_unroll_exchanges(self):
+        return self._exchanged
+
+    def unroll_status_tensor(self):
+        return self._status
+
+    def check_unroll_status(self):
+        if int(self._status[0]):
+            self._status.zero_()
+            self._fault = False
+            raise _abi.L2OPartnerTimeout(_abi.L2O_ERR_TIMEOUT, "oracle engine: injected partner timeout")
 
     def atb(self, A, B):
         """A^T B (the HIP engine's l2o_atb), CPU torch."""
@@ -58,7 +79,16 @@ class OracleEngine(object):
         return self.atb(A, B)
 
     # the HIP engine's ABI v11 vector passes (csrc/l2o_vecops.h), CPU torch restatements of the same formulas
+    @staticmethod
+    def _dense(*ts):
+        """HipEngine passes raw pointers (_engine._ptr asserts is_contiguous()): the CPU stand-ins hold their operands
+        to the same contract, so a strided view that would trip the GPU path trips the CPU suite too."""
+        for t in ts:
+            assert t is None or (t.is_contiguous() and t.dtype == torch.float32), \
+                "vector passes take dense fp32 operands (shape %r, stride %r)" % (tuple(t.shape), t.stride())
+
     def suffix_sums(self, gs, g_final, out):
+        self._dense(g_final, out, *gs)
         acc = g_final.reshape(-1).clone()
         for t in reversed(range(len(gs))):
             out[t] = acc
@@ -66,6 +96,7 @@ class OracleEngine(object):
         return out
 
     def colsum(self, A, out=None, accumulate=False):
+        self._dense(A, out)
         r = A.sum(dim=-2)
         if out is None:
             return r
@@ -73,6 +104,7 @@ class OracleEngine(object):
         return out
 
     def lincomb(self, out, a, ca=1.0, b=None, cb=0.0, c=None, cc=0.0):
+        self._dense(out, a, b, c)
         r = ca * a.reshape(-1)
         if b is not None:
             r = r + cb * b.reshape(-1)
@@ -82,6 +114,7 @@ class OracleEngine(object):
         return out
 
     def rnnprop_input_adjoint(self, Bm, du_col, H, w_fc, g, m, v, pow1, pow2, beta1, beta2, dm, dv, dg):
+        self._dense(w_fc, g, m, v, dm, dv, dg)
         f = np.float32
         du = Bm[:g.numel(), du_col:du_col + H]
         wfc = w_fc.view(2, H)
@@ -123,7 +156,10 @@ class OracleEngine(object):
                 "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
                 "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
 
-    def adam_step(self, w, m, v, g, lr_t, beta1, beta2, epsilon):
+    def adam_step(self, w, m, v, g, lr_t, beta1, beta2, epsilon, guarded=False):
+        if guarded and int(self._status[0]):                # l2o_adam_step_guarded: the failed unroll's update is skipped
+            self.calls.append("adam_step_skipped")
+            return
         self.calls.append("adam_step")
         f = np.float32
         wn, mn, vn, gn = w.numpy(), m.numpy(), v.numpy(), g.numpy()      # views: in place
@@ -197,6 +233,30 @@ class OracleEngine(object):
             if s is not None:
                 gr = gr * s
             g.copy_(torch.from_numpy(gr.astype(np.float32)).view_as(g))
+
+    def problem_hvp(self, p, x, u, out):
+        """out = (d g / d x) u with g what problem_fg returns (l2o_problem_hvp, include/l2o_abi.h): the closed forms of
+        the analytic optimizees' Hessians (DM/problems.py:98-99, 128-131, 206-211 differentiated twice), 1/B_global and
+        the x_scale chain rule included; the l1 term of lasso has no curvature."""
+        self.calls.append("problem_hvp")
+        self._dense(x, u, out)
+        f = np.float32
+        B, D = p.B_local, p.D
+        xs, us = x.numpy().reshape(B, D), u.numpy().reshape(B, D)
+        s = np.ones((B, D), f) if p.x_scale is None else p.x_scale.numpy().reshape(B, D)
+        su = s * us
+        if p.kind == _abi.PROB_SIMPLE:
+            r = f(2.0) * s * su
+        else:
+            W = p.W.numpy().reshape((1 if getattr(p, "w_shared", False) else B), p.M, D)
+            r = np.einsum("bmd,bm->bd", W, np.einsum("bmd,bd->bm", W, su))
+            if p.kind in (_abi.PROB_QUADRATIC, _abi.PROB_SQUARE_COS):      # ||Wx - y||^2 without the 1/2
+                r = f(2.0) * r
+            if p.kind in (_abi.PROB_RASTRIGIN, _abi.PROB_SQUARE_COS):
+                two_pi = f(2.0 * np.pi)
+                r = r + two_pi * two_pi * f(p.alpha) * p.C.numpy().reshape(B, D) * np.cos(two_pi * xs * s) * su
+            r = s * r / f(p.B_global)
+        out.copy_(torch.from_numpy(np.ascontiguousarray(r, f)).view_as(out))
 
     def int_tensor(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32).copy())
@@ -281,6 +341,9 @@ class OracleEngine(object):
         cout, rows = O.net_bwd_step(cfg, params, inputs, state, io["dx_next"].numpy().reshape(N), carry)
         if cout is not None:
             io["carry_out"].copy_(torch.from_numpy(np.stack(cout).astype(np.float32)).view_as(io["carry_out"]))
+        da = rows.pop("da", None)
+        if io.get("dg") is not None:                               # u_t = dL/dg_t (second_derivatives, DM nets)
+            io["dg"].copy_(torch.from_numpy(np.ascontiguousarray(O.preprocess_bwd(cfg, g, da), np.float32)).view_as(io["dg"]))
         for k, v in rows.items():
             t = io[k]
             a = np.ascontiguousarray(v, np.float32)
@@ -355,6 +418,18 @@ class OracleEngine(object):
             st.zero_()
             if m is not None:
                 m.zero_(); v.zero_()
+        self._exchanged = bool(_abi.get_option(_abi.OPT_PAIR))      # (OPT_PAIR = 0: the exchange-free kernels)
+        if self._fault and self._exchanged:                          # a partner timeout: outputs are garbage
+            self.calls.append("unroll_timeout")
+            x.fill_(float("nan")); st.fill_(float("nan")); fx_part.fill_(float("nan"))
+            if fx is not None:
+                fx.fill_(float("nan"))
+            if hist is not None:
+                for t in hist.values():
+                    if t is not None:
+                        t.fill_(float("nan"))
+            self._status.fill_(1)
+            return
         self._unroll(spec, wpack, p, x, st, m, v, T, step0, fx_part, hist)
         if fx is not None:                                         # l2o_unroll_reduce
             self.reduce_fx(fx_part, T + 1, p.B_local, p.B_global, fx)

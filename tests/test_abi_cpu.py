@@ -53,7 +53,7 @@ def test_options_are_caller_owned():
     from open_l2o_amd._engine import NetSpec
     spec = NetSpec(_abi.NET_CW, _abi.PRE_IDENTITY, (20, 20))
     assert _abi.options_word() == 0 and spec.to_c().options == 0
-    assert _abi.get_option(_abi.OPT_PAIR) == 1 and _abi.get_option(_abi.OPT_PAIR_NORMAL) == 0
+    assert _abi.get_option(_abi.OPT_PAIR) == 1 and _abi.get_option(_abi.OPT_EXACT_GATES) == 0
     old = _abi.set_option(_abi.OPT_PAIR, 0)
     try:
         assert old == 1 and spec.to_c().options == (8 | 0) << (4 * _abi.OPT_PAIR)
@@ -64,9 +64,9 @@ def test_options_are_caller_owned():
         # option 12 must not land in the count's bits 48-63 (it did for a while in round 4): its field is the one that
         # option 5 -- the count, which has its own 16 bits -- leaves unused (include/l2o_abi.h: L2O_OPT_FIELD_)
         w0 = spec.to_c().options
-        _abi.set_option(_abi.OPT_ONE_LDS, 3)
+        _abi.set_option(_abi.OPT_ONE_LDS, 2)
         w1 = spec.to_c().options
-        assert (w1 >> 48) == 300 and (w1 ^ w0) == (8 | 3) << (4 * _abi.OPT_BWD_BLOCKS)
+        assert (w1 >> 48) == 300 and (w1 ^ w0) == (8 | 2) << (4 * _abi.OPT_BWD_BLOCKS)
     finally:
         _abi.set_option(_abi.OPT_PAIR, 1)
         _abi.set_option(_abi.OPT_EXACT_GATES, 0)

@@ -1,5 +1,5 @@
-"""bench.py's roofline arithmetic on CPU (no GPU): the work-based figure of round 4 (stated minimal instruction counts x
-measured issue costs / measured cycles per tile-step) and the same-lease counters lookup, on a synthetic counters file."""
+"""bench.py's roofline arithmetic on CPU (no GPU): the work / peak figure (stated minimal instruction counts x measured
+PIPE rates / measured cycles per step) and the counters lookup by build id, on synthetic counters files."""
 import importlib.util
 import json
 import os
@@ -31,45 +31,86 @@ def test_work_model_counts():
     assert b.work_model("lasso", "dm", 512, 256)["valu_plain"] - b.work_model("lasso", "dm", 512, 128)["valu_plain"] == 2 * 32
 
 
-def test_work_block_and_same_lease_lookup(tmp_path, monkeypatch):
+def _counters(build_id=None, collected=None, insts=455.0):
+    c = {"workload": ["quadratic", "dm", 128, 128, 100], "kernel": "void k_unroll_pair<0, 1, 8, false, false>(UnrollPairArgs)",
+         "per_launch": {"SQ_INSTS_VALU": insts * 1024 * 100.3, "SQ_WAVES": 1024.0, "SQ_ACTIVE_INST_VALU": 5.5e7,
+                        "SQ_VALU_MFMA_BUSY_CYCLES": 9.9e7, "SQ_INSTS_MFMA": 6.2e6, "FETCH_SIZE_KiB": 4800.0,
+                        "WRITE_SIZE_KiB": 6100.0},
+         "kernel_ns_profiled": {"p": 183000.0}, "clock_hz_profiled": 2.43e9, "one_wave_per_simd": False}
+    if build_id:
+        c["build_id"] = build_id
+    if collected:
+        c["collected_unix"] = collected
+    return c
+
+
+def test_counters_are_chosen_by_build_id_not_by_file_name(tmp_path, monkeypatch):
+    """`sorted(glob)` picked profiles/r04z_* over the newer r04av_*.  The selection reads what the file says
+    about itself: the build it was collected on, then when."""
     b = _bench()
-    counters = {"workload": ["quadratic", "dm", 128, 128, 100], "kernel": "void k_unroll_pair<0, 1, 8, false, false>(UnrollPairArgs)",
-                "per_launch": {"SQ_INSTS_VALU": 455.0 * 1024 * 100.3, "SQ_WAVES": 1024.0, "SQ_ACTIVE_INST_VALU": 5.5e7,
-                               "SQ_VALU_MFMA_BUSY_CYCLES": 9.9e7, "SQ_INSTS_MFMA": 6.2e6, "FETCH_SIZE_KiB": 4800.0,
-                               "WRITE_SIZE_KiB": 6100.0},
-                "kernel_ns_profiled": {"p": 183000.0}, "clock_hz_profiled": 2.43e9, "one_wave_per_simd": False}
-    (tmp_path / "counters_c2.json").write_text(json.dumps(counters))
+    wl = ["quadratic", "dm", 128, 128, 100]
+    # names sort z > a: the OLD build's file would win a filename sort
+    (tmp_path / "counters_zz_old.json").write_text(json.dumps(_counters("aaaaaaaaaaaaaaaa", 1000.0, insts=455.0)))
+    (tmp_path / "counters_aa_new.json").write_text(json.dumps(_counters("bbbbbbbbbbbbbbbb", 2000.0, insts=423.0)))
+    (tmp_path / "counters_mm_legacy.json").write_text(json.dumps(_counters()))            # (no id, no timestamp)
     monkeypatch.setenv("L2O_COUNTERS_DIR", str(tmp_path))
-    found = b.counters_for(["quadratic", "dm", 128, 128, 100], "k_unroll_pair")
-    assert found is not None and found[0].startswith(str(tmp_path))          # the lease's file wins over profiles/
-    case = {"kern_ms": 0.1834, "kern_ms_min": 0.183, "kernel": "k_unroll_pair", "alg_bytes": 2.746e9, "bpc": 1676.0,
-            "flops": 1.69e10, "hbm_bound": False, "hbm_model_bytes": 0.0, "fused": True, "D": 128, "Mrows": 128, "T": 100,
-            "dispatches": 1}
+    monkeypatch.setattr(b, "ROOT", str(tmp_path / "no_profiles_here"))
+    path, c, status = b.counters_for(wl, "k_unroll_pair", "bbbbbbbbbbbbbbbb")
+    assert status == "same_build" and path.endswith("counters_aa_new.json")
+    path, c, status = b.counters_for(wl, "k_unroll_pair", "aaaaaaaaaaaaaaaa")
+    assert status == "same_build" and path.endswith("counters_zz_old.json")
+    path, c, status = b.counters_for(wl, "k_unroll_pair", "cccccccccccccccc")            # a build nobody profiled
+    assert status == "stale" and path.endswith("counters_aa_new.json")                  # ... the most recently collected
+    assert b.counters_for(wl, "k_unroll_lds", "bbbbbbbbbbbbbbbb") is None                  # another kernel's counters
+    assert b.counters_for(["lasso", "rnnprop", 512, 256, 200, 256], "", "bbbbbbbbbbbbbbbb") is None
+
+
+def test_roofline_frac_is_work_over_peak_at_pipe_rates(tmp_path):
+    """frac = stated minimal instruction counts x PIPE rates / measured cycles (config 2: 1 377 / 4 343 = 0.32, the figure
+    VERDICT r04 asked for) -- from the in-kernel cycle count when there is one; utilisation and issue-cost figures ride
+    along under their own names; stale counters are marked and never enter frac."""
+    b = _bench()
+    case = {"kern_ms": 0.1777, "kern_ms_min": 0.177, "kernel": "k_unroll_pair (every problem on two CUs, one wave per SIMD)",
+            "alg_bytes": 2.746e9, "bpc": 1676.0, "flops": 1.69e10, "hbm_bound": False, "hbm_model_bytes": 0.0, "fused": True,
+            "D": 128, "Mrows": 128, "T": 100, "B": 128, "dispatches": 1, "loop_ticks": 4343.0 * 100.3}
 
     class A:
         problem, net = "quadratic", "dm"
-    roof = b.roofline_block(case, A, found)
-    assert roof["bound"] == "valu_issue" and 0.4 < roof["frac"] < 0.6
-    cyc = 0.1834e-3 * 2.43e9 / 100.3
-    assert abs(roof["cycles_per_tile_step"] - cyc) < 1e-6 * cyc
-    floor = 241 * b.ISSUE_COST["valu"] + 80 * b.ISSUE_COST["trans"] + 60 * b.ISSUE_COST["mfma"]
-    assert abs(roof["issue_floor_cycles_per_tile_step"] - floor) < 1e-9
-    assert abs(roof["frac_work"] - floor / cyc) < 1e-9 and 0.45 < roof["frac_work"] < 0.56
-    assert abs(roof["valu_insts_per_tile_step"] - 455.0) < 1e-6
-    assert abs(roof["traffic"] - (2 * 4800.0 + 6100.0) * 1024.0) < 1.0        # FETCH_SIZE doubled on gfx950
-    # a streaming (HBM-bound) kernel carries no work block
-    case3 = dict(case, hbm_bound=True, kernel="k_unroll_cu")
-    assert "frac_work" not in b.roofline_block(case3, A, found)
-    # a two-waves-per-SIMD kernel (k_unroll_lds): the floor is the SIMD's PIPE time for two tile-steps per step
+    pipe_floor = 241 * b.PIPE_COST["valu"] + 80 * b.PIPE_COST["trans"]
+    assert abs(pipe_floor - 1377.3) < 0.5
+    for counters, status in (((str(tmp_path / "c.json"), _counters("x" * 16), "same_build"), "same_build"),
+                             ((str(tmp_path / "c.json"), _counters("y" * 16), "stale"), "stale"), (None, "none")):
+        roof = b.roofline_block(case, A, counters)
+        assert roof["bound"] == "valu_pipe" and roof["counters"] == status
+        assert abs(roof["cycles_per_step"] - 4343.0) < 1e-6 and "s_memtime" in roof["cycles_source"]
+        assert abs(roof["frac"] - pipe_floor / 4343.0) < 1e-9 and 0.31 < roof["frac"] < 0.33
+        assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-12
+        issue_floor = 241 * b.ISSUE_COST["valu"] + 80 * b.ISSUE_COST["trans"] + 60 * b.ISSUE_COST["mfma"]
+        assert abs(roof["issue_cost_frac"] - issue_floor / 4343.0) < 1e-9
+        if counters is None:
+            assert "valu_active_frac" not in roof and roof["traffic"] is None
+        else:
+            assert 0.4 < roof["valu_active_frac"] < 0.6 and abs(roof["valu_insts_per_tile_step"] - 455.0) < 1e-6
+            assert abs(roof["traffic"] - (2 * 4800.0 + 6100.0) * 1024.0) < 1.0    # FETCH_SIZE doubled on gfx950
+    # without the in-kernel count: live kernel time x the clock
+    case_t = dict(case, loop_ticks=None)
+    roof = b.roofline_block(case_t, A, None)
+    cyc = 0.1777e-3 * 2.4e9 / 100.3
+    assert abs(roof["cycles_per_step"] - cyc) < 1e-6 * cyc and roof["cycles_source"].startswith("kernel_ms_avg")
+    # a streaming (HBM-bound) kernel: bytes of the form / time / 8 TB/s, no work block
+    case3 = dict(case, hbm_bound=True, kernel="k_unroll_cu8", hbm_model_bytes=27.06e9, kern_ms=4.608)
+    r3 = b.roofline_block(case3, A, None)
+    assert r3["bound"] == "hbm" and abs(r3["frac"] - 27.06e9 / 4.608e-3 / 8e12) < 1e-9 and "frac_work" not in r3
+    # two waves per SIMD (k_unroll_lds): two tile-steps per SIMD and step; 1024 problems = four rounds per CU when
+    # the cycles come from the kernel time
     case4 = dict(case, kernel="k_unroll_lds (one problem per CU, two waves per SIMD, fragments in LDS)", kern_ms=1.2263,
-                 D=100, Mrows=100, B=1024, n_cus=256)
+                 D=100, Mrows=100, B=1024, n_cus=256, loop_ticks=None)
 
     class A4:
         problem, net = "rastrigin", "dm"
-    roof4 = b.roofline_block(case4, A4, found)
+    roof4 = b.roofline_block(case4, A4, None)
     wm = b.work_model("rastrigin", "dm", 100, 100)
     floor4 = 2 * (wm["valu_plain"] * b.PIPE_COST["valu"] + wm["transcendental"] * b.PIPE_COST["trans"])
-    cyc4 = 1.2263e-3 * 2.43e9 / (4 * 100.3)                                   # four rounds of problems per CU
+    cyc4 = 1.2263e-3 * 2.4e9 / (4 * 100.3)
     assert abs(roof4["cycles_per_step"] - cyc4) < 1e-6 * cyc4 and roof4["tiles_per_simd"] == 2
-    assert abs(roof4["pipe_floor_cycles_per_step"] - floor4) < 1e-9 and abs(roof4["frac_work"] - floor4 / cyc4) < 1e-9
-    assert 0.3 < roof4["frac_work"] < 0.45 and "cycles_per_tile_step" not in roof4
+    assert abs(roof4["frac"] - floor4 / cyc4) < 1e-9 and 0.3 < roof4["frac"] < 0.45 and "issue_cost_frac" not in roof4

@@ -580,10 +580,9 @@ def test_fused_edge_cases(eng, kind, B, D, M, T, pair):
     assert max_abs(x, res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max()))
 
 
-def test_unroll_preparation_follows_the_problem(eng):
-    """The two-CU unroll takes W^T (W x - y) from H = W^T W, q = W^T y prepared ONCE per problem instance
-    (l2o_unroll_prepare; the engine re-prepares when the W / y tensors are replaced or written in place).
-    A problem changed in place between two launches must give the NEW problem's trajectory."""
+def test_unroll_follows_a_problem_changed_in_place(eng):
+    """The fused unroll keeps no per-problem cache (the normal-matrix form that had one -- l2o_unroll_prepare -- was
+    removed with ABI v12): a problem changed IN PLACE between two launches gives the NEW problem's trajectory."""
     cfg = O.DM_IDENTITY
     params = make_params(cfg, seed=21, trained_like=True)
     B, D, T = 6, 40, 8
@@ -599,43 +598,12 @@ def test_unroll_preparation_follows_the_problem(eng):
         return eng.to_numpy(fx)
 
     res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
-    with lib_option(_abi.OPT_PAIR_NORMAL, 1):                                     # (the form that HAS a preparation)
-        assert rel_err(launch(), res.fx) < 1e-5
-        first = eng._ws_prepared
-        assert rel_err(launch(), res.fx) < 1e-5 and eng._ws_prepared is first      # same instance: prepared once
-        pd.W.mul_(1.25); pd.y.add_(0.5)                                                # the problem changes IN PLACE
-        prob2 = O.Quadratic(prob.w * np.float32(1.25), prob.y + np.float32(0.5))
-        res2 = O.unroll(prob2, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
-        assert rel_err(res2.fx, res.fx) > 1e-2
-        assert rel_err(launch(), res2.fx) < 1e-5 and eng._ws_prepared is not first
-    assert rel_err(launch(), res2.fx) < 1e-5                                       # the default form prepares nothing
-
-
-def test_unroll_preparation_survives_an_unprepared_launch_of_another_problem(eng):
-    """a launch WITHOUT fx= (l2o_unroll / l2o_unroll_record) prepares H, q of ITS problem in the shared
-    workspace; the engine must forget what the fx= path had cached there, or the next fx= launch of the first
-    problem runs on the other problem's H / q (silently wrong iterates)."""
-    cfg = O.DM_IDENTITY
-    params = make_params(cfg, seed=23, trained_like=True)
-    B, D, T = 6, 40, 8
-    spec = spec_of(cfg)
-    wpack = eng.pack_weights(spec, params)
-    probA, x0, arrA = make_problem("quadratic", B, D, seed=24)
-    probB, _, arrB = make_problem("quadratic", B, D, seed=25)
-    pdA, pdB = device_problem(eng, arrA, B, D), device_problem(eng, arrB, B, D)
-    fx = eng.zeros(T + 1)
-    with lib_option(_abi.OPT_PAIR_NORMAL, 1):
-        def launch_a():
-            x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
-            eng.unroll(spec, wpack, pdA, x, st, None, None, T, 1, eng.zeros((T + 1) * B), fx=fx)
-            return eng.to_numpy(fx).copy()
-        first = launch_a()
-        x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
-        eng.unroll(spec, wpack, pdB, x, st, None, None, T, 1, eng.zeros((T + 1) * B))      # no fx=: unprepared launch of B
-        again = launch_a()
-    res = O.unroll(probA, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
-    assert rel_err(first, res.fx) < 1e-5
-    assert np.array_equal(first, again)
+    assert rel_err(launch(), res.fx) < 1e-5
+    pd.W.mul_(1.25); pd.y.add_(0.5)                                                # the problem changes IN PLACE
+    prob2 = O.Quadratic(prob.w * np.float32(1.25), prob.y + np.float32(0.5))
+    res2 = O.unroll(prob2, cfg, params, x0, O.net_initial_state(cfg, B * D), T)
+    assert rel_err(res2.fx, res.fx) > 1e-2
+    assert rel_err(launch(), res2.fx) < 1e-5
 
 
 def test_fused_rejects_what_it_cannot_do(eng):

@@ -234,6 +234,10 @@ def test_bwd_step_kernel_vs_oracle(name, B, D):
              "b_gates2": ("lstm_2", "b_gates"), "w_lin": ("linear", "w"), "b_lin": ("linear", "b"),
              "w_fc": ("input_projection", "w"), "b_fc": ("input_projection", "b")}
     wdev = {kk: t(params[mm][nn]) for kk, (mm, nn) in names.items() if mm in params}
+    da = rows.pop("da")
+    if cfg.kind != "rnnprop":                  # u = dL/dg of the DM nets (second_derivatives): the preprocess adjoint
+        io["dg"] = eng.zeros(N)
+        rows["dg"] = O.preprocess_bwd(cfg, g, da)
     eng.bwd_step(spec, wdev, io, pw, pw, B, D)
     for kk, ref in rows.items():
         got = eng.to_numpy(io[kk]).reshape(ref.shape)

@@ -23,20 +23,10 @@ pytestmark = pytest.mark.gpu
 N_LAUNCHES = int(__import__("os").environ.get("L2O_SOAK_LAUNCHES", "10000"))   # (profiles/r02n: one run with 200 000)
 
 
-@pytest.mark.parametrize("name,kind,D,B,form", [("dm", "quadratic", 128, 128, None), ("rnnprop", "rastrigin", 100, 128, None),
-                                                 ("dm", "rastrigin", 100, 256, 3)])
-def test_pair_exchange_soak(name, kind, D, B, form):
-    """form 3 (round 4): k_unroll_pair2 -- the same exchange with TWO workgroups per CU (256 problems = 512 workgroups, all
-    co-resident by construction: 62 KB of LDS each leave room for exactly two per CU)."""
+@pytest.mark.parametrize("name,kind,D,B", [("dm", "quadratic", 128, 128), ("rnnprop", "rastrigin", 100, 128)])
+def test_pair_exchange_soak(name, kind, D, B):
     from open_l2o_amd._engine import HipEngine
-    eng = HipEngine()
-    if form is not None:
-        old_form = _abi.set_option(_abi.OPT_ONE_LDS, form)
-    try:
-        _soak(eng, name, kind, D, B)
-    finally:
-        if form is not None:
-            _abi.set_option(_abi.OPT_ONE_LDS, old_form)
+    _soak(HipEngine(), name, kind, D, B)
 
 
 def _soak(eng, name, kind, D, B):

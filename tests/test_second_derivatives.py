@@ -12,12 +12,17 @@ from open_l2o_amd import _engine, meta, meta_rnnprop_eval, problems
 from open_l2o_amd.session import Session
 from test_meta_api import _net_config
 
-pytestmark = pytest.mark.gpu
 
-
-@pytest.fixture()
-def hip():
-    eng = _engine.HipEngine()
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def hip(request):
+    """The product engine on the MI355X (gpu) and -- since round 5 -- the oracle-backed engine on CPU, whose
+    vector passes hold their operands to HipEngine's dense-pointer contract: the host logic of the second-derivative
+    BPTT (panel grouping, gradient accumulation over groups, the Hessian-vector recursion) runs in the CPU suite."""
+    if request.param == "oracle":
+        from oracle_engine import OracleEngine
+        eng = OracleEngine()
+    else:
+        eng = _engine.HipEngine()
     old = _engine._default_engine
     _engine.set_default_engine(eng)
     yield eng
@@ -175,3 +180,39 @@ def test_second_derivatives_of_a_weighted_term(hip):
         assert float(np.abs(g - ws).max()) / scale_g < 5e-4, (mod, var)
     assert max(float(np.abs(want[m][v] - unweighted_hvp[m][v]).max()) / max(float(np.abs(want[m][v]).max()), 1e-12)
                for m in want for v in want[m]) > 2e-3        # (the second-order term is visible in this case)
+
+
+def test_second_derivatives_two_variables_share_a_net(hip):
+    """two variables stepped by ONE network with second_derivatives=True go through the BPTT panel by panel,
+    so every weight gradient is the sum of two contraction results -- column blocks of two [KA, KB] matrices, i.e.
+    strided views that the pointer-taking l2o_lincomb must never see.  A 2-term ensemble (DM/problems.py:215-245) of
+    quadratics against autograd of the restated unroll."""
+    cfg = O.NetConfig("cw", (20, 20), "identity", None, 0.05, False)
+    params = make_params(cfg, seed=55)
+    B, D, T = 3, 16, 4
+    probs = [make_problem("quadratic", B, D, seed=56 + i) for i in range(2)]
+    Ws = [torch.tensor(pr.w.astype(np.float64)) for pr, _, _ in probs]
+    ys = [torch.tensor(pr.y.astype(np.float64)) for pr, _, _ in probs]
+
+    def f(xx):                                            # xx: [2, B, D] -- both variables
+        tot = 0
+        for i in range(2):
+            r = torch.matmul(Ws[i], xx[i].unsqueeze(-1)).squeeze(-1) - ys[i]
+            tot = tot + torch.mean(torch.sum(r * r, 1))
+        return tot
+    problem = problems.ensemble([{"name": "quadratic", "options": dict(batch_size=B, num_dims=D,
+                                                                        data={"w": pr.w, "y": pr.y, "x": x0})}
+                                 for pr, x0, _ in probs])
+    x0 = np.stack([x.reshape(B, D) for _, x, _ in probs])
+    got, want = {}, {}
+    for second in (True, False):
+        opt = meta.MetaOptimizer(**_cfg_opts(cfg, params))
+        ms = opt.meta_minimize(problem, T, learning_rate=1e-6, second_derivatives=second)
+        assert len(opt.graph.x) == 2
+        got[second] = _captured_grads(opt, ms)
+        want[second] = _torch_grad(cfg, params, f, x0, T, second)
+    for (mod, var), g in got[True].items():
+        ws, wf = want[True][mod][var].reshape(g.shape), want[False][mod][var].reshape(g.shape)
+        scale_g = max(float(np.abs(ws).max()), 1e-12)
+        assert float(np.abs(g - ws).max()) / scale_g < 5e-4, (mod, var)
+        assert float(np.abs(got[False][(mod, var)] - wf).max()) / scale_g < 5e-4, (mod, var)

@@ -5,14 +5,14 @@ drivers; command lines in the README there).  Every test runs the full-size BASE
 and compares with the fp32 C oracle (and, for the long horizons, the float64 NumPy oracle) on the same inputs:
 
   * configs 2 / 4-shard, T = 100: the whole fx[0..T] at 1e-5 relative (the north_star bar), x_T and the LSTM state, on
-    ALL three fused forms -- the two-CU kernel in its reference-arithmetic form (r = Wx - y, g = W^T r), its
-    normal-matrix form (H x - q) and the one-CU kernel;
-  * the per-step GRADIENT of both two-CU forms against the float64 gradient at the kernel's own iterates, bounded by
-    the error of the reference's own fp32 arithmetic (NumPy two-pass) -- the probe that shows what H x - q costs once
-    |g| has fallen (profiles/r03a_trained_parity_probe.txt);
+    both fused forms -- the two-CU kernel (the reference's arithmetic: r = Wx - y, g = W^T r) and the one-CU kernel
+    (until round 4 also an opt-in normal-matrix form, H x - q: removed with ABI v12, its measurements are
+    profiles/r03a_trained_parity_probe.txt);
+  * the per-step GRADIENT of the two-CU form against the float64 gradient at the kernel's own iterates, bounded by
+    the error of the reference's own fp32 arithmetic (NumPy two-pass);
   * T = 1000 and T = 10 000 (DM/train_dm.py:66, DM/evaluate_dm.py:43) against the float64 oracle, bounded by 3 x the
     drift of the fp32 oracle itself -- the default (bf16x3 gates, reference gradient arithmetic), the exact-gates option
-    and the one-CU kernel; the opt-in normal-matrix form by a stated looser bound;
+    and the one-CU kernel;
   * config 3 (RNNProp on Lasso, T = 200): the l1 term's sign(x) makes the CONVERGED trajectory chaotic -- the fp32
     oracle started one ulp away from x_0 drifts by 2e-3 in fx after ~100 steps -- so the trajectory is held to 1e-5 on
     the prefix where that sensitivity is below 1e-6, to 3 x the oracle's own one-ulp sensitivity beyond, and the
@@ -35,18 +35,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRAINED = os.path.join(ROOT, "tests", "golden", "trained")
 
-FORMS = {"two_pass": {_abi.OPT_PAIR_NORMAL: 0}, "normal": {_abi.OPT_PAIR_NORMAL: 1}, "one_cu": {_abi.OPT_PAIR: 0},
+FORMS = {"two_pass": {}, "one_cu": {_abi.OPT_PAIR: 0},
          # L2O_OPT_EXACT_GATES: the fp32-MFMA gate GEMM (bit-equal to an fmaf chain) instead of the bf16x3 split
-         "two_pass_exact": {_abi.OPT_PAIR_NORMAL: 0, _abi.OPT_EXACT_GATES: 1},
+         "two_pass_exact": {_abi.OPT_EXACT_GATES: 1},
          "one_cu_exact": {_abi.OPT_PAIR: 0, _abi.OPT_EXACT_GATES: 1}}
 # Long horizons.  Every form with the reference's gradient arithmetic -- bf16x3 gates (the default) or exact gates -- is
 # held to 3 x the fp32 oracles' own drift from float64.  (Until round 3 the bf16x3 kernels drifted 1.1e-5 .. 1.6e-5 at
 # T = 1000: the gate bias rode in two K-slots of the gate GEMM and v_mfma_f32_16x16x32_bf16 truncates every product of
 # an 8-slot group at 2^-24 of the group's largest -- the O(1) bias; as the accumulator init it is outside those sums:
 # 2.9e-6.  profiles/r03c_mfma_round_probe.txt, r03c_drift_forms.txt -> r03g_drift_forms_bias_as_acc_init.txt.)
-# The normal-matrix form (opt-in) carries the H x - q gradient error on top: held to this stated bound instead
-# (measured 6.0e-6 at T = 1000, 4.1e-5 at T = 10 000 on config 2).
-NORMAL_FORM_LONG_HORIZON_BOUND = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -97,7 +94,7 @@ CASES = {"c2": ("quadratic", "dm_quadratic_d128", 128, 128, None, 14),
          "c4shard": ("rastrigin", "dm_rastrigin_d100", 128, 100, 1024, 16)}
 
 
-@pytest.mark.parametrize("which", ["two_pass", "normal", "one_cu"])
+@pytest.mark.parametrize("which", ["two_pass", "one_cu"])
 @pytest.mark.parametrize("case", ["c2", "c4shard"])
 def test_trained_full_size_trajectory(eng, case, which):
     """Configs 2 and 4 (this GPU's shard of the 1024 problems), T = 100, the trained L2O-DM optimizer: the loss FALLS
@@ -153,10 +150,9 @@ def grad32_reference_form(kind, prob, x, Bg):
 
 @pytest.mark.parametrize("case", ["c2", "c4shard"])
 def test_gradient_error_in_the_converged_regime(eng, case):
-    """The recorded per-step gradient (hist["g"][t] of l2o_unroll_record) of both two-CU forms against the float64
-    gradient at the kernel's OWN iterate x_t, t = 0 .. 99.  The reference-arithmetic form (two-pass) must stay within
-    2 x the error of a NumPy fp32 evaluation of the same formula; the normal-matrix form is measured next to it and
-    bounded only by what the probe found (its error no longer scales with the residual: DESIGN.md 4)."""
+    """The recorded per-step gradient (hist["g"][t] of l2o_unroll_record) of the two-CU form against the float64
+    gradient at the kernel's OWN iterate x_t, t = 0 .. 99: within 2 x the error of a NumPy fp32 evaluation of the same
+    formula (r = Wx - y, g = W^T r -- an error that shrinks with the residual)."""
     kind, wname, B, D, Bg, seed = CASES[case]
     cfg = O.DM_IDENTITY
     params = load_l2l(wname, "cw")
@@ -164,7 +160,7 @@ def test_gradient_error_in_the_converged_regime(eng, case):
     x0 = x0.reshape(B, D)
     T = 100
     out = {}
-    for which in ("two_pass", "normal"):
+    for which in ("two_pass",):
         with form(which):
             h = fused(eng, cfg, params, arrays, x0, B, D, T, Bg=Bg, hist=True)[5]
             hg = eng.to_numpy(h["g"]).reshape(T, B, D)
@@ -181,19 +177,16 @@ def test_gradient_error_in_the_converged_regime(eng, case):
     assert out["two_pass"][-1][1] < out["two_pass"][0][1] / 20          # the gradient did shrink
     for t, n, e_hip, e_np in out["two_pass"]:
         assert e_hip < 2 * e_np + 1e-7, (t, e_hip, e_np)
-    for (t, n, e_hip, e_np), (_, _, e2, _) in zip(out["normal"], out["two_pass"]):
-        assert e_hip < 20 * max(e2, e_np) + 1e-7, (t, e_hip, e2)
 
 
-@pytest.mark.parametrize("which", ["two_pass", "normal", "one_cu", "two_pass_exact", "one_cu_exact"])
+@pytest.mark.parametrize("which", ["two_pass", "one_cu", "two_pass_exact", "one_cu_exact"])
 @pytest.mark.parametrize("case,T,Bt", [("c2", 1000, 16), ("c2", 10000, 4), ("c4shard", 1000, 16), ("c4shard", 10000, 4)])
 def test_trained_long_horizon(eng, case, T, Bt, which):
     """T = 1000 (the curriculum's horizon, DM/train_dm.py:66) and T = 10 000 (DM/evaluate_dm.py:43) in ONE launch, the
     trained optimizer, a slice of the batch with the 1/B of the full batch: the loss keeps falling.  HIP vs the float64
     oracle within 3 x the worst drift of two fp32 evaluations of the same unroll from their float64 twin (the C oracle,
-    the C oracle started one ulp away) -- the default bf16x3 gates and the exact gates alike; the opt-in normal-matrix
-    form within max(that, NORMAL_FORM_LONG_HORIZON_BOUND); the first 101 steps of every form hold the 1e-5 of the
-    short tests."""
+    the C oracle started one ulp away) -- the default bf16x3 gates and the exact gates alike; the first 101 steps of
+    every form hold the 1e-5 of the short tests."""
     from oracle.c_oracle import c_unroll
     kind, wname, B, D, Bg, seed = CASES[case]
     Bg = Bg or B
@@ -221,7 +214,7 @@ def test_trained_long_horizon(eng, case, T, Bt, which):
           % (case, T, which, r64.fx[0], r64.fx[-1], e64, env, rel_err(fx[:101], r64.fx[:101])))
     assert r64.fx[-1] < r64.fx[100] < r64.fx[0]
     assert rel_err(fx[:101], r64.fx[:101]) < 1e-5
-    assert e64 < (max(3 * env, NORMAL_FORM_LONG_HORIZON_BOUND) if which == "normal" else 3 * env), (e64, env)
+    assert e64 < 3 * env, (e64, env)
 
 
 def test_c3_trained_lasso_rnnprop(eng):

@@ -1,8 +1,7 @@
-"""The fused unroll for LARGE shards (round 4; 5..8 tiles; DM nets, and RNNProp on k_unroll_lds), both forms with the bf16x3 gate GEMM's fragments in LDS
-and two waves per SIMD (L2O_OPT_ONE_LDS):
-  2 / default 1 above #CU / 2 problems   k_unroll_lds   -- one problem per CU, two waves of the same problem per SIMD
-  3                                      k_unroll_pair2 -- the two-CU kernel, TWO workgroups (halves of two different
-                                         problems) per CU (csrc/l2o_unroll_pair.h, LDSF), chunks of #CU problems
+"""The fused unroll for LARGE shards (round 4; 5..8 tiles; DM nets and RNNProp): k_unroll_lds -- one problem per CU, the
+bf16x3 gate GEMM's fragments in LDS, two waves of the same problem per SIMD (L2O_OPT_ONE_LDS = 2: always; the default 1:
+above #CU / 2 problems).  It is also the exchange-free form the host falls back to after a partner timeout of the two-CU
+kernel (tests/test_recovery.py).  (Round 4's second form, k_unroll_pair2, was removed in round 5.)
 Parity against the oracle for every optimizee and both DM preprocessings, ragged sizes, x scaling / B_global /
 continuation, the recording form, and against the chunked two-CU form (0)."""
 import numpy as np
@@ -22,8 +21,8 @@ def eng():
     return HipEngine()
 
 
-@pytest.mark.parametrize("form", [2, 3])
-@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])       # (rnnprop: k_unroll_lds only; form 3 = the plain two-CU kernel)
+@pytest.mark.parametrize("form", [2])
+@pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
 @pytest.mark.parametrize("kind,B,D,M", [("quadratic", 5, 128, None), ("quadratic", 3, 65, None), ("lasso", 4, 100, 70),
                                         ("lasso", 3, 128, 128), ("rastrigin", 6, 100, None), ("square_cos", 3, 81, None),
                                         ("rastrigin", 2, 113, None)])
@@ -39,7 +38,7 @@ def test_forced_lds_form_vs_oracle(eng, name, kind, B, D, M, form):
     if cfg.kind == "rnnprop":
         assert max_abs(m, res.m.reshape(B, D)) < 2e-6 * max(1.0, float(np.abs(res.m).max()))
         assert max_abs(v, res.v.reshape(B, D)) < 4e-6 * max(1.0, float(np.abs(res.v).max()))
-    print("%s %s/%s B=%d D=%d: rel fx=%.3g |dx|=%.3g" % ({2: "k_unroll_lds", 3: "k_unroll_pair2"}[form], name, kind, B, D, e_fx, e_x))
+    print("k_unroll_lds %s/%s B=%d D=%d: rel fx=%.3g |dx|=%.3g" % (name, kind, B, D, e_fx, e_x))
     assert e_fx < 1e-5
     assert e_x < 1e-5 * max(1.0, float(np.abs(res.x).max()))
     # (the cos optimizees turn an fp32-rounding difference of x into a larger one of the LSTM state: alpha = 10 times the
@@ -54,10 +53,9 @@ def test_forced_lds_form_vs_oracle(eng, name, kind, B, D, M, form):
 
 @pytest.mark.parametrize("name", ["dm", "rnnprop"])
 def test_large_shard_forms_equal_chunked_two_cu_form_and_oracle(eng, name):
-    """A shard of 300 problems (more than #CU / 2): the default (1) runs k_unroll_lds, 3 k_unroll_pair2 in chunks of #CU
-    problems, 0 the chunked two-CU form; each against the oracle (x scaling, B_global > B_local, step0); pair2 runs
-    the two-CU kernel's arithmetic in its order (same body, fragments read from LDS): the trajectory of the chunked form to
-    fp32 contraction differences; k_unroll_lds sums the GEMVs in another order; continuation (2 x T/2 == T) bit for bit."""
+    """A shard of 300 problems (more than #CU / 2): the default (1) runs k_unroll_lds, 0 the chunked two-CU form; each
+    against the oracle (x scaling, B_global > B_local, step0); k_unroll_lds sums the GEMVs in another order than the
+    two-CU kernel; continuation (2 x T/2 == T) bit for bit."""
     cfg = ORACLE_CFGS[name]
     params = make_params(cfg, seed=21, trained_like=True)
     B, D, T = 300, 128, 10
@@ -66,19 +64,18 @@ def test_large_shard_forms_equal_chunked_two_cu_form_and_oracle(eng, name):
     xs = np.exp(np.random.default_rng(3).uniform(-0.3, 0.3, (B, D))).astype(np.float32)
     res = O.unroll(prob, cfg, params, x0, O.net_initial_state(cfg, B * D), T, x_scale=xs, step0=1)
     out = {}
-    for mode in (1, 3, 0):
+    for mode in (1, 0):
         with lib_option(_abi.OPT_ONE_LDS, mode):
             out[mode] = _run_fused(eng, cfg, params, arrays, x0, B, D, T, Bg=2 * B, x_scale=xs)
         assert rel_err(out[mode][0], res.fx) < 1e-5, mode
         assert max_abs(out[mode][1], res.x.reshape(B, D)) < 1e-5 * max(1.0, float(np.abs(res.x).max()))
-    print("pair2 vs chunked two-CU: rel fx %.3g, identical x: %s; k_unroll_lds vs chunked: rel fx %.3g"
-          % (rel_err(out[3][0], out[0][0]), np.array_equal(out[3][1], out[0][1]), rel_err(out[1][0], out[0][0])))
-    assert rel_err(out[3][0], out[0][0]) < 1e-6 and rel_err(out[1][0], out[0][0]) < 2e-6
+    print("k_unroll_lds vs chunked two-CU: rel fx %.3g" % rel_err(out[1][0], out[0][0]))
+    assert rel_err(out[1][0], out[0][0]) < 2e-6
     # continuation: two launches of T / 2 carrying x and the LSTM state == one launch of T
     spec = spec_of(cfg)
     wpack = eng.pack_weights(spec, params)
     pd = device_problem(eng, arrays, B, D, B_global=2 * B, x_scale=xs)
-    for mode in (1, 3):
+    for mode in (1,):
         with lib_option(_abi.OPT_ONE_LDS, mode):
             x, st = eng.tensor(x0.reshape(B, D)), eng.state_alloc(B, D)
             m, v = eng.zeros(B, D), eng.zeros(B, D)
@@ -92,7 +89,7 @@ def test_large_shard_forms_equal_chunked_two_cu_form_and_oracle(eng, name):
     eng.check_unroll_status()
 
 
-@pytest.mark.parametrize("name,form", [("dm_logsign", 1), ("dm_logsign", 3), ("rnnprop", 1)])
+@pytest.mark.parametrize("name,form", [("dm_logsign", 1), ("rnnprop", 1)])
 def test_recording_form_equals_plain_unroll_prefixes(eng, name, form):
     """HIST instantiation (l2o_unroll_record on a large shard): the recording launch leaves the same x / fx as the plain
     one (a different instantiation: same arithmetic, the compiler may contract differently -> 1e-5), the recorded state
@@ -139,7 +136,7 @@ def test_recording_form_equals_plain_unroll_prefixes(eng, name, form):
     eng.check_unroll_status()
 
 
-@pytest.mark.parametrize("form", [2, 3])
+@pytest.mark.parametrize("form", [2])
 def test_shared_matrix_equals_replicated(eng, form):
     """L2O_PROB_W_SHARED (one [M, D] matrix for the whole batch, DM/problems.py lasso_fixed) through the LDS-fragment
     kernels == the same matrix replicated per problem, bit for bit."""
