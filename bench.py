@@ -85,7 +85,7 @@ def alg_flops_per_coord_step(problem, net, D, M):
 
 # ---- work-based roofline figure --------------------------------------------------------------
 # Measured ISSUE cost in shader cycles of one wave64 instruction per class, one wave per SIMD, independent operands
-# (scripts/microbench/valu_issue_cost.hip; profiles/r04c_valu_issue_cost.txt).  MFMA: its issue slot; the matrix pipe's
+# (scripts/microbench/valu_issue_cost.hip; profiles/archive_r04/r04c_valu_issue_cost.txt).  MFMA: its issue slot; the matrix pipe's
 # own occupancy (16 cycles per v_mfma_f32_16x16x32_bf16) is reported separately as mfma_pipe_floor.
 # Measured (r04c): v_fma_f32 / v_pk_fma_f32 / v_cvt_pk_bf16_f32 5.2-5.3 cycles (ONE wave per SIMD issues a plain VALU
 # instruction every ~5.3 cycles, not every 4: the 4-cycle rate needs a second wave), v_exp_f32 / v_rcp_f32 8.5,
@@ -93,7 +93,7 @@ def alg_flops_per_coord_step(problem, net, D, M):
 ISSUE_COST = {"valu": 5.26, "trans": 8.51, "mfma": 5.26}
 MFMA_PIPE_CYCLES = 17.89
 # What the SIMD's PIPES take per instruction once two or more waves feed them (scripts/microbench/two_wave_issue.hip,
-# profiles/r04w_two_wave_issue.txt: 1.220 / 3.496 / 6.744 ns per instruction per SIMD, x 2.4 GHz like every cycle figure
+# profiles/archive_r04/r04w_two_wave_issue.txt: 1.220 / 3.496 / 6.744 ns per instruction per SIMD, x 2.4 GHz like every cycle figure
 # here): a plain VALU instruction 2.93 cycles (one wave alone: 5.6), a transcendental 8.39 (the same pipe: their times add),
 # the bf16 MFMA 16.2 on its own pipe (overlaps another wave's VALU).  The floor of the two-waves-per-SIMD kernels.
 PIPE_COST = {"valu": 2.93, "trans": 8.39, "mfma": 16.2}
@@ -126,9 +126,11 @@ def work_model(problem, net, D, M):
 
 def work_block(case, issue, args, clock_hz):
     """The work-based figures of a VALU-bound fused kernel.
-    cycles_per_step: shader-clock cycles one SIMD spends per optimizer step -- MEASURED inside the kernel (s_memtime
-        around the step loop of workgroup 0, workspace bytes 16..23, / (T + 0.3): the T + 1-st loss evaluation is ~1/3 of
-        a step); without that word: live kernel time x clock / (chunk launches x rounds of problems per CU x (T + 0.3)).
+    cycles_per_step: shader-clock cycles one SIMD spends per optimizer step -- MEASURED inside the kernel (s_memtime of
+        wave 0 of workgroup 0 from kernel entry to its last store, workspace bytes 24..31, / (T + 0.3): prologue and
+        epilogue are charged to the steps, the T + 1-st loss evaluation is ~1/3 of a step; cycles_per_step_loop: the step
+        loop alone, bytes 16..23); without those words: live kernel time x clock / (chunk launches x rounds of problems
+        per CU x (T + 0.3)).
     pipe_floor_cycles_per_step: the STATED minimal instruction counts of the tile-steps that SIMD does per step
         (bench.py: work_model; 1 tile per SIMD for the one-wave kernels, 2 for k_unroll_lds) x the PIPE time per
         instruction class (plain VALU 2.93, transcendental 8.39 cycles: two_wave_issue.hip) -- what the SIMD's VALU pipe
@@ -148,15 +150,17 @@ def work_block(case, issue, args, clock_hz):
     dispatches = float(case.get("dispatches", 1))
     rounds = -(-case["B"] // max(1, case.get("n_cus", 256))) if two_waves else 1
     cyc_time = case["kern_ms"] * 1e-3 * clock_hz / (dispatches * rounds * (T + 0.3))
-    ticks = case.get("loop_ticks")
-    cyc = ticks / (T + 0.3) if ticks else cyc_time
+    ticks = case.get("loop_ticks")                       # (step loop, kernel entry to exit) of wave 0 of workgroup 0
+    cyc = ticks[1] / (T + 0.3) if ticks else cyc_time
     floor = tiles_per_simd * per_tile_pipe
-    out = {"cycles_per_step": cyc, "cycles_source": "s_memtime around the step loop of workgroup 0 (workspace bytes 16..23)" if ticks
+    out = {"cycles_per_step": cyc, "cycles_source": "s_memtime, kernel entry to exit of wave 0 of workgroup 0 (workspace bytes 24..31)" if ticks
            else "kernel_ms_avg x clock_hz", "cycles_per_step_from_kernel_time": cyc_time, "clock_hz": clock_hz,
            "tiles_per_simd": tiles_per_simd, "work_model_instructions_per_tile_step": wm,
            "pipe_cost_cycles": dict(PIPE_COST), "pipe_floor_cycles_per_step": floor,
            "mfma_pipe_cycles_per_step": tiles_per_simd * wm["mfma"] * PIPE_COST["mfma"],
            "frac_work": floor / cyc}
+    if ticks:
+        out.update(cycles_per_step_loop=ticks[0] / (T + 0.3), frac_step_loop=floor * (T + 0.3) / ticks[0])
     if not two_waves:
         issue_floor = (wm["valu_plain"] * ISSUE_COST["valu"] + wm["transcendental"] * ISSUE_COST["trans"] + wm["mfma"] * ISSUE_COST["mfma"])
         out.update(issue_cost_cycles=dict(ISSUE_COST), issue_floor_cycles_per_step=issue_floor, issue_cost_frac=issue_floor / cyc)
@@ -373,7 +377,7 @@ def counters_for(workload, kernel_hint, build_id):
     r04av): a file collected on the build being timed (build_id == l2o_build_id() of the loaded library) wins and is
     "same_build"; otherwise the most recently collected one (collected_unix inside the file; files from before round 5
     carry neither and rank oldest) is returned as "stale" -- its instruction counts belong to another build."""
-    paths = glob.glob(os.path.join(ROOT, "profiles", "*_counters_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "*", "*_counters_*.json"))
+    paths = glob.glob(os.path.join(ROOT, "profiles", "*_counters_*.json"))    # (profiles/archive_*: earlier rounds' builds, not consulted)
     if os.environ.get("L2O_COUNTERS_DIR"):
         paths += glob.glob(os.path.join(os.environ["L2O_COUNTERS_DIR"], "counters_*.json"))
     best = None
@@ -531,11 +535,11 @@ def run_case(args, eng, world, rank, Bg, B, label):
     fence()
     # queue-depth rehearsal (untimed, like the warm-up): with prepared calls the host enqueues an unroll in ~11 us and
     # runs hundreds of launches ahead of the GPU; the FIRST time a process has that many commands in flight the HIP
-    # runtime grows its command pools -- one ~37 ms host stall (host-timestamp trace: profiles/r03l_host_enqueue_trace.txt)
+    # runtime grows its command pools -- one ~37 ms host stall (host-timestamp trace: profiles/archive_r01_r03/r03l_host_enqueue_trace.txt)
     # that would otherwise land inside the timed region.  One rehearsal of the timed region's launch count removes it.
     # (config 4's chunked unroll -- 16 launches each -- showed a second one-time stall, 40-50 ms, at the process's ~55th
     #  unroll whatever the flags: `--steps 10` put it at enqueue #3 of the timed region.  At least 128 untimed unrolls
-    #  per process keep it out: profiles/r03last_host_trace_c4.txt)
+    #  per process keep it out: profiles/archive_r01_r03/r03last_host_trace_c4.txt)
     rehearse = max(args.steps * reps, 128 - args.warmup * reps) if args.warmup > 0 else 0
     rtrace = [time.perf_counter()] if os.environ.get("L2O_BENCH_HOST_TRACE") else None
     for _ in range(rehearse):
@@ -772,7 +776,7 @@ def main(argv=None):
                                                                        ", BASELINE.json configs[1]" if is_c2 else "")
         if not full:
             keep = ("kernel", "kernel_ms_avg", "bound", "frac", "achieved", "peak", "unit", "traffic", "traffic_over_model",
-                    "cycles_per_step", "cycles_source", "pipe_floor_cycles_per_step", "tiles_per_simd", "valu_active_frac",
+                    "cycles_per_step", "cycles_per_step_loop", "cycles_source", "pipe_floor_cycles_per_step", "tiles_per_simd", "valu_active_frac",
                     "alg_bytes_frac", "fp32_frac", "counters", "counters_source")
             out = {"workload": workload, "baseline_config": baseline_config, "value": c["value"], "unit": "coordinate-steps/s",
                    "steps": a.steps, "unrolls_per_step": c["reps"], "ms_per_unroll": c["ms_per_unroll"],

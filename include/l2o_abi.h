@@ -138,8 +138,9 @@ int l2o_last_unroll_form(void);
                                         exchange granules with plain stores (L2-resident); 0: agent-scope stores always    */
 #define L2O_OPT_UNROLL_CU 2          /* the streaming fused unroll for D > 128: 1*: on -- RNNProp's plain unroll on eight waves
                                         per workgroup with the fragments in LDS and the LSTM state in registers (k_unroll_cu8),
-                                        everything else on four waves (k_unroll_cu); 2: k_unroll_cu always; 3 / 4: k_unroll_cu8
-                                        always (4 / 3 register tiles per wave); 0: such sizes run step-granular               */
+                                        everything else on four waves (k_unroll_cu) -- since ABI v12 the DM nets and the recording
+                                        unrolls too, where their LDS image fits; 2: k_unroll_cu always; 3 / 4 / 5: k_unroll_cu8
+                                        always (4 / 3 / 2 register tiles per wave); 0: such sizes run step-granular           */
 #define L2O_OPT_FG_TWO_PASS 3        /* (l2o_problem.flags: L2O_PROB_FG_TWO_PASS)                                           */
 #define L2O_OPT_MLP_GENERIC 4        /* (l2o_mlp.flags: L2O_MLP_GENERIC)                                                    */
 #define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups (L2O_OPTW_BWD_BLOCKS) */
@@ -533,8 +534,9 @@ int l2o_wpack_device(const l2o_net_cfg* cfg, const l2o_net_weights* w, float* wp
  * a kernel that exchanges data behaves as if its partners never showed up -- it raises the status at once
  * and its results are invalid; the exchange-free forms ignore it.  Bytes 16..23 (ABI v12, int64): the shader-clock
  * cycles (s_memtime) wave 0 of workgroup 0 spent in the step loop of the LAST launch on this workspace (the two-CU
- * kernel, k_unroll_lds, l2o_mlp_unroll) -- T steps + the final loss evaluation -- a measurement in cycles that needs
- * no clock-frequency assumption (bench.py's roofline block).  A workspace must start zeroed
+ * kernel, k_unroll_lds, l2o_mlp_unroll) -- T steps + the final loss evaluation --, bytes 24..31 the same wave's cycles
+ * from kernel entry to its last store: measurements in cycles that need no clock-frequency assumption (bench.py's
+ * roofline block).  A workspace must start zeroed
  * (see l2o_unroll_workspace_init / _layout below) and must not be shared by two streams at the same time.
  * Problems beyond the LDS-resident sizes (D <= 512, D % 4 == 0, any M) run the streaming
  * form: one workgroup per problem, the matrix streamed once per step, x / state / moments on-chip

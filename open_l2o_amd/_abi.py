@@ -54,7 +54,7 @@ _ENV_OPTIONS = (
     ("L2O_NO_PAIR", OPT_PAIR, lambda v: 0),
     ("L2O_PAIR_AGENT_STORES", OPT_PAIR_PLAIN_STORES, lambda v: 0),
     ("L2O_NO_UNROLL_CU", OPT_UNROLL_CU, lambda v: 0),
-    ("L2O_UNROLL_CU", OPT_UNROLL_CU, lambda v: int(v)),       # 2: k_unroll_cu always; 3 / 4: k_unroll_cu8 always (4 / 3 register tiles per wave)
+    ("L2O_UNROLL_CU", OPT_UNROLL_CU, lambda v: int(v)),       # 2: k_unroll_cu always; 3 / 4 / 5: k_unroll_cu8 always (4 / 3 / 2 register tiles per wave)
     ("L2O_FG_TWO_PASS", OPT_FG_TWO_PASS, lambda v: 1),
     ("L2O_MLP_GENERIC", OPT_MLP_GENERIC, lambda v: 1),
     ("L2O_BWD_BLOCKS", OPT_BWD_BLOCKS, lambda v: int(v)),

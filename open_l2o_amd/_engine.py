@@ -647,13 +647,14 @@ class HipEngine(object):
         return (int(self.lib.l2o_last_unroll_form()) & 0xff) in _abi.FORMS_WITH_EXCHANGE
 
     def last_loop_ticks(self):
-        """Shader-clock cycles workgroup 0 spent in the step loop of the last fused launch (workspace bytes 16..23; the
-        two-CU kernel, k_unroll_lds, l2o_mlp_unroll), or None.  Synchronises the host."""
+        """(step-loop cycles, kernel-entry-to-exit cycles) of wave 0 of workgroup 0 in the last fused launch -- shader-clock
+        cycles (s_memtime), workspace bytes 16..31; the two-CU kernel, k_unroll_lds, l2o_mlp_unroll -- or None.
+        Synchronises the host."""
         ws = self._last_ws
         if ws is None:
             return None
-        v = int(ws[16:24].view(torch.int64).item())
-        return v if v > 0 else None
+        loop, total = (int(v) for v in ws[16:32].view(torch.int64).cpu())
+        return (loop, total) if loop > 0 and total >= loop else None
 
     def unroll_status_tensor(self):
         """The sticky status word of the last fused launch's workspace as a device int32 [1] view (None without a

@@ -306,7 +306,7 @@ __device__ __forceinline__ void lstm_issue_l1_prev(const NetW<PRE>& w, const Til
 //   sigmoid(i) tanh(j) = sgn(j) (1-E_j) / ((1+e_i)(1+E_j))
 // (5 v_exp + 3 v_rcp per unit instead of 5 + 5; no overflow: e_i = inf -> rcp(inf) = 0).
 // The code is STAGE-major over the 5 independent units: MFMA and VALU instructions of one
-// SIMD do not execute concurrently on gfx950 (profiles/r01_b_microbench_*), so what matters
+// SIMD do not execute concurrently on gfx950 (profiles/archive_r01_r03/r01_b_microbench_*), so what matters
 // for the VALU part is instruction-level parallelism -- five independent dependency chains
 // side by side hide the ~8-cycle transcendental / ~4-cycle VALU latencies in one wave.
 __device__ __forceinline__ void lstm_gates5(const f32x4 (&acc)[kNT], float (&c)[kNT], float (&h)[kNT]) {

@@ -1236,15 +1236,22 @@ static int launch_unroll_cu8(const UnrollArgs& a, hipStream_t s) {
 template <int PRE>
 static int launch_unroll_cu(const UnrollArgs& a_in, hipStream_t s) {
   const int form = (int)opt(L2O_OPT_UNROLL_CU);
-  // (default: the eight-wave form for RNNProp's plain unroll -- config 3: kernel 5.55 -> 4.60 ms, 3 spilled registers; the
-  //  DM nets' and the recording instantiations spill 70-250 registers at the 256-register cap and stay on the four-wave
-  //  kernel: DESIGN.md 3.1c)
+  // Default (1): the eight-wave form (k_unroll_cu8) with the number of register-resident state tiles per wave (KR) that the
+  // instantiation holds without spilling at 256 registers (scripts/tu_regs.sh; D = 512): RNNProp's plain unroll 4 (config 3:
+  // 3 spilled registers, measured best), the DM nets' plain unroll 3 (round 5: their input-weight rows moved to LDS; 0
+  // spills -- with 4: 31-37; measured on DM / Lasso 256 x 512, batch 256: 5.25 G four-wave, 5.26 G KR = 4, 6.24 G KR = 3),
+  // every recording unroll 2 (0 / 10 spills) where that LDS image fits (two more 5 KB state slots per wave: D <= 256), the
+  // DM nets' recording unroll at larger D 3 (8 spills); RNNProp's recording unroll at D > 256 stays on the four-wave kernel
+  // (KR = 3: 52 spills).  2: k_unroll_cu always; 3 / 4 / 5: k_unroll_cu8 always with KR = 4 / 3 / 2 where it fits (A/B runs).
   const bool hist0 = a_in.hist_st != nullptr;
-  if ((form == 1 && PRE == L2O_PRE_FC_ELU && !hist0) || form == 3 || form == 4) {
-    const int KR = form == 4 ? 3 : 4;
-    if (unroll_cu8_layout(a_in.pp.D, PRE, KR).lds + sizeof(float) * bx::kBiasWords <= 160 * 1024)
-      return KR == 4 ? launch_unroll_cu8<PRE, 4>(a_in, s) : launch_unroll_cu8<PRE, 3>(a_in, s);
-  }
+  auto fits = [&](int kr) { return unroll_cu8_layout(a_in.pp.D, PRE, kr).lds + sizeof(float) * bx::kBiasWords <= 160 * 1024; };
+  int KR = 0;
+  if (form == 1) {
+    KR = hist0 ? 2 : (PRE == L2O_PRE_FC_ELU ? 4 : 3);
+    if (hist0 && !fits(2) && PRE != L2O_PRE_FC_ELU) KR = 3;
+  } else if (form >= 3 && form <= 5) KR = 7 - form;
+  if (KR && fits(KR))
+    return KR == 4 ? launch_unroll_cu8<PRE, 4>(a_in, s) : (KR == 3 ? launch_unroll_cu8<PRE, 3>(a_in, s) : launch_unroll_cu8<PRE, 2>(a_in, s));
   const UnrollCuLayout L = unroll_cu_layout(a_in.pp.D);
   const UnrollArgs& a = a_in;
   const bool hist = a.hist_st != nullptr;
@@ -1842,7 +1849,7 @@ static bool mlp_unroll_layout(const l2o_mlp* mlp, MlpUnrollLayout* L) {
   L->NSM = (size_t)H + (size_t)H * O + O;
   L->R = (int)((L->NO + L->nwg - 1) / L->nwg);
   L->R = (L->R + 1) & ~1;                                // even: the fast path moves granules in pairs
-  // one 64-byte line per (source, reducer): R = 8 measured best (profiles/r02l: R = 6 / 8 / 12 / 16 -> 1.32 / 1.35 /
+  // one 64-byte line per (source, reducer): R = 8 measured best (profiles/archive_r01_r03/r02l: R = 6 / 8 / 12 / 16 -> 1.32 / 1.35 /
   // 1.28 / 1.24 G on config 5)
   if (L->R < 8 && L->NO >= 8 * 32) L->R = 8;
   if (L->R > kMuMaxR) return false;

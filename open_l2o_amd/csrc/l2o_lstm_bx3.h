@@ -1,7 +1,7 @@
 // l2o_lstm_bx3.h -- the LSTM gate GEMM on the bf16 matrix cores, at fp32 accuracy.
 //
 // Why: on gfx950 the fp32-input MFMA (v_mfma_f32_16x16x4_f32) executes at the fp32 VECTOR
-// rate and does not overlap with VALU work of the same SIMD (profiles/r01_b_microbench_*:
+// rate and does not overlap with VALU work of the same SIMD (profiles/archive_r01_r03/r01_b_microbench_*:
 // 32 cycles each, 80 per tile-step = 35 % of the fused kernel), while bf16 MFMAs run on the
 // matrix pipe concurrently with the VALU.  Every fp32 value is therefore split into three
 // bf16 terms  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
@@ -80,7 +80,7 @@ __host__ __device__ constexpr int win_words(int pre) { return pre == L2O_PRE_FC_
 // (stage_bias) and read as one ds_read_b128 per M-tile.  Round 3: the bias used to ride in two spare K-slots of the
 // gate GEMM (B = 1.0); v_mfma_f32_16x16x32_bf16 chops every product of an 8-slot group at 2^-24 of the group's LARGEST
 // (scripts/microbench/mfma_round_probe.hip) and the O(1) bias was that largest: it cost the unit products next to it
-// their low bits, one-sidedly -- the ~1e-5 drift of every bf16x3 kernel at T = 1000 (profiles/r03c_drift_forms.txt).
+// their low bits, one-sidedly -- the ~1e-5 drift of every bf16x3 kernel at T = 1000 (profiles/archive_r01_r03/r03c_drift_forms.txt).
 constexpr int kBiasWords = 2 * kNT * 4 * 4;
 __host__ __device__ constexpr int bias_off(int pre) { return win_off(pre) + win_words(pre); }
 __host__ __device__ constexpr int words(int pre) { return packed_words(pre) + level_words(pre) + win_words(pre) + kBiasWords; }
@@ -191,6 +191,7 @@ struct NetWB {
   const __attribute__((address_space(3))) f32x4* bias;   // LDS: this lane group's [layer][t] accumulator inits (set_bias)
   static constexpr bool kLdsFrags = false;               // (NetWBL: the A operands are read from LDS at issue time)
   static constexpr int kFragFence = 0;
+  static constexpr bool kLdsWin = false;                 // (NetWBLF: win0 / win1 are read from LDS where they are used)
 };
 // The packed DM network with its weight FRAGMENTS IN LDS (round 4, k_unroll_lds): `a` is never loaded (no registers), an
 // MFMA's A operand is one ds_read_b128 from the workgroup's 60 KB fragment image -- what lets TWO waves share a SIMD
@@ -230,7 +231,7 @@ __device__ __forceinline__ void load_netw(NetWB<PRE, PK>& w, const float* __rest
   const float* p = wp + lane;
 #pragma unroll
   for (int t = 0; t < kNT; ++t) {
-    if (PRE != L2O_PRE_FC_ELU) {
+    if (PRE != L2O_PRE_FC_ELU && !std::decay<decltype(w)>::type::kLdsWin) {
       w.win0[t] = *reinterpret_cast<const f32x4*>(wp + win_off(PRE) + t * 256 + lane * 4);
       if (PRE == L2O_PRE_LOGSIGN)
         w.win1[t] = *reinterpret_cast<const f32x4*>(wp + win_off(PRE) + (kNT + t) * 256 + lane * 4);
@@ -407,6 +408,14 @@ __device__ __forceinline__ float finish(const W& w, TileState& s, BOp<PK>& b1, B
     BOp<PK> bf;
     split5<PK>(fc, 0u, bf);
     issue<PRE, kChL1X, 0, kN, false>(w, bf, acc1);
+  } else if constexpr (W::kLdsWin) {
+    // the DM nets' input-weight rows from LDS (round 5, k_unroll_cu8: 20 / 40 registers per wave that the 256-register
+    // budget of two waves per SIMD does not have): one ds_read_b128 per (feature, M-tile), like the bias table
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      acc1[t] += w.lwin[t * 64] * in0;
+      if (PRE == L2O_PRE_LOGSIGN) acc1[t] += w.lwin[(kNT + t) * 64] * in1;
+    }
   } else {
 #pragma unroll
     for (int t = 0; t < kNT; ++t) {
@@ -421,7 +430,7 @@ __device__ __forceinline__ float finish(const W& w, TileState& s, BOp<PK>& b1, B
 #define L2O_FINISH_PINNED_LDSFRAGS 0
 #endif
   // (LDS-resident fragments: the pinning asm makes the wave wait for the five bias reads on the spot -- behind the
-  //  fragment reads of eight waves; the default leaves the wait to the first MFMA that needs acc1: -1..2 %, profiles/r04x_*)
+  //  fragment reads of eight waves; the default leaves the wait to the first MFMA that needs acc1: -1..2 %, profiles/archive_r04/r04x_*)
   constexpr bool kPinBias = !W::kLdsFrags || L2O_FINISH_PINNED_LDSFRAGS;
   if (REARM || NEXT) preload_bias<0, W, kPinBias>(w, acc1);   // acc1 is dead: the next step's layer-1 accumulator init
   pc.mark(6);
@@ -613,8 +622,26 @@ namespace bx {
 #ifndef L2O_CU8_FRAG_FENCE
 #define L2O_CU8_FRAG_FENCE 0
 #endif
+#ifndef L2O_CU8_LDS_WIN
+#define L2O_CU8_LDS_WIN 1
+#endif
 template <int PRE>
-struct NetWBLF : NetWBL<PRE> { static constexpr int kFragFence = L2O_CU8_FRAG_FENCE; };   // (k_unroll_cu8)
+struct NetWBLF : NetWBL<PRE> {                                                            // (k_unroll_cu8)
+  static constexpr int kFragFence = L2O_CU8_FRAG_FENCE;
+  static constexpr bool kLdsWin = L2O_CU8_LDS_WIN && PRE != L2O_PRE_FC_ELU;
+  const __attribute__((address_space(3))) f32x4* lwin;   // LDS: this lane's 16 bytes of input-weight row 0 ([rows][64 lanes][4])
+  static constexpr int kWinFloats = PRE == L2O_PRE_FC_ELU ? 0 : (PRE == L2O_PRE_LOGSIGN ? 2 : 1) * kNT * 256;
+};
+// every thread copies its share of the input-weight rows of wpack into LDS; the caller's barrier follows
+template <int PRE>
+__device__ __forceinline__ void stage_win(NetWBLF<PRE>& w, float* lds, const float* __restrict__ wp, int tid, int nthreads, int lane) {
+  if constexpr (NetWBLF<PRE>::kLdsWin) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(wp + win_off(PRE));
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i = tid; i < NetWBLF<PRE>::kWinFloats / 4; i += nthreads) dst[i] = src[i];
+    w.lwin = reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const __attribute__((address_space(3))) float*)lds) + lane;
+  }
+}
 }  // namespace bx
 
 // BX packed form with the fragments in LDS (bx::NetWBL): the same interface as LstmCore, <= 256 registers per lane

@@ -62,7 +62,8 @@ struct MlpWs {                 // header of the caller-owned workspace (never cl
   unsigned pad0;
   long long ticks;             // ABI v12 (bytes 16..23): shader-clock cycles wave 0 of workgroup 0 spent in the step loop of
                                // the last launch (see PairWs)
-  unsigned pad[10];
+  long long ticks_total;       // (bytes 24..31) ... from kernel entry to its last store
+  unsigned pad[8];
   long long phases[16];        // phase clock dump of the -DL2O_PROFILE_PHASES build (else unused)
 };
 
@@ -155,7 +156,7 @@ __device__ __forceinline__ void mu_nap() {
 // The step loop's workgroup barrier.  -DL2O_MU_LDS_BARRIERS: wait for LDS traffic only (the barriers order LDS data; the
 // cross-workgroup protocol is self-validating granules) instead of __syncthreads(), which also drains the vector-memory
 // queue -- e.g. the next minibatch's image columns at the barrier behind dH.  Measured 1 % SLOWER (kernel 1.885 vs 1.869 ms
-// per T = 200 unroll, profiles/r04k_c5_barriers_ab.txt): not the default.
+// per T = 200 unroll, profiles/archive_r04/r04k_c5_barriers_ab.txt): not the default.
 __device__ __forceinline__ void mu_barrier() {
 #ifdef L2O_MU_LDS_BARRIERS
   lds_barrier();
@@ -186,6 +187,7 @@ __device__ __forceinline__ mu_u32x4 mu_poll2(const unsigned long long* p, mu_u32
 // (the one at x_T included), T optimizer steps.
 template <int PRE, bool FAST, bool HIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_unroll(MlpUnrollArgs a) {
+  const long long kernel_t0 = __builtin_readcyclecounter();
   __shared__ float xwg_p[32 + 64 + 64];               // the workgroup's 64 scaled coordinates, zero margins (w1 owners)
   float* xwg = xwg_p + 32;
   __shared__ float imgs[2][kMuMaxBatch][kMuMaxKR];    // the image columns the workgroup's w1 rows touch, by step parity
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // first barrier its two dependent latencies sat on the critical path), completed under the forward tail
     // (-DL2O_MU_IDX_LDS: the indices of the next minibatch are requested at the TOP of the step -- nidx below -- and passed
     //  through LDS behind the reduce phase's barrier instead of being loaded here, in front of the image / label loads that
-    //  depend on them.  Measured 2 % SLOWER (kernel 1.904 vs 1.867 ms per T = 200 unroll, profiles/r04j_*): not the default)
+    //  depend on them.  Measured 2 % SLOWER (kernel 1.904 vs 1.867 ms per T = 200 unroll, profiles/archive_r04/r04j_*): not the default)
     auto prefetch_next = [&]() {
 #ifdef L2O_MU_ABL_NOPREFETCH   // (timing ablation: no minibatch gather -- wrong numerics; what do the two dependent loads cost?)
 #pragma unroll
@@ -833,7 +835,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // static trip count (minibatch 64: 16 samples per q lane): all 32 LDS reads in flight, four partial sums --
       // the dynamic-bound loop below waited out one LDS round trip per sample (1.385 -> 1.41 G).  The same cure for
       // the forward tail and dH (79 s_waitcnt lgkmcnt: one per w2 row) does NOT pay: batched reads need 48-60 more
-      // registers in a kernel that already spills 20 (1.41 -> 1.22 G; profiles/r02u_mlp_variants.txt)
+      // registers in a kernel that already spills 20 (1.41 -> 1.22 G; profiles/archive_r01_r03/r02u_mlp_variants.txt)
       const int k = jl / 20, h = jl - k * 20;
       float g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -909,5 +911,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (tile_real) store_tile_state(s, st_tile, lane);
   // every workgroup read ws->seq at its start and none can finish before all have started (the first
   // all-reduce needs every partial): workgroup 0 may advance the sequence word now
-  if (wg == 0 && tid == 0) a.ws->seq = a.ws->seq + 1u;
+  if (wg == 0 && tid == 0) {
+    a.ws->seq = a.ws->seq + 1u;
+    a.ws->ticks_total = __builtin_readcyclecounter() - kernel_t0;
+  }
 }

@@ -29,8 +29,10 @@ static inline UnrollCu8Layout unroll_cu8_layout(int D, int pre, int KR) {
   L.nlds = L.nslots > KR ? L.nslots - KR : 0;
   L.DP = L.tpp * kTile;
   L.frag_floats = (size_t)bx::packed_words(pre);
+  // (+ the DM nets' input-weight rows, read from LDS like the biases: round 5)
+  const size_t win_floats = pre == L2O_PRE_FC_ELU ? 0 : (size_t)(pre == L2O_PRE_LOGSIGN ? 2 : 1) * kNT * 256;
   L.lds = sizeof(float) * (L.frag_floats + (size_t)kCu8Waves * L.nlds * kCuSlotF4 * 4 + (size_t)kCu8Waves * D +
-                           5 * (size_t)L.DP + 8);
+                           5 * (size_t)L.DP + 8 + win_floats);
   return L;
 }
 
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
   float* mL = scL + DP;                  // [DP] RNNProp moments
   float* vL = mL + DP;
   float* red = vL + DP;                  // [8]
+  float* winL = red + 8;                 // [Core WT::kWinFloats] the DM nets' input-weight rows (16-byte aligned: DP % 16 == 0)
 
   const int kind = pp.kind;
   const bool kCos = kind == L2O_PROB_RASTRIGIN || kind == L2O_PROB_SQUARE_COS;
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
   core.stage_frags(frs, a.np.wpack, tid, kCu8Threads, lane);
   __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];
   core.stage_bias(bias_s, a.np.wpack, tid, kCu8Threads, q);
+  bx::stage_win<PRE>(core.w, winL, a.np.wpack, tid, kCu8Threads, lane);
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   float om1 = 1.0f, om2 = 1.0f;
   __syncthreads();

@@ -40,6 +40,7 @@
 
 template <int PRE, int KIND, bool HIST>
 __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
+  const long long kernel_t0 = __builtin_readcyclecounter();
   constexpr int CH = 8, SQ = 16 * CH;
   using Core = LstmCoreLds<PRE>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -212,4 +213,5 @@ __global__ __launch_bounds__(512) void k_unroll_lds(UnrollArgs a) {
     if (PRE == L2O_PRE_FC_ELU) { a.m[idx] = mv; a.v[idx] = vv; }
   }
   store_tile_state(s, st_tile, lane);
+  if (a.ticks && blockIdx.x == 0 && threadIdx.x == 0) a.ticks[1] = __builtin_readcyclecounter() - kernel_t0;   // (PairWs::ticks_total)
 }

@@ -38,7 +38,8 @@ struct PairWs {               // header of the caller-owned workspace (never cle
   long long ticks;            // ABI v12 (bytes 16..23): shader-clock cycles (s_memtime) wave 0 of workgroup 0 spent in the step
                               // loop of the LAST launch on this workspace -- T steps + the final loss evaluation.  What
                               // bench.py's roofline block divides its work model by: measured cycles, no clock assumption
-  unsigned pad[10];
+  long long ticks_total;      // (bytes 24..31) the same wave from kernel entry to its last store: prologue and epilogue included
+  unsigned pad[8];
   long long phases[16];       // phase clock dump of the -DL2O_PROFILE_PHASES build (else unused)
 };
 static_assert(sizeof(PairWs) == 64 + 128, "workspace header layout (include/l2o_abi.h)");
@@ -64,7 +65,7 @@ __device__ __forceinline__ unsigned long long pack_granule(float v, unsigned tag
 // their data from landing in a register an in-flight MFMA still reads as SrcC (the allocator hands dead chain
 // registers out at once).  Every use below sits behind an LDS barrier (>= the 18 wait states of the longest
 // MFMA WAR hazard); an experiment in k_mlp_unroll that issued such reads right after 60 MFMAs produced NaNs
-// (profiles/r02u_mlp_variants.txt).
+// (profiles/archive_r01_r03/r02u_mlp_variants.txt).
 template <int N>
 __device__ __forceinline__ void lds_read_f4(float4 (&v)[N], const float* p) {
   const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void dot4v(const float4 a, const l2o::f32x4 b, float4
 // The same four chains as two v_pk_fma_f32 (lanes x,y | z,w): half the GEMV's instructions; the operands are register
 // quads (W packed once in the prologue, x / r straight from ds_read_b128), so the halves are sub-registers, no copies.
 // hsum4pk adds in hsum4's order: bit-identical to dot4v + hsum4.  (L2O_GEMV_PK=0 restores the scalar FMAs.)
-// Measured (profiles/r04aa_*): config 2, ONE wave per SIMD -- the wave is issue-bound and 32 fewer instructions per step are
+// Measured (profiles/archive_r04/r04aa_*): config 2, ONE wave per SIMD -- the wave is issue-bound and 32 fewer instructions per step are
 // worth 4 % (8.78 -> 9.15 G); with TWO waves per SIMD (k_unroll_lds) the VALU pipe is the limit, a packed FMA
 // occupies it twice as long, and the packed form is 1.5-3 % SLOWER: those keep the scalar FMAs.
 #ifndef L2O_GEMV_PK
@@ -139,6 +140,7 @@ __device__ __forceinline__ void dot4q(const l2o::f32x4 a, const l2o::f32x4 b, fl
 //  k_unroll_lds and was removed in round 5)
 template <int PRE, int KIND, int CH, bool HIST, bool EXACT>
 __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
+  const long long kernel_t0 = __builtin_readcyclecounter();
   constexpr int SQ = 16 * CH;            // padded rows (and columns) of the problem
   constexpr int NWH = CH / 2;            // waves (tiles) per half; tiles beyond the real count idle
   constexpr int NC = 16 * NWH;           // columns (coordinates) owned by a half = SQ / 2
@@ -359,6 +361,11 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
       else
         __hip_atomic_store(mine + par * SQ + myrow, pack_granule(part, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // (round 5) cos / sin of 2 pi x s for the rastrigin / square_cos terms: computed HERE, in front of the recurrent MFMAs
+    // whose issue they interleave with, instead of behind the partner poll (the loss term) and inside the g pass (the
+    // gradient term) -- both on the step's critical path.  Same function, same argument: bit-identical results.
+    l2o::SinCos trig = {0.0f, 1.0f};
+    if (kCos) trig = l2o::sincos_f(kTwoPi * xsv);
     pc.mark(3);                                             // partial r + publish
     // 30 MFMAs (L2B) give the partner time to publish; the first poll load goes out THEN and its L2 round trip
     // is covered by the other 30 MFMAs (L1H) -- in program order, a single wave issues in order
@@ -403,12 +410,12 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     }
     if (live && q == 0) {
       if (KIND == L2O_PROB_LASSO) contrib += pp.l1 * __builtin_fabsf(xsv);
-      if (kCos) contrib += pp.alpha - pp.alpha * cj * l2o::cos_f(kTwoPi * xsv);
+      if (kCos) contrib += pp.alpha - pp.alpha * cj * trig.c;
     }
     // the state BEFORE this step's update, for the meta-gradient.  Stored HERE: the poll above is this step's last wait
     // on vmcnt (loads and stores retire in order), the barriers of the recording kernel wait for LDS traffic only, so
     // the 5 KB per wave drain under the gate blocks instead of sitting in front of a wait (recording kernel / plain
-    // kernel time at config-2 size: 1.26 -> 1.22, profiles/r03t_*)
+    // kernel time at config-2 size: 1.26 -> 1.22, profiles/archive_r01_r03/r03t_*)
     // (non-temporal stores for these records: 240 -> 338 us per recording unroll -- they stall the store path)
     if (HIST && t < a.T && tile_real)
       store_tile_state(s, a.hist_st + ((size_t)t * pp.B_local * tpp + (size_t)b * tpp + tile_in_prob) *
@@ -453,7 +460,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     float gv = quad_q_sum((kR4 && kPk) ? hsum4pk(gaccp) : hsum4(gacc4));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
-    if (kCos) gv += kTwoPi * pp.alpha * cj * l2o::sin_f(kTwoPi * xsv);
+    if (kCos) gv += kTwoPi * pp.alpha * cj * trig.s;
     gv = live ? gv * cg * sc : 0.0f;
     if (HIST && live && q == 0) {
       if (t < a.T) a.hist_g[(size_t)t * hist_n + idx] = gv;
@@ -517,6 +524,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     if (PRE == L2O_PRE_FC_ELU) { a.m[idx] = mv; a.v[idx] = vv; }
   }
   if (tile_real) store_tile_state(s, st_tile, lane);
+  if (bid == 0 && tid == 0) pa.ws->ticks_total = __builtin_readcyclecounter() - kernel_t0;
 }
 
 template <int PRE, int KIND, int CH, bool HIST, bool EXACT = false>

@@ -2,7 +2,7 @@
 // sits between two fp32 values: the returned bits tell round-to-nearest-even from truncation, and whether addends are
 // chopped one by one at the accumulator's ulp or summed first.  (Why: every kernel with the bf16x3 gate GEMM drifts
 // ~1e-5 from the float64 oracle at T = 1000 on a converging trajectory, the fp32-MFMA kernel 1e-6 like the CPU
-// oracles -- profiles/r03c_drift_forms.txt.)
+// oracles -- profiles/archive_r01_r03/r03c_drift_forms.txt.)
 //   hipcc --offload-arch=gfx950 -O2 mfma_round_probe.hip -o mfma_round_probe && ./mfma_round_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,7 +1,7 @@
 // Microbenchmark: the optimizer-network evaluation of a SEQUENCE of independent 16-coordinate tiles by one
 // wave (what k_cwlstm_step and k_unroll_cu do), plain (bx::tile_step per tile) vs software-pipelined across
 // tiles (bx::TilePipe: the next tile's two recurrent MFMA chunks are issued underneath this tile's gate blocks).
-// Result (profiles/r01_k_microbench_tile_pipe.txt): 0 % (RNNProp) to 6 % (DM nets) faster than the plain sequence
+// Result (profiles/archive_r01_r03/r01_k_microbench_tile_pipe.txt): 0 % (RNNProp) to 6 % (DM nets) faster than the plain sequence
 // for any interleaving pattern (-DL2O_PIPE_PAT=0/1/2) -- the matrix pipe does not run beside this gate math.
 // hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize \
 //       -I open_l2o_amd/csrc scripts/microbench/tile_pipe_bench.hip -o build/tile_pipe_bench

@@ -14,7 +14,7 @@ util.get_config("rastrigin") = batch 128, DM/util.py:232-238):
      num_steps 1000), mean loss per iteration over --eval_epochs batches of 128 problems,
   3. write the curves (log-spaced iterations) and the README bands next to them as JSON.
 
-    python scripts/readme_curves.py --out profiles/r04_readme_curves.json [--num_epochs 10000] [--max_seconds 90]
+    python scripts/readme_curves.py --out profiles/archive_r04/r04_readme_curves.json [--num_epochs 10000] [--max_seconds 90]
 """
 import argparse
 import json
@@ -76,7 +76,7 @@ def evaluate(kind, n, path, steps, eval_epochs, seed):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_readme_curves.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "archive_r04", "r04_readme_curves.json"))
     ap.add_argument("--num_epochs", type=int, default=10000)
     ap.add_argument("--max_seconds", type=float, default=90.0)
     ap.add_argument("--eval_epochs", type=int, default=10)

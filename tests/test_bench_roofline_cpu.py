@@ -45,7 +45,7 @@ def _counters(build_id=None, collected=None, insts=455.0):
 
 
 def test_counters_are_chosen_by_build_id_not_by_file_name(tmp_path, monkeypatch):
-    """`sorted(glob)` picked profiles/r04z_* over the newer r04av_*.  The selection reads what the file says
+    """`sorted(glob)` picked profiles/archive_r04/r04z_* over the newer r04av_*.  The selection reads what the file says
     about itself: the build it was collected on, then when."""
     b = _bench()
     wl = ["quadratic", "dm", 128, 128, 100]
@@ -72,7 +72,7 @@ def test_roofline_frac_is_work_over_peak_at_pipe_rates(tmp_path):
     b = _bench()
     case = {"kern_ms": 0.1777, "kern_ms_min": 0.177, "kernel": "k_unroll_pair (every problem on two CUs, one wave per SIMD)",
             "alg_bytes": 2.746e9, "bpc": 1676.0, "flops": 1.69e10, "hbm_bound": False, "hbm_model_bytes": 0.0, "fused": True,
-            "D": 128, "Mrows": 128, "T": 100, "B": 128, "dispatches": 1, "loop_ticks": 4343.0 * 100.3}
+            "D": 128, "Mrows": 128, "T": 100, "B": 128, "dispatches": 1, "loop_ticks": (3944.0 * 100.3, 4343.0 * 100.3)}
 
     class A:
         problem, net = "quadratic", "dm"
@@ -83,6 +83,7 @@ def test_roofline_frac_is_work_over_peak_at_pipe_rates(tmp_path):
         roof = b.roofline_block(case, A, counters)
         assert roof["bound"] == "valu_pipe" and roof["counters"] == status
         assert abs(roof["cycles_per_step"] - 4343.0) < 1e-6 and "s_memtime" in roof["cycles_source"]
+        assert abs(roof["cycles_per_step_loop"] - 3944.0) < 1e-6 and abs(roof["frac_step_loop"] - pipe_floor / 3944.0) < 1e-9
         assert abs(roof["frac"] - pipe_floor / 4343.0) < 1e-9 and 0.31 < roof["frac"] < 0.33
         assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-12
         issue_floor = 241 * b.ISSUE_COST["valu"] + 80 * b.ISSUE_COST["trans"] + 60 * b.ISSUE_COST["mfma"]

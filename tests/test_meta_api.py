@@ -766,3 +766,40 @@ def test_deferred_train_steps_report_a_failed_unroll_and_leave_the_weights_alone
         assert np.isfinite(c)
     finally:
         _engine.set_default_engine(old)
+
+
+# ------------------------------------------------------------- bench.py --emulate-world (round 5)
+def test_emulated_shards_add_up_to_the_global_batch(engine):
+    """_graph_core.emulate_world(rank, world): one shard of a sharded job in a single process -- contiguous batch slice,
+    1/B_global in every gradient, NO collective.  The shards' partial losses add up to the one-process run on the global
+    batch (what the all-reduce of SURVEY.md 8e would have produced), and every shard's iterates are the corresponding
+    rows of the global run."""
+    from open_l2o_amd import _graph_core
+    cfg = ORACLE_CFGS["dm"]
+    params = make_params(cfg, seed=90, trained_like=True)
+    B, D, T, world = 8, 32, 6, 4
+    prob, x0, _ = make_problem("rastrigin", B, D, seed=91)
+
+    def run():
+        problem = problems.rastrigin(B, D, data={"A": prob.A, "B": prob.B, "C": prob.C, "x": x0})
+        opt = meta.MetaOptimizer(**_net_config(cfg, params))
+        ml = opt.meta_loss(problem, T)
+        opt.graph.reset()
+        res = opt.graph.execute({}, commit=True)
+        return opt.graph, res["fx_array"], np.asarray(res["x"][0])
+    graph, fx_full, x_full = run()
+    assert not graph.sharded
+    total = np.zeros_like(fx_full)
+    try:
+        for r in range(world):
+            _graph_core.emulate_world(r, world)
+            g, fx_r, x_r = run()
+            assert g.sharded and g.shard == (r * B // world, (r + 1) * B // world) and x_r.shape[0] == B // world
+            np.testing.assert_allclose(x_r.reshape(B // world, -1), x_full.reshape(B, -1)[r * B // world:(r + 1) * B // world],
+                                       rtol=1e-5, atol=1e-6)
+            total += fx_r
+    finally:
+        _graph_core.emulate_world()
+    np.testing.assert_allclose(total, fx_full, rtol=2e-6)
+    with pytest.raises(ValueError):
+        _graph_core.emulate_world(4, 4)

@@ -20,7 +20,7 @@ from open_l2o_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
-N_LAUNCHES = int(__import__("os").environ.get("L2O_SOAK_LAUNCHES", "10000"))   # (profiles/r02n: one run with 200 000)
+N_LAUNCHES = int(__import__("os").environ.get("L2O_SOAK_LAUNCHES", "10000"))   # (profiles/archive_r01_r03/r02n: one run with 200 000)
 
 
 @pytest.mark.parametrize("name,kind,D,B", [("dm", "quadratic", 128, 128), ("rnnprop", "rastrigin", 100, 128)])

@@ -2,7 +2,7 @@
 (/root/reference/README.md:34-42, Figs/ras.png: generalized Rastrigin n = 2 / n = 10, every optimizer plateaus at
 f ~ 5.5-6.2 / ~ 50-57 after 10^3 iterations).  scripts/readme_curves.py meta-trains L2O-DM and L2O-RNNProp with the
 reference's schedule on the repo's drivers, evaluates 1000 steps and records the curves next to bands read off the
-figure (profiles/r04_readme_curves.json).  Weak evidence -- but the only reference-held quantity that exercises a
+figure (profiles/archive_r04/r04_readme_curves.json).  Weak evidence -- but the only reference-held quantity that exercises a
 non-zero LSTM (the Sonnet cell itself is unpinned)."""
 import json
 import os
@@ -19,9 +19,9 @@ START = {2: 18.0, 10: 125.0}                       # lower edge of where the fig
 def test_committed_curves_are_inside_the_readme_bands():
     """The committed record of the MI355X run: every case inside the stated band, the loss fell below half of the figure's starting level, and the
     kernels that produced it were the fused HIP path."""
-    path = os.path.join(ROOT, "profiles", "r04_readme_curves.json")
+    path = os.path.join(ROOT, "profiles", "archive_r04", "r04_readme_curves.json")
     if not os.path.exists(path):
-        pytest.skip("profiles/r04_readme_curves.json not recorded yet")
+        pytest.skip("profiles/archive_r04/r04_readme_curves.json not recorded yet")
     rec = json.load(open(path))
     assert rec["all_inside_readme_bands"]
     for name, case in rec["cases"].items():

@@ -7,7 +7,7 @@ and compares with the fp32 C oracle (and, for the long horizons, the float64 Num
   * configs 2 / 4-shard, T = 100: the whole fx[0..T] at 1e-5 relative (the north_star bar), x_T and the LSTM state, on
     both fused forms -- the two-CU kernel (the reference's arithmetic: r = Wx - y, g = W^T r) and the one-CU kernel
     (until round 4 also an opt-in normal-matrix form, H x - q: removed with ABI v12, its measurements are
-    profiles/r03a_trained_parity_probe.txt);
+    profiles/archive_r01_r03/r03a_trained_parity_probe.txt);
   * the per-step GRADIENT of the two-CU form against the float64 gradient at the kernel's own iterates, bounded by
     the error of the reference's own fp32 arithmetic (NumPy two-pass);
   * T = 1000 and T = 10 000 (DM/train_dm.py:66, DM/evaluate_dm.py:43) against the float64 oracle, bounded by 3 x the
@@ -43,7 +43,7 @@ FORMS = {"two_pass": {}, "one_cu": {_abi.OPT_PAIR: 0},
 # held to 3 x the fp32 oracles' own drift from float64.  (Until round 3 the bf16x3 kernels drifted 1.1e-5 .. 1.6e-5 at
 # T = 1000: the gate bias rode in two K-slots of the gate GEMM and v_mfma_f32_16x16x32_bf16 truncates every product of
 # an 8-slot group at 2^-24 of the group's largest -- the O(1) bias; as the accumulator init it is outside those sums:
-# 2.9e-6.  profiles/r03c_mfma_round_probe.txt, r03c_drift_forms.txt -> r03g_drift_forms_bias_as_acc_init.txt.)
+# 2.9e-6.  profiles/archive_r01_r03/r03c_mfma_round_probe.txt, r03c_drift_forms.txt -> r03g_drift_forms_bias_as_acc_init.txt.)
 
 
 @pytest.fixture(scope="module")
