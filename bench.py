@@ -737,6 +737,20 @@ def main(argv=None):
 
     build_id = _abi.build_id()
 
+    def _cpu_leg(a, c, Bg_, B_, D, T, full):
+        """The CPU leg of one workload: the oracle's C port (NumPy oracle for the MLP optimizee), timed on this host."""
+        secs = 20.0 if full else args.also_cpu_seconds
+        if a.problem == "mnist":
+            return cpu_baseline_mnist(c["weights"], B_, T, max_seconds=min(secs, 15.0))
+        names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None), "rastrigin": ("A", "B", "C")}[a.problem]
+        g = c["graph"]._by_name
+        arrays = {"W": g[names[0]].eval(), "y": g[names[1]].eval().reshape(B_, -1)}
+        if names[2]:
+            arrays["C"] = g[names[2]].eval().reshape(B_, -1)
+        arrays["l1"], arrays["alpha"] = 0.1, 10.0
+        return cpu_baseline(a.problem, a.net, arrays, c["weights"], eng.to_numpy(c["x0"][0]).reshape(B_, D), T,
+                            max_seconds=secs, B_global=Bg_, numpy_leg=full)
+
     def describe(a, c, Bg_, B_, full):
         """The measurement of one workload as a dict: the whole contract line (full) or its compact form (also)."""
         D, T, Mrows, shared = c["D"], c["T"], c["Mrows"], c["shared"]
@@ -759,19 +773,18 @@ def main(argv=None):
                                     c["kernel"].split(" ")[0] if c["fused"] or "k_mlp_unroll" in c["kernel"] else "", build_id)
         roof = roofline_block(c, a, counters)
         cpu = None
-        if world == 1 and not a.no_cpu_baseline and not shared:
-            secs = 20.0 if full else args.also_cpu_seconds
-            if a.problem == "mnist":
-                cpu = cpu_baseline_mnist(c["weights"], B_, T, max_seconds=min(secs, 15.0))
+        if world == 1 and not a.no_cpu_baseline and not shared and not full:
+            try:
+                cpu = _cpu_leg(a, c, Bg_, B_, D, T, full)
+            except Exception as e:                          # noqa: BLE001  (an also-run's CPU leg: recorded, not fatal)
+                cpu = None
+                cpu_error = "%s: %s" % (type(e).__name__, str(e)[:200])
             else:
-                names = {"quadratic": ("w", "y", None), "lasso": ("w", "y", None), "rastrigin": ("A", "B", "C")}[a.problem]
-                g = c["graph"]._by_name
-                arrays = {"W": g[names[0]].eval(), "y": g[names[1]].eval().reshape(B_, -1)}
-                if names[2]:
-                    arrays["C"] = g[names[2]].eval().reshape(B_, -1)
-                arrays["l1"], arrays["alpha"] = 0.1, 10.0
-                cpu = cpu_baseline(a.problem, a.net, arrays, c["weights"], eng.to_numpy(c["x0"][0]).reshape(B_, D), T,
-                                   max_seconds=secs, B_global=Bg_, numpy_leg=full)
+                cpu_error = None
+        elif world == 1 and not a.no_cpu_baseline and not shared:
+            cpu, cpu_error = _cpu_leg(a, c, Bg_, B_, D, T, full), None
+        else:
+            cpu_error = None
         workload = "%s on %s, batch=%d per GPU (global %d), T=%d%s" % (netname, probname, B_, Bg_, T,
                                                                        ", BASELINE.json configs[1]" if is_c2 else "")
         if not full:
@@ -830,6 +843,8 @@ def main(argv=None):
                 "parity_pin": PARITY_PIN,
                 "roofline": roof,
             }
+        if cpu_error:
+            out["cpu_baseline_error"] = cpu_error
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = c["value"] / cpu["value"]
@@ -848,7 +863,12 @@ def main(argv=None):
         for name, extra_argv in (("config3", ["--config", "3", "--steps", "3"]),
                                  ("config4_one_gpu", ["--config", "4", "--steps", "5"]),
                                  ("config4_shard_of_8", ["--config", "4", "--emulate-world", "8", "--steps", "10", "--unrolls-per-step", "8"]),
-                                 ("config5", ["--config", "5", "--steps", "5"])):
+                                 ("config5", ["--config", "5", "--steps", "5"]),
+                                 # (the 2- and 4-GPU shards of config 4, GPU side only: DESIGN.md 6 projects the scaling curve
+                                 #  from these driver-timed per-shard rates)
+                                 ("config4_shard_of_2", ["--config", "4", "--emulate-world", "2", "--steps", "5", "--no-cpu-baseline"]),
+                                 ("config4_shard_of_4", ["--config", "4", "--emulate-world", "4", "--steps", "5", "--unrolls-per-step", "8",
+                                                         "--no-cpu-baseline"])):
             if time.perf_counter() - t_also > args.also_budget:
                 also[name] = {"skipped": "the also-block's time budget (%g s) was spent" % args.also_budget}
                 continue
@@ -859,12 +879,16 @@ def main(argv=None):
                 Bg2, B2 = a2.batch, a2.batch // a2.emulate_world
             else:
                 Bg2, B2 = sizes(a2)
+            # (an also-run must never take the primary line down with it: a failure is recorded, the line still prints)
             try:
-                c2 = run_case(a2, eng, 1, 0, Bg2, B2, name)
-            finally:
-                _graph_core.emulate_world()
-            also[name] = describe(a2, c2, Bg2, B2, False)
-            del c2
+                try:
+                    c2 = run_case(a2, eng, 1, 0, Bg2, B2, name)
+                finally:
+                    _graph_core.emulate_world()
+                also[name] = describe(a2, c2, Bg2, B2, False)
+                del c2
+            except Exception as e:                          # noqa: BLE001
+                also[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             torch.cuda.empty_cache()
         also["seconds"] = time.perf_counter() - t_also
     if rank == 0:

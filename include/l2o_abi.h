@@ -464,6 +464,18 @@ typedef struct l2o_bwd_unroll_seg {
 int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
                           int32_t nseg, const float* const* table, int32_t T, int64_t step0,
                           const float* carry_in, float* carry_out, float* A, float* Bm, void* stream);
+/* The same launch with the A rows WITHOUT their duplicated columns (ABI v12).  A row of step t is
+ * [in | h1(t-1)] [h1(t) | h2(t-1)] [h2(t)] [feats] [1], and h1(t-1), h2(t-1) are the h1, h2 columns of step t - 1's row: 40 of
+ * the 82 (83, 103) columns are written twice and read back by the contraction.  Here a row keeps [in | h1(t) | h2(t) |
+ * feats | 1] (KA - 40 floats) and Ac holds T + 1 blocks of `rows` rows: block t + 1 = step t, block 0 = the state before
+ * step 0 (zeros in the other columns).  17 % fewer bytes out of this kernel and into l2o_cwlstm_wgrad_compact, which
+ * forms the same [KA][KB] result from the two blocks a step's operands live in.  (h1(t-1) of the product is then the
+ * value this kernel RECOMPUTED for step t - 1, not the recorded one: equal up to the forward kernels' fp32 rounding.)
+ * Matrix-core BPTT kernel only (L2O_OPT_BWD_KERNEL = 0); otherwise as l2o_cwlstm_bwd_unroll. */
+int l2o_cwlstm_bwd_unroll_compact(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
+                                  int32_t nseg, const float* const* table, int32_t T, int64_t step0,
+                                  const float* carry_in, float* carry_out, float* Ac /* [T+1][rows][KA-40] */,
+                                  float* Bm /* [T][rows][KB] */, void* stream);
 
 /* ---- the weight-gradient contraction (ABI v6): out [KA][KB] = A^T B for A [R][KA], B [R][KB] dense row-major device
  * matrices (KA <= 112, KB <= 192, any R): with A = [act1 | act2 | h2 | feats | 1] and B = [dz1 | dz2 | dd | du] as
@@ -484,6 +496,11 @@ int l2o_atb(const float* A, const float* B, int64_t R, int32_t KA, int32_t KB, f
 int32_t l2o_cwlstm_wgrad_dims(const l2o_net_cfg* cfg, int32_t* KA, int32_t* KB);
 int l2o_cwlstm_wgrad(const l2o_net_cfg* cfg, const float* A, const float* Bm, int64_t R, float* G /* device [KA][KB] */,
                      void* workspace, void* stream);
+/* ... from the compact rows of l2o_cwlstm_bwd_unroll_compact (ABI v12): Ac [T + 1][rows][KA - 40], Bm [T][rows][KB]; G and
+ * the workspace (l2o_atb_workspace_bytes(T * rows, KA, KB)) as above.  bf16 pipe only: L2O_ERR_UNSUPPORTED with
+ * L2O_OPT_EXACT_GATES (callers then use the plain pair). */
+int l2o_cwlstm_wgrad_compact(const l2o_net_cfg* cfg, const float* Ac, const float* Bm, int32_t T, int64_t rows,
+                             float* G /* device [KA][KB] */, void* workspace, void* stream);
 
 /* ---- the meta-step on the device (ABI v5): tf.train.AdamOptimizer(learning_rate).minimize(loss)
  * (DM/meta.py:410-414) without a host round trip of the weights.

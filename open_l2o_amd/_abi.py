@@ -26,7 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_build_id", "l2o_last_unroll_form", "l2o_coresident_workgroups", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_record", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
-    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_adam_step_gather", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
+    "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_cwlstm_bwd_unroll_compact", "l2o_cwlstm_wgrad_compact", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_adam_step_gather", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
     "l2o_suffix_sums", "l2o_colsum", "l2o_colsum_scratch_floats", "l2o_lincomb", "l2o_rnnprop_input_adjoint",
 )
@@ -317,6 +317,8 @@ def lib():
     L.l2o_cwlstm_bwd_unroll.restype = C.c_int
     L.l2o_cwlstm_bwd_unroll.argtypes = [C.POINTER(NetCfg), C.POINTER(NetWeights), C.POINTER(BwdUnrollSeg), C.c_int32, vp,
                                         C.c_int32, i64, vp, vp, vp, vp, vp]
+    L.l2o_cwlstm_bwd_unroll_compact.restype = C.c_int
+    L.l2o_cwlstm_bwd_unroll_compact.argtypes = L.l2o_cwlstm_bwd_unroll.argtypes
     L.l2o_adam_step.restype = C.c_int
     L.l2o_adam_step.argtypes = [vp, vp, vp, vp, i64, C.c_float, dbl, dbl, dbl, vp]
     L.l2o_adam_step_guarded.restype = C.c_int
@@ -339,6 +341,8 @@ def lib():
     L.l2o_cwlstm_wgrad_dims.argtypes = [C.POINTER(NetCfg), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.l2o_cwlstm_wgrad.restype = C.c_int
     L.l2o_cwlstm_wgrad.argtypes = [C.POINTER(NetCfg), vp, vp, C.c_int64, vp, vp, vp]
+    L.l2o_cwlstm_wgrad_compact.restype = C.c_int
+    L.l2o_cwlstm_wgrad_compact.argtypes = [C.POINTER(NetCfg), vp, vp, C.c_int32, C.c_int64, vp, vp, vp]
     L.l2o_unroll_workspace_layout.restype = C.c_int64
     L.l2o_unroll_workspace_layout.argtypes = [C.POINTER(NetCfg), C.POINTER(Problem)]
     L.l2o_unroll_workspace_bytes.restype = C.c_size_t

@@ -511,11 +511,15 @@ class HipEngine(object):
 
     bwd_unroll_any_d = True       # l2o_cwlstm_bwd_unroll takes panels of any D (per-problem tiles, ragged last tile)
 
+    bwd_unroll_compact = True     # l2o_cwlstm_bwd_unroll_compact / l2o_cwlstm_wgrad_compact exist (ABI v12)
+
     def bwd_unroll(self, spec: NetSpec, weights: dict, panels, T, step0, A, Bm, carry_in=None, carry_out=None,
-                   table=None):
+                   table=None, compact=False):
         """All T BPTT steps of the panels that share one network in one launch (l2o_cwlstm_bwd_unroll).
         panels: list of dict(B=, D=, gs=[T tensors], sts=[T], ms=[T] | None, vs=, dxs=[T] | None,
-        g_final= tensor | None); A [T, rows, KA], Bm [T, rows, KB], rows = 16 * sum_panels B * ceil(D / 16)."""
+        g_final= tensor | None); A [T, rows, KA], Bm [T, rows, KB], rows = 16 * sum_panels B * ceil(D / 16).
+        compact: A is [T + 1, rows, KA - 40] -- the rows without their duplicated h1(t-1) / h2(t-1) columns
+        (l2o_cwlstm_bwd_unroll_compact; read by wgrad_compact)."""
         cc = spec.to_c()
         w = _abi.NetWeights()
         for k, _ in _abi.NetWeights._fields_:
@@ -526,9 +530,9 @@ class HipEngine(object):
         for a, pn in zip(arr, panels):
             a.B, a.D = int(pn["B"]), int(pn["D"])
             a.g_final = None if pn.get("g_final") is None else pn["g_final"].data_ptr()
-        _abi.check(self.lib.l2o_cwlstm_bwd_unroll(C.byref(cc), C.byref(w), arr, len(panels), C.c_void_p(table.data_ptr()), int(T),
-                                                  int(step0), _ptr(carry_in), _ptr(carry_out), _ptr(A), _ptr(Bm),
-                                                  self._stream()))
+        fn = self.lib.l2o_cwlstm_bwd_unroll_compact if compact else self.lib.l2o_cwlstm_bwd_unroll
+        _abi.check(fn(C.byref(cc), C.byref(w), arr, len(panels), C.c_void_p(table.data_ptr()), int(T),
+                      int(step0), _ptr(carry_in), _ptr(carry_out), _ptr(A), _ptr(Bm), self._stream()))
         self._bwd_table = table                              # keep the pointer table alive until the stream has run the kernel
 
     def bwd_table(self, panels, T):
@@ -712,6 +716,24 @@ class HipEngine(object):
             ws = self._atb_ws = self.empty((n + 3) // 4)
         out = self.empty(KA, KB)
         _abi.check(self.lib.l2o_cwlstm_wgrad(C.byref(cc), _ptr(A), _ptr(B), int(R), _ptr(out), _ptr(ws), self._stream()))
+        return out
+
+    def wgrad_compact(self, spec: NetSpec, Ac, Bm):
+        """wgrad for the compact rows of bwd_unroll(compact=True): Ac [T + 1, rows, KA - 40], Bm [T, rows, KB] -> [KA, KB]
+        (l2o_cwlstm_wgrad_compact)."""
+        T, R, KB = Bm.shape
+        cc = spec.to_c()
+        ka, kb = C.c_int32(0), C.c_int32(0)
+        _abi.check(self.lib.l2o_cwlstm_wgrad_dims(C.byref(cc), C.byref(ka), C.byref(kb)))
+        KA = ka.value
+        assert kb.value == KB and tuple(Ac.shape) == (T + 1, R, KA - 40), (tuple(Ac.shape), (T + 1, R, KA - 40), KB)
+        n = int(self.lib.l2o_atb_workspace_bytes(int(T * R), int(KA), int(KB)))
+        ws = self.__dict__.get("_atb_ws")
+        if ws is None or ws.numel() * 4 < n:
+            ws = self._atb_ws = self.empty((n + 3) // 4)
+        out = self.empty(KA, KB)
+        _abi.check(self.lib.l2o_cwlstm_wgrad_compact(C.byref(cc), _ptr(Ac), _ptr(Bm), int(T), int(R), _ptr(out), _ptr(ws),
+                                                     self._stream()))
         return out
 
     # -- small vector passes of the meta-gradient (ABI v11, csrc/l2o_vecops.h) -------------------------------

@@ -170,15 +170,20 @@ class BpttMixin(object):
             offs = np.concatenate([[0], np.cumsum(rows)]).astype(int)   # row blocks (whole tiles)
             R = int(offs[-1])
             ragged = any(n % 16 for n in Ns)
+            # (round 5) the A rows without their duplicated h1(t-1) / h2(t-1) columns: 17 % fewer bytes out of the BPTT kernel
+            # and into the contraction (l2o_cwlstm_bwd_unroll_compact / l2o_cwlstm_wgrad_compact; bf16 contraction only)
+            compact = (fused and getattr(eng, "bwd_unroll_compact", False) and not _abi.get_option(_abi.OPT_EXACT_GATES)
+                       and not os.environ.get("L2O_BWD_FULL_ROWS"))
             if fused:                                       # all T steps in one launch, the carries in registers;
-                A, Bm = eng.empty(T, R, KA), eng.empty(T, R, KB)   # the kernel writes every row (padding rows as zeros)
+                A = eng.empty(T + 1, R, KA - 2 * H) if compact else eng.empty(T, R, KA)
+                Bm = eng.empty(T, R, KB)                    # the kernel writes every row (padding rows as zeros)
                 tkey = ("bwd_table", id(net), T)
                 table = None if cache is None else cache.get(tkey)
                 if table is None:
                     table = eng.bwd_table(grp, T) if hasattr(eng, "bwd_table") else None
                     if cache is not None:
                         cache[tkey] = table
-                eng.bwd_unroll(spec, wdev, grp, T, step0, A, Bm, table=table)
+                eng.bwd_unroll(spec, wdev, grp, T, step0, A, Bm, table=table, **({"compact": True} if compact else {}))
             else:
                 A = (eng.zeros if ragged else eng.empty)(T, R, KA)     # zero padding rows add nothing to A^T Bm
                 Bm = (eng.zeros if ragged else eng.empty)(T, R, KB)
@@ -213,7 +218,7 @@ class BpttMixin(object):
                         hess_update(pn, t, N)
                 carry_in, carry_out = carry_out, carry_in
             # l2o_cwlstm_wgrad: every weight gradient is a block of A^T Bm (only those blocks are computed)
-            Gm = eng.wgrad(spec, A.view(T * R, KA), Bm.view(T * R, KB))
+            Gm = eng.wgrad_compact(spec, A, Bm) if compact else eng.wgrad(spec, A.view(T * R, KA), Bm.view(T * R, KB))
             blocks = [("lstm_1", "w_gates", 0, K1, 0, 4 * H), ("lstm_1", "b_gates", KA - 1, KA, 0, 4 * H),
                       ("lstm_2", "w_gates", K1, K1 + 2 * H, 4 * H, 8 * H), ("lstm_2", "b_gates", KA - 1, KA, 4 * H, 8 * H),
                       ("linear", "w", K1 + 2 * H, K1 + 3 * H, 8 * H, 8 * H + 1), ("linear", "b", KA - 1, KA, 8 * H, 8 * H + 1)]

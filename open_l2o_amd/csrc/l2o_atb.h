@@ -227,10 +227,27 @@ __device__ unsigned long long g_atb_phase[8];
 #else
 #define L2O_ATB_LOAD(p) (*reinterpret_cast<const float*>(p))
 #endif
+// The COMPACT A of l2o_cwlstm_bwd_unroll_compact (round 5): rows [in (P) | h1(t) | h2(t) | feats | 1] in T + 1 blocks of
+// R / T rows (block ts + 1 = step ts, block 0 = the state before step 0).  The product is still taken over the VIRTUAL
+// columns [in | h1(t-1) | h1(t) | h2(t-1) | h2(t) | feats | 1]: a virtual column is a physical column of the row in block ts
+// (the previous step's outputs) or in block ts + 1 -- byte offset of virtual column v relative to row g of block 0 (row g of
+// Bm is step g / rows-per-block): h1(t-1), h2(t-1) at their physical column, everything else `slice_bytes` further on.
+// A lane computes its <= 2 offsets once per block; everything downstream of the loads is unchanged.
+__device__ __forceinline__ unsigned atb_compact_off(unsigned v, unsigned P, unsigned slice_bytes) {
+  if (v < P) return 4u * v + slice_bytes;
+  const unsigned w = v - P;
+  if (w < 20u) return 4u * (P + w);                          // h1(t-1): block ts
+  if (w < 40u) return 4u * (P + w - 20u) + slice_bytes;      // h1(t)
+  if (w < 60u) return 4u * (P + 20u + w - 40u);              // h2(t-1): block ts
+  if (w < 80u) return 4u * (P + 20u + w - 60u) + slice_bytes;   // h2(t)
+  return 4u * (P + 40u + w - 80u) + slice_bytes;             // feats, 1
+}
+
+// KAs: floats per row of A in memory (KA; compact: KA - 40).  a_slice_bytes: 0 = the plain [R][KA] operand.
 template <int MT, int NT, int MASK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(atb_bx3_wgs_per_cu<MT, NT>())))
 void k_atb_bx3(const float* __restrict__ A, const float* __restrict__ B, long R, int KA, int KB,
-               float* __restrict__ part) {
+               float* __restrict__ part, int KAs, unsigned a_slice_bytes, int P) {
   using l2o::bx::u32x4;
   using l2o::bx::f32x2;
   constexpr int CA = 16 * MT, CB = 16 * NT;
@@ -260,7 +277,10 @@ void k_atb_bx3(const float* __restrict__ A, const float* __restrict__ B, long R,
     unsigned l4 = lane4;
     asm volatile("" : "+v"(l4));
 #pragma unroll
-    for (int u = 0; u < NLA; ++u) oa[u] = min(l4 + 256u * u, enda);
+    for (int u = 0; u < NLA; ++u) {
+      oa[u] = min(l4 + 256u * u, enda);
+      if (a_slice_bytes) oa[u] = atb_compact_off(oa[u] >> 2, (unsigned)P, a_slice_bytes);   // (wave-uniform branch)
+    }
 #pragma unroll
     for (int u = 0; u < NLB; ++u) ob[u] = min(l4 + 256u * u, endb);
     // row pointers: scalar, advanced by one row unless that would pass the end (the rows past R re-read row R - 1,
@@ -270,8 +290,8 @@ void k_atb_bx3(const float* __restrict__ A, const float* __restrict__ B, long R,
     const long r0 = row0 < R ? row0 : R - 1;
     const long left = R - row0;
     const int nv = left >= RPW ? RPW : (left > 0 ? (int)left : 0);  // valid rows of the octet
-    const unsigned stepa = 4u * KA, stepb = 4u * KB;
-    const char* pa = reinterpret_cast<const char*>(A + r0 * KA);
+    const unsigned stepa = 4u * KAs, stepb = 4u * KB;
+    const char* pa = reinterpret_cast<const char*>(A + r0 * KAs);
     const char* pb = reinterpret_cast<const char*>(B + r0 * KB);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {

@@ -40,6 +40,11 @@ struct BwdParams {
   const float* const* table;
   const float* seg_gfinal[8];         // dx_next == NULL: dL/d(delta_t) = g_final + sum_{tau > t} g_tau
   double pw1_last, pw2_last;          // beta^(step0 + T - 1)
+  // k_cwlstm_bwd_mfma, T > 0 only (l2o_cwlstm_bwd_unroll_compact, round 5): the A rows WITHOUT their duplicated columns.
+  // h1(t-1), h2(t-1) of step t are h1(t), h2(t) of step t - 1, so a row keeps [in | h1(t) | h2(t) | feats | 1] (KAc = KA - 40
+  // columns) and A holds T + 1 blocks of rows_total rows: block ts + 1 = step ts, block 0 = [0 | h1, h2 before step 0 | 0].
+  // The contraction reads [in | h1(t-1)], [h1(t) | h2(t-1)] from blocks ts and ts + 1 (l2o_atb.h: k_atb_bx3's column map).
+  int compact_a;
 };
 
 // weights are read through the CONSTANT address space: the addresses are wave-uniform, so the
@@ -276,6 +281,7 @@ struct BwdTileGeom {
   static constexpr int P = PRE == L2O_PRE_FC_ELU ? kH : (PRE == L2O_PRE_LOGSIGN ? 2 : 1);
   static constexpr int K1 = P + kH, G = 4 * kH, NC = 16;
   static constexpr int KA = K1 + 3 * kH + (PRE == L2O_PRE_FC_ELU ? 2 : 0) + 1;   // act1 | act2 | h2 | feats | 1
+  static constexpr int KAC = KA - 2 * kH;                                        // compact: in | h1 | h2 | feats | 1
   static constexpr int KB = 2 * G + 1 + (PRE == L2O_PRE_FC_ELU ? kH : 0);        // dz1 | dz2 | dd | du
   static constexpr int kWaveFloats = 2 * kH * NC + kStateFloatsPerTile + 4 * NC * kH + NC * KA + NC * KB;
   static constexpr int kLdsFloats = K1 * G + 2 * kH * G + 4 * kWaveFloats;

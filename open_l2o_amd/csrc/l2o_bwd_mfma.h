@@ -257,7 +257,9 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
       om1 = (float)(1.0 - pw1); om2 = (float)(1.0 - pw2);
       pw1 /= (double)p.beta1; pw2 /= (double)p.beta2;
     }
-    float* const a_t = p.act1 + ((size_t)ts * RT + n0) * KA;
+    constexpr int KAC = Geo::KAC;
+    const bool compact = p.compact_a != 0;                  // (wave-uniform; T > 0 launches only)
+    float* const a_t = compact ? p.act1 + ((size_t)(ts + 1) * RT + n0) * KAC : p.act1 + ((size_t)ts * RT + n0) * KA;
     float* const b_t = p.dz1 + ((size_t)ts * RT + n0) * KB;
     const TileState s = cur.s;                              // h1, c1, h2, c2 BEFORE the step
     const float gv = cur.g;
@@ -324,28 +326,58 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     // (the rows of a ragged last tile that do not exist are written as zeros: they add nothing to A^T Bm
     //  and the caller need not clear A / Bm)
     const float live = c < nv ? 1.0f : 0.0f;
+    if (compact && ts == 0) {
+      // block 0 of the compact A: the state BEFORE the unroll's first step in the h1 / h2 columns, zeros elsewhere -- the
+      // contraction's h1(t-1) / h2(t-1) operands of step 0 (once per tile: 1 / T of the row traffic)
+      float* arow = stg + c * KAC;
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) {
+        if (FC || t == 0) { if (4 * t + q < P) arow[4 * t + q] = 0.0f; }
+        arow[P + 4 * t + q] = s.h1[t] * live;
+        arow[P + kH + 4 * t + q] = s.h2[t] * live;
+      }
+      if (q == 0) { for (int e = P + 2 * kH; e < KAC; ++e) arow[e] = 0.0f; }
+      wave_lds_fence();
+      if (valid) {
+        float* const a0 = p.act1 + n0 * KAC;
+        const int na = NC * KAC;
+        for (int i = lane; i < na / 4; i += 64) reinterpret_cast<float4*>(a0)[i] = reinterpret_cast<const float4*>(stg)[i];
+        for (int e = (na & ~3) + lane; e < na; e += 64) a0[e] = stg[e];
+      }
+      wave_lds_fence();
+    }
     {
-      float* arow = stg + c * KA;
+      float* arow = stg + c * (compact ? KAC : KA);
+      const int o_ft = compact ? P + 2 * kH : K1 + 3 * kH;  // feats (RNNProp), then the ones column
       if (FC) {
 #pragma unroll
         for (int t = 0; t < kNT; ++t) arow[4 * t + q] = fcv[t] * live;
-        if (q == 0) { arow[K1 + 3 * kH] = f0 * live; arow[K1 + 3 * kH + 1] = f1 * live; }
+        if (q == 0) { arow[o_ft] = f0 * live; arow[o_ft + 1] = f1 * live; }
       } else if (q == 0) {
         arow[0] = in0 * live;
         if (PRE == L2O_PRE_LOGSIGN) arow[1] = in1 * live;
       }
+      if (compact) {
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) {
-        arow[P + 4 * t + q] = s.h1[t] * live;
-        arow[K1 + 4 * t + q] = h1n[t] * live;
-        arow[K1 + kH + 4 * t + q] = s.h2[t] * live;
-        arow[K1 + 2 * kH + 4 * t + q] = h2n[t] * live;
+        for (int t = 0; t < kNT; ++t) {
+          arow[P + 4 * t + q] = h1n[t] * live;
+          arow[P + kH + 4 * t + q] = h2n[t] * live;
+        }
+        if (q == 0) arow[KAC - 1] = live;
+      } else {
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+          arow[P + 4 * t + q] = s.h1[t] * live;
+          arow[K1 + 4 * t + q] = h1n[t] * live;
+          arow[K1 + kH + 4 * t + q] = s.h2[t] * live;
+          arow[K1 + 2 * kH + 4 * t + q] = h2n[t] * live;
+        }
+        if (q == 0) arow[KA - 1] = live;
       }
-      if (q == 0) arow[KA - 1] = live;
     }
     wave_lds_fence();
     if (valid) {
-      const int na = (p.T > 0 ? NC : nv) * KA;
+      const int na = (p.T > 0 ? NC : nv) * (compact ? KAC : KA);
       for (int i = lane; i < na / 4; i += 64) reinterpret_cast<float4*>(a_t)[i] = reinterpret_cast<const float4*>(stg)[i];
       for (int e = (na & ~3) + lane; e < na; e += 64) a_t[e] = stg[e];
     }

@@ -1692,24 +1692,33 @@ size_t l2o_atb_workspace_bytes(int64_t R, int32_t KA, int32_t KB) {
 // mask 0: the dense product (fp32 matrix pipe, exact products).  mask 1 | 2: the weight-gradient blocks -- on the
 // bf16 pipe (k_atb_bx3) unless the call asks for exact gates (L2O_OPT_EXACT_GATES: the fp32 pipe, bit-equal to the
 // dense product on those blocks)
+// compact_rows > 0 (mask 1 | 2, bf16 pipe only): A is the COMPACT operand of l2o_cwlstm_bwd_unroll_compact -- T + 1 blocks of
+// compact_rows rows of KA - 40 floats -- and R = T * compact_rows rows of B (csrc/l2o_atb.h: atb_compact_off)
 static int atb_launch(const float* A, const float* B, int64_t R, int KA, int KB, int mask, float* out, void* workspace,
-                      hipStream_t s) {
+                      hipStream_t s, int64_t compact_rows = 0, int P = 0) {
   float* part = static_cast<float*>(workspace);
   const int MT = (KA + 15) / 16, NT = (KB + 15) / 16;
   void (*fn)(const float*, const float*, long, int, int, float*) = nullptr;
+  void (*fx)(const float*, const float*, long, int, int, float*, int, unsigned, int) = nullptr;
   int wgs = L2O_ATB_WGS_PER_CU;
   const bool bx3 = mask != 0 && !opt(L2O_OPT_EXACT_GATES);
+  if (compact_rows > 0 && !bx3) return fail(L2O_ERR_UNSUPPORTED, "the compact A operand is read by the bf16x3 contraction only");
   if (mask == 1) {
-    fn = bx3 ? k_atb_bx3<6, 11, 1> : k_atb<6, 11, 1>;
-    if (bx3) wgs = atb_bx3_wgs_per_cu<6, 11>();
+    if (bx3) { fx = k_atb_bx3<6, 11, 1>; wgs = atb_bx3_wgs_per_cu<6, 11>(); } else fn = k_atb<6, 11, 1>;
   } else if (mask == 2) {
-    fn = bx3 ? k_atb_bx3<7, 12, 2> : k_atb<7, 12, 2>;
-    if (bx3) wgs = atb_bx3_wgs_per_cu<7, 12>();
+    if (bx3) { fx = k_atb_bx3<7, 12, 2>; wgs = atb_bx3_wgs_per_cu<7, 12>(); } else fn = k_atb<7, 12, 2>;
   } else if (MT <= 1 && NT <= 1) fn = k_atb<1, 1>;
   else if (MT <= 6 && NT <= 11) fn = k_atb<6, 11>;
   else fn = k_atb<7, 12>;
   const int groups = atb_groups(R, wgs, s);
-  hipLaunchKernelGGL(fn, dim3(groups), dim3(256), 0, s, A, B, (long)R, KA, KB, part);
+  if (fx) {
+    const int KAs = compact_rows > 0 ? KA - 2 * kH : KA;
+    const uint64_t slice = compact_rows > 0 ? (uint64_t)compact_rows * KAs * sizeof(float) : 0;
+    if (slice > 0xf0000000ull) return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_wgrad_compact: %lld rows per step is too many", (long long)compact_rows);
+    hipLaunchKernelGGL(fx, dim3(groups), dim3(256), 0, s, A, B, (long)R, KA, KB, part, KAs, (unsigned)slice, P);
+  } else {
+    hipLaunchKernelGGL(fn, dim3(groups), dim3(256), 0, s, A, B, (long)R, KA, KB, part);
+  }
   HIP_TRY(hipGetLastError());
   const int n = KA * KB;
   hipLaunchKernelGGL(k_atb_reduce, dim3((n + 31) / 32), dim3(256), 0, s, part, groups, n, out, mask,
@@ -1741,6 +1750,18 @@ int l2o_cwlstm_wgrad(const l2o_net_cfg* cfg, const float* A, const float* Bm, in
   if (rc) return rc;
   if (!A || !Bm || !G || !workspace || R <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_wgrad: bad argument");
   return atb_launch(A, Bm, R, KA, KB, cfg->preprocess == L2O_PRE_FC_ELU ? 2 : 1, G, workspace, (hipStream_t)stream);
+}
+
+int l2o_cwlstm_wgrad_compact(const l2o_net_cfg* cfg, const float* Ac, const float* Bm, int32_t T, int64_t rows, float* G,
+                             void* workspace, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
+  int32_t KA = 0, KB = 0;
+  const int rc = l2o_cwlstm_wgrad_dims(cfg, &KA, &KB);
+  if (rc) return rc;
+  if (!Ac || !Bm || !G || !workspace || T <= 0 || rows <= 0) return fail(L2O_ERR_ARG, "l2o_cwlstm_wgrad_compact: bad argument");
+  const bool fc = cfg->preprocess == L2O_PRE_FC_ELU;
+  const int P = fc ? kH : (cfg->preprocess == L2O_PRE_LOGSIGN ? 2 : 1);
+  return atb_launch(Ac, Bm, (int64_t)T * rows, KA, KB, fc ? 2 : 1, G, workspace, (hipStream_t)stream, rows, P);
 }
 
 // ---- generic-`layers` optimizer step (csrc/l2o_generic.h) --------------------------------------------------
@@ -2118,9 +2139,22 @@ int l2o_cwlstm_bwd_multi(const l2o_net_cfg* cfg, const l2o_net_weights* w, const
   return launch_bwd_tile(p, pre, (hipStream_t)stream);
 }
 
+static int bwd_unroll_impl(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
+                           int32_t nseg, const float* const* table, int32_t T, int64_t step0, const float* carry_in,
+                           float* carry_out, float* A, float* Bm, void* stream, int compact);
 int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
                           int32_t nseg, const float* const* table, int32_t T, int64_t step0, const float* carry_in,
                           float* carry_out, float* A, float* Bm, void* stream) {
+  return bwd_unroll_impl(cfg, w, segs, nseg, table, T, step0, carry_in, carry_out, A, Bm, stream, 0);
+}
+int l2o_cwlstm_bwd_unroll_compact(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
+                                  int32_t nseg, const float* const* table, int32_t T, int64_t step0, const float* carry_in,
+                                  float* carry_out, float* Ac, float* Bm, void* stream) {
+  return bwd_unroll_impl(cfg, w, segs, nseg, table, T, step0, carry_in, carry_out, Ac, Bm, stream, 1);
+}
+static int bwd_unroll_impl(const l2o_net_cfg* cfg, const l2o_net_weights* w, const l2o_bwd_unroll_seg* segs,
+                           int32_t nseg, const float* const* table, int32_t T, int64_t step0, const float* carry_in,
+                           float* carry_out, float* A, float* Bm, void* stream, int compact) {
   OptScope opt_scope(cfg_optw(cfg));
   if (!cfg || !w || !segs || nseg < 1 || !table || T < 1 || step0 < 0 || !A || !Bm)
     return fail(L2O_ERR_ARG, "l2o_cwlstm_bwd_unroll: bad argument");
@@ -2135,6 +2169,9 @@ int l2o_cwlstm_bwd_unroll(const l2o_net_cfg* cfg, const l2o_net_weights* w, cons
   fill_bwd_net(p, cfg, w, 0.0, 0.0);
   p.carry_in = carry_in; p.carry_out = carry_out; p.act1 = A; p.dz1 = Bm;
   p.nseg = nseg; p.T = T; p.table = table;
+  if (compact && opt(L2O_OPT_BWD_KERNEL) != 0)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_cwlstm_bwd_unroll_compact: the matrix-core BPTT kernel only (L2O_OPT_BWD_KERNEL = 0)");
+  p.compact_a = compact;
   p.pw1_last = std::pow((double)p.beta1, (double)(step0 + T - 1));
   p.pw2_last = std::pow((double)p.beta2, (double)(step0 + T - 1));
   long tiles = 0;

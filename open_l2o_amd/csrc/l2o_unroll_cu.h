@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   const int i_first = 4 * wv;
   // (round 4: every conditional refill has a zeroing else-branch.  Without it a ring array is a phi with its OLD values on
   //  the not-taken path and stays live through the whole optimizer phase -- what made k_unroll_cu8 spill 100 registers,
-  //  DESIGN.md 3.1c; -DL2O_CU_RING_PHI restores the old form)
+  //  DESIGN.md 3.1c)
   auto zero4 = [&](float4 (&w4)[4][NV]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -116,11 +116,7 @@ __global__ __launch_bounds__(kCuThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int v = 0; v < NV; ++v) w4[k][v] = float4{0.f, 0.f, 0.f, 0.f};
   };
   auto load4z = [&](int i0, float4 (&w4)[4][NV]) {
-#ifdef L2O_CU_RING_PHI
-    if (i0 < M) load4(i0, w4);
-#else
     if (i0 < M) load4(i0, w4); else zero4(w4);
-#endif
   };
   auto load_head = [&]() {                 // the ring's groups of a step's first trip
     load4z(i_first, wa);

@@ -280,34 +280,23 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
   f32x4 acc1[kNT], acc2[kNT];
   core.init(s, q);
   core.preload(acc1, acc2);                                 // accumulator inits of the first step (the biases)
-#ifdef L2O_PAIR_L1H_UNDER_GATES
-  // variant: chunk L1H of step t+1 (fed by h1(t)) rides underneath the layer-2 gate block of step t
-  // (Core::finish<true>); only the first step's is issued up front
-  core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
-#endif
   // (both recurrent chunks -- L1H: h1(t-1) -> layer 1, L2B: h2(t-1) -> layer 2 -- are issued inside the step loop,
   //  in the window where the wave waits for its partner's partial residuals)
   PhaseClock pc;
   pc.start();
 
-  // Round 4 step order (L2O_PAIR_R3_ORDER restores round 3's for A/B runs): the scaled iterate goes to LDS the moment
-  // the update exists -- at the END of a step, ahead of the split of h2 (27 VALU + the register copies of the loop-carried
-  // B operands sat between the update and its LDS write: ~200 cycles of the step's critical path) -- and the split runs
-  // at the top of the next step UNDER the xs reads; the loss reduction runs under the residual reads of the g pass; the two
-  // row partials share one swap butterfly.
-#ifndef L2O_PAIR_R3_ORDER
-  constexpr bool kR4 = true;
+  // Step order (round 4; round 3's order and the variants measured against it: docs/DESIGN_history_r04.md 3.1b): the scaled
+  // iterate goes to LDS the moment the update exists -- at the END of a step, ahead of the split of h2 (27 VALU + the
+  // register copies of the loop-carried B operands sat between the update and its LDS write: ~200 cycles of the step's
+  // critical path) -- and the split runs at the top of the next step UNDER the xs reads; the loss reduction runs under the
+  // residual reads of the g pass; the two row partials share one swap butterfly.
   if (q == 0) xs[wv * kTile + c] = live ? xv * sc : 0.0f;
-#else
-  constexpr bool kR4 = false;
-#endif
   const size_t hist_n = (size_t)pp.B_local * D;
   const long long loop_t0 = __builtin_readcyclecounter();
   for (int t = 0;; ++t) {
     const float xsv = xv * sc;
     const unsigned tag = salt | ((unsigned)t + 1u);     // (T + 1 < 65 535 when salt != 0; the handshake tag ends in 0xffff)
     const int par = t & 1;
-    if (!kR4 && q == 0) xs[wv * kTile + c] = live ? xsv : 0.0f;
     pc.mark(0);
     // (recording: barriers that wait for LDS traffic only -- a __syncthreads() also waits for the write acknowledgement
     //  of the 5 KB of history the wave has just stored)
@@ -318,38 +307,23 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     {
       float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
       Acc4pk r0p = {{0.f, 0.f}, {0.f, 0.f}}, r1p = {{0.f, 0.f}, {0.f, 0.f}};
-      if (kR4) {
-        l2o::f32x4 x4v[NWH];
-        lds_load_f4<NWH>(x4v, xsq);
-        core.refresh(s);                     // split h2(t-1) -> chunk L2B operand, under the LDS latency (t = 0: repeats core.init)
-        __builtin_amdgcn_sched_group_barrier(0x100, NWH, 0);     // the DS reads first ...
-        __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);      // ... then the split's VALU block, then the FMAs
+      l2o::f32x4 x4v[NWH];
+      lds_load_f4<NWH>(x4v, xsq);
+      core.refresh(s);                     // split h2(t-1) -> chunk L2B operand, under the LDS latency (t = 0: repeats core.init)
+      __builtin_amdgcn_sched_group_barrier(0x100, NWH, 0);     // the DS reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);      // ... then the split's VALU block, then the FMAs
 #pragma unroll
-        for (int m = 0; m < NWH; ++m) {
-          if (kPk) { dot4pk(wrq[0][m], x4v[m], r0p); dot4pk(wrq[1][m], x4v[m], r1p); }
-          else { dot4v(wr[0][m], x4v[m], r0); dot4v(wr[1][m], x4v[m], r1); }
-        }
-      } else {
-        float4 x4[NWH];
-        lds_read_f4<NWH>(x4, xsq);
-#pragma unroll
-        for (int m = 0; m < NWH; ++m) {
-          dot4(wr[0][m], x4[m], r0);
-          dot4(wr[1][m], x4[m], r1);
-        }
+      for (int m = 0; m < NWH; ++m) {
+        if (kPk) { dot4pk(wrq[0][m], x4v[m], r0p); dot4pk(wrq[1][m], x4v[m], r1p); }
+        else { dot4v(wr[0][m], x4v[m], r0); dot4v(wr[1][m], x4v[m], r1); }
       }
-      if (kR4) {
-        // both row partials through ONE butterfly: the 16-lane swap pairs row groups (0,1) and (2,3) of p0 AND p1 at once,
-        // the 32-lane swap finishes both; odd lane groups end with the p1 sum, even ones with the p0 sum -- the lanes
-        // that publish them.  Same additions in the same order as two quad_q_sum calls (bit-identical), 5 instead of 13
-        // instructions and one dependent swap chain instead of two.
-        const float h0 = kPk ? hsum4pk(r0p) : hsum4(r0), h1 = kPk ? hsum4pk(r1p) : hsum4(r1);
-        const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h0), __float_as_uint(h1), false, false);
-        part = xor32_add(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
-      } else {
-        const float p0 = quad_q_sum(hsum4(r0)), p1 = quad_q_sum(hsum4(r1));
-        part = (gq & 1) ? p1 : p0;
-      }
+      // both row partials through ONE butterfly: the 16-lane swap pairs row groups (0,1) and (2,3) of p0 AND p1 at once,
+      // the 32-lane swap finishes both; odd lane groups end with the p1 sum, even ones with the p0 sum -- the lanes
+      // that publish them.  Same additions in the same order as two quad_q_sum calls (bit-identical), 5 instead of 13
+      // instructions and one dependent swap chain instead of two.
+      const float h0 = kPk ? hsum4pk(r0p) : hsum4(r0), h1 = kPk ? hsum4pk(r1p) : hsum4(r1);
+      const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h0), __float_as_uint(h1), false, false);
+      part = xor32_add(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
     }
     // ---- exchange the partial sums (one granule per row), the previous-h2 matrix work covers the latency
     if (gq < 2) {
@@ -375,9 +349,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     constexpr int kPollAt = L2O_PAIR_POLL_AT < Core::kTotal ? L2O_PAIR_POLL_AT : Core::kTotal;   // MFMAs before the first poll load
     constexpr int kPollAt1 = L2O_PAIR_POLL_AT > Core::kTotal ? L2O_PAIR_POLL_AT - Core::kTotal : 0;
     core.template issue_l2_prev<0, kPollAt>(s, acc2);
-#ifndef L2O_PAIR_L1H_UNDER_GATES
     if (kPollAt1 > 0) core.template issue_l1_prev<0, kPollAt1>(s, acc1);
-#endif
     const unsigned long long* src = theirs + par * SQ + (gq < 2 ? myrow : 0);
     unsigned long long g = 0;
 #ifdef L2O_ABLATE_EXCHANGE
@@ -387,9 +359,7 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     if (gq < 2 && !dead) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_sched_barrier(0);
     if (kPollAt < Core::kTotal) core.template issue_l2_prev<kPollAt, Core::kTotal>(s, acc2);
-#ifndef L2O_PAIR_L1H_UNDER_GATES
     core.template issue_l1_prev<kPollAt1, Core::kTotal>(s, acc1);
-#endif
     float contrib = 0.0f;
     if (gq < 2) {
       int spins = 0;
@@ -429,13 +399,11 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     // (round 4: the residual reads of the g pass go out FIRST; the reduction's DPP chain and the store fill their latency --
     //  in round 3's ISA the chain sat in front of reads that carried their own wait)
     l2o::f32x4 rv4v[CH];
-    if (kR4) lds_load_f4<CH>(rv4v, rsq);
+    lds_load_f4<CH>(rv4v, rsq);
     {
       const float fw = wave_sum64(contrib);
-      if (kR4) {
-        __builtin_amdgcn_sched_group_barrier(0x100, CH, 0);    // the DS reads, then the reduction's DPP chain
-        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
-      }
+      __builtin_amdgcn_sched_group_barrier(0x100, CH, 0);      // the DS reads, then the reduction's DPP chain
+      __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
       if (lane == 0) pa.fx_half[((size_t)t * pa.nb + bl) * (2 * NWH) + half * NWH + wv] = fw;
     }
     if (t == a.T && !HIST) break;
@@ -445,19 +413,12 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     // quad otherwise: CH x LDS latency on the critical path), one wait, then the FMAs
     float4 gacc4 = {0.f, 0.f, 0.f, 0.f};
     Acc4pk gaccp = {{0.f, 0.f}, {0.f, 0.f}};
-    if (kR4) {
 #pragma unroll
-      for (int m = 0; m < CH; ++m) {
-        if (kPk) dot4pk(wtq[m], rv4v[m], gaccp);
-        else dot4v(wt[m], rv4v[m], gacc4);
-      }
-    } else {
-      float4 rv4[CH];
-      lds_read_f4<CH>(rv4, rsq);
-#pragma unroll
-      for (int m = 0; m < CH; ++m) dot4(wt[m], rv4[m], gacc4);
+    for (int m = 0; m < CH; ++m) {
+      if (kPk) dot4pk(wtq[m], rv4v[m], gaccp);
+      else dot4v(wt[m], rv4v[m], gacc4);
     }
-    float gv = quad_q_sum((kR4 && kPk) ? hsum4pk(gaccp) : hsum4(gacc4));
+    float gv = quad_q_sum(kPk ? hsum4pk(gaccp) : hsum4(gacc4));
     if (KIND == L2O_PROB_SQUARE_COS) gv *= 2.0f;            // only the ||wx-y||^2 part carries the 2
     if (KIND == L2O_PROB_LASSO) gv += pp.l1 * (xsv > 0.f ? 1.f : (xsv < 0.f ? -1.f : 0.f));
     if (kCos) gv += kTwoPi * pp.alpha * cj * trig.s;
@@ -484,34 +445,21 @@ __device__ __forceinline__ void unroll_pair_body(const UnrollPairArgs& pa) {
     } else {
       preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
     }
-#ifdef L2O_PAIR_L1H_UNDER_GATES
-    float d = core.template finish<true>(s, acc1, acc2, in0, in1, q, pc);
-#elif defined(L2O_PAIR_R3_ORDER) || defined(L2O_PAIR_REARM_IN_FINISH)
-    float d = core.template finish<false>(s, acc1, acc2, in0, in1, q, pc);
-#else
     float d = core.template finish<false, bx::NoShadow, false>(s, acc1, acc2, in0, in1, q, pc);   // (re-armed below)
-#endif
-#ifndef L2O_PAIR_L1H_UNDER_GATES
-    if (!kR4) core.refresh(s);   // marks 5 (g pass .. inputs), 6, 7, 10, 8
-#endif
     if (a.np.tanh_output) {                                 // a real (uniform) branch: as a select hipcc computes the
       asm volatile("");                                      // exp + rcp of tanh on every step of the nets without it
       d = tanhf_(d);
     }
     xv = __builtin_fmaf(d, a.np.scale, xv);
-    if (kR4) {
-      // the next step's scaled iterate -> LDS NOW (its readers sit behind barrier B1; this step's readers of xs all
-      // passed barrier B2 before any wave gets here)
-      __builtin_amdgcn_sched_barrier(0);
-      if (q == 0) xs[wv * kTile + c] = live ? xv * sc : 0.0f;
-      __builtin_amdgcn_sched_barrier(0);
-#if !defined(L2O_PAIR_L1H_UNDER_GATES) && !defined(L2O_PAIR_REARM_IN_FINISH)
-      // the next step's accumulator inits (the gate biases: 10 ds_read_b128) go out HERE: their latency overlaps the wait
-      // for barrier B1, which drains this wave's LDS queue anyway
-      core.preload_unpinned(acc1, acc2);
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
+    // the next step's scaled iterate -> LDS NOW (its readers sit behind barrier B1; this step's readers of xs all
+    // passed barrier B2 before any wave gets here)
+    __builtin_amdgcn_sched_barrier(0);
+    if (q == 0) xs[wv * kTile + c] = live ? xv * sc : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    // the next step's accumulator inits (the gate biases: 10 ds_read_b128) go out HERE: their latency overlaps the wait
+    // for barrier B1, which drains this wave's LDS queue anyway
+    core.preload_unpinned(acc1, acc2);
+    __builtin_amdgcn_sched_barrier(0);
     pc.mark(9);
   }
 #ifdef L2O_PROFILE_PHASES

@@ -375,8 +375,36 @@ class OracleEngine(object):
             carry_out[:, row:row + N] = cout
             row += (N + 15) // 16 * 16
 
-    def bwd_unroll(self, spec, weights, panels, T, step0, A, Bm, carry_in=None, carry_out=None, table=None):
+    bwd_unroll_compact = True
+
+    @staticmethod
+    def _compact_geom(spec):
+        fc = spec.preprocess == _abi.PRE_FC_ELU
+        P = 20 if fc else (2 if spec.preprocess == _abi.PRE_LOGSIGN else 1)
+        return P, P + 20 + 60 + (2 if fc else 0) + 1
+
+    def wgrad_compact(self, spec, Ac, Bm):
+        """HipEngine.wgrad_compact: the [KA, KB] product over the VIRTUAL columns [in | h1(t-1) | h1(t) | h2(t-1) | h2(t) |
+        feats | 1] of the compact rows (block t + 1 = step t, block 0 = the state before step 0)."""
+        T, R, KB = Bm.shape
+        P, KA = self._compact_geom(spec)
+        assert tuple(Ac.shape) == (T + 1, R, KA - 40)
+        cur, prev = Ac[1:], Ac[:-1]
+        A = torch.cat([cur[..., :P], prev[..., P:P + 20], cur[..., P:P + 20], prev[..., P + 20:P + 40], cur[..., P + 20:P + 40],
+                       cur[..., P + 40:]], dim=-1)
+        return self.atb(A.reshape(T * R, KA), Bm.reshape(T * R, KB))
+
+    def bwd_unroll(self, spec, weights, panels, T, step0, A, Bm, carry_in=None, carry_out=None, table=None, compact=False):
         """Same contract as HipEngine.bwd_unroll, step by step through bwd_multi."""
+        if compact:                                        # the full rows, then packed: block t + 1 <- [in | h1(t) | h2(t) | rest]
+            P, KA = self._compact_geom(spec)
+            full = torch.zeros(T, A.shape[1], KA)
+            self.bwd_unroll(spec, weights, panels, T, step0, full, Bm, carry_in, carry_out, table)
+            A.zero_()
+            A[1:] = torch.cat([full[..., :P], full[..., P + 20:P + 40], full[..., P + 60:P + 80], full[..., P + 80:]], dim=-1)
+            A[0, :, P:P + 20] = full[0][:, P:P + 20]        # h1, h2 BEFORE step 0
+            A[0, :, P + 20:P + 40] = full[0][:, P + 40:P + 60]
+            return
         R = A.shape[1]
         b1, b2 = float(np.float32(spec.beta1)), float(np.float32(spec.beta2))
         cin = torch.zeros(4, R, 20) if carry_in is None else carry_in.clone()
