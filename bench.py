@@ -126,11 +126,14 @@ def work_model(problem, net, D, M):
 
 def work_block(case, issue, args, clock_hz):
     """The work-based figures of a VALU-bound fused kernel.
-    cycles_per_step: shader-clock cycles one SIMD spends per optimizer step -- MEASURED inside the kernel (s_memtime of
-        wave 0 of workgroup 0 from kernel entry to its last store, workspace bytes 24..31, / (T + 0.3): prologue and
-        epilogue are charged to the steps, the T + 1-st loss evaluation is ~1/3 of a step; cycles_per_step_loop: the step
-        loop alone, bytes 16..23); without those words: live kernel time x clock / (chunk launches x rounds of problems
-        per CU x (T + 0.3)).
+    cycles_per_step: shader-clock cycles one SIMD spends per optimizer step = the LIVE kernel time of this run (HIP events
+        around replays of one instance: the unroll kernel + its epilogue) x clock / (chunk launches x rounds of problems
+        per CU x (T + 0.3): the T + 1-st loss evaluation is ~1/3 of a step).  clock = GRBM_GUI_ACTIVE / kernel time of the
+        PMC passes when counters of this build exist, else the nominal 2.4 GHz.  The conservative denominator: launch
+        ramp, the slowest workgroup and the epilogue launch are all charged to the steps.
+    cycles_per_step_in_kernel / _loop: the same quantity COUNTED inside the kernel (s_memtime of wave 0 of workgroup 0 from
+        kernel entry to its last store, workspace bytes 24..31; the step loop alone, bytes 16..23) -- no clock assumption;
+        frac_in_kernel_cycles / frac_step_loop are the fractions over those.
     pipe_floor_cycles_per_step: the STATED minimal instruction counts of the tile-steps that SIMD does per step
         (bench.py: work_model; 1 tile per SIMD for the one-wave kernels, 2 for k_unroll_lds) x the PIPE time per
         instruction class (plain VALU 2.93, transcendental 8.39 cycles: two_wave_issue.hip) -- what the SIMD's VALU pipe
@@ -151,16 +154,18 @@ def work_block(case, issue, args, clock_hz):
     rounds = -(-case["B"] // max(1, case.get("n_cus", 256))) if two_waves else 1
     cyc_time = case["kern_ms"] * 1e-3 * clock_hz / (dispatches * rounds * (T + 0.3))
     ticks = case.get("loop_ticks")                       # (step loop, kernel entry to exit) of wave 0 of workgroup 0
-    cyc = ticks[1] / (T + 0.3) if ticks else cyc_time
+    cyc = cyc_time
     floor = tiles_per_simd * per_tile_pipe
-    out = {"cycles_per_step": cyc, "cycles_source": "s_memtime, kernel entry to exit of wave 0 of workgroup 0 (workspace bytes 24..31)" if ticks
-           else "kernel_ms_avg x clock_hz", "cycles_per_step_from_kernel_time": cyc_time, "clock_hz": clock_hz,
+    out = {"cycles_per_step": cyc, "cycles_source": "kernel_ms_avg (live HIP events) x clock_hz", "clock_hz": clock_hz,
            "tiles_per_simd": tiles_per_simd, "work_model_instructions_per_tile_step": wm,
            "pipe_cost_cycles": dict(PIPE_COST), "pipe_floor_cycles_per_step": floor,
            "mfma_pipe_cycles_per_step": tiles_per_simd * wm["mfma"] * PIPE_COST["mfma"],
            "frac_work": floor / cyc}
     if ticks:
-        out.update(cycles_per_step_loop=ticks[0] / (T + 0.3), frac_step_loop=floor * (T + 0.3) / ticks[0])
+        out.update(cycles_per_step_in_kernel=ticks[1] / (T + 0.3), frac_in_kernel_cycles=floor * (T + 0.3) / ticks[1],
+                   cycles_per_step_loop=ticks[0] / (T + 0.3), frac_step_loop=floor * (T + 0.3) / ticks[0],
+                   in_kernel_cycles_source="s_memtime of wave 0 of workgroup 0: kernel entry to exit (workspace bytes 24..31), "
+                                           "the step loop alone (bytes 16..23)")
     if not two_waves:
         issue_floor = (wm["valu_plain"] * ISSUE_COST["valu"] + wm["transcendental"] * ISSUE_COST["trans"] + wm["mfma"] * ISSUE_COST["mfma"])
         out.update(issue_cost_cycles=dict(ISSUE_COST), issue_floor_cycles_per_step=issue_floor, issue_cost_frac=issue_floor / cyc)
@@ -407,7 +412,7 @@ def roofline_block(case, args, counters):
         figure -- achieved = tile-steps per second a SIMD completes (measured cycles per step: work_block), peak = the
         tile-steps per second its VALU pipe could retire from the stated minimal instruction counts at the measured
         pipe rates; frac = achieved / peak = pipe_floor_cycles / measured cycles.  Independent of what the compiler
-        emitted and -- with the in-kernel cycle count -- of any clock assumption.
+        emitted; frac_in_kernel_cycles is the same fraction over cycles counted inside the kernel (no clock assumption).
     Named secondaries: valu_active_frac (the UTILISATION round 4 reported as frac: 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles;
     needs counters), issue_cost_frac (single-wave issue costs), alg_bytes_frac (SURVEY.md 8(d)'s step-granular contract
     figure: exceeds 1 for a fused kernel, those bytes never move), fp32_frac.  counters = "same_build" | "stale" | "none"
@@ -450,8 +455,7 @@ def roofline_block(case, args, counters):
             per_tile = floor / wb["tiles_per_simd"]
             out.update(bound="valu_pipe", unit="tile-steps/s per SIMD",
                        achieved=wb["tiles_per_simd"] * clock_hz / cyc, peak=clock_hz / per_tile, frac=floor / cyc,
-                       traffic=traffic, clock_source=clock_src if not case.get("loop_ticks") else
-                       "cycles counted in the kernel (s_memtime); clock_hz (%s) only scales achieved / peak alike" % clock_src)
+                       traffic=traffic, clock_source=clock_src)
             out.update(wb)
         else:   # the step-granular launches: the fp32-equivalent FLOP fraction stands in
             out.update(bound="fp32_flops", unit="TFLOP/s", achieved=out["fp32_tflops"], peak=FP32_PEAK / 1e12,
@@ -789,7 +793,7 @@ def main(argv=None):
                                                                        ", BASELINE.json configs[1]" if is_c2 else "")
         if not full:
             keep = ("kernel", "kernel_ms_avg", "bound", "frac", "achieved", "peak", "unit", "traffic", "traffic_over_model",
-                    "cycles_per_step", "cycles_per_step_loop", "cycles_source", "pipe_floor_cycles_per_step", "tiles_per_simd", "valu_active_frac",
+                    "cycles_per_step", "cycles_per_step_in_kernel", "frac_in_kernel_cycles", "cycles_source", "clock_hz", "pipe_floor_cycles_per_step", "tiles_per_simd", "valu_active_frac",
                     "alg_bytes_frac", "fp32_frac", "counters", "counters_source")
             out = {"workload": workload, "baseline_config": baseline_config, "value": c["value"], "unit": "coordinate-steps/s",
                    "steps": a.steps, "unrolls_per_step": c["reps"], "ms_per_unroll": c["ms_per_unroll"],
@@ -868,7 +872,11 @@ def main(argv=None):
                                  #  from these driver-timed per-shard rates)
                                  ("config4_shard_of_2", ["--config", "4", "--emulate-world", "2", "--steps", "5", "--no-cpu-baseline"]),
                                  ("config4_shard_of_4", ["--config", "4", "--emulate-world", "4", "--steps", "5", "--unrolls-per-step", "8",
-                                                         "--no-cpu-baseline"])):
+                                                         "--no-cpu-baseline"]),
+                                 # (config 2's shape with a second tile per SIMD: 256 problems, global batch 256 -- what the
+                                 #  chip does when a shard is large enough for k_unroll_lds; NOT the contract workload)
+                                 ("config2_shape_256_problems", ["--batch", "256", "--steps", "5", "--unrolls-per-step", "8",
+                                                                 "--no-cpu-baseline"])):
             if time.perf_counter() - t_also > args.also_budget:
                 also[name] = {"skipped": "the also-block's time budget (%g s) was spent" % args.also_budget}
                 continue

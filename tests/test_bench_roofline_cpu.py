@@ -82,22 +82,26 @@ def test_roofline_frac_is_work_over_peak_at_pipe_rates(tmp_path):
                              ((str(tmp_path / "c.json"), _counters("y" * 16), "stale"), "stale"), (None, "none")):
         roof = b.roofline_block(case, A, counters)
         assert roof["bound"] == "valu_pipe" and roof["counters"] == status
-        assert abs(roof["cycles_per_step"] - 4343.0) < 1e-6 and "s_memtime" in roof["cycles_source"]
+        clock = 2.43e9 if counters is not None else 2.4e9                      # (the PMC passes' clock, else nominal)
+        cyc = 0.1777e-3 * clock / 100.3                                        # live kernel time x clock: the denominator of frac
+        assert abs(roof["cycles_per_step"] - cyc) < 1e-6 * cyc and roof["cycles_source"].startswith("kernel_ms_avg")
+        assert abs(roof["frac"] - pipe_floor / cyc) < 1e-9 and 0.31 < roof["frac"] < 0.33
+        assert abs(roof["cycles_per_step_in_kernel"] - 4343.0) < 1e-6 and "s_memtime" in roof["in_kernel_cycles_source"]
+        assert abs(roof["frac_in_kernel_cycles"] - pipe_floor / 4343.0) < 1e-9
         assert abs(roof["cycles_per_step_loop"] - 3944.0) < 1e-6 and abs(roof["frac_step_loop"] - pipe_floor / 3944.0) < 1e-9
-        assert abs(roof["frac"] - pipe_floor / 4343.0) < 1e-9 and 0.31 < roof["frac"] < 0.33
         assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-12
         issue_floor = 241 * b.ISSUE_COST["valu"] + 80 * b.ISSUE_COST["trans"] + 60 * b.ISSUE_COST["mfma"]
-        assert abs(roof["issue_cost_frac"] - issue_floor / 4343.0) < 1e-9
+        assert abs(roof["issue_cost_frac"] - issue_floor / cyc) < 1e-9
         if counters is None:
             assert "valu_active_frac" not in roof and roof["traffic"] is None
         else:
             assert 0.4 < roof["valu_active_frac"] < 0.6 and abs(roof["valu_insts_per_tile_step"] - 455.0) < 1e-6
             assert abs(roof["traffic"] - (2 * 4800.0 + 6100.0) * 1024.0) < 1.0    # FETCH_SIZE doubled on gfx950
-    # without the in-kernel count: live kernel time x the clock
+    # without the in-kernel count: the primary figure is unchanged, the in-kernel secondaries are absent
     case_t = dict(case, loop_ticks=None)
     roof = b.roofline_block(case_t, A, None)
     cyc = 0.1777e-3 * 2.4e9 / 100.3
-    assert abs(roof["cycles_per_step"] - cyc) < 1e-6 * cyc and roof["cycles_source"].startswith("kernel_ms_avg")
+    assert abs(roof["cycles_per_step"] - cyc) < 1e-6 * cyc and "frac_in_kernel_cycles" not in roof
     # a streaming (HBM-bound) kernel: bytes of the form / time / 8 TB/s, no work block
     case3 = dict(case, hbm_bound=True, kernel="k_unroll_cu8", hbm_model_bytes=27.06e9, kern_ms=4.608)
     r3 = b.roofline_block(case3, A, None)
