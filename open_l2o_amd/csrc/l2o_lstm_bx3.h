@@ -192,6 +192,18 @@ struct NetWB {
   static constexpr bool kLdsFrags = false;               // (NetWBL: the A operands are read from LDS at issue time)
   static constexpr int kFragFence = 0;
   static constexpr bool kLdsWin = false;                 // (NetWBLF: win0 / win1 are read from LDS where they are used)
+  static constexpr int kLdsChunk = -1;                   // (NetWBH: ONE chunk's A operands are read from LDS)
+};
+// The 6-product network with ONE chunk's fragments in LDS (round 5, k_mlp_unroll): the four chunks of the RNNProp net are
+// 240 AGPRs, which leaves the step's VALU operands 256 registers and the allocator spilling per-thread addresses to
+// scratch -- every reload then drains the whole memory queue (s_waitcnt vmcnt(0): the granule stores and the prefetched
+// image loads in flight with it).  Chunk LDSCH costs 15 ds_read_b128 per step instead of 60 registers; lch points at this
+// lane's 16 bytes of its fragment (M-tile 0, level 0), fragment (t, level) sits 1 KB x (3 t + level) further.
+template <int PRE, int LDSCH>
+struct NetWBH : NetWB<PRE, false> {
+  static constexpr int kLdsChunk = LDSCH;
+  static constexpr int kChunkFloats = kNT * 3 * 256;
+  const __attribute__((address_space(3))) u32x4* lch;
 };
 // The packed DM network with its weight FRAGMENTS IN LDS (round 4, k_unroll_lds): `a` is never loaded (no registers), an
 // MFMA's A operand is one ds_read_b128 from the workgroup's 60 KB fragment image -- what lets TWO waves share a SIMD
@@ -216,7 +228,7 @@ __device__ __forceinline__ void set_bias(W& w, const float* lds, int q) {
 
 // FRAGS = false: the caller fills w.a itself (k_cwlstm_step stages the fragments through LDS once
 // per workgroup instead of 4 x 61 KB of L2 reads)
-template <int PRE, bool FRAGS = true, bool PK = packed_default(PRE)>
+template <int PRE, bool FRAGS = true, bool PK = packed_default(PRE), int SKIP = -1>
 __device__ __forceinline__ void load_netw(NetWB<PRE, PK>& w, const float* __restrict__ wp, int lane) {
   const unsigned* wu = reinterpret_cast<const unsigned*>(wp);
   if (FRAGS) {
@@ -226,7 +238,7 @@ __device__ __forceinline__ void load_netw(NetWB<PRE, PK>& w, const float* __rest
       for (int t = 0; t < kNT; ++t)
 #pragma unroll
         for (int j = 0; j < frags(PK); ++j)
-          w.a[ch][t][j] = *reinterpret_cast<const u32x4*>(wu + frag_off(PRE, PK, ch, t, j) + lane * 4);
+          if (ch != SKIP) w.a[ch][t][j] = *reinterpret_cast<const u32x4*>(wu + frag_off(PRE, PK, ch, t, j) + lane * 4);
   }
   const float* p = wp + lane;
 #pragma unroll
@@ -294,6 +306,7 @@ __device__ __forceinline__ void issue(const W& w, const BOp<PK>& b, f32x4 (&acc)
         if ((n - LO) % W::kFragFence == W::kFragFence - 1) __builtin_amdgcn_sched_barrier(0);
       }
     } else if constexpr (PK) acc[t] = mfma_bf(w.a[CH][t][p], b.m[p], acc[t]);
+    else if constexpr (CH == W::kLdsChunk) acc[t] = mfma_bf(w.lch[(t * 3 + prod_w(p)) * 64], b.m[prod_x(p)], acc[t]);
     else acc[t] = mfma_bf(w.a[CH][t][prod_w(p)], b.m[prod_x(p)], acc[t]);
   });
 }
@@ -556,13 +569,13 @@ struct LstmCore<PRE, false, PK> {
   __device__ __forceinline__ void refresh(const TileState&) {}
 };
 
-template <int PRE, bool PK>
-struct LstmCore<PRE, true, PK> {
+template <int PRE, bool PK, class WT>
+struct LstmCoreRegs {
   static constexpr int kTotal = bx::chunk_mfmas(PK), kHalf = kTotal / 2;
-  bx::NetWB<PRE, PK> w;
+  WT w;
   bx::BOp<PK> b1, b2;      // split h1(t-1), h2(t-1): the recurrent chunks' B operands
   unsigned one;
-  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, true, PK>(w, wpack, lane); }
+  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, true, PK, WT::kLdsChunk>(w, wpack, lane); }
   // the bias table -> LDS (all threads; the caller puts a barrier between this and the first issue_*), then the lane's view
   static constexpr int kBiasFloats = bx::kBiasWords;
   __device__ __forceinline__ void stage_bias(float* lds, const float* __restrict__ wpack, int tid, int nthreads, int q) {
@@ -575,11 +588,12 @@ struct LstmCore<PRE, true, PK> {
   __device__ __forceinline__ void pin() {
 #ifndef L2O_NO_AGPR_PIN
 #pragma unroll
-    for (int ch = 0; ch < bx::NetWB<PRE, PK>::NCH; ++ch)
+    for (int ch = 0; ch < WT::NCH; ++ch)
 #pragma unroll
       for (int t = 0; t < kNT; ++t)
 #pragma unroll
-        for (int j = 0; j < bx::frags(PK); ++j) asm volatile("" : "+a"(w.a[ch][t][j]));
+        for (int j = 0; j < bx::frags(PK); ++j)
+          if (ch != WT::kLdsChunk) asm volatile("" : "+a"(w.a[ch][t][j]));
 #endif
   }
   __device__ __forceinline__ void init(const TileState& s, int q) {
@@ -595,8 +609,8 @@ struct LstmCore<PRE, true, PK> {
   }
   // the same ten reads without the pinning asm (see preload_bias): the caller fences them and drains the LDS queue later
   __device__ __forceinline__ void preload_unpinned(f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT]) {
-    bx::preload_bias<0, bx::NetWB<PRE, PK>, false>(w, acc1);
-    bx::preload_bias<1, bx::NetWB<PRE, PK>, false>(w, acc2);
+    bx::preload_bias<0, WT, false>(w, acc1);
+    bx::preload_bias<1, WT, false>(w, acc2);
   }
   template <int LO, int HI>
   __device__ __forceinline__ void issue_l1_prev(const TileState&, f32x4 (&acc1)[kNT]) {
@@ -612,10 +626,27 @@ struct LstmCore<PRE, true, PK> {
   template <bool NEXT, class Shadow = bx::NoShadow, bool REARM = true>
   __device__ __forceinline__ float finish(TileState& s, f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1,
                                           int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
-    return bx::finish<PRE, NEXT, PK, Shadow, REARM>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, static_cast<Shadow&&>(shadow));
+    return bx::finish<PRE, NEXT, PK, Shadow, REARM, WT>(w, s, b1, b2, acc1, acc2, in0, in1, one, q, pc, static_cast<Shadow&&>(shadow));
   }
   // after finish<false>: b1 already holds split h1(t) (finish builds it for chunk L2A); split h2(t) for chunk L2B
   __device__ __forceinline__ void refresh(const TileState& s) { bx::split5<PK>(s.h2, one, b2); }
+};
+template <int PRE, bool PK>
+struct LstmCore<PRE, true, PK> : LstmCoreRegs<PRE, PK, bx::NetWB<PRE, PK>> {};
+// the 6-product form with chunk LDSCH in LDS (bx::NetWBH); stage_chunk: every thread copies its share, a barrier follows
+template <int PRE, int LDSCH>
+struct LstmCoreHyb : LstmCoreRegs<PRE, false, bx::NetWBH<PRE, LDSCH>> {
+  static constexpr int kChunkFloats = bx::NetWBH<PRE, LDSCH>::kChunkFloats;
+  __device__ __forceinline__ void stage_chunk(float* lds, const float* __restrict__ wpack, int tid, int nthreads, int lane) {
+    const unsigned* wu = reinterpret_cast<const unsigned*>(wpack);
+    bx::u32x4* dst = reinterpret_cast<bx::u32x4*>(lds);
+    for (int i = tid; i < kChunkFloats / 4; i += nthreads) {
+      const int f = i >> 6, l = i & 63;                               // fragment 3 t + level, lane
+      dst[i] = *reinterpret_cast<const bx::u32x4*>(wu + bx::frag_off(PRE, false, LDSCH, f / 3, f % 3) + l * 4);
+    }
+    this->w.lch = reinterpret_cast<const __attribute__((address_space(3))) bx::u32x4*>(
+                      (const __attribute__((address_space(3))) float*)lds) + lane;
+  }
 };
 
 namespace bx {

@@ -130,43 +130,67 @@ __device__ __forceinline__ void mu_store2_local(unsigned long long* p, float v0,
   mu_u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
   asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory");
 }
+// The same three accesses as SCALAR base + 32-bit per-lane byte offset (round 5): no 64-bit per-lane pointer exists, so there is
+// nothing for LICM to hoist out of the step loop and for the allocator to spill (see `poff` in k_mlp_unroll).  `base` must be
+// wave-uniform (mu_uniform makes a pointer that the compiler cannot prove uniform scalar).
+// The `s_nop 4` is NOT optional: gfx9 needs five wait states between a VALU write of an SGPR and a vector-memory read of it,
+// the hazard recogniser does not look into inline asm, and a base reloaded from its spill lane (v_readlane, i.e. a VALU
+// SGPR write) directly in front of the asm makes the access use the STALE pair -- the -DL2O_PROFILE_PHASES build (more
+// SGPR spills) died with a memory access fault exactly there.
+__device__ __forceinline__ const unsigned long long* mu_uniform(const unsigned long long* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const unsigned long long*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void mu_store2_at(const unsigned long long* base, unsigned byte_off, float v0, float v1, unsigned tag) {
+  mu_u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(d), "s"(base) : "memory");
+}
+__device__ __forceinline__ void mu_store2_local_at(const unsigned long long* base, unsigned byte_off, float v0, float v1, unsigned tag) {
+  mu_u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" ::"v"(byte_off), "v"(d), "s"(base) : "memory");
+}
+__device__ __forceinline__ mu_u32x4 mu_load2_at(const unsigned long long* base, unsigned byte_off) {
+  mu_u32x4 d;
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=v"(d) : "v"(byte_off), "s"(base) : "memory");
+  return d;
+}
 __device__ __forceinline__ mu_u32x4 mu_load2(const unsigned long long* p) {
   mu_u32x4 d;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory");
   return d;
 }
 __device__ __forceinline__ void mu_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// A failed first poll costs a whole L2 / fabric round trip before the retry can see the granule (the no-wait build says
-// waiting is 19 % of the config-5 step, i.e. about half a round trip per hop): -DL2O_MU_DELAY_{A,B,C}=n holds the FIRST load
-// of a hop back by n x 64 clocks so that it arrives just after the granules do (A: local reduce, B: the fabric hop, C: gather)
-#ifndef L2O_MU_DELAY_A
-#define L2O_MU_DELAY_A 0
-#endif
-#ifndef L2O_MU_DELAY_B
-#define L2O_MU_DELAY_B 0
-#endif
-#ifndef L2O_MU_DELAY_C
-#define L2O_MU_DELAY_C 0
-#endif
-template <int N>
-__device__ __forceinline__ void mu_nap() {
-#pragma unroll
-  for (int i = 0; i < N; ++i) __builtin_amdgcn_s_sleep(1);
-}
-// The step loop's workgroup barrier.  -DL2O_MU_LDS_BARRIERS: wait for LDS traffic only (the barriers order LDS data; the
-// cross-workgroup protocol is self-validating granules) instead of __syncthreads(), which also drains the vector-memory
-// queue -- e.g. the next minibatch's image columns at the barrier behind dH.  Measured 1 % SLOWER (kernel 1.885 vs 1.869 ms
-// per T = 200 unroll, profiles/archive_r04/r04k_c5_barriers_ab.txt): not the default.
+// (Measured and removed in round 5, docs/DESIGN_history_r04.md 3.3 / 8.2: holding the FIRST load of a hop back by n x 64
+//  clocks so that it arrives behind the granules -- +-0.3 .. +3.5 %, the waiting is for partners that really are late;
+//  LDS-only workgroup barriers in the step loop -- 1 % slower; the next minibatch's indices requested a step ahead and passed
+//  through LDS -- 2 % slower; the forward tail on the VALU -- the matrix-core tail is 14 % faster.  Both memory-side ideas
+//  were measured AGAIN on the spill-free kernel (profiles/r05j_c5_prefetch_barriers_ab.txt): indices staged a step ahead in
+//  registers, all gathers issued back to back -- the phase clock's 1.8 k-cycle wait at the head of the tail goes, the kernel
+//  is 1 % SLOWER (1.830 vs 1.813 ms); LDS-only barriers on top -- 2.6 % slower (1.877 ms).  Vector memory returns in order
+//  and every poll ends in vmcnt(0): a minibatch gather (HBM / MALL latency) that is in flight when a hop starts sits in
+//  front of the hop's granule loads.  The dependent index -> column chain and the draining barriers keep it out.)
+// The step loop's workgroup barrier
 __device__ __forceinline__ void mu_barrier() {
-#ifdef L2O_MU_LDS_BARRIERS
-  lds_barrier();
-#else
   __syncthreads();
-#endif
 }
 
 // two granules at p until both carry `tag` (bounded, with back-off: a failed poll is a fabric request that competes
 // with the stores it waits for)
+__device__ __forceinline__ mu_u32x4 mu_poll2_at(const unsigned long long* base, unsigned byte_off, mu_u32x4 d, unsigned tag, bool& dead,
+                                                unsigned* status) {
+  int spins = 0;
+#ifdef L2O_MU_ABL_NOWAIT
+  return d;
+#endif
+  while ((d[1] != tag || d[3] != tag) && !dead) {
+    if (++spins > (1 << 17)) { dead = true; atomicExch(status, 2u); break; }
+    __builtin_amdgcn_s_sleep(L2O_MU_SLEEP2);
+    d = mu_load2_at(base, byte_off);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  return d;
+}
 __device__ __forceinline__ mu_u32x4 mu_poll2(const unsigned long long* p, mu_u32x4 d, unsigned tag, bool& dead, unsigned* status) {
   int spins = 0;
 #ifdef L2O_MU_ABL_NOWAIT
@@ -223,12 +247,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int k_end = (min(j0 + 64, a.n[0]) - 1) / H;   // inclusive
   const int KR = owns_w1 ? k_end - k0 + 1 : 0;
 
-  using Core = LstmCore<PRE, true, false>;             // bf16x3 gate GEMM (6-product form: the packed fragments spill here), pinned to AGPRs
+  // bf16x3 gate GEMM, 6-product form, fragments pinned to AGPRs.  RNNProp's four chunks would be 240 of them; its feature
+  // chunk is read from LDS instead (LstmCoreHyb, 15 KB) -- the 60 registers are what keeps the step loop out of scratch
+#ifndef L2O_MU_LDS_CHUNK
+#define L2O_MU_LDS_CHUNK 1
+#endif
+  constexpr bool kHyb = L2O_MU_LDS_CHUNK && PRE != L2O_PRE_IDENTITY;      // (LogAndSign: 40 registers of input-weight rows)
+  constexpr int kHybCh = PRE == L2O_PRE_FC_ELU ? bx::kChL1X : bx::kChL2A;
+  using Core = typename std::conditional<kHyb, LstmCoreHyb<PRE, kHybCh>, LstmCore<PRE, true, false>>::type;
   Core core;
   core.load(a.np.wpack, lane);
   core.pin();
   __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];   // the gate biases = accumulator inits
   core.stage_bias(bias_s, a.np.wpack, tid, 256, q);          // (ordered by the __syncthreads() of the prologue below)
+  if constexpr (kHyb) {
+    __shared__ __attribute__((aligned(16))) float chunk_s[LstmCoreHyb<PRE, kHybCh>::kChunkFloats];
+    core.stage_chunk(chunk_s, a.np.wpack, tid, 256, lane);
+  }
   f32x4 acc1[kNT], acc2[kNT];
   TileState s;
   float* st_tile = a.st[var] + (size_t)tile_in_var * kStateFloatsPerTile;
@@ -270,13 +305,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __shared__ unsigned xcc_s[256];
   __shared__ float redh[16][kMuHierR1Max];             // stage A: [source chunk][output] partial sums
   __shared__ float redx[kMuHierG][kMuHierR1Max];       // stage B: [XCD][output] per-XCD partial sums
-  bool hier = false;                                   // (constant false when the protocol is compiled out)
-#ifdef L2O_MU_NO_HIER
-  constexpr bool kHierBuilt = false;
-#else
-  constexpr bool kHierBuilt = true;
-#endif
-  if constexpr (FAST && kHierBuilt) {
+  bool hier = false;
+  if constexpr (FAST) {
     if (a.hier_R1 > 0) {
       const unsigned kHs = 0x80000000u | salt | 0xfffeu;
       if (tid == 0) {
@@ -298,33 +328,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const float invB = 1.0f / (float)Bn;
   // this thread's slots of the image-column panel: slot e = tid + 256 u -> (sample e / KR, k-row e % KR).  The two per-step
   // loops over the panel divided by the runtime KR ten times per step (~350 instructions); round 4: one multiply by a
-  // 16-bit reciprocal (exact for e < 2^12, KR <= 10) -- or, -DL2O_MU_SLOT_REGS, the slots kept in five registers
+  // 16-bit reciprocal (exact for e < 2^12, KR <= 10)
   constexpr int kPre = (kMuMaxBatch * kMuMaxKR + 255) / 256;
   const unsigned kr_rcp = KR > 0 ? (65536u + (unsigned)KR - 1u) / (unsigned)KR : 0u;
-#ifdef L2O_MU_SLOT_REGS
-  int pre_slot[kPre];
-#pragma unroll
-  for (int u = 0; u < kPre; ++u) {
-    const int e = tid + 256 * u;
-    pre_slot[u] = -1;
-    if (KR > 0 && e < Bn * KR) { const int sidx = e / KR; pre_slot[u] = (sidx << 8) | (e - sidx * KR); }
-  }
-  auto slot_of = [&](int u) { return pre_slot[u]; };
-#else
   auto slot_of = [&](int u) {
     const int e = tid + 256 * u;
     if (e >= Bn * KR) return -1;
     const int sidx = (int)(((unsigned)e * kr_rcp) >> 16);
     return (sidx << 8) | (e - sidx * KR);
   };
-#endif
-  __shared__ int idx_s[kMuMaxBatch];                     // the NEXT evaluation's minibatch indices (see prefetch_next)
   core.init(s, q);
   core.preload(acc1, acc2);                                 // accumulator inits of the first step (the biases)
   PhaseClock pc;
   pc.start();
+  // (round 5) where this thread's <= 3 granule pairs of partial pre-activations go: element offsets into P for the protocol
+  // in use, computed ONCE (they hold a runtime division); every other per-thread address of the step loop is re-derived from
+  // an opaque copy of the thread index each step.  Before: LICM hoisted ~30 such 64-bit addresses out of the step loop,
+  // the register allocator spilled them (60 dwords of scratch in a kernel at 512 registers), and every reload came with an
+  // `s_waitcnt vmcnt(0)` -- which on gfx9 also waits for the ACKs of the granule stores just issued and for the next
+  // minibatch's image loads in flight: the store phase serialised on its own write acknowledgements.
+  unsigned poff[3] = {0u, 0u, 0u};
+  if constexpr (FAST) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int o = 2 * (tid + 256 * u);
+      if (hier) {
+        const int mr = o / a.hier_R1;
+        poff[u] = (unsigned)((((wg & (kMuHierG - 1)) * kMuHierM + mr) * kMuHierM + (wg >> 3)) * a.hier_R1 + (o - mr * a.hier_R1));
+      } else {
+        const int r = o / a.R;
+        poff[u] = (unsigned)((r * a.nw1 + wg) * a.R + (o - r * a.R));
+      }
+    }
+  }
+  const int tid_outer = tid;
   const long long loop_t0 = __builtin_readcyclecounter();
   for (int t = 0;; ++t) {
+    int oz_step = 0;
+    asm volatile("" : "+v"(oz_step));
+    const int tid = tid_outer + oz_step;                // (opaque per step: see poff above)
     const int par = t & 1;
     const unsigned tag = salt | ((unsigned)t + 1u);
     const float xsv = xv * sc;
@@ -342,9 +384,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the next evaluation's image columns / labels -> registers: requested once the sums of THIS evaluation are in
     // (vector-memory returns in order: ahead of the polls the gather would delay them, and in front of the step's
     // first barrier its two dependent latencies sat on the critical path), completed under the forward tail
-    // (-DL2O_MU_IDX_LDS: the indices of the next minibatch are requested at the TOP of the step -- nidx below -- and passed
-    //  through LDS behind the reduce phase's barrier instead of being loaded here, in front of the image / label loads that
-    //  depend on them.  Measured 2 % SLOWER (kernel 1.904 vs 1.867 ms per T = 200 unroll, profiles/archive_r04/r04j_*): not the default)
     auto prefetch_next = [&]() {
 #ifdef L2O_MU_ABL_NOPREFETCH   // (timing ablation: no minibatch gather -- wrong numerics; what do the two dependent loads cost?)
 #pragma unroll
@@ -356,23 +395,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int u = 0; u < kPre; ++u) {
           pre_img[u] = 0.0f;
           const int sl = slot_of(u);
-#ifndef L2O_MU_IDX_LDS
           if (sl >= 0) pre_img[u] = a.images[(size_t)a.idx[(size_t)(t + 1) * Bn + (sl >> 8)] * n_in + k0 + (sl & 0xff)];
-#else
-          if (sl >= 0) pre_img[u] = a.images[(size_t)idx_s[sl >> 8] * n_in + k0 + (sl & 0xff)];
-#endif
         }
-#ifndef L2O_MU_IDX_LDS
         if (tid < Bn) pre_lab = a.labels[a.idx[(size_t)(t + 1) * Bn + tid]];
-#else
-        if (tid < Bn) pre_lab = a.labels[idx_s[tid]];
-#endif
       }
     };
-    int nidx = 0;
-#ifdef L2O_MU_IDX_LDS
-    if (have_next && tid < Bn) nidx = a.idx[(size_t)(t + 1) * Bn + tid];
-#endif
     mu_barrier();                                   // xwg complete
     pc.mark(0);
     if constexpr (FAST) {
@@ -394,14 +421,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               acc0 = __builtin_fmaf(im, xwg[jj], acc0);
               acc1 = __builtin_fmaf(im, xwg[jj + 1], acc1);
             }
-            if (hier) {                                  // -> the inbox of the reducer of these outputs on THIS XCD
-              const int mr = o / a.hier_R1;
-              mu_store2_local(a.P + ((((size_t)(wg & (kMuHierG - 1)) * kMuHierM + mr) * kMuHierM + (wg >> 3)) * a.hier_R1 +
-                                     (o - mr * a.hier_R1)), acc0, acc1, tag);
-            } else {
-              const int r = o / R;
-              mu_store2(a.P + ((size_t)r * a.nw1 + wg) * R + (o - r * R), acc0, acc1, tag);
-            }
+            // hier: the inbox of the reducer of these outputs on THIS XCD (plain store: the line stays in that L2); flat:
+            // the inbox of the reducing workgroup, write-through
+            if (hier) mu_store2_local_at(a.P, 8u * poff[u], acc0, acc1, tag);
+            else mu_store2_at(a.P, 8u * poff[u], acc0, acc1, tag);
           }
         }
       }
@@ -416,9 +439,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (tid >= FH && tid < FH + FH * FO) { const int e = tid - FH; w2p[e / FO][e % FO] = val; }
       }
       pc.mark(1);
-#ifdef L2O_MU_IDX_LDS
-      if (have_next && tid < Bn) idx_s[tid] = nidx;      // (its readers sit behind the reduce phase's barrier)
-#endif
       if (hier) {
         // ---- (A) local reduce: member (g, mr) sums outputs [mr R1, mr R1 + R1) over the w1 owners of ITS XCD.
         // thread = (output pair p, source chunk ch): sources ch, ch + nch, ... in ascending order, then the chunks in
@@ -440,7 +460,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           float s0 = 0.0f, s1 = 0.0f;
           if (ch < nch) {
             const unsigned long long* inbox = a.P + (((size_t)g * kMuHierM + mr) * kMuHierM) * R1 + 2 * pq;
-            mu_nap<L2O_MU_DELAY_A>();
             for (int base = ch; base < cnt; base += 3 * nch) {   // up to 3 sources in flight per thread, then their tags
               mu_u32x4 d[3];
 #pragma unroll
@@ -471,7 +490,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int g2 = tid / np, p2 = tid - g2 * np;
             if (g2 != g) {
               const unsigned long long* xp = a.X + (((size_t)par * kMuHierG + g2) * kMuHierM + mr) * R1 + 2 * p2;
-              mu_nap<L2O_MU_DELAY_B>();
               mu_u32x4 d = mu_load2(xp);
               mu_wait_loads();
               d = mu_poll2(xp, d, tag, dead, status);
@@ -532,14 +550,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       pc.mark(2);
       // ---- gather the sums (pairs), bias + activation fused into the LDS write
       {
-        const unsigned long long* Sp = hier ? a.S1 + ((size_t)par * kMuHierG + (wg & (kMuHierG - 1))) * kMuHierS
-                                            : a.S + (size_t)par * FNO;
+        const unsigned long long* Sp = mu_uniform(hier ? a.S1 + ((size_t)par * kMuHierG + (wg & (kMuHierG - 1))) * kMuHierS
+                                                       : a.S + (size_t)par * FNO);
         mu_u32x4 g[3];
-        mu_nap<L2O_MU_DELAY_C>();
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int pr = tid + 256 * u;
-          if (pr < FNO / 2) g[u] = mu_load2(Sp + 2 * pr);
+          if (pr < FNO / 2) g[u] = mu_load2_at(Sp, 16u * (unsigned)pr);
         }
         mu_wait_loads();
         // (small[] was written before the barrier inside the reduce phase)
@@ -547,7 +564,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int u = 0; u < 3; ++u) {
           const int pr = tid + 256 * u;
           if (pr < FNO / 2) {
-            g[u] = mu_poll2(Sp + 2 * pr, g[u], tag, dead, status);
+            g[u] = mu_poll2_at(Sp, 16u * (unsigned)pr, g[u], tag, dead, status);
             const int o = 2 * pr, sidx = o / FH, h = o - sidx * FH;
             const float a0 = __uint_as_float(g[u][0]) + small[h], a1 = __uint_as_float(g[u][2]) + small[h + 1];
             Hs[sidx][h] = a.act == 0 ? sigmoidf_(a0) : fmaxf(a0, 0.0f);
@@ -559,61 +576,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       pc.mark(3);
       prefetch_next();
       pc.mark(9);                                      // (profiling build: the next minibatch's loads are requested)
-#ifdef L2O_MU_TAIL_VALU
-      // ---- forward tail, every wave for all 64 samples (lane = sample): logits, softmax, loss, dZ in registers
-      float hrow[FH], dz[FO];
-      {
-        const float4* hp = reinterpret_cast<const float4*>(&Hs[lane][0]);
-#pragma unroll
-        for (int j4 = 0; j4 < FH / 4; ++j4) {
-          const float4 v4 = hp[j4];
-          hrow[4 * j4] = v4.x; hrow[4 * j4 + 1] = v4.y; hrow[4 * j4 + 2] = v4.z; hrow[4 * j4 + 3] = v4.w;
-        }
-        float z[FO];
-#pragma unroll
-        for (int o = 0; o < FO; ++o) z[o] = small[FH + FH * FO + o];
-#pragma unroll
-        for (int h = 0; h < FH; ++h) {
-          const float4* wp = reinterpret_cast<const float4*>(&w2p[h][0]);
-          const float4 wa = wp[0], wb = wp[1], wc = wp[2];
-          const float wr[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
-#pragma unroll
-          for (int o = 0; o < FO; ++o) z[o] = __builtin_fmaf(hrow[h], wr[o], z[o]);
-        }
-        const int lab = labs[par][lane];
-        constexpr float kLog2e = 1.4426950408889634f;
-        float zmax = z[0];
-#pragma unroll
-        for (int o = 1; o < FO; ++o) zmax = fmaxf(zmax, z[o]);
-        float se = 0.0f, zl = 0.0f;
-#pragma unroll
-        for (int o = 0; o < FO; ++o) { se += fast_exp2((z[o] - zmax) * kLog2e); zl = o == lab ? z[o] : zl; }
-        const float lse = zmax + __builtin_amdgcn_logf(se) * 0.6931471805599453f;      // v_log_f32 (log2), 1 ulp
-#pragma unroll
-        for (int o = 0; o < FO; ++o) dz[o] = (fast_exp2((z[o] - lse) * kLog2e) - (o == lab ? 1.0f : 0.0f)) * invB;
-        const float lsum = wave_sum64(lse - zl);
-        if (wg == 0 && tid == 0) a.fx[t] = lsum * invB;
-        if (wv == 0) {
-#pragma unroll
-          for (int o = 0; o < FO; ++o) dZs[lane][o] = dz[o];
-        }
-      }
-      pc.mark(4);
-      if (t == a.T && !HIST) break;
-      // ---- dH for hidden units 5 wv .. 5 wv + 4 of the lane's sample
-#pragma unroll
-      for (int hh = 0; hh < 5; ++hh) {
-        const int h = 5 * wv + hh;
-        const float4* wp = reinterpret_cast<const float4*>(&w2p[h][0]);
-        const float4 wa = wp[0], wb = wp[1], wc = wp[2];
-        const float wr[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
-        float d = 0.0f;
-#pragma unroll
-        for (int o = 0; o < FO; ++o) d = __builtin_fmaf(dz[o], wr[o], d);
-        const float hv = Hs[lane][h];
-        dHs[lane][h] = a.act == 0 ? d * hv * (1.0f - hv) : (hv > 0.0f ? d : 0.0f);
-      }
-#else
       // ---- forward tail + dH on the fp32 matrix cores (round 4).  Until round 3 every wave evaluated the layer-2 forward,
       // the softmax and dH for ALL 64 samples with 400 dependent FMAs against w2 rows read from LDS one s_waitcnt at a time
       // (5.0 k + 2.7 k of the step's 27 k ticks, four-fold redundant).  Now wave w owns samples 16 w .. 16 w + 15 and runs
@@ -698,7 +660,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           *reinterpret_cast<f32x4*>(&dHs[s_l][16]) = o1;
         }
       }
-#endif
     } else {
     // ---- partial hidden pre-activations over the workgroup's own w1 coordinates
     if (owns_w1) {
@@ -716,9 +677,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     core.template issue_l2_prev<0, Core::kTotal>(s, acc2);
     core.template issue_l1_prev<0, Core::kTotal>(s, acc1);
     pc.mark(1);                                        // partial + publish
-#ifdef L2O_MU_IDX_LDS
-    if (have_next && tid < Bn) idx_s[tid] = nidx;      // (its readers sit behind the gather's barrier)
-#endif
     // ---- reduce-scatter: this workgroup sums outputs [wg R, wg R + R) over all partials, fixed order.
     // All R granules of a source are requested before the first tag is checked (one L2 / fabric round trip
     // per source, not R of them)
@@ -825,9 +783,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     }
     mu_barrier();
-#ifndef L2O_MU_TAIL_VALU
     if (FAST && wg == 0 && tid == 0) a.fx[t] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * invB;
-#endif
     pc.mark(5);                                        // dH
     // ---- the gradient of this lane's coordinate: a sum over the samples, split over the four q lanes
     float gv = 0.0f;

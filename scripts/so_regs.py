@@ -22,6 +22,6 @@ for _ in range(n):
             if pat not in name:
                 continue
             g = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, b).group(1))
-            print('%-70s vgpr %3d (agpr %3d) sgpr %3d spill %3d scratch %4d lds %6d' % (
-                name[:70], g('vgpr_count'), int(b.split('\n')[0]), g('sgpr_count'), g('vgpr_spill_count'),
+            print('%-70s vgpr %3d (agpr %3d) sgpr %3d (spilled %3d) spill %3d scratch %4d lds %6d' % (
+                name[:70], g('vgpr_count'), int(b.split('\n')[0]), g('sgpr_count'), g('sgpr_spill_count'), g('vgpr_spill_count'),
                 g('private_segment_fixed_size'), g('group_segment_fixed_size')))
