@@ -225,6 +225,8 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         yes), afterwards what the library reported for it (l2o_last_unroll_form)."""
         if restart_fused or os.environ.get("L2O_NO_RECOVERY") or not hasattr(self.engine, "last_unroll_exchanges"):
             return False
+        if self.__dict__.get("_last_launch", {}).get("restart") is not None:
+            return False                                 # (restart= launches are re-run from the caller's x0: nothing to keep)
         return self.__dict__.get("_exchanges", True)
 
     def _sync_or_recover(self, fx, xs, feed, commit):
