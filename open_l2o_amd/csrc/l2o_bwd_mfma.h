@@ -155,10 +155,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     for (int b0 = tid; b0 < n4; b0 += 256 * 8) {
       bx::u32x4 v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = b0 + 256 * k;
-        if (i < n4) v[k] = src[i];
-      }
+      for (int k = 0; k < 8; ++k) v[k] = src[min(b0 + 256 * k, n4 - 1)];   // (unconditional: a predicated v[k] lands in scratch)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int i = b0 + 256 * k;
@@ -210,15 +207,15 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4) {
       float4* cd = reinterpret_cast<float4*>(cio + a4 * NC * kH);
-      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      // (values, not a `cond ? load : zero4` of a const object: that form put the zero vector into scratch)
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
       if (p.carry_in) {
         const float4* cs = reinterpret_cast<const float4*>(p.carry_in + ((size_t)a4 * RT + n0) * kH);
-        cd[lane] = lane < nv * 5 ? cs[lane] : zero4;
-        if (lane < NC * kH / 4 - 64) cd[64 + lane] = 64 + lane < nv * 5 ? cs[64 + lane] : zero4;
-      } else {
-        cd[lane] = zero4;
-        if (lane < NC * kH / 4 - 64) cd[64 + lane] = zero4;
+        if (lane < nv * 5) v0 = cs[lane];
+        if (lane < NC * kH / 4 - 64 && 64 + lane < nv * 5) v1 = cs[64 + lane];
       }
+      cd[lane] = v0;
+      if (lane < NC * kH / 4 - 64) cd[64 + lane] = v1;
     }
     __syncthreads();                                        // carries are in LDS
     float cdh1[kNT], cdc1[kNT], cdh2[kNT], cdc2[kNT];
