@@ -413,7 +413,7 @@ __device__ __forceinline__ float finish(const W& w, TileState& s, BOp<PK>& b1, B
                                         f32x4 (&acc1)[kNT], f32x4 (&acc2)[kNT], float in0, float in1, unsigned one,
                                         int q, PhaseClock& pc, Shadow&& shadow = Shadow()) {
   constexpr int kN = chunk_mfmas(PK);
-  if (PRE == L2O_PRE_FC_ELU) {
+  if constexpr (PRE == L2O_PRE_FC_ELU) {   // (constexpr: chunk L1X does not exist for the DM nets)
     float fc[kNT];
 #pragma unroll
     for (int t = 0; t < kNT; ++t)

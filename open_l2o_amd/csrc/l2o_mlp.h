@@ -227,7 +227,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpParams p) {
   const float* gH = p.scratch;
   const float* gdZ = gH + Bn * H;
   const float* gdH = gdZ + Bn * O;
-  const float* gloss = gdH + Bn * H;
   const int tid = threadIdx.x;
   const int nkb = (n_in + kMlpKPB - 1) / kMlpKPB;
   if ((int)blockIdx.x == nkb) {                         // the small tensors + the loss
