@@ -14,6 +14,7 @@
 #   cu8_ring            k_unroll_cu8: ring depth (variants -DL2O_CU8_RING=n) x register tiles (L2O_UNROLL_CU = 3 | 4), config 3
 #   cu_fourwave         the four-wave streaming kernel (L2O_UNROLL_CU=2) over the library variants, config 3
 #   onecu_vs_pair       L2O_NO_PAIR / L2O_ONE_LDS forms at config-2 / config-4 sizes
+#   c3_libs             config 3 (default form) over the library variants, e.g. -DL2O_CU8_NT=1 (non-temporal matrix stream)
 #   c5_hier             l2o_mlp_unroll: hierarchical all-reduce on / off (L2O_NO_MLP_HIER=1) + library variants, config 5
 NAME=${1:?usage: ab.sh NAME [OUTDIR]}; O=${2:-gpurun_out/ab}; mkdir -p $O
 cd "$(dirname "$0")/.."
@@ -71,6 +72,8 @@ case $NAME in
   cu_fourwave)
     export L2O_UNROLL_CU=2
     for v in $(libs); do for rep in 1 2; do L2O_HIP_LIB=$PWD/$v run "$(basename $v .so) four-wave" --config 3 --steps 4; done; done ;;
+  c3_libs)
+    for rep in 1 2; do for v in $(libs); do L2O_HIP_LIB=$PWD/$v run "$(basename $v .so)" --config 3 --steps 4; done; done ;;
   onecu_vs_pair)
     for rep in 1 2; do
       L2O_ONE_LDS=0 run "c4 pair-chunks" --config 4 --steps 10; run "c4 default" --config 4 --steps 10
