@@ -448,6 +448,12 @@ def roofline_block(case, args, counters):
                    achieved=model / kern_s / 1e9, frac=model / kern_s / HBM_PEAK)
         if traffic is not None:
             out.update(traffic_GBps=traffic / kern_s / 1e9, traffic_over_model=traffic / model if model else None)
+        if case.get("streaming"):
+            # (measured, not assumed: the same kernel with 32 of the 256 problems -- 32 busy CUs, everything cache-resident
+            #  -- takes 0.93 of the full launch's time; non-temporal loads on the stream are 21 % SLOWER)
+            out["bound_note"] = ("hbm is the byte roofline this row is priced against; the streaming unroll itself is paced by the "
+                                 "CU's instruction stream, not by the bytes (profiles/r05w_c3_problem_count_sweep.txt, "
+                                 "r05v_c3_nontemporal_stream_ab.txt; DESIGN.md 3.1c)")
     else:
         wb = work_block(case, issue, args, clock_hz)
         if wb is not None:
@@ -648,7 +654,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
             "bpc": bpc, "alg_bytes": bpc * coord_steps,
             "flops": alg_flops_per_coord_step(args.problem, args.net, D, Mrows) * coord_steps,
             "fused": fused, "kernel": kernel, "dispatches": dispatches, "loop_ticks": loop_ticks,
-            "n_cus": int(getattr(eng, "coresident_cus", 256)), "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")),
+            "n_cus": int(getattr(eng, "coresident_cus", 256)), "hbm_bound": bool(streaming or (not fused and args.problem != "mnist")), "streaming": bool(streaming),
             "hbm_model_bytes": hbm_model, "t_reset": t_reset, "D": D, "B": B, "Bg": Bg, "T": T, "Mrows": Mrows,
             "shared": shared}
 
@@ -803,7 +809,7 @@ def main(argv=None):
         if not full:
             keep = ("kernel", "kernel_ms_avg", "bound", "frac", "achieved", "peak", "unit", "traffic", "traffic_over_model",
                     "cycles_per_step", "cycles_per_step_in_kernel", "frac_in_kernel_cycles", "cycles_source", "clock_hz", "pipe_floor_cycles_per_step", "tiles_per_simd", "valu_active_frac",
-                    "alg_bytes_frac", "fp32_frac", "counters", "counters_source")
+                    "alg_bytes_frac", "fp32_frac", "counters", "counters_source", "bound_note")
             out = {"workload": workload, "baseline_config": baseline_config, "value": c["value"], "unit": "coordinate-steps/s",
                    "steps": a.steps, "unrolls_per_step": c["reps"], "ms_per_unroll": c["ms_per_unroll"],
                    "timed_regions_ms": c["timed_regions_ms"],   # (`value` is the faster of these equal regions)
