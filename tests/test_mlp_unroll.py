@@ -91,6 +91,34 @@ def test_rnnprop_fused_equals_step_path(hip, activation, batch):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("batch", [64, 40])
+def test_dm_identity_net_vs_oracle(hip, batch):
+    """The plain L2O-DM net (no gradient preprocessing: the kernel's PRE = IDENTITY instantiations, all fragment chunks
+    in registers) on the MLP optimizee against O.unroll_multi: minibatch 64 = the FAST instantiation, 40 = the generic one."""
+    data = problems.synthetic_mnist(256, seed=6)
+    T = 40
+    idx = np.random.default_rng(90).integers(0, 256, size=(T + 1, batch))
+    cfg = O.DM_IDENTITY
+    params = make_params(cfg, seed=91, trained_like=True)
+    meta.set_random_seed(13)
+    problem = problems.mnist(layers=(20,), batch_size=batch, data=data, sampler=_sampler(idx))
+    optimizer = meta.MetaOptimizer(**_net_config(cfg, params))
+    ml = optimizer.meta_loss(problem, T)
+    with Session() as sess:
+        sess.run(ml.reset)
+        v0 = [v.eval() for v in optimizer.graph.x]
+        sess.run([ml.fx, ml.update])
+        fx_array = hip.to_numpy(optimizer.graph._fx_cache[T]["bufs"][0])
+        xT = [v.eval() for v in optimizer.graph.x]
+    assert optimizer.graph.last_path == "mlp_unroll"
+    ref = O.MnistMLP(data["images"], data["labels"].astype(np.int32), "sigmoid")
+    states = [O.net_initial_state(cfg, a.size) for a in v0]
+    fx_ref, v_ref, _ = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[t], wg), cfg, params, v0, states, T)
+    assert rel_err(fx_array, fx_ref) < 1e-5
+    for got, want in zip(xT, v_ref):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+
+
 def test_unsupported_shapes_fall_back(hip):
     """Hidden width 6 (below the kernel's range): no fused kernel, the step path takes over."""
     data = problems.synthetic_mnist(100, seed=5)
