@@ -15,6 +15,7 @@
 #   cu_fourwave         the four-wave streaming kernel (L2O_UNROLL_CU=2) over the library variants, config 3
 #   onecu_vs_pair       L2O_NO_PAIR / L2O_ONE_LDS forms at config-2 / config-4 sizes
 #   c3_libs             config 3 (default form) over the library variants, e.g. -DL2O_CU8_NT=1 (non-temporal matrix stream)
+#   c3dm_libs           the DM nets on config 3's optimizee (Lasso 256 x 512, batch 256) over the library variants
 #   c5_hier             l2o_mlp_unroll: hierarchical all-reduce on / off (L2O_NO_MLP_HIER=1) + library variants, config 5
 NAME=${1:?usage: ab.sh NAME [OUTDIR]}; O=${2:-gpurun_out/ab}; mkdir -p $O
 cd "$(dirname "$0")/.."
@@ -74,6 +75,11 @@ case $NAME in
     for v in $(libs); do for rep in 1 2; do L2O_HIP_LIB=$PWD/$v run "$(basename $v .so) four-wave" --config 3 --steps 4; done; done ;;
   c3_libs)
     for rep in 1 2; do for v in $(libs); do L2O_HIP_LIB=$PWD/$v run "$(basename $v .so)" --config 3 --steps 4; done; done ;;
+  c3dm_libs)
+    for rep in 1 2; do for v in $(libs); do
+      L2O_HIP_LIB=$PWD/$v run "$(basename $v .so) dm" --problem lasso --net dm --dims 512 --rows 256 --batch 256 --unroll 200 --steps 4 --untrained
+      L2O_HIP_LIB=$PWD/$v run "$(basename $v .so) dm_logsign" --problem lasso --net dm_logsign --dims 512 --rows 256 --batch 256 --unroll 200 --steps 4 --untrained
+    done; done ;;
   onecu_vs_pair)
     for rep in 1 2; do
       L2O_ONE_LDS=0 run "c4 pair-chunks" --config 4 --steps 10; run "c4 default" --config 4 --steps 10
