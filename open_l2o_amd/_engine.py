@@ -684,8 +684,12 @@ class HipEngine(object):
             else:
                 hdr = ws[:4].cpu().numpy().tobytes()
             if hdr != b"\0\0\0\0":
-                ws[:4].zero_()                               # the status word is sticky: handled here, cleared here
-                ws[8:12].zero_()                             # (an injected fault is one-shot)
+                # The status word is sticky: handled here, cleared here -- together with the WHOLE workspace:
+                # a launch that timed out may have left granules tagged for steps it never completed, and the persistent
+                # MLP kernel advances its tag salt from inside the kernel, so a dead launch can leave valid-looking tags
+                # for the next one.  Zero memory is the initial state of both workspaces (l2o_unroll_workspace_init);
+                # this also clears the test hook's one-shot fault word (bytes 8..11).
+                ws.zero_()
             _abi.check(self.lib.l2o_unroll_status(hdr))
 
     def atb(self, A, B):

@@ -256,20 +256,29 @@ def _term_vars(term):
 
 
 _EMULATED_WORLD = None
+_EMULATED_COLLECTIVES = False
 
 
-def emulate_world(rank=None, world=None):
-    """Run ONE shard of a sharded job in a single process, without a process group: graphs built afterwards behave as
-    rank ``rank`` of ``world`` (contiguous batch slice, 1/B_global in every gradient) and skip the collectives -- the losses
-    they report are the SHARD's partial sums / B_global.  For measuring the per-rank rate of a configuration that is defined
-    on more GPUs than the box has (bench.py --emulate-world: BASELINE config 4's shard of 8).  emulate_world() ends it."""
-    global _EMULATED_WORLD
+def emulate_world(rank=None, world=None, collectives=False):
+    """Run ONE shard of a sharded job in a single process: graphs built afterwards behave as rank ``rank`` of ``world``
+    (contiguous batch slice, 1/B_global in every gradient); the losses they report are the SHARD's partial sums / B_global.
+    For measuring the per-rank rate of a configuration that is defined on more GPUs than the box has (bench.py
+    --emulate-world: BASELINE config 4's shard of 8).  collectives=False: no process group, the collectives are skipped.
+    collectives=True (round 6): every collective of the data path is ISSUED through the initialised torch.distributed
+    group of this process (a world-size-1 RCCL group on a 1-GPU box: the communicator, the stream hand-over and the
+    enqueue path are the real ones, the result is unchanged) -- what a rank pays for the collective, measurable without a
+    second GPU.  emulate_world() ends it."""
+    global _EMULATED_WORLD, _EMULATED_COLLECTIVES
     if rank is None or world is None or int(world) <= 1:
-        _EMULATED_WORLD = None
+        _EMULATED_WORLD, _EMULATED_COLLECTIVES = None, False
     else:
         if not 0 <= int(rank) < int(world):
             raise ValueError("emulate_world: rank %r outside world %r" % (rank, world))
-        _EMULATED_WORLD = (int(rank), int(world))
+        if collectives:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("emulate_world(collectives=True) needs an initialised torch.distributed process group")
+        _EMULATED_WORLD, _EMULATED_COLLECTIVES = (int(rank), int(world)), bool(collectives)
 
 
 def _world():
@@ -284,8 +293,8 @@ def _world():
 def _all_reduce(t, async_op=False, op=None):
     """torch.distributed.all_reduce(t) over the job's ranks -- the ONLY collective of the data path (the
     T + 1 partial losses per unroll; the flat weight gradient and the unroll status word per training step).  A no-op
-    under emulate_world (one shard measured on its own)."""
-    if _EMULATED_WORLD is not None:
+    under emulate_world (one shard measured on its own) unless it was asked to keep the collectives."""
+    if _EMULATED_WORLD is not None and not _EMULATED_COLLECTIVES:
         return None
     import torch.distributed as dist
     if op is None:

@@ -228,7 +228,9 @@ __device__ __forceinline__ void set_bias(W& w, const float* lds, int q) {
 
 // FRAGS = false: the caller fills w.a itself (k_cwlstm_step stages the fragments through LDS once
 // per workgroup instead of 4 x 61 KB of L2 reads)
-template <int PRE, bool FRAGS = true, bool PK = packed_default(PRE), int SKIP = -1>
+// LDSWIN: the input-weight rows win0 / win1 are read from LDS where they are used (NetWBLF) -- passed explicitly by the
+// caller: `w` is seen as its base class here, whose kLdsWin is always false
+template <int PRE, bool FRAGS = true, bool PK = packed_default(PRE), int SKIP = -1, bool LDSWIN = false>
 __device__ __forceinline__ void load_netw(NetWB<PRE, PK>& w, const float* __restrict__ wp, int lane) {
   const unsigned* wu = reinterpret_cast<const unsigned*>(wp);
   if (FRAGS) {
@@ -243,7 +245,7 @@ __device__ __forceinline__ void load_netw(NetWB<PRE, PK>& w, const float* __rest
   const float* p = wp + lane;
 #pragma unroll
   for (int t = 0; t < kNT; ++t) {
-    if (PRE != L2O_PRE_FC_ELU && !std::decay<decltype(w)>::type::kLdsWin) {
+    if constexpr (PRE != L2O_PRE_FC_ELU && !LDSWIN) {
       w.win0[t] = *reinterpret_cast<const f32x4*>(wp + win_off(PRE) + t * 256 + lane * 4);
       if (PRE == L2O_PRE_LOGSIGN)
         w.win1[t] = *reinterpret_cast<const f32x4*>(wp + win_off(PRE) + (kNT + t) * 256 + lane * 4);
@@ -683,7 +685,7 @@ struct LstmCoreLds {
   WT w;                                                              // (bx::NetWBL<PRE>, or its fenced variant NetWBLF)
   bx::BOp<true> b1, b2;
   unsigned one;
-  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, false, true>(w, wpack, lane); }
+  __device__ __forceinline__ void load(const float* __restrict__ wpack, int lane) { bx::load_netw<PRE, false, true, -1, WT::kLdsWin>(w, wpack, lane); }
   // every thread copies its share of the packed fragment section of wpack into LDS (16-byte pieces); a barrier follows
   __device__ __forceinline__ void stage_frags(float* lds, const float* __restrict__ wpack, int tid, int nthreads, int lane) {
     const bx::u32x4* src = reinterpret_cast<const bx::u32x4*>(wpack + bx::base(PRE));

@@ -229,25 +229,65 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
             return False                                 # (restart= launches are re-run from the caller's x0: nothing to keep)
         return self.__dict__.get("_exchanges", True)
 
+    def _reduce_status(self):
+        """Sharded graphs: MAX-reduce the sticky status word of this unroll over the ranks, on the device and ahead of the
+        host sync, so that EVERY rank sees a partner timeout of ANY rank (a rank that recovers alone issues
+        one loss all-reduce more than its peers, and the healthy ranks keep the contaminated fx).  The collective is
+        unconditional on a sharded graph -- ranks whose launch has no workspace contribute 0 -- so it pairs up whatever
+        kernel form each rank's shard selected.  Returns the reduced word (device int32 [1]) or None."""
+        eng = self.engine
+        if not (self.sharded and hasattr(eng, "unroll_status_tensor")):
+            return None
+        stw = eng.unroll_status_tensor() if self.last_path in ("fused", "mlp_unroll") else None
+        red = self.__dict__.get("_status_red")
+        if red is None:
+            red = self._status_red = torch.zeros(1, dtype=torch.int32, device=eng.device)
+        if stw is None:
+            red.zero_()
+        else:
+            red.copy_(stw)
+        _all_reduce(red, op="MAX")
+        if stw is not None:
+            stw.copy_(red)                               # (this rank's own check below then raises on a peer's timeout too)
+        return red
+
     def _sync_or_recover(self, fx, xs, feed, commit):
         """The host sync of an evaluation unroll + the status check; on a partner timeout the unroll is re-run on the
-        exchange-free kernels.  Returns (fx on the host, fx, xs)."""
+        exchange-free kernels -- by every rank of a sharded job together.  Returns (fx on the host, fx, xs)."""
         eng = self.engine
         self.wait_fx()
-        fused = self.last_path in ("fused", "mlp_unroll") and hasattr(eng, "check_unroll_status")
+        has_status = hasattr(eng, "check_unroll_status")
+        fused = self.last_path in ("fused", "mlp_unroll") and has_status
+        red = self._reduce_status() if has_status else None
         if fused and hasattr(eng, "prefetch_unroll_status"):
             eng.prefetch_unroll_status()                 # (rides on the sync below)
         fx_host = eng.to_numpy(fx)                       # host sync
-        if not fused:
+        if not fused and red is None:
             return fx_host, fx, xs
-        if hasattr(eng, "last_unroll_exchanges"):
+        if fused and hasattr(eng, "last_unroll_exchanges"):
             self._exchanges = bool(eng.last_unroll_exchanges())
         try:
-            self._check_unroll_status()
+            if fused:
+                self._check_unroll_status()
+            if red is not None and int(red[0]):          # (a rank without a status word of its own: a peer timed out)
+                raise _abi.L2OPartnerTimeout(_abi.L2O_ERR_TIMEOUT, "a peer rank's unroll reported a partner timeout")
         except _abi.L2OPartnerTimeout as err:
             info = self.__dict__.get("_last_launch", {})
-            if os.environ.get("L2O_NO_RECOVERY") or not (info.get("restart") is not None or info.get("snapshot")
-                                                         or not info.get("commit", True)):
+            # a sticky status raised by ANOTHER graph's deferred training unroll on this engine is not ours to recover
+            # from (ADVICE r05): that graph takes its Adam step counts back and the error surfaces
+            other = getattr(eng, "_deferred_graph", None)
+            other = other() if other is not None else None
+            if other is not None and other is not self and other.__dict__.get("_guarded_pending", 0):
+                other._take_back_pending()
+                raise
+            can = not os.environ.get("L2O_NO_RECOVERY") and (info.get("restart") is not None or info.get("snapshot")
+                                                             or not info.get("commit", True))
+            if red is not None:
+                # every rank must take the same decision: recover only if ALL ranks hold what their unroll started from
+                flag = torch.full((1,), 1 if can else 0, dtype=torch.int32, device=eng.device)
+                _all_reduce(flag, op="MIN")
+                can = bool(int(flag[0]))
+            if not can:
                 raise
             import warnings
             warnings.warn("open_l2o_amd: %s -- re-running this unroll on the exchange-free kernels" % (err,), RuntimeWarning)
@@ -579,13 +619,11 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         # device-side update is GUARDED by that unroll's status word (l2o_adam_step_guarded) and does not run; the host
         # learns of it at the sync below, takes the Adam step count back and raises.
         early = all(self._device_adam(self.nets[k]) for k in grads)
-        if fused and self.sharded and hasattr(eng, "unroll_status_tensor"):
+        if self.sharded and hasattr(eng, "check_unroll_status"):
             # every rank must take the SAME decision about this meta-step: the status words of the ranks'
             # unrolls are MAX-reduced in place, on the device, ahead of the guarded update -- one rank's partner timeout
             # skips the update (and raises at the next host check) on all of them
-            stw = eng.unroll_status_tensor()
-            if stw is not None:
-                _all_reduce(stw, op="MAX")
+            self._reduce_status()
         if early:
             self._adam_apply(grads, learning_rate, guarded=fused)
         pend = self.__dict__.setdefault("_guarded_pending", 0)
@@ -593,6 +631,9 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
             # nothing is read back: a failed unroll's status word is sticky, so the guarded updates of this and of every
             # later deferred step stay off until a synchronous step checks it, takes the step counts back and raises
             self._guarded_pending = pend + (1 if fused else 0)
+            if fused:
+                import weakref
+                eng._deferred_graph = weakref.ref(self)     # (whose sticky status it is, should an evaluation see it first)
             return {"loss": None, "fx": None, "fx_array": None,
                     "x": _LazyHost(eng, xs, [self._local_shape(var) for var in self.x])}
         if fused and hasattr(eng, "prefetch_unroll_status"):
@@ -619,11 +660,14 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         try:
             self.engine.check_unroll_status()
         except Exception:
-            n = self.__dict__.get("_guarded_pending", 0)
-            if n and "_adam" in self.__dict__:
-                self.__dict__["_adam"]["t"] -= n
-            self._guarded_pending = 0
+            self._take_back_pending()
             raise
+
+    def _take_back_pending(self):
+        n = self.__dict__.get("_guarded_pending", 0)
+        if n and "_adam" in self.__dict__:
+            self.__dict__["_adam"]["t"] -= n
+        self._guarded_pending = 0
 
     def gradients(self, feed=None):
         """[d f(x * scale) / d x_j] at the current variables as device tensors (panel shaped),

@@ -53,3 +53,31 @@ def test_config4_line_is_primary_when_sharded():
     assert one["config"]["baseline_config"].startswith("BASELINE.json configs[3]")
     assert two["final_loss_fx_T"] == pytest.approx(one["final_loss_fx_T"], rel=1e-6)
     assert two["final_loss_fx_T"] < two["fx_0"] / 5
+
+
+def test_eight_gloo_ranks_one_device_rehearse_the_config4_line():
+    """The command the first driver with an 8-GPU node will run, `bench.py --gpus 8 --config 4`, end to end with EIGHT ranks
+    (gloo, all on cuda:0): the primary line is BASELINE configs[3] (1024 Rastrigin problems, 128 per rank, strong
+    scaling), all eight ranks hold the same all-reduced loss, the line carries `roofline` and a rank-0-only, bounded
+    `cpu_baseline`, and the whole command finishes in two minutes."""
+    import time
+    t0 = time.time()
+    line = _bench(["--gpus", "8", "--config", "4", "--steps", "2", "--warmup", "1", "--unrolls-per-step", "2", "--no-also"],
+                  {"L2O_BENCH_BACKEND": "gloo", "L2O_BENCH_ONE_DEVICE": "1"})
+    secs = time.time() - t0
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and cfg["n_ranks_seen"] == 8 and line["scaling"] == "strong"
+    assert cfg["baseline_config"] == "BASELINE.json configs[3]"
+    assert "Rastrigin d=100" in cfg["workload"] and "batch=128 per GPU (global 1024)" in cfg["workload"]
+    ranks = line["final_loss_fx_T_per_rank"]
+    assert len(ranks) == 8 and len(set(ranks)) == 1, ranks
+    assert line["final_loss_fx_T"] < line["fx_0"] / 5                         # (the trained optimizer: the loss falls)
+    roof, cpu = line["roofline"], line["cpu_baseline"]
+    assert roof["bound"] == "valu_pipe" and 0.0 < roof["frac"] < 1.0 and roof["kernel"].startswith("k_unroll_pair")
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and 1 <= cpu["cores"] <= (os.cpu_count() or 1)
+    assert "rank 0" in cpu["sample"]
+    one = _bench(["--gpus", "1", "--config", "4", "--steps", "2", "--warmup", "1", "--unrolls-per-step", "1",
+                  "--no-cpu-baseline", "--no-also"])
+    assert line["final_loss_fx_T"] == pytest.approx(one["final_loss_fx_T"], rel=1e-6)
+    print("8 gloo ranks on one device: %.1f s, fx_T %.9g, cpu leg: %s" % (secs, line["final_loss_fx_T"], cpu["sample"]))
+    assert secs < 120.0, secs

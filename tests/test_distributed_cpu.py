@@ -280,3 +280,76 @@ def test_two_rank_partner_timeout_skips_the_update_on_both_ranks():
         _assert_same_weights(good, final, 0.0)                      # the failed step changed nothing ...
     assert "unroll_timeout" in results[1][3] and "unroll_timeout" not in results[0][3]
     _assert_same_weights(results[0][1], results[1][1], 0.0)         # ... and the replicas are still identical
+
+
+# ---------------------------------------------------------------------------
+# a partner timeout on ONE rank of a sharded EVALUATION (round 6): the status word is MAX-reduced ahead of the
+# host check, so BOTH ranks re-run the unroll together on the exchange-free kernels -- the loss all-reduces stay paired,
+# nobody keeps the contaminated fx, and the four runs give the single-process answer
+# ---------------------------------------------------------------------------
+def _eval_with_fault(faulty_rank, fault_before_run=1, runs=4):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import warnings
+    from helpers import ORACLE_CFGS, make_params, make_problem
+    from open_l2o_amd import _engine, meta, problems
+    from open_l2o_amd.session import Session
+    from oracle_engine import OracleEngine
+    from test_meta_api import _net_config
+
+    eng = OracleEngine()
+    _engine.set_default_engine(eng)
+    cfg = ORACLE_CFGS["dm"]
+    params = make_params(cfg, seed=60, trained_like=True)
+    prob, x0, _ = make_problem("quadratic", 8, 16, seed=61)
+    problem = problems.quadratic(8, 16, data={"w": prob.w, "y": prob.y, "x": x0})
+    opt = meta.MetaOptimizer(**_net_config(cfg, params))
+    ml = opt.meta_loss(problem, 4)
+    out, warned = [], 0
+    with Session() as sess:
+        sess.run(ml.reset)
+        for i in range(runs):
+            if i == fault_before_run and dist.is_initialized() and dist.get_rank() == faulty_rank:
+                eng.inject_unroll_fault()
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                fx, _ = sess.run([ml.fx, ml.update])
+            warned += sum(issubclass(x.category, RuntimeWarning) for x in w)
+            out.append(float(fx))
+    return out, warned, list(eng.calls), getattr(opt._graph, "recoveries", 0)
+
+
+def _eval_fault_worker(rank, world, port, faulty_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _eval_with_fault(faulty_rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_partner_timeout_in_evaluation_recovers_on_both_ranks():
+    ref, _, _, _ = _eval_with_fault(faulty_rank=-1)                 # single process, the global batch, no fault
+    assert np.all(np.isfinite(ref))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_fault_worker, args=(r, 2, port, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(2):
+        item = q.get(timeout=300)
+        results[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        out, warned, calls, recoveries = results[rank]
+        assert np.all(np.isfinite(out)), "rank %d kept a contaminated loss: %r" % (rank, out)
+        np.testing.assert_allclose(out, ref, rtol=2e-6)             # (the all-reduce adds two partial means)
+        assert recoveries == 1 and warned == 1, (rank, recoveries, warned)
+    assert "unroll_timeout" in results[1][2] and "unroll_timeout" not in results[0][2]
+    assert results[0][0] == results[1][0]                            # same all-reduced losses on both ranks, all four runs
