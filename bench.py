@@ -734,6 +734,13 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner through
+    # C stdio when its first communicator is created -- flushed at process exit, i.e. BEHIND the line): from here on fd 1
+    # is stderr for everybody, and the line goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from open_l2o_amd import _abi, _engine, _graph_core
@@ -1071,14 +1078,16 @@ def main(argv=None):
                 if "oracle_self_sensitivity" in e:
                     out[pre + "_oracle_self_sensitivity"] = e["oracle_self_sensitivity"]
         also["seconds"] = time.perf_counter() - t_also
-    if rank == 0:
-        if also:
-            out["also"] = also
-        print(json.dumps(out))
     if world > 1:
         dist.barrier()                                      # (ranks > 0 wait here while rank 0 times its CPU leg)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        if also:
+            out["also"] = also
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
+    os.close(line_fd)
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define L2O_ABI_VERSION 12
+#define L2O_ABI_VERSION 13
 
 #define L2O_OK 0
 #define L2O_ERR_ARG (-1)
@@ -124,6 +124,7 @@ int l2o_last_unroll_form(void);
 #define L2O_FORM_MLP_UNROLL 8          /* + k_mlp_unroll, fast instantiation, flat all-reduce                            */
 #define L2O_FORM_MLP_UNROLL_HIER 9     /* + k_mlp_unroll, fast instantiation, XCD-hierarchical all-reduce                */
 #define L2O_FORM_MLP_UNROLL_GENERIC 10 /* + k_mlp_unroll, generic loops                                                  */
+#define L2O_FORM_MLP_XCD 11            /* + k_mlp_xcd: one optimizee instance per XCD (l2o_mlp_unroll_multi)             */
 
 /* ---- options (ABI v9: per call, caller-owned) -------------------------------
  * A/B switches between kernels that compute the same thing (all results stay within the parity tolerance).  The
@@ -290,6 +291,32 @@ int l2o_mlp_unroll_record(const l2o_net_cfg* cfg, const float* wpack /* device *
                           const int32_t* indices, float* const* x, float* const* st, float* const* m, float* const* v,
                           const float* const* x_scale, int32_t T, int32_t step0, float* fx, const l2o_mlp_hist* hist,
                           void* workspace, void* stream);
+
+/* The same unroll for UP TO EIGHT independent optimizee instances in ONE launch, every instance confined to one XCD
+ * (ABI v13, csrc/l2o_mlp_xcd.h): the replicas of BASELINE config 5 / a meta-training batch of optimizees
+ * (DM/meta_rnnprop_train.py:397-423 runs one such unroll per sess.run; N of them are N independent unrolls).  Instance j
+ * runs on the 32 CUs of XCD j -- eight tile-steps per SIMD and step, the all-reduce of the hidden pre-activations through
+ * that XCD's own L2 -- so a launch of 8 instances has ~3-4 x the throughput of 8 l2o_mlp_unroll launches, and a launch of
+ * ONE instance a longer latency than l2o_mlp_unroll: the caller chooses per call.
+ *   inst[j]   indices / x / st / m / v / x_scale / fx of instance j, each as in l2o_mlp_unroll (all instances share the
+ *             network, `mlp` (shape and data set) and T / step0; every instance draws its own minibatches)
+ * Supported (l2o_mlp_unroll_multi_supported() != 0) for the reference's shape only (hidden 20, 10 classes, minibatch 64,
+ * n_in * 20 + 230 coordinates <= 16 368), 1 <= n_inst <= 8, and a device whose 8 XCDs x 32 CUs are all available to the
+ * stream.  A team that does not assemble (masked / shared device) raises the sticky status word -> L2O_ERR_TIMEOUT. */
+typedef struct l2o_mlp_instance {
+  const int32_t* indices;      /* device [T + 1][batch] */
+  float* x[4];
+  float* st[4];
+  float* m[4];                 /* RNNProp only (else NULL) */
+  float* v[4];
+  const float* x_scale[4];     /* NULLs allowed */
+  float* fx;                   /* device [T + 1] */
+} l2o_mlp_instance;
+int l2o_mlp_unroll_multi_supported(const l2o_net_cfg* cfg, const l2o_mlp* mlp, int32_t n_inst, void* stream);
+size_t l2o_mlp_unroll_multi_workspace_bytes(const l2o_mlp* mlp, int32_t n_inst);
+int l2o_mlp_unroll_multi(const l2o_net_cfg* cfg, const float* wpack /* device */, const l2o_mlp* mlp,
+                         const l2o_mlp_instance* inst /* host [n_inst] */, int32_t n_inst, int32_t T, int32_t step0,
+                         void* workspace, void* stream);
 
 /* ---- one optimizer step on a gradient panel: the closure `update`
  * (DM/meta.py:319-336; RNNProp DM/meta_rnnprop_train.py:371-395) for ONE variable:

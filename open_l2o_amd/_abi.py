@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # L2O_HIP_LIB: alternative build of the SAME library (timing ablations, scripts/ablate.sh)
 LIB_PATH = os.environ.get("L2O_HIP_LIB") or os.path.join(_HERE, "libl2o_hip.so")
 
-L2O_ABI_VERSION = 12
+L2O_ABI_VERSION = 13
 L2O_OK, L2O_ERR_ARG, L2O_ERR_UNSUPPORTED, L2O_ERR_HIP, L2O_ERR_TIMEOUT = 0, -1, -2, -3, -4
 
 NET_CW, NET_RNNPROP = 0, 1
@@ -26,6 +26,7 @@ SYMBOLS = (
     "l2o_abi_version", "l2o_last_error", "l2o_build_id", "l2o_last_unroll_form", "l2o_coresident_workgroups", "l2o_wpack_floats", "l2o_wpack_host",
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_record", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
+    "l2o_mlp_unroll_multi", "l2o_mlp_unroll_multi_supported", "l2o_mlp_unroll_multi_workspace_bytes",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_cwlstm_bwd_unroll_compact", "l2o_cwlstm_wgrad_compact", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_adam_step_gather", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
     "l2o_suffix_sums", "l2o_colsum", "l2o_colsum_scratch_floats", "l2o_lincomb", "l2o_rnnprop_input_adjoint",
@@ -44,8 +45,9 @@ OPT_DEFAULTS = {OPT_PAIR: 1, OPT_PAIR_PLAIN_STORES: 1, OPT_UNROLL_CU: 1, OPT_FG_
                 OPT_WPACK_NO_CLEAR: 0, OPT_MLP_HIER: 1, OPT_ONE_LDS: 1}
 # l2o_last_unroll_form(): which kernel a fused launch ran (include/l2o_abi.h L2O_FORM_*)
 FORM_NAMES = {1: "k_unroll", 2: "k_unroll_pair", 5: "k_unroll_lds", 6: "k_unroll_cu", 7: "k_unroll_cu8",
-              8: "k_mlp_unroll (flat all-reduce)", 9: "k_mlp_unroll (XCD-hierarchical all-reduce)", 10: "k_mlp_unroll (generic loops)"}
-FORMS_WITH_EXCHANGE = (2, 8, 9, 10)    # workgroups wait for partner workgroups: can end in L2OPartnerTimeout
+              8: "k_mlp_unroll (flat all-reduce)", 9: "k_mlp_unroll (XCD-hierarchical all-reduce)", 10: "k_mlp_unroll (generic loops)",
+              11: "k_mlp_xcd (one optimizee instance per XCD)"}
+FORMS_WITH_EXCHANGE = (2, 8, 9, 10, 11)    # workgroups wait for partner workgroups: can end in L2OPartnerTimeout
 PROB_FG_TWO_PASS = 2      # l2o_problem.flags
 MLP_GENERIC = 1           # l2o_mlp.flags
 _options = {}
@@ -150,6 +152,11 @@ class Mlp(C.Structure):
 
 class MlpHist(C.Structure):            # l2o_mlp_hist: per variable (w1, b1, w2, b2) history of l2o_mlp_unroll_record
     _fields_ = [("st", C.c_void_p * 4), ("g", C.c_void_p * 4), ("m", C.c_void_p * 4), ("v", C.c_void_p * 4)]
+
+
+class MlpInstance(C.Structure):        # l2o_mlp_instance: one replica of l2o_mlp_unroll_multi
+    _fields_ = [("indices", C.c_void_p), ("x", C.c_void_p * 4), ("st", C.c_void_p * 4), ("m", C.c_void_p * 4),
+                ("v", C.c_void_p * 4), ("x_scale", C.c_void_p * 4), ("fx", C.c_void_p)]
 
 
 class GenNet(C.Structure):
@@ -298,6 +305,12 @@ def lib():
     L.l2o_mlp_unroll_record.restype = C.c_int
     L.l2o_mlp_unroll_record.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Mlp), vp, vp, vp, vp, vp, vp, i32, i32, vp,
                                         C.POINTER(MlpHist), vp, vp]
+    L.l2o_mlp_unroll_multi_supported.restype = C.c_int
+    L.l2o_mlp_unroll_multi_supported.argtypes = [C.POINTER(NetCfg), C.POINTER(Mlp), i32, vp]
+    L.l2o_mlp_unroll_multi_workspace_bytes.restype = C.c_size_t
+    L.l2o_mlp_unroll_multi_workspace_bytes.argtypes = [C.POINTER(Mlp), i32]
+    L.l2o_mlp_unroll_multi.restype = C.c_int
+    L.l2o_mlp_unroll_multi.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Mlp), C.POINTER(MlpInstance), i32, i32, i32, vp, vp]
     L.l2o_cwlstm_step.restype = C.c_int
     L.l2o_cwlstm_step.argtypes = [C.POINTER(NetCfg), vp, vp, vp, vp, dbl, dbl, vp, vp, i64, i64, vp]
     L.l2o_gen_state_floats.restype = C.c_size_t

@@ -339,6 +339,52 @@ class HipEngine(object):
                                            am, av, asc, int(T), int(step0), _ptr(fx), C.c_void_p(ws.data_ptr()),
                                            self._stream()))
 
+    def mlp_unroll_multi_supported(self, spec: NetSpec, d: MlpDesc, n_inst):
+        """l2o_mlp_unroll_multi applies: up to eight independent optimizee instances, one per XCD, in one launch."""
+        cc, cm = spec.to_c(), self._cmlp(d)
+        return bool(self.lib.l2o_mlp_unroll_multi_supported(C.byref(cc), C.byref(cm), int(n_inst), self._stream()))
+
+    def mlp_unroll_multi(self, spec: NetSpec, wpack, d: MlpDesc, instances, T, step0):
+        """T optimizer steps on up to EIGHT independent instances of the MLP optimizee in ONE launch, one instance per XCD
+        (l2o_mlp_unroll_multi).  instances: list of dicts(indices=, xs=, sts=, ms=, vs=, scales=, fx=) as the arguments of
+        mlp_unroll (all instances share the network, the data set and T / step0).  The argument block of a repeated
+        launch (same buffers) is built once."""
+        def ptr(t):
+            return 0 if t is None else t.data_ptr()
+        key = ("multi", _abi.options_word(), id(d), spec.kind, spec.preprocess, float(spec.scale), bool(spec.tanh_output),
+               float(spec.logsign_k), float(spec.beta1), float(spec.beta2), wpack.data_ptr(), int(T),
+               tuple((ptr(i["indices"]), ptr(i["fx"])) + tuple(ptr(t) for k in ("xs", "sts", "ms", "vs", "scales") for t in i[k])
+                     for i in instances))
+        memo = self.__dict__.setdefault("_mlp_unroll_memo", {})
+        ent = memo.get(key)
+        if ent is None:
+            cc, cm = spec.to_c(), self._cmlp(d)
+            n = int(self.lib.l2o_mlp_unroll_multi_workspace_bytes(C.byref(cm), len(instances)))
+            if not n:
+                raise _abi.L2OUnsupported(_abi.L2O_ERR_UNSUPPORTED, "l2o_mlp_unroll_multi: unsupported shape / instance count")
+            ws = self.__dict__.get("_mlp_ws")
+            if ws is None or ws.numel() < n:
+                ws = self._mlp_ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            arr = (_abi.MlpInstance * len(instances))()
+            for j, i in enumerate(instances):
+                arr[j].indices, arr[j].fx = i["indices"].data_ptr(), i["fx"].data_ptr()
+                for k in range(4):
+                    arr[j].x[k], arr[j].st[k] = i["xs"][k].data_ptr(), i["sts"][k].data_ptr()
+                    arr[j].m[k] = None if i["ms"][k] is None else i["ms"][k].data_ptr()
+                    arr[j].v[k] = None if i["vs"][k] is None else i["vs"][k].data_ptr()
+                    arr[j].x_scale[k] = None if i["scales"][k] is None else i["scales"][k].data_ptr()
+            ent = dict(cc=cc, cm=cm, ws=ws, arr=arr, keep=(d, wpack, [dict(i) for i in instances]))
+            if len(memo) >= 8:
+                memo.pop(next(iter(memo)))
+            memo[key] = ent
+        ws = ent["ws"]
+        if self.__dict__.get("_mlp_ws") is not ws:           # (a larger workspace replaced it since)
+            memo.pop(key, None)
+            return self.mlp_unroll_multi(spec, wpack, d, instances, T, step0)
+        self._last_ws = ws
+        _abi.check(self.lib.l2o_mlp_unroll_multi(C.byref(ent["cc"]), _ptr(wpack), C.byref(ent["cm"]), ent["arr"], len(instances),
+                                                 int(T), int(step0), C.c_void_p(ws.data_ptr()), self._stream()))
+
     # -- prepared calls: the ctypes argument objects are built ONCE for launches that repeat with the same
     #    buffers (the T steps of a recorded unroll); per call only what changes is passed ------------------
     def prepared_mlp_fg(self, d: MlpDesc, indices, w1, b1, w2, b2, grads):

@@ -132,6 +132,40 @@ class StepPlanMixin(object):
                 return 0
         return int(eng.mlp_unroll_supported(net.spec, self._mlp_desc(self.terms[0])))   # 2: the kernel's FAST form
 
+    def mlp_instance(self, feed=None, dry=False):
+        """What this graph contributes to a launch of several optimizee instances (replicas.Replicas ->
+        l2o_mlp_unroll_multi): its minibatch indices (drawn here, like a launch of its own would), the live x / LSTM
+        state / moment buffers of the four variables in the order w1, b1, w2, b2 and its loss buffer -- or None when
+        the fused MLP unroll does not apply to it.  dry: no draw, no buffers -- only whether it applies."""
+        self._ensure_init()
+        T = self.len_unroll
+        feed = feed or {}
+        if any(ph in feed for ph in self.scale):
+            return None
+        slots = self.slots
+        states = [s.state for s in slots]
+        if not self._mlp_unroll_ok(slots, states, [None] * len(self.x)):
+            return None
+        term = self.terms[0]
+        net = slots[0].net
+        desc = self._mlp_desc(term)
+        if dry:
+            return dict(net=net, desc=desc)
+        if self.rnnprop and self.step not in feed:
+            raise ValueError("You must feed a value for placeholder 'step' (DM/util.py:59-60)")
+        self._draw_minibatches(T)
+        index_of = {v.decl.name: j for j, v in enumerate(self.x)}
+        js = [index_of[tv.name] for tv in _term_vars(term)]               # w1, b1, w2, b2 -> variable index
+        slot_of = {s.var_index: si for si, s in enumerate(slots)}
+        sis = [slot_of[j] for j in js]
+        panels = [v.value.view(*self._panel_shape(v)) for v in self.x]
+        ring = self._fx_cache.get(T)
+        if ring is None:
+            ring = self._fx_cache[T] = {"bufs": [self.engine.zeros(T + 1)], "work": [None], "i": 0}
+        return dict(net=net, desc=desc, indices=self._mlp_idx[0], xs=[panels[j] for j in js],
+                    sts=[states[si].packed for si in sis], ms=[slots[si].m for si in sis], vs=[slots[si].v for si in sis],
+                    scales=[None] * 4, fx=ring["bufs"][0])
+
     def _draw_minibatches(self, T):
         """A fresh uniform minibatch per evaluation of a neural optimizee (DM/problems.py:282-286: tf.random_uniform
         indices -- a device op there): indices [T+1, batch] in a PERSISTENT device buffer (so that a captured launch

@@ -859,6 +859,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 #include "l2o_mlp.h"
 
 #include "l2o_mlp_unroll.h"
+#include "l2o_mlp_xcd.h"
 
 #include "l2o_generic.h"
 
@@ -1993,6 +1994,95 @@ int l2o_mlp_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_
                           void* workspace, void* stream) {
   if (!hist) return fail(L2O_ERR_ARG, "l2o_mlp_unroll_record: NULL hist");
   return mlp_unroll_launch(cfg, wpack, mlp, indices, x, st, m, v, x_scale, T, step0, fx, hist, workspace, stream);
+}
+
+// ---- one optimizee instance per XCD (csrc/l2o_mlp_xcd.h) ------------------------------------------------------------
+struct MlpXcdLayout { int n[4], tile_begin[5], nw1; size_t team_off, inst_off, p_bytes, s_bytes, sm_bytes, inst_bytes, total; };
+static bool mlp_xcd_layout(const l2o_mlp* mlp, int n_inst, MlpXcdLayout* L) {
+  if (!mlp || n_inst < 1 || n_inst > kMxMaxInst) return false;
+  if (mlp->n_hidden != kMxH || mlp->n_out != kMxO || mlp->batch != kMxB || mlp->n_in < 1) return false;
+  L->n[0] = mlp->n_in * kMxH; L->n[1] = kMxH; L->n[2] = kMxH * kMxO; L->n[3] = kMxO;
+  L->tile_begin[0] = 0;
+  for (int v = 0; v < 4; ++v) L->tile_begin[v + 1] = L->tile_begin[v] + tiles_per_problem(L->n[v]);
+  if (L->tile_begin[4] > kMxMembers * kMxSlots) return false;
+  L->nw1 = (L->n[0] + kMxCoords - 1) / kMxCoords;
+  L->team_off = sizeof(MlpWs);
+  L->inst_off = L->team_off + 64;
+  L->p_bytes = sizeof(unsigned long long) * kMxMembers * kMxMembers * kMxR;
+  L->s_bytes = sizeof(unsigned long long) * 2 * kMxNO;
+  L->sm_bytes = sizeof(unsigned long long) * 2 * kMxNSMp;
+  L->inst_bytes = (L->p_bytes + L->s_bytes + L->sm_bytes + 255) & ~(size_t)255;
+  L->total = L->inst_off + (size_t)n_inst * L->inst_bytes;
+  return true;
+}
+
+int l2o_mlp_unroll_multi_supported(const l2o_net_cfg* cfg, const l2o_mlp* mlp, int32_t n_inst, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
+  MlpXcdLayout L;
+  if (!cfg || !net_ok_for_mfma(cfg) || !opt(L2O_OPT_MLP_UNROLL) || !mlp_xcd_layout(mlp, n_inst, &L)) return 0;
+  // every XCD's 32 CUs must be able to host one workgroup each at the same time
+  return coresident_cus((hipStream_t)stream) >= kMxMaxInst * kMxMembers ? 1 : 0;
+}
+
+size_t l2o_mlp_unroll_multi_workspace_bytes(const l2o_mlp* mlp, int32_t n_inst) {
+  MlpXcdLayout L;
+  return mlp_xcd_layout(mlp, n_inst, &L) ? L.total : 0;
+}
+
+int l2o_mlp_unroll_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_mlp* mlp, const l2o_mlp_instance* inst,
+                         int32_t n_inst, int32_t T, int32_t step0, void* workspace, void* stream) {
+  OptScope opt_scope(cfg_optw(cfg));
+  if (!cfg || !wpack || !mlp || !inst || !workspace || T < 0 || !mlp->images || !mlp->labels)
+    return fail(L2O_ERR_ARG, "l2o_mlp_unroll_multi: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  MlpXcdLayout L;
+  if (!net_ok_for_mfma(cfg) || !mlp_xcd_layout(mlp, n_inst, &L) || coresident_cus(s) < kMxMaxInst * kMxMembers)
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_unroll_multi: no one-XCD kernel for n_in=%d hidden=%d out=%d batch=%d x %d instances "
+                "(needs the reference's shape and all 8 x 32 CUs)", mlp->n_in, mlp->n_hidden, mlp->n_out, mlp->batch, (int)n_inst);
+  const bool rn = cfg->preprocess == L2O_PRE_FC_ELU;
+  MlpXcdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.np = make_net_params(cfg, wpack);
+  a.n_in = mlp->n_in; a.act = mlp->activation; a.T = T; a.ninst = n_inst;
+  a.images = mlp->images; a.labels = mlp->labels;
+  for (int k = 0; k < 4; ++k) a.n[k] = L.n[k];
+  for (int k = 0; k < 5; ++k) a.tile_begin[k] = L.tile_begin[k];
+  a.nw1 = L.nw1;
+  pow_ff(cfg->beta1, step0, &a.p1_hi, &a.p1_lo);
+  pow_ff(cfg->beta2, step0, &a.p2_hi, &a.p2_lo);
+  char* wsb = static_cast<char*>(workspace);
+  a.ws = reinterpret_cast<MlpWs*>(wsb);
+  a.team = reinterpret_cast<unsigned*>(wsb + L.team_off);
+  for (int j = 0; j < n_inst; ++j) {
+    const l2o_mlp_instance& in = inst[j];
+    MxInst& o = a.inst[j];
+    if (!in.indices || !in.fx) return fail(L2O_ERR_ARG, "l2o_mlp_unroll_multi: NULL indices / fx of instance %d", j);
+    o.idx = in.indices; o.fx = in.fx;
+    for (int k = 0; k < 4; ++k) {
+      if (!in.x[k] || !in.st[k] || (rn && (!in.m[k] || !in.v[k])))
+        return fail(L2O_ERR_ARG, "l2o_mlp_unroll_multi: NULL buffer of variable %d of instance %d", k, j);
+      o.x[k] = in.x[k]; o.st[k] = in.st[k]; o.m[k] = rn ? in.m[k] : nullptr; o.v[k] = rn ? in.v[k] : nullptr;
+      o.xscale[k] = in.x_scale[k];
+    }
+    char* ib = wsb + L.inst_off + (size_t)j * L.inst_bytes;
+    o.P = reinterpret_cast<unsigned long long*>(ib);
+    o.S = reinterpret_cast<unsigned long long*>(ib + L.p_bytes);
+    o.Sm = reinterpret_cast<unsigned long long*>(ib + L.p_bytes + L.s_bytes);
+  }
+  HIP_TRY(hipMemsetAsync(wsb + L.team_off, 0, L.total - L.team_off, s));   // team counters + granules: the header survives
+  void (*fn)(MlpXcdArgs) = nullptr;
+  size_t lds = 0;
+  switch (cfg->preprocess) {
+    case L2O_PRE_IDENTITY: fn = k_mlp_xcd<L2O_PRE_IDENTITY>; lds = mlp_xcd_lds_bytes<L2O_PRE_IDENTITY>(); break;
+    case L2O_PRE_LOGSIGN: fn = k_mlp_xcd<L2O_PRE_LOGSIGN>; lds = mlp_xcd_lds_bytes<L2O_PRE_LOGSIGN>(); break;
+    default: fn = k_mlp_xcd<L2O_PRE_FC_ELU>; lds = mlp_xcd_lds_bytes<L2O_PRE_FC_ELU>();
+  }
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // one workgroup per CU of the whole chip: the 32 that land on XCD j < n_inst form instance j's team, the others exit
+  hipLaunchKernelGGL(fn, dim3(kMxMaxInst * kMxMembers), dim3(kMxThreads), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  note_form(L2O_FORM_MLP_XCD);
+  return L2O_OK;
 }
 
 int l2o_cwlstm_step_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_step_seg* segs, int32_t nseg,

@@ -76,8 +76,25 @@ def test_eight_gloo_ranks_one_device_rehearse_the_config4_line():
     assert roof["bound"] == "valu_pipe" and 0.0 < roof["frac"] < 1.0 and roof["kernel"].startswith("k_unroll_pair")
     assert cpu["kind"] == "port" and cpu["value"] > 0 and 1 <= cpu["cores"] <= (os.cpu_count() or 1)
     assert "rank 0" in cpu["sample"]
-    one = _bench(["--gpus", "1", "--config", "4", "--steps", "2", "--warmup", "1", "--unrolls-per-step", "1",
-                  "--no-cpu-baseline", "--no-also"])
+    one = _bench(["--gpus", "1", "--config", "4", "--steps", "2", "--warmup", "1", "--unrolls-per-step", "2",
+                  "--no-cpu-baseline", "--no-also"])                           # (same launch count: the same instance of the ring)
     assert line["final_loss_fx_T"] == pytest.approx(one["final_loss_fx_T"], rel=1e-6)
     print("8 gloo ranks on one device: %.1f s, fx_T %.9g, cpu leg: %s" % (secs, line["final_loss_fx_T"], cpu["sample"]))
     assert secs < 120.0, secs
+
+
+def test_stdout_is_one_json_line_even_with_a_real_rccl_communicator():
+    """The driver reads ONE JSON line from stdout.  RCCL prints a version banner through C stdio when its first
+    communicator is created (seen in round 6's first lease: five lines BEHIND the JSON line): bench.py keeps fd 1 for its
+    line alone.  The run itself is config 4's shard of 8 with its all-reduce issued through a world-size-1 RCCL group."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--emulate-world", "8", "--real-collective",
+                        "--steps", "2", "--warmup", "1", "--unrolls-per-step", "2", "--no-cpu-baseline", "--no-also"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["config"]["collective"]["backend"] == "nccl" and line["config"]["collective"]["world_size"] == 1
+    assert line["roofline"]["kernel"].startswith("k_unroll_pair")

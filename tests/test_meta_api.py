@@ -803,3 +803,49 @@ def test_emulated_shards_add_up_to_the_global_batch(engine):
     np.testing.assert_allclose(total, fx_full, rtol=2e-6)
     with pytest.raises(ValueError):
         _graph_core.emulate_world(4, 4)
+
+
+# ------------------------------------------------------------- replicas.Replicas (round 6)
+def test_replicas_share_one_network_and_equal_separate_graphs(engine):
+    """Replicas: N optimizee instances stepped by ONE optimizer, run together.  On every engine the result equals N separate
+    meta_loss graphs run one after the other (same seeds: same initial weights, same minibatches); the HIP engine takes
+    the one-instance-per-XCD kernel for the reference's shape."""
+    from open_l2o_amd.replicas import Replicas
+    data = problems.synthetic_mnist(200, seed=8)
+    cfg = ORACLE_CFGS["rnnprop"]
+    params = make_params(cfg, seed=83, trained_like=True)
+    T, n = 5, 3
+    idxs = [np.random.default_rng(100 + j).integers(0, 200, size=(2 * (T + 1), 64)) for j in range(n)]
+
+    def sampler_of(ix):
+        calls = {"n": 0}
+
+        def sampler(n_evals, b, n_data):
+            out = ix[calls["n"]:calls["n"] + n_evals]
+            calls["n"] += n_evals
+            return out
+        return sampler
+
+    def probs():
+        return [problems.mnist(layers=(20,), batch_size=64, data=data, sampler=sampler_of(ix)) for ix in idxs]
+
+    meta.set_random_seed(21)
+    reps = Replicas(meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp")), probs(), T)
+    assert all(g.nets is reps.graphs[0].nets for g in reps.graphs)
+    reps.reset()
+    got = [reps.run({reps.step: 1 + i * T}) for i in range(2)]
+    assert reps.last_form == ("xcd" if engine.name == "hip" else "chip")
+    # the same three instances as three separate graphs
+    meta.set_random_seed(21)
+    want = []
+    graphs = []
+    for p in probs():
+        opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+        ml, _, _, step = opt.meta_loss(p, T)
+        graphs.append((opt, ml, step))
+    with Session() as sess:
+        for _, ml, _ in graphs:
+            sess.run(ml.reset)
+        for i in range(2):
+            want.append([sess.run([ml.fx, ml.update], feed_dict={step: 1 + i * T})[0] for _, ml, step in graphs])
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=3e-5)

@@ -1,0 +1,142 @@
+"""l2o_mlp_unroll_multi / k_mlp_xcd (round 6) -- the fused persistent unroll of the MLP optimizee with every optimizee
+INSTANCE confined to one XCD, up to eight instances per launch: parity against the oracle's multi-variable unroll
+(BASELINE config 5's shape, T = 200), against the whole-chip kernel k_mlp_unroll on the same minibatches (RNNProp: moments,
+bias corrections, carries across launches), partial launches (fewer instances than XCDs, more than eight replicas), and
+the recovery from a team that does not assemble.  All through open_l2o_amd.replicas.Replicas -> the C ABI."""
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import make_params, rel_err
+from open_l2o_amd import _abi, _engine, meta, meta_rnnprop_eval, problems
+from open_l2o_amd.replicas import Replicas
+from test_meta_api import _net_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def hip():
+    eng = _engine.HipEngine()
+    old = _engine._default_engine
+    _engine.set_default_engine(eng)
+    yield eng
+    _engine.set_default_engine(old)
+
+
+def _sampler(idx):
+    calls = {"n": 0}
+
+    def sampler(n_evals, b, n_data):
+        out = idx[calls["n"]:calls["n"] + n_evals]
+        calls["n"] += n_evals
+        return out
+    return sampler
+
+
+def _replicas(cfg, params, data, idxs, T, activation="sigmoid", seed=9):
+    meta.set_random_seed(seed)
+    probs = [problems.mnist(layers=(20,), activation=activation, batch_size=64, data=data, sampler=_sampler(ix)) for ix in idxs]
+    if cfg.kind == "rnnprop":
+        opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+    else:
+        opt = meta.MetaOptimizer(**_net_config(cfg, params))
+    return Replicas(opt, probs, T)
+
+
+@pytest.mark.parametrize("netname", ["dm_logsign", "dm"])
+def test_config5_shape_vs_oracle_T200(hip, netname):
+    """Minibatch 64, T = 200 (BASELINE config 5's optimizee): TWO instances in one launch (XCDs 0 and 1), each against
+    O.unroll_multi on its own minibatch sequence and its own initial weights: the whole loss trajectory and x_T."""
+    data = problems.synthetic_mnist(512, seed=3)
+    T = 200
+    idxs = [np.random.default_rng(70 + j).integers(0, 512, size=(T + 1, 64)) for j in range(2)]
+    cfg = O.DM_LOGSIGN if netname == "dm_logsign" else O.DM_IDENTITY
+    params = make_params(cfg, seed=71, trained_like=True)
+    reps = _replicas(cfg, params, data, idxs, T)
+    reps.reset()
+    v0 = [[v.eval() for v in g.x] for g in reps.graphs]
+    fx = reps.run(form="xcd")
+    assert reps.last_form == "xcd" and hip.last_unroll_form()[0].startswith("k_mlp_xcd")
+    ref = O.MnistMLP(data["images"], data["labels"].astype(np.int32), "sigmoid")
+    for j, g in enumerate(reps.graphs):
+        states = [O.net_initial_state(cfg, a.size) for a in v0[j]]
+        fx_ref, v_ref, _ = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idxs[j][t], wg), cfg, params, v0[j], states, T)
+        e = rel_err(reps.fx_arrays[j], fx_ref)
+        print("k_mlp_xcd %s instance %d T=200 vs oracle: rel fx=%.3g fx0=%.5g fx200=%.5g" % (netname, j, e, fx_ref[0], fx_ref[-1]))
+        assert e < 1e-5 and rel_err(fx[j], fx_ref[-1]) < 1e-5
+        for got, want in zip([v.eval() for v in g.x], v_ref):
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+    assert not np.allclose(reps.fx_arrays[0], reps.fx_arrays[1])            # (two different instances)
+
+
+@pytest.mark.parametrize("activation,n", [("sigmoid", 8), ("relu", 3), ("sigmoid", 11)])
+def test_rnnprop_instances_equal_the_whole_chip_kernel(hip, activation, n):
+    """RNNProp (moments in LDS, bias corrections beta^(step0 + t)): n instances through k_mlp_xcd (n = 8: every XCD; 3: five
+    XCDs exit at once; 11: two launches) against the same n instances stepped one after the other by k_mlp_unroll, on the
+    same minibatches; two chained unrolls (carry of x, LSTM state, m, v across launches; step0 = 1 and 1 + T)."""
+    data = problems.synthetic_mnist(300, seed=4)
+    T = 12
+    idxs = [np.random.default_rng(80 + j).integers(0, 300, size=(2 * (T + 1), 64)) for j in range(n)]
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=81, trained_like=True)
+    res = {}
+    for form in ("xcd", "chip"):
+        reps = _replicas(cfg, params, data, idxs, T, activation=activation, seed=11)
+        reps.reset()
+        out = []
+        for i in range(2):
+            fx = reps.run({reps.step: 1 + i * T}, form=form)
+            out.append(np.array(reps.fx_arrays, np.float64))
+            assert fx.shape == (n,) and np.all(np.isfinite(fx))
+        assert reps.last_form == form
+        res[form] = (np.array(out), [[v.eval() for v in g.x] for g in reps.graphs])
+    np.testing.assert_allclose(res["xcd"][0], res["chip"][0], rtol=2e-5)
+    for xa, xb in zip(res["xcd"][1], res["chip"][1]):
+        for a, b in zip(xa, xb):
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6)
+    assert not np.allclose(res["xcd"][0][0][0], res["xcd"][0][0][1])       # (different instances)
+
+
+def test_a_team_that_does_not_assemble_is_recovered(hip):
+    """The injected timeout (workspace fault word): no member waits for anybody, the status word is raised -- Replicas.run
+    restores every replica's inputs and re-runs them on the step-granular kernels, same minibatches."""
+    data = problems.synthetic_mnist(256, seed=6)
+    T = 8
+    idxs = [np.random.default_rng(90 + j).integers(0, 256, size=(2 * (T + 1), 64)) for j in range(4)]
+    cfg = O.RNNPROP
+    params = make_params(cfg, seed=91, trained_like=True)
+    outs = {}
+    for fault in (False, True):
+        reps = _replicas(cfg, params, data, idxs, T, seed=13)
+        reps.reset()
+        reps.run({reps.step: 1}, form="xcd")                              # (allocates the workspace)
+        if fault:
+            hip.inject_unroll_fault()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fx = reps.run({reps.step: 1 + T}, form="xcd")
+        assert reps.recoveries == (1 if fault else 0)
+        assert sum(issubclass(x.category, RuntimeWarning) for x in w) == (1 if fault else 0)
+        outs[fault] = (np.array(reps.fx_arrays, np.float64), [[v.eval() for v in g.x] for g in reps.graphs])
+        assert np.all(np.isfinite(fx))
+    np.testing.assert_allclose(outs[True][0], outs[False][0], rtol=3e-5)
+    for xa, xb in zip(outs[True][1], outs[False][1]):
+        for a, b in zip(xa, xb):
+            np.testing.assert_allclose(a, b, rtol=3e-4, atol=2e-6)
+
+
+def test_unsupported_shapes_say_so(hip):
+    data = problems.synthetic_mnist(100, seed=5)
+    cfg = O.DM_LOGSIGN
+    meta.set_random_seed(12)
+    probs = [problems.mnist(layers=(20,), batch_size=32, data=data) for _ in range(2)]     # minibatch 32: not the kernel's shape
+    reps = Replicas(meta.MetaOptimizer(**_net_config(cfg, make_params(cfg, seed=82, trained_like=True))), probs, 3)
+    reps.reset()
+    assert not reps.xcd_supported()
+    with pytest.raises(_abi.L2OUnsupported):
+        reps.run(form="xcd")
+    fx = reps.run()                                                        # auto: the whole-chip kernel, one after the other
+    assert reps.last_form == "chip" and fx.shape == (2,) and np.all(np.isfinite(fx))
