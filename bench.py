@@ -148,12 +148,13 @@ def work_block(case, issue, args, clock_hz):
         slot) / measured -- the share of the step ONE wave's issue port needs; named secondary."""
     name = case["kernel"]
     T = case["T"]
-    if not case["fused"] and "k_mlp_unroll" not in name:
+    if not case["fused"] and "k_mlp_" not in name:
         return None
     if case["hbm_bound"]:
         return None
     two_waves = "k_unroll_lds" in name
-    tiles_per_simd = 2 if two_waves else 1
+    xcd = "k_mlp_xcd" in name                            # one optimizee instance per XCD: 32 tiles per CU, two waves per SIMD
+    tiles_per_simd = 8 if xcd else (2 if two_waves else 1)
     wm = work_model(args.problem, args.net, case["D"], case["Mrows"])
     per_tile_pipe = wm["valu_plain"] * PIPE_COST["valu"] + wm["transcendental"] * PIPE_COST["trans"]
     dispatches = float(case.get("dispatches", 1))
@@ -175,7 +176,7 @@ def work_block(case, issue, args, clock_hz):
                    cycles_per_step_loop=ticks[0] / (T + 0.3), frac_step_loop=guide_floor * (T + 0.3) / ticks[0],
                    in_kernel_cycles_source="s_memtime of wave 0 of workgroup 0: kernel entry to exit (workspace bytes 24..31), "
                                            "the step loop alone (bytes 16..23)")
-    if not two_waves:
+    if not two_waves and not xcd:
         issue_floor = (wm["valu_plain"] * ISSUE_COST["valu"] + wm["transcendental"] * ISSUE_COST["trans"] + wm["mfma"] * ISSUE_COST["mfma"])
         out.update(issue_cost_cycles=dict(ISSUE_COST), issue_floor_cycles_per_step=issue_floor, issue_cost_frac=issue_floor / cyc)
     if issue is not None and issue.get("insts_valu") and issue.get("waves"):
@@ -322,6 +323,16 @@ def build_workload(args, Bg):
     cfg["net_options"] = dict(cfg["net_options"], initializer=weights)
     net_config = {key: cfg}
     feed = {}
+    if args.problem == "mnist" and (args.replicas > 1 or args.xcd_form):
+        # N independent instances of the optimizee stepped by ONE optimizer, one per XCD (replicas.Replicas)
+        from open_l2o_amd.replicas import Replicas
+        optimizer = (meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **net_config) if args.net == "rnnprop"
+                     else meta.MetaOptimizer(**net_config))
+        reps = Replicas(optimizer, [problem] * args.replicas, T, net_assignments=net_assignments)
+        if args.net == "rnnprop":
+            feed = {reps.step: 1}
+        optimizer._replica_graph = ReplicaGraph(reps)
+        return optimizer, None, feed, weights
     if args.net == "rnnprop":
         optimizer = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **net_config)
         ml, _, _, step = optimizer.meta_loss(problem, T, net_assignments=net_assignments)
@@ -330,6 +341,35 @@ def build_workload(args, Bg):
         optimizer = meta.MetaOptimizer(**net_config)
         ml = optimizer.meta_loss(problem, T, net_assignments=net_assignments)
     return optimizer, ml, feed, weights
+
+
+class ReplicaGraph(object):
+    """What run_case needs of an unroll graph, for N replicas launched together (replicas.Replicas.launch)."""
+
+    def __init__(self, reps):
+        self.reps = reps
+        self.x, self.constants = [], []
+        self.last_path = None
+        self._x0 = None
+
+    def reset(self):
+        self.reps.reset()
+        self._x0 = [[v.value.clone() for v in g.x] for g in self.reps.graphs]
+
+    def launch(self, feed, commit=True, events=None, use_graph=False, restart=None):
+        if restart is not None:                              # every replica from ITS initial weights, zero state / moments
+            for g, x0 in zip(self.reps.graphs, self._x0):
+                g.rewind(x0)
+        if events is not None:
+            events[0].record()
+        fx = self.reps.launch(feed)
+        if events is not None:
+            events[1].record()
+        self.last_path = "mlp_unroll"
+        return fx[0], None
+
+    def wait_fx(self):
+        pass
 
 
 def parse_args(argv=None):
@@ -363,6 +403,11 @@ def parse_args(argv=None):
     ap.add_argument("--emulate-world", dest="emulate_world", type=int, default=0,
                     help="run ONE shard (rank 0) of a job sharded over this many GPUs in this single process: batch / N "
                          "problems, 1/B_global = 1/batch, no collective (with --config 4: the per-rank work of BASELINE configs[3])")
+    ap.add_argument("--replicas", type=int, default=1,
+                    help="config 5 only: this many independent optimizee instances (replicas) per unroll launch, one per XCD "
+                         "(k_mlp_xcd, l2o_mlp_unroll_multi); 1 = one instance on the whole chip (k_mlp_unroll)")
+    ap.add_argument("--xcd-form", dest="xcd_form", action="store_true",
+                    help="config 5 with --replicas 1: run the single instance on the one-XCD kernel (its latency)")
     ap.add_argument("--problem", default="quadratic", choices=["quadratic", "lasso", "rastrigin", "mnist"])
     ap.add_argument("--rows", type=int, default=None, help="lasso rows M (default: dims)")
     ap.add_argument("--shared-matrix", dest="shared_matrix", action="store_true",
@@ -394,7 +439,7 @@ def default_reps(args, B_local):
     elif args.problem == "lasso":
         ms = 4.6 * max(1.0, B_local / 256.0) * args.unroll / 200.0
     else:
-        ms = 1.8 * args.unroll / 200.0
+        ms = (4.6 if (args.replicas > 1 or args.xcd_form) else 1.8) * args.unroll / 200.0
     return max(1, int(np.ceil(args.min_timed_seconds * 1e3 / max(1, args.steps) / ms)))
 
 
@@ -538,7 +583,8 @@ def run_case(args, eng, world, rank, Bg, B, label):
     if args.problem == "mnist":                    # 784-20-10 MLP: 15 910 coordinates, `batch` = minibatch
         D = 784 * 20 + 20 + 20 * 10 + 10
     optimizer, ml, feed, weights = build_workload(args, Bg)
-    graph = optimizer.graph
+    graph = getattr(optimizer, "_replica_graph", None) or optimizer.graph
+    n_rep = max(1, args.replicas) if args.problem == "mnist" else 1
     graph.reset()                                           # (first call: allocator / context warm-up)
     torch.cuda.synchronize()
     # ---- a ring of problem instances, sampled and uploaded BEFORE the timed region (H2D excluded):
@@ -672,7 +718,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
     torch.cuda.synchronize()
     kt = [a.elapsed_time(b) for a, b in ev]
     kern_all = ev_rep[0].elapsed_time(ev_rep[1]) / max(10, reps)
-    coord_steps = (1 if args.problem == "mnist" else B) * D * T     # per GPU per unroll
+    coord_steps = (n_rep if args.problem == "mnist" else B) * D * T     # per GPU per unroll
     Mrows = B if args.problem == "mnist" else (args.rows or D)
     shared = args.problem == "lasso" and args.shared_matrix
     bpc = (alg_bytes_lasso_shared(args.net, B, D, Mrows) if shared
@@ -682,7 +728,7 @@ def run_case(args, eng, world, rank, Bg, B, label):
     # no mirror of the selection logic here), and the step-loop cycle count that kernel left in the workspace header
     form, dispatches = eng.last_unroll_form() if graph.last_path in ("fused", "mlp_unroll") else (None, 1)
     dispatches = max(1, dispatches)
-    loop_ticks = eng.last_loop_ticks() if form in ("k_unroll_pair", "k_unroll_lds") or (form or "").startswith("k_mlp_unroll") else None
+    loop_ticks = eng.last_loop_ticks() if form in ("k_unroll_pair", "k_unroll_lds") or (form or "").startswith("k_mlp_") else None
     streaming = form in ("k_unroll_cu", "k_unroll_cu8")
     notes = {"k_unroll_pair": "every problem on two CUs, one wave per SIMD", "k_unroll_lds": "one problem per CU, two waves per "
              "SIMD, fragments in LDS", "k_unroll_cu8": "streaming, eight waves, fragments in LDS, LSTM state in registers",
@@ -724,7 +770,9 @@ def workload_names(args, D, B, Bg, T, Mrows, shared):
     probname = {"quadratic": "Quadratic d=%d" % D,
                 "lasso": "Lasso A in R^{%dx%d} l=0.1%s" % (Mrows, D, " (one A shared by the batch)" if shared else ""),
                 "rastrigin": "Rastrigin d=%d" % D,
-                "mnist": "MLP 784-20-10 (sigmoid) on synthetic MNIST-shaped data, minibatch %d" % B}[args.problem]
+                "mnist": "MLP 784-20-10 (sigmoid) on synthetic MNIST-shaped data, minibatch %d%s" % (
+                    B, ", %d independent replica(s) per launch (one per XCD)" % args.replicas
+                    if (args.replicas > 1 or getattr(args, "xcd_form", False)) else "")}[args.problem]
     return netname, probname
 
 
@@ -896,10 +944,14 @@ def main(argv=None):
                 if a.emulate_world > 1 else (" -- all 1024 problems on ONE GPU" if world == 1 else ""))
         elif (a.problem, a.net, B_, T) == ("mnist", "rnnprop", 64, 200):
             baseline_config = "BASELINE.json configs[4] (forward unroll, one replica per GPU)"
+            if a.replicas > 1 or a.xcd_form:
+                baseline_config = ("BASELINE.json configs[4], %d independent replica(s) per GPU in one launch, one per XCD "
+                                   "(k_mlp_xcd)" % a.replicas)
         counters = None
         if world == 1 and not shared:
-            counters = counters_for([a.problem, a.net, D, B_, T] + ([Mrows] if a.problem == "lasso" else []),
-                                    c["kernel"].split(" ")[0] if c["fused"] or "k_mlp_unroll" in c["kernel"] else "", build_id)
+            counters = counters_for([a.problem, a.net, D, B_, T] + ([Mrows] if a.problem == "lasso" else [])
+                                    + (["replicas", a.replicas] if a.problem == "mnist" and (a.replicas > 1 or a.xcd_form) else []),
+                                    c["kernel"].split(" ")[0] if c["fused"] or "k_mlp_" in c["kernel"] else "", build_id)
         roof = roofline_block(c, a, counters)
         cpu = None
         if not a.no_cpu_baseline and not shared and (not full or world > 1):
@@ -1014,6 +1066,10 @@ def main(argv=None):
                                  ("config4_shard_of_8_rccl", ["--config", "4", "--emulate-world", "8", "--real-collective",
                                                               "--steps", "10", "--no-cpu-baseline"] + short),
                                  ("config5", ["--config", "5", "--steps", "5"] + short),
+                                 # (config 5's two kernel forms, VERDICT r05 item 1: EIGHT replicas per launch, one per XCD --
+                                 #  the throughput form -- and ONE instance on one XCD -- that form's latency)
+                                 ("config5_replicas8", ["--config", "5", "--replicas", "8", "--steps", "5", "--no-cpu-baseline"] + short),
+                                 ("config5_one_xcd", ["--config", "5", "--xcd-form", "--steps", "5", "--no-cpu-baseline"] + short),
                                  # (the 2- and 4-GPU shards of config 4, GPU side only: DESIGN.md 6 projects the scaling curve
                                  #  from these driver-timed per-shard rates)
                                  ("config4_shard_of_2", ["--config", "4", "--emulate-world", "2", "--steps", "5", "--no-cpu-baseline"] + short),
@@ -1065,7 +1121,8 @@ def main(argv=None):
             out["collective_us_per_unroll"] = {"error": pb["error"]}
         # ---- flat copies of the other configurations' headline figures (they survive a consumer that keeps top-level
         # scalars only: VERDICT r05 item 4)
-        for name, pre in (("config3", "c3"), ("config4_one_gpu", "c4"), ("config4_shard_of_8", "c4s8"), ("config5", "c5")):
+        for name, pre in (("config3", "c3"), ("config4_one_gpu", "c4"), ("config4_shard_of_8", "c4s8"), ("config5", "c5"),
+                          ("config5_replicas8", "c5x8"), ("config5_one_xcd", "c5xcd1")):
             e = also.get(name) or {}
             if "value" in e:
                 out[pre + "_value"] = e["value"]
@@ -1077,6 +1134,8 @@ def main(argv=None):
                     out[pre + "_rel_diff_vs_cpu_port"] = e["final_loss_rel_diff_vs_cpu_port"]
                 if "oracle_self_sensitivity" in e:
                     out[pre + "_oracle_self_sensitivity"] = e["oracle_self_sensitivity"]
+                if pre.startswith("c5"):
+                    out[pre + "_ms_per_unroll"] = e["ms_per_unroll"]   # (latency of one launch: 1 instance, or 8 together)
         also["seconds"] = time.perf_counter() - t_also
     if world > 1:
         dist.barrier()                                      # (ranks > 0 wait here while rank 0 times its CPU leg)

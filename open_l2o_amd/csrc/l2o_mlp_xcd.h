@@ -98,6 +98,41 @@ __host__ __device__ constexpr MlpXcdLds mlp_xcd_lds(int frag_floats, int win_flo
   return L;
 }
 
+// Granule loads of this kernel: request AND wait inside ONE asm statement.  l2o_mlp_unroll.h issues the load in one statement
+// and the s_waitcnt in another; between the two the compiler is free to copy the (not yet written) destination and to
+// hand its registers to another value, which the returning load then overwrites -- the first build of this kernel hung
+// or passed depending on an unrelated diagnostic store (round 6).  Two independent loads that should overlap go out in
+// one statement too.
+__device__ __forceinline__ mu_u32x4 mx_load2_wait(const unsigned long long* p) {
+  mu_u32x4 d;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(p) : "memory");
+  return d;
+}
+__device__ __forceinline__ void mx_load2x2_wait(const unsigned long long* p0, const unsigned long long* p1, mu_u32x4& d0, mu_u32x4& d1) {
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(d0), "=&v"(d1) : "v"(p0), "v"(p1) : "memory");
+}
+// two granules at p until both carry `tag` (bounded, with back-off)
+__device__ __forceinline__ mu_u32x4 mx_poll2(const unsigned long long* p, mu_u32x4 d, unsigned tag, bool& dead, unsigned* status) {
+  int spins = 0;
+L2O_MU_POLL_PRAGMA
+  while ((d[1] != tag || d[3] != tag) && !dead) {
+    if (++spins > (1 << 17)) { dead = true; atomicExch(status, 2u); break; }
+    __builtin_amdgcn_s_sleep(L2O_MU_SLEEP2);
+    d = mx_load2_wait(p);
+  }
+  return d;
+}
+// a store of matrix-core results: the hazard recogniser does not see the VMEM read inside an inline asm, so the wait states
+// between the last MFMA that wrote `v` and the store are spelled out (18 covers the 8-pass v_mfma_f32_16x16x4_f32)
+__device__ __forceinline__ void mx_settle(f32x4& v) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(v)); }
+// two granules with a PLAIN store (same-XCD readers: the line stays in this L2) + the wait state gfx9 wants between a store
+// of more than 8 bytes and a VALU write of its data registers (the compiler does not see the store inside the asm)
+__device__ __forceinline__ void mx_store2(unsigned long long* p, float v0, float v1, unsigned tag) {
+  mu_u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+}
+
 template <int PRE>
 static size_t mlp_xcd_lds_bytes() {
   return sizeof(float) * (size_t)mlp_xcd_lds(LstmCoreLds<PRE, bx::NetWBLF<PRE>>::kFragWords, bx::NetWBLF<PRE>::kWinFloats).total;
@@ -130,6 +165,14 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   if (mem < 0 || mem >= kMxMembers) return;       // an XCD without an instance, or a 33rd arrival
   const MxInst& I = a.inst[inst];
   unsigned* status = &a.ws->status;
+  // which wait gave up FIRST (diagnostics; workspace header pad[0]: step * 16 + phase, pad[1]: instance * 32 + member)
+  bool dead_seen = false;
+  auto note_dead = [&](bool dead, int t, int phase) __attribute__((always_inline)) {
+    if (dead && !dead_seen) {
+      dead_seen = true;
+      if (atomicCAS(&a.ws->pad[0], 0u, (unsigned)(t * 16 + phase)) == 0u) a.ws->pad[1] = (unsigned)(inst * kMxMembers + mem);
+    }
+  };
 
   float* frs = mx_smem;
   float* winL = frs + Core::kFragWords;
@@ -283,11 +326,12 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
         const float av = arow ? xw[(k0 + krow) * kMxH + 16 * ht + cc - j0] : 0.0f;     // A[row = hidden][k]
         acc = mfma16(av, imgs[par][16 * st_ + cc][krow], acc);                         // B[k][col = sample]
       }
+      mx_settle(acc);
       if (ht == 0 || q == 0) {
         const int sidx = 16 * st_ + cc;
         unsigned long long* dst = I.P + ((size_t)((sidx >> 1) * kMxMembers + mem)) * kMxR + (sidx & 1) * kMxH + 16 * ht + 4 * q;
-        mu_store2_local(dst, acc[0], acc[1], tag);
-        mu_store2_local(dst + 2, acc[2], acc[3], tag);
+        mx_store2(dst, acc[0], acc[1], tag);
+        mx_store2(dst + 2, acc[2], acc[3], tag);
       }
     }
     // ---- the small parameters (published at the start of the step)
@@ -297,23 +341,25 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
       if (tid >= kMxH && tid < kMxH + kMxH * kMxO) { const int e = tid - kMxH; w2p[e / kMxO][e % kMxO] = val; }
     }
     pc.mark(1);
+    note_dead(dead, t, 2);
     // ---- reduce: this member's 40 outputs over the w1 owners: thread = (pair p, source), all loads first, then the tags
     {
       const int pq = tid % (kMxR / 2), s0 = tid / (kMxR / 2);                           // 20 pairs x 25 sources (+ 25)
       const unsigned long long* inbox = I.P + ((size_t)mem * kMxMembers) * kMxR + 2 * pq;
       const int s1 = s0 + kMxThreads / (kMxR / 2);
       const bool v0 = s0 < nw1 && tid < (kMxThreads / (kMxR / 2)) * (kMxR / 2), v1 = v0 && s1 < nw1;
+      // (both loads unconditionally, from a clamped source: no conditionally defined asm results)
+      const unsigned long long* p0 = inbox + (size_t)(v0 ? s0 : 0) * kMxR;
+      const unsigned long long* p1 = inbox + (size_t)(v1 ? s1 : 0) * kMxR;
       mu_u32x4 d0, d1;
-      if (v0) d0 = mu_load2(inbox + (size_t)s0 * kMxR);
-      if (v1) d1 = mu_load2(inbox + (size_t)s1 * kMxR);
-      mu_wait_loads();
+      mx_load2x2_wait(p0, p1, d0, d1);
       if (v0) {
-        d0 = mu_poll2(inbox + (size_t)s0 * kMxR, d0, tag, dead, status);
+        d0 = mx_poll2(p0, d0, tag, dead, status);
         redr[s0][2 * pq] = __uint_as_float(d0[0]);
         redr[s0][2 * pq + 1] = __uint_as_float(d0[2]);
       }
       if (v1) {
-        d1 = mu_poll2(inbox + (size_t)s1 * kMxR, d1, tag, dead, status);
+        d1 = mx_poll2(p1, d1, tag, dead, status);
         redr[s1][2 * pq] = __uint_as_float(d1[0]);
         redr[s1][2 * pq + 1] = __uint_as_float(d1[2]);
       }
@@ -321,18 +367,19 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
       if (tid < kMxR / 2) {                                 // ascending source order: the same sum whoever computes it
         float t0 = 0.0f, t1 = 0.0f;
         for (int s = 0; s < nw1; ++s) { t0 += redr[s][2 * tid]; t1 += redr[s][2 * tid + 1]; }
-        mu_store2_local(I.S + (size_t)par * kMxNO + mem * kMxR + 2 * tid, t0, t1, tag);
+        mx_store2(I.S + (size_t)par * kMxNO + mem * kMxR + 2 * tid, t0, t1, tag);
       }
     }
     pc.mark(2);
+    note_dead(dead, t, 3);
     // ---- gather the 1 280 sums (pairs), bias + activation fused into the LDS write
     {
       const unsigned long long* Sp = I.S + (size_t)par * kMxNO;
       mu_u32x4 g0, g1;
       const bool two = tid + kMxThreads < kMxNO / 2;
-      g0 = mu_load2(Sp + 2 * tid);
-      if (two) g1 = mu_load2(Sp + 2 * (tid + kMxThreads));
-      mu_wait_loads();
+      const unsigned long long* q0 = Sp + 2 * tid;
+      const unsigned long long* q1 = Sp + 2 * (two ? tid + kMxThreads : tid);
+      mx_load2x2_wait(q0, q1, g0, g1);
       auto put = [&](int pr, mu_u32x4 g) {
         const int o = 2 * pr, sidx = o / kMxH, h = o - sidx * kMxH;
         const float a0 = __uint_as_float(g[0]) + small[h], a1 = __uint_as_float(g[2]) + small[h + 1];
@@ -340,15 +387,16 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
         Hs[sidx][h + 1] = a.act == 0 ? sigmoidf_(a1) : fmaxf(a1, 0.0f);
       };
       // (small[] was written before the barrier inside the reduce phase)
-      g0 = mu_poll2(Sp + 2 * tid, g0, tag, dead, status);
+      g0 = mx_poll2(q0, g0, tag, dead, status);
       put(tid, g0);
       if (two) {
-        g1 = mu_poll2(Sp + 2 * (tid + kMxThreads), g1, tag, dead, status);
+        g1 = mx_poll2(q1, g1, tag, dead, status);
         put(tid + kMxThreads, g1);
       }
     }
     __syncthreads();
     pc.mark(3);
+    note_dead(dead, t, 4);
     // ---- waves 0-3: forward tail + dH on the fp32 matrix cores (k_mlp_unroll's tail: wave w owns samples 16 w .. 16 w + 15);
     //      waves 4-7: the NEXT evaluation's image columns and labels -> the other parity buffer
     if (wv < 4) {

@@ -82,6 +82,25 @@ class Replicas(object):
         inst = g.mlp_instance(None, dry=True)
         return inst is not None and eng.mlp_unroll_multi_supported(inst["net"].spec, inst["desc"], min(8, len(self.graphs)))
 
+    def launch(self, feed=None):
+        """ENQUEUE one committed unroll of every replica on the one-instance-per-XCD kernel (launches of up to eight) without
+        synchronising the host, without a recovery snapshot and without a status check -- the caller syncs and calls
+        engine.check_unroll_status() itself (bench.py's timed region).  Returns the replicas' loss buffers (device, [T + 1])."""
+        graphs = self.graphs
+        eng = graphs[0].engine
+        insts = [g.mlp_instance(self._feed(g, feed)) for g in graphs]
+        if any(i is None for i in insts):
+            raise _abi.L2OUnsupported(_abi.L2O_ERR_UNSUPPORTED, "Replicas.launch: l2o_mlp_unroll_multi does not apply")
+        net, desc = insts[0]["net"], insts[0]["desc"]
+        step0 = int(feed[graphs[0].step]) if graphs[0].rnnprop else 1
+        wpack = net.wpack(eng)
+        for k in range(0, len(insts), 8):
+            eng.mlp_unroll_multi(net.spec, wpack, desc, insts[k:k + 8], self.len_unroll, step0)
+        self.last_form = "xcd"
+        for g in graphs:
+            g.last_path = "mlp_xcd"
+        return [i["fx"] for i in insts]
+
     def run(self, feed=None, form="auto"):
         """One committed unroll of every replica from its current variables (== N x sess.run([fx, update])).
         form: "xcd" (launches of up to eight instances, one per XCD), "chip" (one instance after the other on the whole
