@@ -2004,7 +2004,8 @@ static bool mlp_xcd_layout(const l2o_mlp* mlp, int n_inst, MlpXcdLayout* L) {
   L->n[0] = mlp->n_in * kMxH; L->n[1] = kMxH; L->n[2] = kMxH * kMxO; L->n[3] = kMxO;
   L->tile_begin[0] = 0;
   for (int v = 0; v < 4; ++v) L->tile_begin[v + 1] = L->tile_begin[v] + tiles_per_problem(L->n[v]);
-  if (L->tile_begin[4] > kMxMembers * kMxSlots) return false;
+  // members 0 .. 30: the w1 tiles (32 each); member 31: b1 | w2 | b2
+  if (L->tile_begin[1] > (kMxMembers - 1) * kMxSlots || L->tile_begin[4] - L->tile_begin[1] > kMxSlots) return false;
   L->nw1 = (L->n[0] + kMxCoords - 1) / kMxCoords;
   L->team_off = sizeof(MlpWs);
   L->inst_off = L->team_off + 64;

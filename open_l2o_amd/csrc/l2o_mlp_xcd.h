@@ -21,8 +21,8 @@
 //                        sample pair s / 2, PLAIN stores: the lines stay in the XCD's L2
 //               reduce   member r adds the <= 31 partials of its 40 outputs in ascending source order, publishes the sums
 //               gather   every member polls the 1 280 sums (L1-bypassing loads: they hit the same L2), bias + sigmoid fused
-//               tail     logits / softmax / dZ / dH on the matrix cores (waves 0-3, as k_mlp_unroll's tail) while waves 4-7
-//                        gather the NEXT minibatch's image columns
+//               tail     logits / softmax / dZ / dH on the matrix cores (waves 0-3, as k_mlp_unroll's tail); the NEXT minibatch's
+//                        indices / image columns are requested at the head of the step / behind the gather, landed before the LSTM phase
 //               gradient G[k][h] = sum_s img[s][k] dH[s][h] for the member's 512 coordinates: 16 MFMAs per wave (waves 0-3)
 //               LSTM     every wave steps its four tiles (bx::tile_step_w on the LDS fragments), x += delta
 //   Two hops through ONE coherent L2 instead of three hops of which one crosses the fabric; no XCC_ID table, no flat
@@ -196,8 +196,17 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   const int ntiles = a.tile_begin[4];
   // the member's w1 range: flat [j0, j1) -> image columns [k0, k0 + 28)
   const int j0 = mem * kMxCoords;
-  const bool owns_w1 = j0 < a.n[0];
+  const bool owns_w1 = mem < kMxMembers - 1 && j0 < a.n[0];
   const int k0 = j0 / kMxH;
+  // slot -> tile of the instance (or ntiles: none).  Members 0 .. 30 hold the w1 tiles, 32 consecutive ones each; the LAST
+  // member holds b1 | w2 | b2 (16 tiles) and nothing else: it is the only one whose gradients are VALU sums over the samples
+  // and whose coordinates everybody polls at the start of a step -- with half a member's LSTM work it publishes early
+  // (first build: those tiles rode behind member 30's w1 tiles and every member waited ~5 k cycles for them each step)
+  const int nt1 = a.tile_begin[1];
+  auto tile_of = [&](int slot) {
+    const int ti = mem == kMxMembers - 1 ? nt1 + slot : mem * kMxSlots + slot;
+    return (mem == kMxMembers - 1 ? ti < ntiles : ti < nt1) ? ti : ntiles;
+  };
   // tile slot -> (variable, tile inside it); wave-uniform per slot
   auto var_of = [&](int ti) {
     int var = 0;
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   __syncthreads();
   {
     const int pos = tid;                                   // 512 threads = 512 coordinate positions
-    const int ti = mem * kMxSlots + (pos >> 4);
+    const int ti = tile_of(pos >> 4);
     float xv = 0.0f, sc = 1.0f, mv = 0.0f, vv = 0.0f;
     bool w1pos = false;
     if (ti < ntiles) {
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   for (int k = 0; k < 4; ++k) {
 #pragma unroll
     for (int t5 = 0; t5 < kNT; ++t5) { sr[k].h1[t5] = 0.f; sr[k].c1[t5] = 0.f; sr[k].h2[t5] = 0.f; sr[k].c2[t5] = 0.f; }
-    const int ti = mem * kMxSlots + wv + kMxWaves * k;
+    const int ti = tile_of(wv + kMxWaves * k);
     if (ti < ntiles) {
       const int var = var_of(ti);
       load_tile_state(sr[k], I.st[var] + (size_t)(ti - a.tile_begin[var]) * kStateFloatsPerTile, lane);
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     // ---- publish: the owners of b1 / w2 / b2 broadcast their scaled coordinates as granules (plain stores: same L2)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ti = mem * kMxSlots + wv + kMxWaves * k;
+      const int ti = tile_of(wv + kMxWaves * k);
       if (ti >= a.tile_begin[1] && ti < ntiles && q == 0) {
         const int var = var_of(ti);
         const int jl = (ti - a.tile_begin[var]) * kTile + cc;
@@ -311,6 +320,22 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
                              __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+    }
+    // ---- the NEXT evaluation's minibatch, stage A: its indices -> registers (stage B, behind the gather: the image columns;
+    // stage C, in front of the LSTM phase: -> the other parity buffer).  Two dependent global latencies, neither of them
+    // waited for where it is issued.
+    constexpr int kPf = (kMxB * kMxKR + kMxThreads - 1) / kMxThreads;
+    int pf_row[kPf], pf_lab = 0;
+    float pf_val[kPf];
+    const bool have_next = t < a.T;
+    if (have_next) {
+      const int* ix1 = I.idx + (size_t)(t + 1) * kMxB;
+#pragma unroll
+      for (int u = 0; u < kPf; ++u) {
+        const int e = tid + kMxThreads * u;
+        pf_row[u] = e < kMxB * kMxKR ? ix1[e / kMxKR] : 0;
+      }
+      if (tid < kMxB) pf_lab = ix1[tid];
     }
     pc.mark(0);
     // ---- partial hidden pre-activations on the fp32 matrix cores: wave = (sample tile st, hidden tile ht);
@@ -394,11 +419,18 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
         put(tid + kMxThreads, g1);
       }
     }
+    if (have_next) {                                        // stage B: the image columns of the next minibatch
+#pragma unroll
+      for (int u = 0; u < kPf; ++u) {
+        const int e = tid + kMxThreads * u, kk = e % kMxKR;
+        pf_val[u] = (e < kMxB * kMxKR && owns_w1 && k0 + kk < n_in) ? a.images[(size_t)pf_row[u] * n_in + k0 + kk] : 0.0f;
+      }
+      if (tid < kMxB) pf_lab = a.labels[pf_lab];
+    }
     __syncthreads();
     pc.mark(3);
     note_dead(dead, t, 4);
-    // ---- waves 0-3: forward tail + dH on the fp32 matrix cores (k_mlp_unroll's tail: wave w owns samples 16 w .. 16 w + 15);
-    //      waves 4-7: the NEXT evaluation's image columns and labels -> the other parity buffer
+    // ---- waves 0-3: forward tail + dH on the fp32 matrix cores (k_mlp_unroll's tail: wave w owns samples 16 w .. 16 w + 15)
     if (wv < 4) {
       const int s_l = 16 * wv + cc;
       f32x4 zacc;
@@ -461,8 +493,6 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
           *reinterpret_cast<f32x4*>(&dHs[s_l][16]) = o1;
         }
       }
-    } else if (t < a.T) {
-      load_eval(t + 1, par ^ 1, tid - 256, std::integral_constant<int, 256>());
     }
     __syncthreads();
     if (mem == 0 && tid == 0) I.fx[t] = ((red[0] + red[1]) + (red[2] + red[3])) * invB;
@@ -490,6 +520,15 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
         }
       }
     }
+    // stage C: the next minibatch -> the other parity buffer (nobody reads it before the next step's partial phase)
+    if (have_next) {
+#pragma unroll
+      for (int u = 0; u < kPf; ++u) {
+        const int e = tid + kMxThreads * u;
+        if (e < kMxB * kMxKR) imgs[par ^ 1][e / kMxKR][e % kMxKR] = pf_val[u];
+      }
+      if (tid < kMxB) labs[par ^ 1][tid] = pf_lab;
+    }
     __syncthreads();
     pc.mark(5);
     // ---- optimizer network on this wave's four tiles
@@ -499,7 +538,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
       const int slot = wv + kMxWaves * k;
-      const int ti = mem * kMxSlots + slot;
+      const int ti = tile_of(slot);
       if (ti < a.tile_begin[1] || ti >= ntiles) continue;
       const int var = var_of(ti);
       const int jl = (ti - a.tile_begin[var]) * kTile + cc;
@@ -519,7 +558,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     }
     auto do_tile = [&](int k, TileState& s) __attribute__((always_inline)) {
       const int slot = wv + kMxWaves * k;
-      const int ti = mem * kMxSlots + slot;
+      const int ti = tile_of(slot);
       if (ti >= ntiles) return;
       const bool is_w1 = ti < a.tile_begin[1];
       const int var = var_of(ti);
@@ -568,7 +607,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   // ---- write back: x, moments, LSTM state -------------------------------------------------------
   {
     const int pos = tid;
-    const int ti = mem * kMxSlots + (pos >> 4);
+    const int ti = tile_of(pos >> 4);
     if (ti < ntiles) {
       const int var = var_of(ti);
       const int jl = (ti - a.tile_begin[var]) * kTile + (pos & 15);
@@ -580,7 +619,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int ti = mem * kMxSlots + wv + kMxWaves * k;
+    const int ti = tile_of(wv + kMxWaves * k);
     if (ti < ntiles) {
       const int var = var_of(ti);
       store_tile_state(sr[k], I.st[var] + (size_t)(ti - a.tile_begin[var]) * kStateFloatsPerTile, lane);

@@ -30,6 +30,8 @@ bench_args() { # CFG -> the bench.py arguments of that BASELINE configuration
     3) echo "--config 3 --steps 5" ;;
     4) echo "--config 4 --steps 10" ;;
     5) echo "--config 5 --steps 5" ;;
+    5x8) echo "--config 5 --replicas 8 --steps 5" ;;      # eight replicas per launch, one per XCD (k_mlp_xcd)
+    4s8) echo "--config 4 --emulate-world 8 --steps 10" ;; # config 4's shard of 8
     *) echo "--config $1" ;;
   esac
 }
@@ -39,9 +41,11 @@ workload_json() { # the `workload` key scripts/counters_to_json.py stores and be
     3) echo '["lasso", "rnnprop", 512, 256, 200, 256]' ;;
     4) echo '["rastrigin", "dm", 100, 1024, 100]' ;;
     5) echo '["mnist", "rnnprop", 15910, 64, 200]' ;;
+    5x8) echo '["mnist", "rnnprop", 15910, 64, 200, "replicas", 8]' ;;
+    4s8) echo '["rastrigin", "dm", 100, 128, 100]' ;;
   esac
 }
-kernel_of() { case $1 in 2) echo 'k_unroll_pair<' ;; 4) echo 'k_unroll_lds<' ;; 3) echo 'k_unroll_cu' ;; 5) echo 'k_mlp_unroll' ;; esac; }
+kernel_of() { case $1 in 2|4s8) echo 'k_unroll_pair<' ;; 4) echo 'k_unroll_lds<' ;; 3) echo 'k_unroll_cu' ;; 5) echo 'k_mlp_unroll' ;; 5x8) echo 'k_mlp_xcd' ;; esac; }
 train_cmd() { # NAME SECONDS -> command line (the ones recorded in tests/golden/trained/README.md)
   local S=$2
   case $1 in

@@ -140,3 +140,28 @@ def test_unsupported_shapes_say_so(hip):
         reps.run(form="xcd")
     fx = reps.run()                                                        # auto: the whole-chip kernel, one after the other
     assert reps.last_form == "chip" and fx.shape == (2,) and np.all(np.isfinite(fx))
+
+
+@pytest.mark.parametrize("netname", ["rnnprop", "dm"])
+def test_soak_a_thousand_launches(hip, netname):
+    """1 000 back-to-back launches of eight instances (T = 3) with no host sync in between, for the net whose first build hung
+    depending on unrelated code: no member ever gives up waiting, and the loss of every instance stays
+    what the SAME sequence gives on a second pass (the launches are deterministic: fixed summation orders everywhere)."""
+    data = problems.synthetic_mnist(256, seed=7)
+    T, n, launches = 3, 8, 1000
+    cfg = O.RNNPROP if netname == "rnnprop" else O.DM_IDENTITY
+    params = make_params(cfg, seed=95, trained_like=True)
+    finals = []
+    for _ in range(2):
+        meta.set_random_seed(17)
+        probs = [problems.mnist(layers=(20,), batch_size=64, data=data) for _ in range(n)]
+        opt = (meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp")) if cfg.kind == "rnnprop"
+               else meta.MetaOptimizer(**_net_config(cfg, params)))
+        reps = Replicas(opt, probs, T)
+        reps.reset()
+        for i in range(launches):
+            fx = reps.launch({reps.step: 1 + i * T} if cfg.kind == "rnnprop" else None)
+        finals.append(np.array([hip.to_numpy(f) for f in fx]))
+        hip.check_unroll_status()                                            # raises on a timeout of any launch (sticky)
+    assert np.all(np.isfinite(finals[0]))
+    np.testing.assert_array_equal(finals[0], finals[1])
