@@ -161,7 +161,8 @@ class StepPlanMixin(object):
         panels = [v.value.view(*self._panel_shape(v)) for v in self.x]
         ring = self._fx_cache.get(T)
         if ring is None:
-            ring = self._fx_cache[T] = {"bufs": [self.engine.zeros(T + 1)], "work": [None], "i": 0}
+            store = self.engine.zeros(1, T + 1)
+            ring = self._fx_cache[T] = {"store": store, "bufs": [store[0]], "work": [None], "i": 0, "pending": []}
         return dict(net=net, desc=desc, indices=self._mlp_idx[0], xs=[panels[j] for j in js],
                     sts=[states[si].packed for si in sis], ms=[slots[si].m for si in sis], vs=[slots[si].v for si in sis],
                     scales=[None] * 4, fx=ring["bufs"][0])

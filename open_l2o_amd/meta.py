@@ -381,14 +381,12 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
                 ring = self._fx_cache[T]
                 i = ring["i"]
                 ring["i"] = (i + 1) % len(ring["bufs"])
-                if ring["work"][i] is not None:
-                    ring["work"][i].wait()
-                    ring["work"][i] = None
+                self._claim_fx(ring, i)
                 fx = ring["bufs"][i]
                 if ent["call"](fx, int(feed[self.step]) if self.rnnprop else 1):
                     self.last_path = "fused"
                     if self.sharded:
-                        ring["work"][i] = _all_reduce(fx, async_op=True)
+                        self._queue_fx(ring, i)
                     return fx, [self.x[0].value]
                 self._fast_unrolls.pop(fast_key, None)      # stale (the engine's workspace / layout changed): general path
         # restart = list of device tensors x0: run this unroll from x0 and the zero LSTM state / moments on the SAME
@@ -458,8 +456,10 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
         key = T
         ring = self._fx_cache.get(key)
         if ring is None:
-            n = 4 if self.sharded else 1
-            ring = self._fx_cache[key] = {"bufs": [eng.zeros(T + 1) for _ in range(n)], "work": [None] * n, "i": 0}
+            n = self.FX_RING if self.sharded else 1
+            store = eng.zeros(n, T + 1)                      # (ONE tensor: a run of pending buffers is one contiguous all-reduce)
+            ring = self._fx_cache[key] = {"store": store, "bufs": [store[k] for k in range(n)], "work": [None] * n, "i": 0,
+                                          "pending": []}
         fused_path = record is None and self._fused_ok(descs)
         if restart_fused and not fused_path:
             self.rewind(restart)                            # (panels / states are views of the live tensors: still valid)
@@ -468,9 +468,7 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
             ring["i"] = 0                                  # a captured launch sequence owns buffer 0
         i = ring["i"]
         ring["i"] = (i + 1) % len(ring["bufs"]) if fused_path else 0
-        if ring["work"][i] is not None:
-            ring["work"][i].wait()
-            ring["work"][i] = None
+        self._claim_fx(ring, i)
         fx = ring["bufs"][i]
 
         if events is not None:
@@ -584,18 +582,60 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
                 events[1].record()
 
         if self.sharded:
-            ring["work"][i] = _all_reduce(fx, async_op=True)
+            self._queue_fx(ring, i)
         if commit:
             for s, st in zip(slots, states):
                 s.state = st
         return fx, xs
 
+    # -- the loss all-reduce of a sharded job: DEFERRED and COALESCED (round 6) --------------------------------------------------
+    # Nothing reads an unroll's losses before the host asks for them (Session.run: wait_fx + a copy; bench.py: at the end of the
+    # timed region), so the T + 1 partial sums of an unroll stay in their ring buffer, marked pending, and ONE all-reduce over
+    # the contiguous run of pending buffers goes out when somebody reads (wait_fx) or when the ring is about to wrap.  Why it
+    # matters: the two-CU unroll needs every CU of the device at once, so a collective kernel running beside it on RCCL's
+    # stream holds back the NEXT unroll's launch until it has finished -- measured with a world-size-1 RCCL group, one
+    # all-reduce per unroll cost 11.8 us of a 188 us unroll (6.84 -> 6.43 G on config 4's shard of 8); a real 8-rank ring is
+    # slower than that.  One collective per FX_RING - 1 unrolls makes the cost vanish from a run that does not read the losses.
+    FX_RING = 16
+
+    def _claim_fx(self, ring, i):
+        """Buffer i is about to be overwritten: its pending / in-flight reduction must have gone out and finished."""
+        if i in ring.get("pending", ()):
+            self._flush_fx(ring)
+        if ring["work"][i] is not None:
+            ring["work"][i].wait()
+            ring["work"][i] = None
+
+    def _queue_fx(self, ring, i):
+        ring["pending"].append(i)
+        if len(ring["pending"]) >= len(ring["bufs"]) - 1:
+            self._flush_fx(ring)
+
+    def _flush_fx(self, ring):
+        """One asynchronous all-reduce per contiguous run of pending loss buffers."""
+        pend = sorted(ring.get("pending", ()))
+        ring["pending"] = []
+        k = 0
+        while k < len(pend):
+            e = k
+            while e + 1 < len(pend) and pend[e + 1] == pend[e] + 1:
+                e += 1
+            w = _all_reduce(ring["store"][pend[k]:pend[e] + 1], async_op=True)
+            for j in range(k, e + 1):
+                ring["work"][pend[j]] = w
+            k = e + 1
+
     def wait_fx(self):
-        """Make the current stream (NCCL) / the host (gloo) wait for the loss all-reduces in flight."""
+        """Issue the pending loss all-reduces and make the current stream (NCCL) / the host (gloo) wait for them."""
         for ring in self._fx_cache.values():
+            if ring.get("pending"):
+                self._flush_fx(ring)
+            done = set()
             for k, w in enumerate(ring["work"]):
                 if w is not None:
-                    w.wait()
+                    if id(w) not in done:
+                        w.wait()
+                        done.add(id(w))
                     ring["work"][k] = None
 
     # -- meta-gradient (DM/meta.py:398-414) --------------------------------------------

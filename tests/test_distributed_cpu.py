@@ -353,3 +353,77 @@ def test_two_rank_partner_timeout_in_evaluation_recovers_on_both_ranks():
         assert recoveries == 1 and warned == 1, (rank, recoveries, warned)
     assert "unroll_timeout" in results[1][2] and "unroll_timeout" not in results[0][2]
     assert results[0][0] == results[1][0]                            # same all-reduced losses on both ranks, all four runs
+
+
+# ---------------------------------------------------------------------------
+# the loss all-reduce is deferred and coalesced (round 6): launches that nobody reads cost one collective per FX_RING - 1
+# unrolls, and what is read afterwards is the all-reduced loss of the right unroll
+# ---------------------------------------------------------------------------
+def _launch_many(n_launch, count):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import ORACLE_CFGS, make_params, make_problem
+    from open_l2o_amd import _engine, _graph_core, meta, problems
+    from oracle_engine import OracleEngine
+    from test_meta_api import _net_config
+
+    _engine.set_default_engine(OracleEngine())
+    cfg = ORACLE_CFGS["dm"]
+    params = make_params(cfg, seed=62, trained_like=True)
+    prob, x0, _ = make_problem("quadratic", 8, 16, seed=63)
+    problem = problems.quadratic(8, 16, data={"w": prob.w, "y": prob.y, "x": x0})
+    opt = meta.MetaOptimizer(**_net_config(cfg, params))
+    opt.meta_loss(problem, 3)
+    g = opt.graph
+    g.reset()
+    calls = []
+    if count:
+        real = meta._all_reduce
+
+        def counting(t, async_op=False, op=None):
+            calls.append(int(t.numel()))
+            return real(t, async_op=async_op, op=op)
+        meta._all_reduce = counting
+    last = None
+    for _ in range(n_launch):
+        last, _ = g.launch({}, commit=True)
+    g.wait_fx()
+    return [float(v) for v in last], calls, g.FX_RING if g.sharded else 1
+
+
+def _launch_many_worker(rank, world, port, n_launch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _launch_many(n_launch, True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_loss_all_reduce_is_deferred_and_coalesced():
+    n_launch = 40
+    ref, _, _ = _launch_many(n_launch, False)                          # single process, the global batch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_launch_many_worker, args=(r, 2, port, n_launch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(2):
+        item = q.get(timeout=300)
+        results[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        fx, calls, ring = results[rank]
+        np.testing.assert_allclose(fx, ref, rtol=2e-6)
+        assert ring == 16
+        # 40 unrolls nobody read: a collective when the ring is about to wrap (every 15 launches; a wrapping run is two
+        # contiguous pieces) + the one wait_fx() issues -- not 40
+        assert len(calls) <= 6, calls
+        assert sum(calls) == n_launch * 4, calls                       # every unroll's T + 1 = 4 losses reduced exactly once
+    assert results[0][0] == results[1][0]
