@@ -252,6 +252,22 @@ int l2o_mlp_fg(const l2o_mlp* mlp, const int32_t* indices /* device [batch] rows
                float* loss /* device [1] */, float* gw1, float* gb1, float* gw2, float* gb2,
                float* scratch /* device [l2o_mlp_scratch_floats] */, void* stream);
 
+/* problems.mnist with MORE than one hidden layer (ABI v13; DM/problems.py:254-288 with layers = (20, 20): DM/util.py:157-163
+ * "mnist_deeper").  The step-granular evaluation only -- loss + gradients of one minibatch, two launches; the fused unrolls
+ * serve the one-hidden-layer optimizee.  w / g: HOST arrays of 2 (n_hidden_layers + 1) device pointers in Sonnet's order
+ * linear_0/w [n_in, h0], linear_0/b [h0], linear_1/w [h0, h1], ..., linear_L/w [h_{L-1}, n_out], linear_L/b [n_out]
+ * (g may be NULL: forward only).  n_hidden_layers in [1, 3], widths <= 32, n_out <= 16, n_in <= 1024, batch <= 4096. */
+typedef struct l2o_mlp_deep {
+  int32_t n_in, n_out, batch, activation /* 0 sigmoid, 1 relu */, n_data, n_hidden_layers;
+  int32_t hidden[3];
+  int32_t reserved;
+  const float* images;   /* device [n_data, n_in] */
+  const int32_t* labels; /* device [n_data]       */
+} l2o_mlp_deep;
+size_t l2o_mlp_deep_scratch_floats(const l2o_mlp_deep* mlp);
+int l2o_mlp_deep_fg(const l2o_mlp_deep* mlp, const int32_t* indices /* device [batch] */, const float* const* w,
+                    float* loss /* device [1] */, float* const* g, float* scratch /* device */, void* stream);
+
 /* ---- the fused unroll for the neural optimizee (ABI v6): MetaOptimizer.meta_loss's tf.while_loop
  * (DM/meta.py:338-376; RNNProp DM/meta_rnnprop_eval.py time_step) over problems.mnist (DM/problems.py:246-288) as ONE
  * persistent launch: T x { fx_t = loss(minibatch_t; x_t * s); g = s * grad; delta, state = net(g, state) for each of

@@ -27,6 +27,7 @@ SYMBOLS = (
     "l2o_state_floats", "l2o_state_pack", "l2o_state_unpack", "l2o_problem_fg", "l2o_problem_hvp", "l2o_mlp_fg",
     "l2o_mlp_scratch_floats", "l2o_mlp_unroll", "l2o_mlp_unroll_record", "l2o_mlp_unroll_supported", "l2o_mlp_unroll_workspace_bytes",
     "l2o_mlp_unroll_multi", "l2o_mlp_unroll_multi_supported", "l2o_mlp_unroll_multi_workspace_bytes",
+    "l2o_mlp_deep_fg", "l2o_mlp_deep_scratch_floats",
     "l2o_cwlstm_step", "l2o_cwlstm_step_multi", "l2o_cwlstm_step_generic", "l2o_cwlstm_bwd_step_generic", "l2o_gen_state_floats", "l2o_cwlstm_bwd_step", "l2o_cwlstm_bwd_multi", "l2o_cwlstm_bwd_unroll", "l2o_cwlstm_bwd_unroll_compact", "l2o_cwlstm_wgrad_compact", "l2o_unroll", "l2o_unroll_record", "l2o_unroll_reduce", "l2o_unroll_workspace_init", "l2o_unroll_workspace_layout", "l2o_cwlstm_wgrad", "l2o_cwlstm_wgrad_dims", "l2o_unroll_supported", "l2o_unroll_record_supported", "l2o_adam_step", "l2o_adam_step_guarded", "l2o_adam_step_gather", "l2o_wpack_device", "l2o_unroll_workspace_bytes",
     "l2o_unroll_status", "l2o_reduce_fx", "l2o_atb", "l2o_atb_workspace_bytes",
     "l2o_suffix_sums", "l2o_colsum", "l2o_colsum_scratch_floats", "l2o_lincomb", "l2o_rnnprop_input_adjoint",
@@ -51,25 +52,21 @@ FORMS_WITH_EXCHANGE = (2, 8, 9, 10, 11)    # workgroups wait for partner workgro
 PROB_FG_TWO_PASS = 2      # l2o_problem.flags
 MLP_GENERIC = 1           # l2o_mlp.flags
 _options = {}
-# The library never reads the environment; this binding applies these variables ONCE, when it loads it.
-_ENV_OPTIONS = (
-    ("L2O_NO_PAIR", OPT_PAIR, lambda v: 0),
-    ("L2O_PAIR_AGENT_STORES", OPT_PAIR_PLAIN_STORES, lambda v: 0),
-    ("L2O_NO_UNROLL_CU", OPT_UNROLL_CU, lambda v: 0),
-    ("L2O_UNROLL_CU", OPT_UNROLL_CU, lambda v: int(v)),       # 2: k_unroll_cu always; 3 / 4 / 5: k_unroll_cu8 always (4 / 3 / 2 register tiles per wave)
-    ("L2O_FG_TWO_PASS", OPT_FG_TWO_PASS, lambda v: 1),
-    ("L2O_MLP_GENERIC", OPT_MLP_GENERIC, lambda v: 1),
-    ("L2O_BWD_BLOCKS", OPT_BWD_BLOCKS, lambda v: int(v)),
-    ("L2O_BWD_TILE", OPT_BWD_KERNEL, lambda v: 1),
-    ("L2O_BWD_GENERIC", OPT_BWD_KERNEL, lambda v: 2),
-    ("L2O_NO_MLP_UNROLL", OPT_MLP_UNROLL, lambda v: 0),
-    ("L2O_EXACT_GATES", OPT_EXACT_GATES, lambda v: 1),
-    ("L2O_NO_MLP_HIER", OPT_MLP_HIER, lambda v: 0),
-    ("L2O_ONE_LDS", OPT_ONE_LDS, lambda v: int(v)),
-)
-for _name, _opt, _conv in _ENV_OPTIONS:
-    if os.environ.get(_name):
-        _options[_opt] = int(_conv(os.environ[_name]))
+# The library never reads the environment; this binding applies two variables ONCE, when it is imported:
+#   L2O_EXACT_GATES=1          the fmaf-chain-equal fp32 MFMA gate GEMM (an accuracy choice a user may want: DESIGN.md 4)
+#   L2O_OPTIONS=name=v,...     any option by name (pair, one_lds, unroll_cu, mlp_hier, ...): the A/B scripts' escape hatch.
+# (Until round 5 every option had its own variable -- thirteen of them; tests and callers use set_option / option_scope.)
+OPTION_NAMES = {"pair": OPT_PAIR, "pair_plain_stores": OPT_PAIR_PLAIN_STORES, "unroll_cu": OPT_UNROLL_CU,
+                "fg_two_pass": OPT_FG_TWO_PASS, "mlp_generic": OPT_MLP_GENERIC, "bwd_blocks": OPT_BWD_BLOCKS,
+                "bwd_kernel": OPT_BWD_KERNEL, "mlp_unroll": OPT_MLP_UNROLL, "exact_gates": OPT_EXACT_GATES,
+                "mlp_hier": OPT_MLP_HIER, "one_lds": OPT_ONE_LDS}
+if os.environ.get("L2O_EXACT_GATES"):
+    _options[OPT_EXACT_GATES] = 1
+for _item in filter(None, os.environ.get("L2O_OPTIONS", "").split(",")):
+    _name, _, _val = _item.partition("=")
+    if _name.strip() not in OPTION_NAMES:
+        raise ValueError("L2O_OPTIONS: unknown option %r (known: %s)" % (_name, ", ".join(sorted(OPTION_NAMES))))
+    _options[OPTION_NAMES[_name.strip()]] = int(_val)
 
 
 def set_option(opt, value):
@@ -152,6 +149,13 @@ class Mlp(C.Structure):
 
 class MlpHist(C.Structure):            # l2o_mlp_hist: per variable (w1, b1, w2, b2) history of l2o_mlp_unroll_record
     _fields_ = [("st", C.c_void_p * 4), ("g", C.c_void_p * 4), ("m", C.c_void_p * 4), ("v", C.c_void_p * 4)]
+
+
+class MlpDeep(C.Structure):
+    """struct l2o_mlp_deep"""
+    _fields_ = [("n_in", C.c_int32), ("n_out", C.c_int32), ("batch", C.c_int32), ("activation", C.c_int32),
+                ("n_data", C.c_int32), ("n_hidden_layers", C.c_int32), ("hidden", C.c_int32 * 3), ("reserved", C.c_int32),
+                ("images", C.c_void_p), ("labels", C.c_void_p)]
 
 
 class MlpInstance(C.Structure):        # l2o_mlp_instance: one replica of l2o_mlp_unroll_multi
@@ -305,6 +309,10 @@ def lib():
     L.l2o_mlp_unroll_record.restype = C.c_int
     L.l2o_mlp_unroll_record.argtypes = [C.POINTER(NetCfg), vp, C.POINTER(Mlp), vp, vp, vp, vp, vp, vp, i32, i32, vp,
                                         C.POINTER(MlpHist), vp, vp]
+    L.l2o_mlp_deep_scratch_floats.restype = C.c_size_t
+    L.l2o_mlp_deep_scratch_floats.argtypes = [C.POINTER(MlpDeep)]
+    L.l2o_mlp_deep_fg.restype = C.c_int
+    L.l2o_mlp_deep_fg.argtypes = [C.POINTER(MlpDeep), vp, vp, vp, vp, vp, vp]
     L.l2o_mlp_unroll_multi_supported.restype = C.c_int
     L.l2o_mlp_unroll_multi_supported.argtypes = [C.POINTER(NetCfg), C.POINTER(Mlp), i32, vp]
     L.l2o_mlp_unroll_multi_workspace_bytes.restype = C.c_size_t

@@ -81,6 +81,18 @@ class MlpDesc:
     labels: torch.Tensor      # [n_data] int32
 
 
+@dataclasses.dataclass
+class MlpDeepDesc:
+    """Device-side view of problems.mnist with several hidden layers (struct l2o_mlp_deep)."""
+    n_in: int
+    hidden: tuple
+    n_out: int
+    batch: int
+    activation: int
+    images: torch.Tensor
+    labels: torch.Tensor
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -281,6 +293,27 @@ class HipEngine(object):
         c.flags = _abi.MLP_GENERIC if _abi.get_option(_abi.OPT_MLP_GENERIC) else 0
         c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
         return c
+
+    def mlp_deep_fg(self, d: MlpDeepDesc, indices, ws, loss, grads):
+        """Loss and gradients of the MLP optimizee with SEVERAL hidden layers on ONE minibatch (l2o_mlp_deep_fg).  ws / grads:
+        lists [w0, b0, w1, b1, ..., wL, bL] of device tensors (grads may be None: forward only)."""
+        c = _abi.MlpDeep()
+        c.n_in, c.n_out, c.batch, c.activation = d.n_in, d.n_out, d.batch, d.activation
+        c.n_data, c.n_hidden_layers = int(d.images.shape[0]), len(d.hidden)
+        for k, h in enumerate(d.hidden):
+            c.hidden[k] = int(h)
+        c.images, c.labels = C.c_void_p(d.images.data_ptr()), C.c_void_p(d.labels.data_ptr())
+        n = int(self.lib.l2o_mlp_deep_scratch_floats(C.byref(c)))
+        if not n:
+            raise _abi.L2OUnsupported(_abi.L2O_ERR_UNSUPPORTED, "l2o_mlp_deep_fg: unsupported MLP shape %r" % (d.hidden,))
+        scr = self.__dict__.get("_mlp_deep_scratch")
+        if scr is None or scr.numel() < n:
+            scr = self._mlp_deep_scratch = self.empty(n)
+        nptr = len(ws)
+        wa = (C.c_void_p * nptr)(*[t.data_ptr() for t in ws])
+        ga = None if grads is None else (C.c_void_p * nptr)(*[t.data_ptr() for t in grads])
+        _abi.check(self.lib.l2o_mlp_deep_fg(C.byref(c), C.c_void_p(indices.data_ptr()), wa, _ptr(loss), ga, _ptr(scr),
+                                            self._stream()))
 
     def mlp_unroll_supported(self, spec: NetSpec, d: MlpDesc):
         """A fused persistent unroll exists for this (net, MLP optimizee) pair on this device (l2o_mlp_unroll)."""

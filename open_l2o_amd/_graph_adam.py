@@ -36,7 +36,7 @@ class AdamMixin(object):
         # reads them in place through a static index map -- no slicing copies, no concatenation, no zero fills
         srcs = [getattr(acc.get(names[k]), "src", None) for k in offs]
         if (hasattr(eng, "adam_step_gather") and all(sr is not None for sr in srcs)
-                and all(sr[0] is srcs[0][0] for sr in srcs) and not os.environ.get("L2O_NO_ADAM_GATHER")):
+                and all(sr[0] is srcs[0][0] for sr in srcs)):
             G, KB = srcs[0][0], srcs[0][1]
             mkey = (KB, tuple((k, o, tuple(shp), srcs[i][2], srcs[i][3]) for i, (k, (o, shp)) in enumerate(offs.items())))
             gmap = ent.get("gmap")

@@ -155,7 +155,7 @@ class BpttMixin(object):
         # the T-step launch takes ANY D (per-problem tiles with a ragged last one, the forward's packed-state layout);
         # the step-granular multi-panel kernel needs tile-aligned panels
         fused = (len(panels) <= 8 and not second and wdev.get("wpack") is not None
-                 and not os.environ.get("L2O_BWD_STEPWISE") and hasattr(eng, "bwd_unroll")
+                 and hasattr(eng, "bwd_unroll")
                  and (multi or (getattr(eng, "bwd_unroll_any_d", False) and not os.environ.get("L2O_BWD_ALIGNED_ONLY")))
                  and _abi.get_option(_abi.OPT_BWD_KERNEL) == 0)                                   # A/B switches of the tests
         groups = [panels] if (multi or fused) else [[pn] for pn in panels]
@@ -172,8 +172,7 @@ class BpttMixin(object):
             ragged = any(n % 16 for n in Ns)
             # (round 5) the A rows without their duplicated h1(t-1) / h2(t-1) columns: 17 % fewer bytes out of the BPTT kernel
             # and into the contraction (l2o_cwlstm_bwd_unroll_compact / l2o_cwlstm_wgrad_compact; bf16 contraction only)
-            compact = (fused and getattr(eng, "bwd_unroll_compact", False) and not _abi.get_option(_abi.OPT_EXACT_GATES)
-                       and not os.environ.get("L2O_BWD_FULL_ROWS"))
+            compact = fused and getattr(eng, "bwd_unroll_compact", False) and not _abi.get_option(_abi.OPT_EXACT_GATES)
             if fused:                                       # all T steps in one launch, the carries in registers;
                 A = eng.empty(T + 1, R, KA - 2 * H) if compact else eng.empty(T, R, KA)
                 Bm = eng.empty(T, R, KB)                    # the kernel writes every row (padding rows as zeros)

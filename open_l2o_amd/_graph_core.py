@@ -92,12 +92,10 @@ class Variable(object):
         Random initializers are drawn ON THE DEVICE when the engine can (HipEngine.sample: a torch generator seeded from
         the stream of set_random_seed): the host draw + upload of config 2's 128 x 128 x 128 matrix batch was 4 ms per
         reset, twice the five 20-step training unrolls of an epoch.  Every rank draws the GLOBAL array from the same
-        seed and keeps its shard (the ranks together hold the problem batch a single process would).
-        L2O_HOST_SAMPLING=1: the NumPy draw."""
+        seed and keeps its shard (the ranks together hold the problem batch a single process would)."""
         eng = self._graph.engine
         init = self.decl.initializer
-        if (init is not None and init[0] in ("normal", "uniform") and hasattr(eng, "sample")
-                and not os.environ.get("L2O_HOST_SAMPLING")):
+        if init is not None and init[0] in ("normal", "uniform") and hasattr(eng, "sample"):
             seed = int(rng().integers(0, 2 ** 62))
             t = eng.sample(init[0], tuple(self.shape), float(init[1]), float(init[2]), seed)
             if self.sharded:

@@ -27,7 +27,7 @@ class StepPlanMixin(object):
         term = self.terms[0]
         d = self._mlp_desc(term)
         sampler = term.hyper.get("sampler")
-        if sampler is None and hasattr(eng, "sample_int") and not os.environ.get("L2O_HOST_SAMPLING"):
+        if sampler is None and hasattr(eng, "sample_int"):
             idx = eng.empty_int(n, L + 1, d.batch)           # drawn on the device, like _draw_minibatches (one call)
             eng.sample_int(idx, d.images.shape[0], int(rng().integers(0, 2 ** 62)))
         else:
@@ -172,7 +172,7 @@ class StepPlanMixin(object):
         indices -- a device op there): indices [T+1, batch] in a PERSISTENT device buffer (so that a captured launch
         sequence sees the new indices).  Drawn ON THE DEVICE when the engine can (HipEngine.sample_int: a torch
         generator seeded from the stream of set_random_seed -- no host draw, no pageable upload that waits for the
-        previous unroll); a `sampler` of the problem (parity tests) or L2O_HOST_SAMPLING=1: the host draw + upload."""
+        previous unroll); a `sampler` of the problem (parity tests): the host draw + upload."""
         bufs = self.__dict__.setdefault("_mlp_idx", {})
         eng = self.engine
         if self.__dict__.get("_reuse_minibatches") and bufs:
@@ -183,7 +183,7 @@ class StepPlanMixin(object):
             d = self._mlp_desc(term)
             sampler = term.hyper.get("sampler")
             shape = (T + 1, d.batch)
-            if sampler is None and hasattr(eng, "sample_int") and not os.environ.get("L2O_HOST_SAMPLING"):
+            if sampler is None and hasattr(eng, "sample_int"):
                 if k not in bufs or tuple(bufs[k].shape) != shape:
                     bufs[k] = eng.empty_int(*shape)
                 eng.sample_int(bufs[k], d.images.shape[0], int(rng().integers(0, 2 ** 62)))
@@ -202,15 +202,17 @@ class StepPlanMixin(object):
         """Device copy of the dataset of a problems.mnist term (uploaded once)."""
         cache = self.__dict__.setdefault("_mlp_cache", {})
         key = id(term.hyper["images"])
+        layers = tuple(term.hyper.get("layers") or (term.var[0].shape[1],))
+        key = (key, layers)
         if key not in cache:
-            from ._engine import MlpDesc
+            from ._engine import MlpDeepDesc, MlpDesc
             images = np.ascontiguousarray(term.hyper["images"], np.float32).reshape(len(term.hyper["labels"]), -1)
-            w1 = term.var[0]
-            cache[key] = MlpDesc(n_in=images.shape[1], n_hidden=w1.shape[1], n_out=term.var[2].shape[1],
-                                 batch=int(term.hyper["batch_size"]),
-                                 activation=0 if term.hyper["activation"] == "sigmoid" else 1,
-                                 images=self.engine.tensor(images),
-                                 labels=self.engine.int_tensor(term.hyper["labels"]))
+            common = dict(batch=int(term.hyper["batch_size"]), activation=0 if term.hyper["activation"] == "sigmoid" else 1,
+                          images=self.engine.tensor(images), labels=self.engine.int_tensor(term.hyper["labels"]))
+            if len(layers) == 1:
+                cache[key] = MlpDesc(n_in=images.shape[1], n_hidden=term.var[0].shape[1], n_out=term.var[2].shape[1], **common)
+            else:                                           # "mnist_deeper": the step-granular kernels (l2o_mlp_deep_fg)
+                cache[key] = MlpDeepDesc(n_in=images.shape[1], hidden=layers, n_out=term.var[-1].shape[0], **common)
         return cache[key]
 
     def _run_steps(self, T, step0, descs, panels, slots, states, ms, vs, fx, record=None):
@@ -245,8 +247,12 @@ class StepPlanMixin(object):
                     xin = [panels[j] if sc[j] is None else
                            torch.mul(panels[j], sc[j], out=self._scratch("xs%d" % j, panels[j].numel()).view(panels[j].shape))
                            for j in js]
-                    eng.mlp_fg(self._mlp_desc(term), mlp_idx[k][t], *xin, out,
-                               [grads[j] for j in js] if want_grad else None)
+                    if len(js) == 4:
+                        eng.mlp_fg(self._mlp_desc(term), mlp_idx[k][t], *xin, out,
+                                   [grads[j] for j in js] if want_grad else None)
+                    else:                                   # several hidden layers
+                        eng.mlp_deep_fg(self._mlp_desc(term), mlp_idx[k][t], xin, out,
+                                        [grads[j] for j in js] if want_grad else None)
                     if want_grad:
                         for j in js:
                             if sc[j] is not None:
@@ -342,7 +348,7 @@ class StepPlanMixin(object):
             return False
         if len(self.terms) != 1 or self.terms[0].kind != _abi.PROB_MLP or self.terms[0].weight != 1.0:
             return False
-        if len(_term_vars(self.terms[0])) != nvar:
+        if len(_term_vars(self.terms[0])) != nvar or nvar != 4:    # (the prepared calls are l2o_mlp_fg's: one hidden layer)
             return False
         per_net = collections.Counter()
         for s, st in zip(slots, states):

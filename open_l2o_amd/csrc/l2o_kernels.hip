@@ -860,6 +860,7 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 
 #include "l2o_mlp_unroll.h"
 #include "l2o_mlp_xcd.h"
+#include "l2o_mlp_deep.h"
 
 #include "l2o_generic.h"
 
@@ -1994,6 +1995,49 @@ int l2o_mlp_unroll_record(const l2o_net_cfg* cfg, const float* wpack, const l2o_
                           void* workspace, void* stream) {
   if (!hist) return fail(L2O_ERR_ARG, "l2o_mlp_unroll_record: NULL hist");
   return mlp_unroll_launch(cfg, wpack, mlp, indices, x, st, m, v, x_scale, T, step0, fx, hist, workspace, stream);
+}
+
+// ---- problems.mnist with several hidden layers (csrc/l2o_mlp_deep.h) ---------------------------------------------------
+static bool mlp_deep_ok(const l2o_mlp_deep* m) {
+  if (!m || m->n_hidden_layers < 1 || m->n_hidden_layers > kMdMaxHidden || m->n_in < 1 || m->n_in > kMdMaxIn) return false;
+  if (m->n_out < 1 || m->n_out > kMdMaxOut || m->batch < 1 || m->batch > 4096) return false;
+  for (int l = 0; l < m->n_hidden_layers; ++l)
+    if (m->hidden[l] < 1 || m->hidden[l] > kMdMaxWidth) return false;
+  return true;
+}
+size_t l2o_mlp_deep_scratch_floats(const l2o_mlp_deep* m) {
+  if (!mlp_deep_ok(m)) return 0;
+  return (size_t)m->batch * kMdMaxWidth * (2 * m->n_hidden_layers + 1) + m->batch;
+}
+int l2o_mlp_deep_fg(const l2o_mlp_deep* m, const int32_t* indices, const float* const* w, float* loss, float* const* g,
+                    float* scratch, void* stream) {
+  if (!mlp_deep_ok(m))
+    return fail(L2O_ERR_UNSUPPORTED, "l2o_mlp_deep_fg: 1-3 hidden layers of <= 32 units, n_in <= 1024, n_out <= 16, batch <= 4096");
+  if (!indices || !w || !loss || !scratch || !m->images || !m->labels) return fail(L2O_ERR_ARG, "l2o_mlp_deep_fg: NULL argument");
+  MlpDeepArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n_in = m->n_in; a.n_out = m->n_out; a.batch = m->batch; a.act = m->activation; a.nh = m->n_hidden_layers;
+  for (int l = 0; l < a.nh; ++l) a.width[l] = m->hidden[l];
+  a.width[a.nh] = m->n_out;
+  a.images = m->images; a.labels = m->labels; a.idx = indices;
+  long ncoord = 0;
+  for (int l = 0; l <= a.nh; ++l) {
+    if (!w[2 * l] || !w[2 * l + 1] || (g && (!g[2 * l] || !g[2 * l + 1]))) return fail(L2O_ERR_ARG, "l2o_mlp_deep_fg: NULL buffer of layer %d", l);
+    a.w[l] = w[2 * l]; a.b[l] = w[2 * l + 1];
+    if (g) { a.gw[l] = g[2 * l]; a.gb[l] = g[2 * l + 1]; }
+    ncoord += (long)(l == 0 ? a.n_in : a.width[l - 1]) * a.width[l] + a.width[l];
+  }
+  a.acts = scratch;
+  a.deltas = a.acts + (size_t)a.nh * a.batch * kMdMaxWidth;
+  a.loss_s = a.deltas + (size_t)(a.nh + 1) * a.batch * kMdMaxWidth;
+  a.loss = loss;
+  a.want_grad = g ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mlp_deep_sample, dim3(a.batch), dim3(kMdThreads), 0, s, a);
+  const long nthreads = g ? ncoord : 1;
+  hipLaunchKernelGGL(k_mlp_deep_grad, dim3((unsigned)((nthreads + kMdThreads - 1) / kMdThreads)), dim3(kMdThreads), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return L2O_OK;
 }
 
 // ---- one optimizee instance per XCD (csrc/l2o_mlp_xcd.h) ------------------------------------------------------------

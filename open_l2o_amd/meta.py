@@ -595,8 +595,9 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
     # matters: the two-CU unroll needs every CU of the device at once, so a collective kernel running beside it on RCCL's
     # stream holds back the NEXT unroll's launch until it has finished -- measured with a world-size-1 RCCL group, one
     # all-reduce per unroll cost 11.8 us of a 188 us unroll (6.84 -> 6.43 G on config 4's shard of 8); a real 8-rank ring is
-    # slower than that.  One collective per FX_RING - 1 unrolls makes the cost vanish from a run that does not read the losses.
-    FX_RING = 16
+    # slower than that.  With one collective per 15 unrolls the same measurement still showed 6.8 us per unroll (a collective
+    # costs the device ~100 us of hiccup whatever its size), hence a ring of 64: one collective per 63 unread unrolls.
+    FX_RING = 64
 
     def _claim_fx(self, ring, i):
         """Buffer i is about to be overwritten: its pending / in-flight reduction must have gone out and finished."""

@@ -295,14 +295,16 @@ def _load_mnist(mode):
 def mnist(layers, activation="sigmoid", batch_size=128, mode="train", data=None, sampler=None):
     """Mnist classification with a multi-layer perceptron.  DM/problems.py:254-288.
 
-    One hidden layer is implemented (``layers=(20,)``, what util.get_config("mnist") uses).
+    ``layers=(20,)`` (util.get_config("mnist")) has the fused persistent unrolls; more hidden layers (``(20, 20)``:
+    "mnist_deeper", DM/util.py:157-163; up to three of <= 32 units) run on the step-granular kernels (l2o_mlp_deep_fg).
     ``data`` / ``sampler(n_evals, batch, n_data) -> indices`` are ours (offline / parity tests);
     by default every evaluation draws a fresh uniform minibatch like the reference (:282-284)."""
     if activation not in ("sigmoid", "relu"):
         raise ValueError("{} activation not supported".format(activation))
     layers = tuple(layers)
-    if len(layers) != 1:
-        raise NotImplementedError("problems.mnist is implemented for one hidden layer (got layers=%r)" % (layers,))
+    if not 1 <= len(layers) <= 3 or any(not 1 <= int(h) <= 32 for h in layers):
+        raise NotImplementedError("problems.mnist is implemented for one to three hidden layers of at most 32 units "
+                                  "(got layers=%r)" % (layers,))
     if data is None:
         data = _load_mnist(mode)
     images = np.asarray(data["images"], np.float32)
@@ -312,15 +314,16 @@ def mnist(layers, activation="sigmoid", batch_size=128, mode="train", data=None,
     def build():
         _scope.append("mlp")
         try:
-            w1 = get_variable("linear_0/w", [n_in, layers[0]], initializer=_nn_initializers["w"])
-            b1 = get_variable("linear_0/b", [layers[0]], initializer=_nn_initializers["b"])
-            w2 = get_variable("linear_1/w", [layers[0], 10], initializer=_nn_initializers["w"])
-            b2 = get_variable("linear_1/b", [10], initializer=_nn_initializers["b"])
+            widths = [n_in] + [int(h) for h in layers] + [10]       # snt.nets.MLP(list(layers) + [10]), DM/problems.py:275
+            vs = []
+            for l in range(len(widths) - 1):
+                vs.append(get_variable("linear_%d/w" % l, [widths[l], widths[l + 1]], initializer=_nn_initializers["w"]))
+                vs.append(get_variable("linear_%d/b" % l, [widths[l + 1]], initializer=_nn_initializers["b"]))
         finally:
             _scope.pop()
         hyper = {"images": images, "labels": labels, "batch_size": int(batch_size), "activation": activation,
-                 "sampler": sampler}
-        return [Term(_abi.PROB_MLP, (w1, b1, w2, b2), {}, hyper, 1.0)]
+                 "sampler": sampler, "layers": tuple(int(h) for h in layers)}
+        return [Term(_abi.PROB_MLP, tuple(vs), {}, hyper, 1.0)]
 
     return _Build("mnist", build)
 

@@ -187,13 +187,17 @@ def get_config(problem_name, path=None, mode=None, num_hidden_layer=None, net_na
                                                  activation="sigmoid" if problem_name == "mnist" else "relu"))
         net_config = {"cw": get_default_net_config(path)}
         net_assignments = None
-    elif problem_name in ("mnist_deeper", "mnist_conv", "cifar_conv", "lenet", "nas",
+    elif problem_name == "mnist_deeper":                                 # DM/util.py:157-163: two hidden layers of 20
+        if mode is None:
+            mode = "train" if path is None else "test"
+        problem = problems.mnist(**with_defaults(layers=(20, 20), mode=mode, activation="sigmoid"))
+        net_config = {"cw": get_default_net_config(path)}
+        net_assignments = None
+    elif problem_name in ("mnist_conv", "cifar_conv", "lenet", "nas",
                           "vgg16", "cifar-multi", "confocal_microscopy_3d"):
         # neural-network / data-dependent optimizees of DM/util.py:144-230: the net config is
         # reproduced, the problem factory raises (out of the accelerated hot path).
-        if problem_name == "mnist_deeper":
-            problems.mnist(layers=(20, 20), data=problems.synthetic_mnist(8))     # raises: one hidden layer only
-        problem = getattr(problems, {"mnist_deeper": "mnist", "cifar_conv": "cifar10",
+        problem = getattr(problems, {"cifar_conv": "cifar10",
                                      "lenet": "LeNet", "nas": "NAS", "vgg16": "vgg16_cifar10",
                                      "cifar-multi": "cifar10"}.get(problem_name, problem_name))()
         net_config = {"cw": get_default_net_config(path)}

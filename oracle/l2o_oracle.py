@@ -423,10 +423,44 @@ class MnistMLP(_Problem):
 
     def init_vars(self, rng, hidden=20, n_out=10, dtype=np.float32):
         n_in = self.images.shape[1]
+        widths = [n_in] + ([hidden] if np.isscalar(hidden) else list(hidden)) + [n_out]
         return [(rng.standard_normal(shape) * 0.01).astype(dtype)
-                for shape in ((n_in, hidden), (hidden,), (hidden, n_out), (n_out,))]
+                for l in range(len(widths) - 1) for shape in ((widths[l], widths[l + 1]), (widths[l + 1],))]
+
+    def fg_deep(self, variables, indices, want_grad=True):
+        """Any number of hidden layers (snt.nets.MLP(list(layers) + [10]), DM/problems.py:275-276; "mnist_deeper" =
+        layers (20, 20), DM/util.py:157-163): variables = [w0, b0, w1, b1, ..., wL, bL]."""
+        ws, bs = variables[0::2], variables[1::2]
+        dt = ws[0].dtype.type
+        x = self.images[indices].astype(ws[0].dtype)
+        lab = self.labels[indices]
+        acts = [x]
+        for l in range(len(ws) - 1):
+            a = acts[-1] @ ws[l] + bs[l]
+            acts.append(sigmoid(a) if self.activation == "sigmoid" else np.maximum(a, dt(0)))
+        z = acts[-1] @ ws[-1] + bs[-1]
+        zmax = z.max(axis=1, keepdims=True)
+        lse = zmax[:, 0] + np.log(np.sum(np.exp(z - zmax), axis=1))
+        n = np.arange(len(indices))
+        loss = np.sum(lse - z[n, lab]) / dt(len(indices))
+        if not want_grad:
+            return loss, None
+        d = np.exp(z - lse[:, None])
+        d[n, lab] -= dt(1)
+        d = d / dt(len(indices))
+        grads = [None] * len(variables)
+        for l in range(len(ws) - 1, -1, -1):
+            grads[2 * l] = acts[l].T @ d
+            grads[2 * l + 1] = d.sum(axis=0)
+            if l > 0:
+                h = acts[l]
+                d = d @ ws[l].T
+                d = d * h * (dt(1) - h) if self.activation == "sigmoid" else d * (h > 0)
+        return loss, grads
 
     def fg(self, variables, indices, want_grad=True):
+        if len(variables) != 4:
+            return self.fg_deep(variables, indices, want_grad)
         w1, b1, w2, b2 = variables
         dt = w1.dtype.type
         x = self.images[indices].astype(w1.dtype)

@@ -31,14 +31,14 @@ libs() { ls build/var/lib_*.so 2>/dev/null; }
 case $NAME in
   large_shard_forms)
     for rep in 1 2; do
-      for f in 0 2; do export L2O_ONE_LDS=$f
+      for f in 0 2; do export L2O_OPTIONS=one_lds=$f
         run "ONE_LDS=$f" --config 4 --steps 6; run "ONE_LDS=$f" --batch 256 --steps 10
         run "ONE_LDS=$f" --batch 512 --steps 6 --unrolls-per-step 8; run "ONE_LDS=$f" --batch 1024 --steps 4 --unrolls-per-step 4
       done
-      L2O_ONE_LDS=0 run "ONE_LDS=0" --batch 128 --steps 10
+      L2O_OPTIONS=one_lds=0 run "ONE_LDS=0" --batch 128 --steps 10
     done ;;
   rnnprop_large)
-    for rep in 1 2; do for f in 0 1; do export L2O_ONE_LDS=$f
+    for rep in 1 2; do for f in 0 1; do export L2O_OPTIONS=one_lds=$f
       run "ONE_LDS=$f" --net rnnprop --untrained --batch 256 --steps 10
       run "ONE_LDS=$f" --net rnnprop --untrained --batch 1024 --steps 4 --unrolls-per-step 4
       run "ONE_LDS=$f" --net rnnprop --untrained --problem rastrigin --dims 100 --batch 1024 --steps 4 --unrolls-per-step 4
@@ -48,30 +48,30 @@ case $NAME in
       run "$(basename $v .so)" --batch 256 --steps 10; run "$(basename $v .so)" --config 4 --steps 6
     done; done ;;
   ablate_lds)
-    export L2O_ONE_LDS=2
+    export L2O_OPTIONS=one_lds=2
     for v in $(libs); do export L2O_HIP_LIB=$PWD/$v; l=$(basename $v .so)
       run "$l" --batch 256 --steps 10
       case $l in *anynw*) for d in 64 80 96 112; do run "$l" --batch 256 --dims $d --steps 10; done ;; esac
     done ;;
   pk)
-    for rep in 1 2; do for v in $(libs); do export L2O_HIP_LIB=$PWD/$v; l=$(basename $v .so); unset L2O_ONE_LDS
+    for rep in 1 2; do for v in $(libs); do export L2O_HIP_LIB=$PWD/$v; l=$(basename $v .so); unset L2O_OPTIONS
       run "$l" --steps 20; run "$l" --config 4 --steps 6; run "$l" --batch 256 --steps 10
     done; done ;;
   cu_forms)
-    for rep in 1 2; do for f in 2 3 4; do L2O_UNROLL_CU=$f run "UNROLL_CU=$f" --config 3 --steps 4; done; done
-    for f in 2 3; do export L2O_UNROLL_CU=$f
+    for rep in 1 2; do for f in 2 3 4; do L2O_OPTIONS=unroll_cu=$f run "UNROLL_CU=$f" --config 3 --steps 4; done; done
+    for f in 2 3; do export L2O_OPTIONS=unroll_cu=$f
       run "UNROLL_CU=$f" --problem lasso --net dm --untrained --dims 512 --rows 256 --batch 256 --unroll 100 --steps 4
       run "UNROLL_CU=$f" --problem lasso --net rnnprop --untrained --dims 256 --rows 128 --batch 256 --unroll 100 --steps 4
     done ;;
   cu8_ring)
     for rep in 1 2; do
       for v in $(libs); do export L2O_HIP_LIB=$PWD/$v
-        for f in 3 4; do L2O_UNROLL_CU=$f run "$(basename $v .so) UNROLL_CU=$f" --config 3 --steps 4; done
+        for f in 3 4; do L2O_OPTIONS=unroll_cu=$f run "$(basename $v .so) UNROLL_CU=$f" --config 3 --steps 4; done
       done
-      L2O_UNROLL_CU=2 run "four-wave" --config 3 --steps 4
+      L2O_OPTIONS=unroll_cu=2 run "four-wave" --config 3 --steps 4
     done ;;
   cu_fourwave)
-    export L2O_UNROLL_CU=2
+    export L2O_OPTIONS=unroll_cu=2
     for v in $(libs); do for rep in 1 2; do L2O_HIP_LIB=$PWD/$v run "$(basename $v .so) four-wave" --config 3 --steps 4; done; done ;;
   c3_libs)
     for rep in 1 2; do for v in $(libs); do L2O_HIP_LIB=$PWD/$v run "$(basename $v .so)" --config 3 --steps 4; done; done ;;
@@ -82,14 +82,14 @@ case $NAME in
     done; done ;;
   onecu_vs_pair)
     for rep in 1 2; do
-      L2O_ONE_LDS=0 run "c4 pair-chunks" --config 4 --steps 10; run "c4 default" --config 4 --steps 10
-      L2O_ONE_LDS=0 run "B=256 pair-chunks" --batch 256 --steps 10; run "B=256 default" --batch 256 --steps 10
-      L2O_NO_PAIR=1 run "B=128 no two-CU form" --steps 10; L2O_ONE_LDS=2 run "B=128 k_unroll_lds" --steps 10
+      L2O_OPTIONS=one_lds=0 run "c4 pair-chunks" --config 4 --steps 10; run "c4 default" --config 4 --steps 10
+      L2O_OPTIONS=one_lds=0 run "B=256 pair-chunks" --batch 256 --steps 10; run "B=256 default" --batch 256 --steps 10
+      L2O_OPTIONS=pair=0 run "B=128 no two-CU form" --steps 10; L2O_OPTIONS=one_lds=2 run "B=128 k_unroll_lds" --steps 10
     done ;;
   c5_hier)
     for rep in 1 2; do
-      unset L2O_HIP_LIB L2O_NO_MLP_HIER; run "in-tree hier=on" --config 5 --steps 5
-      L2O_NO_MLP_HIER=1 run "in-tree hier=off (runtime)" --config 5 --steps 5
+      unset L2O_HIP_LIB L2O_OPTIONS; run "in-tree hier=on" --config 5 --steps 5
+      L2O_OPTIONS=mlp_hier=0 run "in-tree hier=off (runtime)" --config 5 --steps 5
       for v in $(libs); do L2O_HIP_LIB=$PWD/$v run "$(basename $v .so)" --config 5 --steps 5; done
     done ;;
   *) echo "unknown A/B $NAME"; exit 2 ;;

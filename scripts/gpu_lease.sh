@@ -14,7 +14,7 @@
 #   final:CFG[:ARGS]         bench + trace + counters of ONE config back to back in this lease (same build, same box):
 #                            what the roofline block of the round's bench line is recomputed from
 #   train:NAME[:SECONDS]     meta-train one committed optimizer (NAME = c2|c3|c4|c5) -> trained/<dir>/
-#   env:VAR=VALUE            export VAR=VALUE for the jobs that follow (env:VAR= unsets it), e.g. env:L2O_ONE_LDS=2 tests:-k+fused
+#   env:VAR=VALUE            export VAR=VALUE for the jobs that follow (env:VAR= unsets it), e.g. env:L2O_OPTIONS=one_lds=2 tests:-k+fused
 #   bench2ranks              the N > 1 bench path as two gloo ranks on this one device
 #   py:SCRIPT[:ARGS]         python SCRIPT ARGS  > SCRIPT-basename.txt
 #   sh:COMMAND               bash -c COMMAND      > sh_N.txt   ('+' separates words, as above)

@@ -33,8 +33,8 @@ if __name__ == "__main__":
         one(*a)
     else:
         print("B=%d D=%d T=%d, %d unrolls per epoch, %d epochs" % tuple(a))
-        for label, env in (("default", {}), ("host sampling (L2O_HOST_SAMPLING=1)", {"L2O_HOST_SAMPLING": "1"}),
+        for label, env in (("default", {}), 
                            ("one sync per unroll (L2O_NO_DEFER=1)", {"L2O_NO_DEFER": "1"}),
-                           ("both off", {"L2O_HOST_SAMPLING": "1", "L2O_NO_DEFER": "1"})):
+                           ("one sync per unroll, again", {"L2O_NO_DEFER": "1"})):
             e = dict(os.environ, L2O_LABEL=label, **env)
             subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(v) for v in a], env=e, check=False)

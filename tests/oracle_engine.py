@@ -272,6 +272,19 @@ class OracleEngine(object):
             for t, a in zip(grads, g):
                 t.copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)).view_as(t))
 
+    def mlp_deep_fg(self, d, indices, ws, loss, grads):
+        self.calls.append("mlp_deep_fg")
+        prob = O.MnistMLP(d.images.numpy(), d.labels.numpy(), "sigmoid" if d.activation == 0 else "relu")
+        widths = [d.n_in] + list(d.hidden) + [d.n_out]
+        variables = []
+        for l in range(len(widths) - 1):
+            variables += [ws[2 * l].numpy().reshape(widths[l], widths[l + 1]), ws[2 * l + 1].numpy().reshape(-1)]
+        f, g = prob.fg_deep(variables, indices.numpy(), want_grad=grads is not None)
+        loss.copy_(torch.from_numpy(np.array([f], np.float32)))
+        if grads is not None:
+            for t, a in zip(grads, g):
+                t.copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)).view_as(t))
+
     def lstm_step_multi(self, spec, wpack, segs, pow1, pow2):
         for seg in segs:
             g, m, v, st, x, B, D = seg[:7]

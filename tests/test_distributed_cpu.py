@@ -403,7 +403,7 @@ def _launch_many_worker(rank, world, port, n_launch, q):
 
 
 def test_two_rank_loss_all_reduce_is_deferred_and_coalesced():
-    n_launch = 40
+    n_launch = 150
     ref, _, _ = _launch_many(n_launch, False)                          # single process, the global batch
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -421,9 +421,9 @@ def test_two_rank_loss_all_reduce_is_deferred_and_coalesced():
     for rank in (0, 1):
         fx, calls, ring = results[rank]
         np.testing.assert_allclose(fx, ref, rtol=2e-6)
-        assert ring == 16
-        # 40 unrolls nobody read: a collective when the ring is about to wrap (every 15 launches; a wrapping run is two
-        # contiguous pieces) + the one wait_fx() issues -- not 40
+        assert ring == 64
+        # 150 unrolls nobody read: a collective when the ring is about to wrap (every 63 launches; a wrapping run is two
+        # contiguous pieces) + the one wait_fx() issues -- not 150
         assert len(calls) <= 6, calls
         assert sum(calls) == n_launch * 4, calls                       # every unroll's T + 1 = 4 losses reduced exactly once
     assert results[0][0] == results[1][0]

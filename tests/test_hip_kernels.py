@@ -131,6 +131,14 @@ def test_problem_fg(eng, kind, B, D, M):
     fx = eng.zeros(1)
     eng.reduce_fx(f, 1, B, Bg, fx)
     assert rel_err(eng.to_numpy(fx)[0], prob.f(xin)) < 1e-5
+    # L2O_OPT_FG_TWO_PASS (l2o_problem.flags): the two-pass form of the same entry point (what a matrix SHARED by the batch
+    # takes by default) gives the same numbers as the single pass
+    from open_l2o_amd import _abi
+    with lib_option(_abi.OPT_FG_TWO_PASS, 1):
+        pd2 = device_problem(eng, arrays, B, D, B_global=Bg, x_scale=xs)
+        f2, g2 = eng.zeros(B), eng.zeros(B, D)
+        eng.problem_fg(pd2, eng.tensor(x2), f2, g2)
+    assert rel_err(eng.to_numpy(f2), f_ref) < 2e-5 and max_abs(eng.to_numpy(g2), g_ref) / np.abs(g_ref).max() < 5e-6
 
 
 @pytest.mark.parametrize("name", ["dm_logsign", "rnnprop"])
@@ -532,8 +540,17 @@ def test_c3_lasso_rnnprop_full_size(eng):
 
 
 @pytest.mark.parametrize("activation,batch", [("sigmoid", 128), ("relu", 100), ("sigmoid", 7)])
-def test_mlp_fg_kernel(eng, activation, batch):
-    """l2o_mlp_fg (problems.mnist forward + gradient) against the oracle."""
+@pytest.mark.parametrize("generic", [0, 1])
+def test_mlp_fg_kernel(eng, activation, batch, generic):
+    """l2o_mlp_fg (problems.mnist forward + gradient) against the oracle: the wave-per-sample kernels for hidden width 20
+    and (L2O_OPT_MLP_GENERIC = 1 / l2o_mlp.flags) the generic ones that serve every other shape."""
+    from open_l2o_amd._engine import MlpDesc
+    from open_l2o_amd import _abi
+    with lib_option(_abi.OPT_MLP_GENERIC, generic):
+        _mlp_fg_kernel(eng, activation, batch)
+
+
+def _mlp_fg_kernel(eng, activation, batch):
     from open_l2o_amd._engine import MlpDesc
     rng = np.random.default_rng(80)
     n_data, n_in, H, Oo = 500, 784, 20, 10
@@ -553,6 +570,36 @@ def test_mlp_fg_kernel(eng, activation, batch):
         assert max_abs(eng.to_numpy(g), gr) < 5e-6 * max(1.0, float(np.abs(gr).max()))
     loss2 = eng.zeros(1)
     eng.mlp_fg(d, eng.int_tensor(idx), *dv, loss2, None)            # forward only
+    assert eng.to_numpy(loss2)[0] == eng.to_numpy(loss)[0]
+
+
+@pytest.mark.parametrize("hidden,activation,batch", [((20, 20), "sigmoid", 128), ((20, 20), "relu", 50), ((32, 8, 20), "sigmoid", 7),
+                                                     ((20,), "sigmoid", 64)])
+def test_mlp_deep_fg_kernel(eng, hidden, activation, batch):
+    """l2o_mlp_deep_fg (problems.mnist with several hidden layers: "mnist_deeper", DM/util.py:157-163) against the oracle."""
+    from open_l2o_amd._engine import MlpDeepDesc
+    rng = np.random.default_rng(84)
+    n_data, n_in, Oo = 400, 784, 10
+    images = rng.random((n_data, n_in)).astype(np.float32)
+    labels = rng.integers(0, Oo, n_data).astype(np.int32)
+    idx = rng.integers(0, n_data, batch).astype(np.int32)
+    ref = O.MnistMLP(images, labels, activation)
+    widths = [n_in] + list(hidden) + [Oo]
+    variables = []
+    for l in range(len(widths) - 1):
+        variables += [(rng.standard_normal((widths[l], widths[l + 1])) * 0.3).astype(np.float32),
+                      (rng.standard_normal(widths[l + 1]) * 0.3).astype(np.float32)]
+    f_ref, g_ref = ref.fg_deep(variables, idx)
+    d = MlpDeepDesc(n_in, tuple(hidden), Oo, batch, 0 if activation == "sigmoid" else 1, eng.tensor(images), eng.int_tensor(labels))
+    dv = [eng.tensor(v) for v in variables]
+    loss = eng.zeros(1)
+    grads = [eng.zeros(*v.shape) for v in variables]
+    eng.mlp_deep_fg(d, eng.int_tensor(idx), dv, loss, grads)
+    assert rel_err(eng.to_numpy(loss)[0], f_ref) < 5e-6
+    for g, gr in zip(grads, g_ref):
+        assert max_abs(eng.to_numpy(g), gr) < 5e-6 * max(1.0, float(np.abs(gr).max()))
+    loss2 = eng.zeros(1)
+    eng.mlp_deep_fg(d, eng.int_tensor(idx), dv, loss2, None)           # forward only
     assert eng.to_numpy(loss2)[0] == eng.to_numpy(loss)[0]
 
 

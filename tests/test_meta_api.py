@@ -266,6 +266,8 @@ def test_get_config_registry():
         util.get_config("mnist")                       # no dataset offline: must be passed / pointed to
     with pytest.raises(NotImplementedError):
         util.get_config("mnist_conv")
+    deeper = util.get_config("mnist_deeper", problem_options={"data": problems.synthetic_mnist(32)})[0]
+    assert [v.shape for v in deeper().variables] == [(784, 20), (20,), (20, 20), (20,), (20, 10), (10,)]
     problem, net_config, _ = util.get_config("mnist", problem_options={"data": problems.synthetic_mnist(32)})
     assert [v.name for v in problem().variables] == ["mlp/linear_0/w", "mlp/linear_0/b", "mlp/linear_1/w",
                                                      "mlp/linear_1/b"]
@@ -444,6 +446,68 @@ def test_mnist_mlp_optimizee(engine, activation):
     assert rel_err(fx2, fx_b[-1]) < 2e-5 and rel_err(loss2, fx_b.sum()) < 2e-5
     for got, want in zip(x2, vb):
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("net", ["dm_logsign", "rnnprop"])
+def test_mnist_deeper_optimizee(engine, net):
+    """util.get_config("mnist_deeper") (DM/util.py:157-163: problems.mnist(layers=(20, 20)), DM/problems.py:254-288) -- the
+    784-20-20-10 MLP, six variables stepped by one shared net, a fresh minibatch per evaluation -- against the oracle's
+    multi-variable unroll over two chained unrolls; and the meta-gradient path runs on it (one training step)."""
+    data = problems.synthetic_mnist(300, seed=3)
+    T, batch = 5, 32
+    idx = np.random.default_rng(72).integers(0, 300, size=(2 * (T + 1), batch))
+    calls = {"n": 0}
+
+    def sampler(n_evals, b, n_data):
+        out = idx[calls["n"]:calls["n"] + n_evals]
+        calls["n"] += n_evals
+        return out
+
+    cfg = O.DM_LOGSIGN if net == "dm_logsign" else O.RNNPROP
+    params = make_params(cfg, seed=73, trained_like=True)
+    meta.set_random_seed(9)
+    problem, default_cfg, na = util.get_config("mnist_deeper", problem_options={"data": data, "batch_size": batch, "sampler": sampler})
+    assert default_cfg["cw"]["net_options"]["preprocess_name"] == "LogAndSign" and na is None
+    feeds = [{}, {}]
+    if cfg.kind == "rnnprop":
+        optimizer = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
+        ml, _, _, step = optimizer.meta_loss(problem, T)
+        feeds = [{step: 1}, {step: 1 + T}]
+    else:
+        optimizer = meta.MetaOptimizer(**_net_config(cfg, params))
+        ml = optimizer.meta_loss(problem, T)
+    with Session() as sess:
+        sess.run(ml.reset)
+        v0 = [v.eval() for v in optimizer.graph.x]
+        assert [a.shape for a in v0] == [(784, 20), (20,), (20, 20), (20,), (20, 10), (10,)]
+        loss1, fx1, _ = sess.run([ml.loss, ml.fx, ml.update], feed_dict=feeds[0])
+        loss2, fx2, x2, _ = sess.run([ml.loss, ml.fx, ml.x, ml.update], feed_dict=feeds[1])
+    assert optimizer.graph.last_path == "steps"
+    ref = O.MnistMLP(data["images"], data["labels"].astype(np.int32), "sigmoid")
+    states = [O.net_initial_state(cfg, a.size) for a in v0]
+    kw = {}
+    if cfg.kind == "rnnprop":
+        fx_a, va, sa, ma, va2 = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[t], wg), cfg, params, v0, states, T,
+                                               return_moments=True)
+        fx_b, vb, _ = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[T + 1 + t], wg), cfg, params, va, sa, T, ms=ma, vs=va2,
+                                     step0=1 + T)
+    else:
+        fx_a, va, sa = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[t], wg), cfg, params, v0, states, T)
+        fx_b, vb, _ = O.unroll_multi(lambda vs, t, wg: ref.fg(vs, idx[T + 1 + t], wg), cfg, params, va, sa, T)
+    assert rel_err(fx1, fx_a[-1]) < 1e-5 and rel_err(loss1, fx_a.sum()) < 1e-5
+    assert rel_err(fx2, fx_b[-1]) < 2e-5 and rel_err(loss2, fx_b.sum()) < 2e-5
+    for got, want in zip(x2, vb):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+    # the training path (recorded step-granular unroll -> BPTT -> Adam) accepts the six-variable optimizee
+    meta.set_random_seed(10)
+    opt2 = meta.MetaOptimizer(**_net_config(O.DM_LOGSIGN, make_params(O.DM_LOGSIGN, seed=73, trained_like=True)))
+    ms = opt2.meta_minimize(util.get_config("mnist_deeper", problem_options={"data": data, "batch_size": batch})[0], 3,
+                            learning_rate=1e-3)
+    with Session() as sess:
+        sess.run(ms.reset)
+        c1 = sess.run([ms.fx, ms.update, ms.step])[0]
+        c2 = sess.run([ms.fx, ms.update, ms.step])[0]
+    assert np.isfinite(c1) and np.isfinite(c2)
 
 
 def test_lasso_fixed_shared_matrix(engine):

@@ -319,8 +319,8 @@ def test_recording_fused_unroll_equals_step_path(engine, name, B, D, monkeypatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["dm", "dm_logsign", "rnnprop"])
 def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
-    """k_cwlstm_bwd_tile (tile-aligned panels, LDS-tiled I/O, four lanes per coordinate) against
-    the generic one-thread-per-coordinate kernel (L2O_BWD_GENERIC=1): same meta-gradient."""
+    """L2O_OPT_BWD_KERNEL: the matrix-core BPTT (0, the default) and k_cwlstm_bwd_tile (1: tile-aligned panels, LDS-tiled
+    I/O, four lanes per coordinate) against the generic one-thread-per-coordinate kernel (2): same meta-gradient."""
     eng = _engine.HipEngine()
     old = _engine._default_engine
     _engine.set_default_engine(eng)
@@ -331,8 +331,8 @@ def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
         B, D, T = 3, 32, 4                                   # D % 16 == 0 -> the tile kernel
         prob, x0, _ = make_problem("quadratic", B, D, seed=82)
         got = {}
-        for mode in ("tile", "generic"):
-            _abi.set_option(_abi.OPT_BWD_KERNEL, 2 if mode == "generic" else 0)
+        for mode in ("mfma", "tile", "generic"):
+            _abi.set_option(_abi.OPT_BWD_KERNEL, {"mfma": 0, "tile": 1, "generic": 2}[mode])
             problem = problems.quadratic(B, D, data={"w": prob.w, "y": prob.y, "x": x0})
             if rn:
                 opt = meta_rnnprop_eval.MetaOptimizer(0.95, 0.95, **_net_config(cfg, params, key="rp"))
@@ -351,7 +351,8 @@ def test_bwd_tile_kernel_equals_generic_kernel(name, monkeypatch):
             got[mode] = cap["grads"]["rp" if rn else "cw"]
         for k, gref in got["generic"].items():
             scale = max(float(np.abs(gref).max()), 1e-12)
-            assert float(np.abs(np.asarray(got["tile"][k]) - np.asarray(gref)).max()) / scale < 1e-4, k
+            for mode in ("mfma", "tile"):
+                assert float(np.abs(np.asarray(got[mode][k]) - np.asarray(gref)).max()) / scale < 1e-4, (mode, k)
     finally:
         _abi.set_option(_abi.OPT_BWD_KERNEL, 0)
         _engine.set_default_engine(old)
