@@ -147,9 +147,10 @@ int l2o_last_unroll_form(void);
 #define L2O_OPT_BWD_BLOCKS 5         /* 0*: BPTT step kernels use one workgroup per CU; n > 0: n workgroups (L2O_OPTW_BWD_BLOCKS) */
 #define L2O_OPT_BWD_KERNEL 6         /* 0*: matrix-core BPTT step (needs wpack); 1: fp32 tile kernel; 2: generic kernel     */
 #define L2O_OPT_MLP_UNROLL 7         /* 1*: l2o_mlp_unroll available to the host layer (0: it reports "unsupported")       */
-/* (option 8 was L2O_OPT_PAIR_NORMAL -- the two-CU unroll on a prepared normal matrix H = W^T W, l2o_unroll_prepare, ABI
- *  v7..v11: 14 % less kernel time on a replayed instance, but a gradient error that no longer shrinks with the residual and
- *  a preparation pass per fresh instance; removed in ABI v12, docs/DESIGN_history_r04.md.  Its field is ignored.) */
+#define L2O_OPT_MLP_XCD_WAVES 8       /* l2o_mlp_unroll_multi (ABI v13): 0*: the form measured faster for the net (RNNProp: four
+                                        waves per member, one per SIMD, eight tiles each stepped two at a time; the DM nets: eight
+                                        waves, two per SIMD, four tiles each); 1: eight waves always; 2: four waves always.
+                                        (Until ABI v11 option 8 was L2O_OPT_PAIR_NORMAL, removed in v12.)                         */
 #define L2O_OPT_EXACT_GATES 9        /* 0*: LSTM gate GEMM as a 3-way bf16 split on v_mfma_f32_16x16x32_bf16 (fp32-level error,
                                         but the matrix pipe TRUNCATES small products inside an 8-slot group: a deterministic
                                         bias that shows as ~1e-5 drift at T = 1000); 1: v_mfma_f32_16x16x4_f32 (bit-equal to

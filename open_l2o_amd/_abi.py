@@ -38,11 +38,11 @@ SYMBOLS = (
 # This binding keeps the caller's side of it: one process-wide dict of non-default values (applied from the L2O_*
 # environment variables once at import, changed by set_option) that NetSpec.to_c() / the problem and MLP descriptors
 # encode into every struct they hand to the library.
-# (id 8 was OPT_PAIR_NORMAL -- the normal-matrix two-CU form, removed with ABI v12)
+# (id 8 was OPT_PAIR_NORMAL until ABI v11; since v13 it is OPT_MLP_XCD_WAVES)
 OPT_PAIR, OPT_PAIR_PLAIN_STORES, OPT_UNROLL_CU, OPT_FG_TWO_PASS, OPT_MLP_GENERIC, OPT_BWD_BLOCKS, OPT_BWD_KERNEL, \
-    OPT_MLP_UNROLL, _OPT_REMOVED_8, OPT_EXACT_GATES, OPT_WPACK_NO_CLEAR, OPT_MLP_HIER, OPT_ONE_LDS = range(13)
+    OPT_MLP_UNROLL, OPT_MLP_XCD_WAVES, OPT_EXACT_GATES, OPT_WPACK_NO_CLEAR, OPT_MLP_HIER, OPT_ONE_LDS = range(13)
 OPT_DEFAULTS = {OPT_PAIR: 1, OPT_PAIR_PLAIN_STORES: 1, OPT_UNROLL_CU: 1, OPT_FG_TWO_PASS: 0, OPT_MLP_GENERIC: 0,
-                OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_EXACT_GATES: 0,
+                OPT_BWD_BLOCKS: 0, OPT_BWD_KERNEL: 0, OPT_MLP_UNROLL: 1, OPT_MLP_XCD_WAVES: 0, OPT_EXACT_GATES: 0,
                 OPT_WPACK_NO_CLEAR: 0, OPT_MLP_HIER: 1, OPT_ONE_LDS: 1}
 # l2o_last_unroll_form(): which kernel a fused launch ran (include/l2o_abi.h L2O_FORM_*)
 FORM_NAMES = {1: "k_unroll", 2: "k_unroll_pair", 5: "k_unroll_lds", 6: "k_unroll_cu", 7: "k_unroll_cu8",
@@ -59,7 +59,7 @@ _options = {}
 OPTION_NAMES = {"pair": OPT_PAIR, "pair_plain_stores": OPT_PAIR_PLAIN_STORES, "unroll_cu": OPT_UNROLL_CU,
                 "fg_two_pass": OPT_FG_TWO_PASS, "mlp_generic": OPT_MLP_GENERIC, "bwd_blocks": OPT_BWD_BLOCKS,
                 "bwd_kernel": OPT_BWD_KERNEL, "mlp_unroll": OPT_MLP_UNROLL, "exact_gates": OPT_EXACT_GATES,
-                "mlp_hier": OPT_MLP_HIER, "one_lds": OPT_ONE_LDS}
+                "mlp_hier": OPT_MLP_HIER, "one_lds": OPT_ONE_LDS, "mlp_xcd_waves": OPT_MLP_XCD_WAVES}
 if os.environ.get("L2O_EXACT_GATES"):
     _options[OPT_EXACT_GATES] = 1
 for _item in filter(None, os.environ.get("L2O_OPTIONS", "").split(",")):

@@ -1002,7 +1002,7 @@ static bool unroll_geom(const l2o_problem* p, UnrollGeom* g) {
 static const int64_t kOptDefault[L2O_OPT_COUNT_] = {
     /* L2O_OPT_PAIR */ 1, /* L2O_OPT_PAIR_PLAIN_STORES */ 1, /* L2O_OPT_UNROLL_CU */ 1,
     /* L2O_OPT_FG_TWO_PASS */ 0, /* L2O_OPT_MLP_GENERIC */ 0, /* L2O_OPT_BWD_BLOCKS */ 0,
-    /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* (8: was L2O_OPT_PAIR_NORMAL, removed in ABI v12) */ 0, /* L2O_OPT_EXACT_GATES */ 0,
+    /* L2O_OPT_BWD_KERNEL */ 0, /* L2O_OPT_MLP_UNROLL */ 1, /* L2O_OPT_MLP_XCD_WAVES */ 0, /* L2O_OPT_EXACT_GATES */ 0,
     /* L2O_OPT_WPACK_NO_CLEAR */ 0, /* L2O_OPT_MLP_HIER */ 1, /* L2O_OPT_ONE_LDS */ 1};
 static thread_local uint64_t t_optw = 0;
 struct OptScope {
@@ -2040,6 +2040,9 @@ int l2o_mlp_deep_fg(const l2o_mlp_deep* m, const int32_t* indices, const float* 
   return L2O_OK;
 }
 
+#ifndef L2O_MLP_XCD_DEFAULT_FOUR
+#define L2O_MLP_XCD_DEFAULT_FOUR 0     // (set from the A/B measurement: profiles/r06_c5_xcd_forms_ab.txt)
+#endif
 // ---- one optimizee instance per XCD (csrc/l2o_mlp_xcd.h) ------------------------------------------------------------
 struct MlpXcdLayout { int n[4], tile_begin[5], nw1; size_t team_off, inst_off, p_bytes, s_bytes, sm_bytes, inst_bytes, total; };
 static bool mlp_xcd_layout(const l2o_mlp* mlp, int n_inst, MlpXcdLayout* L) {
@@ -2115,16 +2118,20 @@ int l2o_mlp_unroll_multi(const l2o_net_cfg* cfg, const float* wpack, const l2o_m
     o.Sm = reinterpret_cast<unsigned long long*>(ib + L.p_bytes + L.s_bytes);
   }
   HIP_TRY(hipMemsetAsync(wsb + L.team_off, 0, L.total - L.team_off, s));   // team counters + granules: the header survives
+  // which form: four waves per member stepping tile PAIRS (a lone wave per SIMD with two independent chains; RNNProp: no
+  // spills at 438 registers) or eight waves stepping single tiles (two waves per SIMD; the DM nets' pair form spills)
+  const int wopt = (int)opt(L2O_OPT_MLP_XCD_WAVES);
+  const bool four = wopt == 2 || (wopt == 0 && rn && L2O_MLP_XCD_DEFAULT_FOUR);
   void (*fn)(MlpXcdArgs) = nullptr;
   size_t lds = 0;
   switch (cfg->preprocess) {
-    case L2O_PRE_IDENTITY: fn = k_mlp_xcd<L2O_PRE_IDENTITY>; lds = mlp_xcd_lds_bytes<L2O_PRE_IDENTITY>(); break;
-    case L2O_PRE_LOGSIGN: fn = k_mlp_xcd<L2O_PRE_LOGSIGN>; lds = mlp_xcd_lds_bytes<L2O_PRE_LOGSIGN>(); break;
-    default: fn = k_mlp_xcd<L2O_PRE_FC_ELU>; lds = mlp_xcd_lds_bytes<L2O_PRE_FC_ELU>();
+    case L2O_PRE_IDENTITY: fn = four ? k_mlp_xcd<L2O_PRE_IDENTITY, 4> : k_mlp_xcd<L2O_PRE_IDENTITY, 8>; lds = mlp_xcd_lds_bytes<L2O_PRE_IDENTITY>(); break;
+    case L2O_PRE_LOGSIGN: fn = four ? k_mlp_xcd<L2O_PRE_LOGSIGN, 4> : k_mlp_xcd<L2O_PRE_LOGSIGN, 8>; lds = mlp_xcd_lds_bytes<L2O_PRE_LOGSIGN>(); break;
+    default: fn = four ? k_mlp_xcd<L2O_PRE_FC_ELU, 4> : k_mlp_xcd<L2O_PRE_FC_ELU, 8>; lds = mlp_xcd_lds_bytes<L2O_PRE_FC_ELU>();
   }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // one workgroup per CU of the whole chip: the 32 that land on XCD j < n_inst form instance j's team, the others exit
-  hipLaunchKernelGGL(fn, dim3(kMxMaxInst * kMxMembers), dim3(kMxThreads), lds, s, a);
+  hipLaunchKernelGGL(fn, dim3(kMxMaxInst * kMxMembers), dim3(four ? kMxThreads4 : kMxThreads), lds, s, a);
   HIP_TRY(hipGetLastError());
   note_form(L2O_FORM_MLP_XCD);
   return L2O_OK;

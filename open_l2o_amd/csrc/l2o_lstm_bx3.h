@@ -530,6 +530,90 @@ __device__ __forceinline__ float tile_step(const NetWB<PRE, PK>& w, TileState& s
   return tile_step_w<PRE, PK, NetWB<PRE, PK>>(w, s, in0, in1, q);
 }
 
+// ---- TWO tiles stepped together on LDS-resident packed fragments (round 6, k_mlp_xcd's four-wave form) -----------------
+// One wave per SIMD issues in order and has nobody to issue from while it waits for a dependent result (an accumulator
+// out of the matrix pipe, an exp ahead of its rcp): 40 % of a lone wave's tile step is such waiting.  Two tiles are two
+// INDEPENDENT dependent chains in one instruction stream; every fragment read (one ds_read_b128) feeds two MFMAs.  Same
+// arithmetic per tile, in the same order per accumulator, as tile_step_w: results are bit-identical.
+template <int PRE, int CH, class W>
+__device__ __forceinline__ void issue2(const W& w, const BOp<true>& ba, const BOp<true>& bb, f32x4 (&acca)[kNT], f32x4 (&accb)[kNT]) {
+  static_assert(W::kLdsFrags, "issue2: the LDS-resident packed fragments");
+  static_for<0, chunk_mfmas(true)>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    constexpr int p = n / kNT, t = n % kNT;
+    const u32x4 fr = w.lfr[((CH * kNT + t) * kPack + p) * 64];
+    acca[t] = mfma_bf(fr, ba.m[p], acca[t]);
+    accb[t] = mfma_bf(fr, bb.m[p], accb[t]);
+  });
+}
+__device__ __forceinline__ float linear_out(const float (&h2)[kNT], const float (&wl)[kNT]) {
+  float d0 = h2[0] * wl[0], d1 = h2[1] * wl[1];
+  d0 = __builtin_fmaf(h2[2], wl[2], d0);
+  d1 = __builtin_fmaf(h2[3], wl[3], d1);
+  d0 = __builtin_fmaf(h2[4], wl[4], d0);
+  return d0 + d1;
+}
+template <int PRE, class W>
+__device__ __forceinline__ void tile_step2_w(const W& w, TileState& sa, TileState& sb, float ina0, float ina1, float inb0,
+                                             float inb1, int q, float& da, float& db) {
+  const unsigned one = bias_one<true>(q);
+  f32x4 a1a[kNT], a2a[kNT], a1b[kNT], a2b[kNT];
+  preload_bias<1, W, false>(w, a2a);
+  preload_bias<1, W, false>(w, a2b);
+  preload_bias<0, W, false>(w, a1a);
+  preload_bias<0, W, false>(w, a1b);
+  {
+    BOp<true> ba, bb;
+    split5<true>(sa.h2, one, ba);
+    split5<true>(sb.h2, one, bb);
+    issue2<PRE, kChL2B>(w, ba, bb, a2a, a2b);
+  }
+  BOp<true> b1a, b1b;
+  split5<true>(sa.h1, one, b1a);
+  split5<true>(sb.h1, one, b1b);
+  issue2<PRE, kChL1H>(w, b1a, b1b, a1a, a1b);
+  if constexpr (PRE == L2O_PRE_FC_ELU) {
+    float fca[kNT], fcb_[kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      fca[t] = eluf_(__builtin_fmaf(w.fcw1[t], ina1, __builtin_fmaf(w.fcw0[t], ina0, w.fcb[t])));
+      fcb_[t] = eluf_(__builtin_fmaf(w.fcw1[t], inb1, __builtin_fmaf(w.fcw0[t], inb0, w.fcb[t])));
+    }
+    BOp<true> bfa, bfb;
+    split5<true>(fca, 0u, bfa);
+    split5<true>(fcb_, 0u, bfb);
+    issue2<PRE, kChL1X>(w, bfa, bfb, a1a, a1b);
+  } else if constexpr (W::kLdsWin) {
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      const f32x4 w0 = w.lwin[t * 64];
+      a1a[t] += w0 * ina0;
+      a1b[t] += w0 * inb0;
+      if (PRE == L2O_PRE_LOGSIGN) {
+        const f32x4 w1 = w.lwin[(kNT + t) * 64];
+        a1a[t] += w1 * ina1;
+        a1b[t] += w1 * inb1;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      a1a[t] += w.win0[t] * ina0;
+      a1b[t] += w.win0[t] * inb0;
+      if (PRE == L2O_PRE_LOGSIGN) { a1a[t] += w.win1[t] * ina1; a1b[t] += w.win1[t] * inb1; }
+    }
+  }
+  gates5(a1a, sa.c1, sa.h1);
+  gates5(a1b, sb.c1, sb.h1);
+  split5<true>(sa.h1, one, b1a);
+  split5<true>(sb.h1, one, b1b);
+  issue2<PRE, kChL2A>(w, b1a, b1b, a2a, a2b);
+  gates5(a2a, sa.c2, sa.h2);
+  gates5(a2b, sb.c2, sb.h2);
+  da = quad_q_sum(linear_out(sa.h2, w.wl)) + w.bl;
+  db = quad_q_sum(linear_out(sb.h2, w.wl)) + w.bl;
+}
+
 }  // namespace bx
 
 // ---- one interface over the two gate-GEMM forms, for the fused unroll kernels -----------

@@ -33,8 +33,8 @@
 namespace l2o {
 
 constexpr int kMxMembers = 32;                    // workgroups per instance = the CUs of one XCD
-constexpr int kMxThreads = 512;                   // eight waves, two per SIMD
-constexpr int kMxWaves = kMxThreads / 64;
+constexpr int kMxThreads = 512;                   // form 8: eight waves, two per SIMD, four tiles per wave
+constexpr int kMxThreads4 = 256;                  // form 4: four waves, one per SIMD, eight tiles per wave stepped in PAIRS
 constexpr int kMxSlots = 32;                      // tiles per member (four per wave)
 constexpr int kMxCoords = kMxSlots * kTile;       // 512 coordinate positions per member
 constexpr int kMxMaxInst = 8;                     // instances per launch = XCDs
@@ -112,6 +112,12 @@ __device__ __forceinline__ void mx_load2x2_wait(const unsigned long long* p0, co
   asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                : "=&v"(d0), "=&v"(d1) : "v"(p0), "v"(p1) : "memory");
 }
+__device__ __forceinline__ void mx_load2x3_wait(const unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
+                                                mu_u32x4& d0, mu_u32x4& d1, mu_u32x4& d2) {
+  asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(d0), "=&v"(d1), "=&v"(d2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
 // two granules at p until both carry `tag` (bounded, with back-off)
 __device__ __forceinline__ mu_u32x4 mx_poll2(const unsigned long long* p, mu_u32x4 d, unsigned tag, bool& dead, unsigned* status) {
   int spins = 0;
@@ -138,8 +144,12 @@ static size_t mlp_xcd_lds_bytes() {
   return sizeof(float) * (size_t)mlp_xcd_lds(LstmCoreLds<PRE, bx::NetWBLF<PRE>>::kFragWords, bx::NetWBLF<PRE>::kWinFloats).total;
 }
 
-template <int PRE>
-__global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
+// WV = waves per member: 8 (two per SIMD, four tiles each, one tile step at a time) or 4 (one per SIMD, eight tiles each,
+// stepped two at a time: every fragment read from LDS feeds two MFMAs and the wave has two independent dependent chains to
+// issue from -- what a lone wave per SIMD otherwise lacks)
+template <int PRE, int WV>
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV == 4 ? 1 : 2, WV == 4 ? 1 : 8))) void k_mlp_xcd(MlpXcdArgs a) {
+  constexpr int kThreads = 64 * WV, kMxWaves = WV, kTPW = kMxSlots / WV;
   const long long kernel_t0 = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) float mx_smem[];
   using Core = LstmCoreLds<PRE, bx::NetWBLF<PRE>>;
@@ -215,12 +225,13 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   };
 
   // ---- prologue: coordinates -> LDS, LSTM state -> registers, fragments / biases / input rows -> LDS ---------------
-  for (int e = tid; e < kMxXwFront + kMxCoords + kMxXwBack; e += kMxThreads) (xw - kMxXwFront)[e] = 0.0f;
-  for (int e = tid; e < 2 * kMxB * kMxKR; e += kMxThreads) (&imgs[0][0][0])[e] = 0.0f;
-  for (int e = tid; e < kMxH * 12; e += kMxThreads) (&w2p[0][0])[e] = 0.0f;
+  for (int e = tid; e < kMxXwFront + kMxCoords + kMxXwBack; e += kThreads) (xw - kMxXwFront)[e] = 0.0f;
+  for (int e = tid; e < 2 * kMxB * kMxKR; e += kThreads) (&imgs[0][0][0])[e] = 0.0f;
+  for (int e = tid; e < kMxH * 12; e += kThreads) (&w2p[0][0])[e] = 0.0f;
   __syncthreads();
-  {
-    const int pos = tid;                                   // 512 threads = 512 coordinate positions
+#pragma unroll
+  for (int pi = 0; pi < kMxCoords / kThreads; ++pi) {      // (static trip count: 1 | 2)
+    const int pos = tid + kThreads * pi;
     const int ti = tile_of(pos >> 4);
     float xv = 0.0f, sc = 1.0f, mv = 0.0f, vv = 0.0f;
     bool w1pos = false;
@@ -237,9 +248,9 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     xL[pos] = xv; scL[pos] = sc; mL[pos] = mv; vL[pos] = vv; gL[pos] = 0.0f;
     if (w1pos) xw[pos] = xv * sc;
   }
-  TileState sr[4];                                         // tiles 32 mem + wv + 8 k
+  TileState sr[kTPW];                                      // tile slots wv + WV k
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < kTPW; ++k) {
 #pragma unroll
     for (int t5 = 0; t5 < kNT; ++t5) { sr[k].h1[t5] = 0.f; sr[k].c1[t5] = 0.f; sr[k].h2[t5] = 0.f; sr[k].c2[t5] = 0.f; }
     const int ti = tile_of(wv + kMxWaves * k);
@@ -250,10 +261,10 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   }
   Core core;
   core.load(a.np.wpack, lane);
-  core.stage_frags(frs, a.np.wpack, tid, kMxThreads, lane);
+  core.stage_frags(frs, a.np.wpack, tid, kThreads, lane);
   __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];
-  core.stage_bias(bias_s, a.np.wpack, tid, kMxThreads, q);
-  bx::stage_win<PRE>(core.w, winL, a.np.wpack, tid, kMxThreads, lane);
+  core.stage_bias(bias_s, a.np.wpack, tid, kThreads, q);
+  bx::stage_win<PRE>(core.w, winL, a.np.wpack, tid, kThreads, lane);
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   float om1 = 1.0f, om2 = 1.0f;
   bool dead = false;
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     }
     if (first < kMxB) labs[par][first] = lab;
   };
-  load_eval(0, 0, tid, std::integral_constant<int, kMxThreads>());
+  load_eval(0, 0, tid, std::integral_constant<int, kThreads>());
   const float invB = 1.0f / (float)kMxB;
   const int nw1 = a.nw1;
   PhaseClock pc;
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     const int cc = tid & 15, q = (tid >> 4) & 3, lane = tid & 63;
     // ---- publish: the owners of b1 / w2 / b2 broadcast their scaled coordinates as granules (plain stores: same L2)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kTPW; ++k) {
       const int ti = tile_of(wv + kMxWaves * k);
       if (ti >= a.tile_begin[1] && ti < ntiles && q == 0) {
         const int var = var_of(ti);
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     // ---- the NEXT evaluation's minibatch, stage A: its indices -> registers (stage B, behind the gather: the image columns;
     // stage C, in front of the LSTM phase: -> the other parity buffer).  Two dependent global latencies, neither of them
     // waited for where it is issued.
-    constexpr int kPf = (kMxB * kMxKR + kMxThreads - 1) / kMxThreads;
+    constexpr int kPf = (kMxB * kMxKR + kThreads - 1) / kThreads;
     int pf_row[kPf], pf_lab = 0;
     float pf_val[kPf];
     const bool have_next = t < a.T;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
       const int* ix1 = I.idx + (size_t)(t + 1) * kMxB;
 #pragma unroll
       for (int u = 0; u < kPf; ++u) {
-        const int e = tid + kMxThreads * u;
+        const int e = tid + kThreads * u;
         pf_row[u] = e < kMxB * kMxKR ? ix1[e / kMxKR] : 0;
       }
       if (tid < kMxB) pf_lab = ix1[tid];
@@ -341,8 +352,11 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     // ---- partial hidden pre-activations on the fp32 matrix cores: wave = (sample tile st, hidden tile ht);
     // D lands as lane (sample 16 st + c, q) <- hidden units 16 ht + 4 q + r: four consecutive outputs of one sample ->
     // two granule pairs in the inbox of the member that reduces sample pair s / 2
-    if (owns_w1) {
-      const int st_ = wv & 3, ht = wv >> 2;
+    if (owns_w1)
+#pragma unroll
+    for (int ci = 0; ci < 8 / kMxWaves; ++ci) {              // eight (sample tile, hidden tile) products over the member's waves
+      const int cb = wv + kMxWaves * ci;
+      const int st_ = cb & 3, ht = cb >> 2;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const bool arow = ht == 0 || cc < kMxH - 16;         // hidden rows 16 .. 19 only
 #pragma unroll
@@ -369,15 +383,19 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     note_dead(dead, t, 2);
     // ---- reduce: this member's 40 outputs over the w1 owners: thread = (pair p, source), all loads first, then the tags
     {
-      const int pq = tid % (kMxR / 2), s0 = tid / (kMxR / 2);                           // 20 pairs x 25 sources (+ 25)
+      constexpr int kSrcRound = kThreads / (kMxR / 2);                                  // sources per round: 25 (form 8) | 12 (form 4)
+      constexpr int kRounds = (kMxMembers - 1 + kSrcRound - 1) / kSrcRound;             // 2 | 3
+      const int pq = tid % (kMxR / 2), s0 = tid / (kMxR / 2);
       const unsigned long long* inbox = I.P + ((size_t)mem * kMxMembers) * kMxR + 2 * pq;
-      const int s1 = s0 + kMxThreads / (kMxR / 2);
-      const bool v0 = s0 < nw1 && tid < (kMxThreads / (kMxR / 2)) * (kMxR / 2), v1 = v0 && s1 < nw1;
-      // (both loads unconditionally, from a clamped source: no conditionally defined asm results)
+      const bool vt = tid < kSrcRound * (kMxR / 2);
+      // (all loads unconditionally, from a clamped source: no conditionally defined asm results)
+      const bool v0 = vt && s0 < nw1, v1 = vt && s0 + kSrcRound < nw1, v2 = kRounds > 2 && vt && s0 + 2 * kSrcRound < nw1;
       const unsigned long long* p0 = inbox + (size_t)(v0 ? s0 : 0) * kMxR;
-      const unsigned long long* p1 = inbox + (size_t)(v1 ? s1 : 0) * kMxR;
-      mu_u32x4 d0, d1;
-      mx_load2x2_wait(p0, p1, d0, d1);
+      const unsigned long long* p1 = inbox + (size_t)(v1 ? s0 + kSrcRound : 0) * kMxR;
+      const unsigned long long* p2 = inbox + (size_t)(v2 ? s0 + 2 * kSrcRound : 0) * kMxR;
+      mu_u32x4 d0, d1, d2;
+      if constexpr (kRounds == 2) mx_load2x2_wait(p0, p1, d0, d1);
+      else mx_load2x3_wait(p0, p1, p2, d0, d1, d2);
       if (v0) {
         d0 = mx_poll2(p0, d0, tag, dead, status);
         redr[s0][2 * pq] = __uint_as_float(d0[0]);
@@ -385,8 +403,15 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
       }
       if (v1) {
         d1 = mx_poll2(p1, d1, tag, dead, status);
-        redr[s1][2 * pq] = __uint_as_float(d1[0]);
-        redr[s1][2 * pq + 1] = __uint_as_float(d1[2]);
+        redr[s0 + kSrcRound][2 * pq] = __uint_as_float(d1[0]);
+        redr[s0 + kSrcRound][2 * pq + 1] = __uint_as_float(d1[2]);
+      }
+      if constexpr (kRounds > 2) {
+        if (v2) {
+          d2 = mx_poll2(p2, d2, tag, dead, status);
+          redr[s0 + 2 * kSrcRound][2 * pq] = __uint_as_float(d2[0]);
+          redr[s0 + 2 * kSrcRound][2 * pq + 1] = __uint_as_float(d2[2]);
+        }
       }
       lds_barrier();
       if (tid < kMxR / 2) {                                 // ascending source order: the same sum whoever computes it
@@ -400,11 +425,14 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     // ---- gather the 1 280 sums (pairs), bias + activation fused into the LDS write
     {
       const unsigned long long* Sp = I.S + (size_t)par * kMxNO;
-      mu_u32x4 g0, g1;
-      const bool two = tid + kMxThreads < kMxNO / 2;
-      const unsigned long long* q0 = Sp + 2 * tid;
-      const unsigned long long* q1 = Sp + 2 * (two ? tid + kMxThreads : tid);
-      mx_load2x2_wait(q0, q1, g0, g1);
+      constexpr int kG = (kMxNO / 2 + kThreads - 1) / kThreads;                         // pairs per thread: 2 | 3
+      const bool w0 = tid < kMxNO / 2, w1 = tid + kThreads < kMxNO / 2, w2 = kG > 2 && tid + 2 * kThreads < kMxNO / 2;
+      const unsigned long long* q0 = Sp + 2 * (w0 ? tid : 0);
+      const unsigned long long* q1 = Sp + 2 * (w1 ? tid + kThreads : 0);
+      const unsigned long long* q2 = Sp + 2 * (w2 ? tid + 2 * kThreads : 0);
+      mu_u32x4 g0, g1, g2;
+      if constexpr (kG == 2) mx_load2x2_wait(q0, q1, g0, g1);
+      else mx_load2x3_wait(q0, q1, q2, g0, g1, g2);
       auto put = [&](int pr, mu_u32x4 g) {
         const int o = 2 * pr, sidx = o / kMxH, h = o - sidx * kMxH;
         const float a0 = __uint_as_float(g[0]) + small[h], a1 = __uint_as_float(g[2]) + small[h + 1];
@@ -412,17 +440,25 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
         Hs[sidx][h + 1] = a.act == 0 ? sigmoidf_(a1) : fmaxf(a1, 0.0f);
       };
       // (small[] was written before the barrier inside the reduce phase)
-      g0 = mx_poll2(q0, g0, tag, dead, status);
-      put(tid, g0);
-      if (two) {
+      if (w0) {
+        g0 = mx_poll2(q0, g0, tag, dead, status);
+        put(tid, g0);
+      }
+      if (w1) {
         g1 = mx_poll2(q1, g1, tag, dead, status);
-        put(tid + kMxThreads, g1);
+        put(tid + kThreads, g1);
+      }
+      if constexpr (kG > 2) {
+        if (w2) {
+          g2 = mx_poll2(q2, g2, tag, dead, status);
+          put(tid + 2 * kThreads, g2);
+        }
       }
     }
     if (have_next) {                                        // stage B: the image columns of the next minibatch
 #pragma unroll
       for (int u = 0; u < kPf; ++u) {
-        const int e = tid + kMxThreads * u, kk = e % kMxKR;
+        const int e = tid + kThreads * u, kk = e % kMxKR;
         pf_val[u] = (e < kMxB * kMxKR && owns_w1 && k0 + kk < n_in) ? a.images[(size_t)pf_row[u] * n_in + k0 + kk] : 0.0f;
       }
       if (tid < kMxB) pf_lab = a.labels[pf_lab];
@@ -524,7 +560,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     if (have_next) {
 #pragma unroll
       for (int u = 0; u < kPf; ++u) {
-        const int e = tid + kMxThreads * u;
+        const int e = tid + kThreads * u;
         if (e < kMxB * kMxKR) imgs[par ^ 1][e / kMxKR][e % kMxKR] = pf_val[u];
       }
       if (tid < kMxB) labs[par ^ 1][tid] = pf_lab;
@@ -536,7 +572,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     // the gradients of b1 / w2 / b2 (16 tiles of the whole instance: members 30 and 31): a sum over the samples, split over
     // the q lanes, into the same gL slots the w1 tiles read (same wave writes and reads: LDS operations of a wave are ordered)
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kTPW; ++k) {
       const int slot = wv + kMxWaves * k;
       const int ti = tile_of(slot);
       if (ti < a.tile_begin[1] || ti >= ntiles) continue;
@@ -556,37 +592,83 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
       gv = quad_q_sum(gv);
       if (q == 0) gL[slot * kTile + cc] = gv;
     }
-    auto do_tile = [&](int k, TileState& s) __attribute__((always_inline)) {
+    if constexpr (WV == 8) {                                 // one tile step at a time, two waves per SIMD fill each other's stalls
+      auto do_tile = [&](int k, TileState& s) __attribute__((always_inline)) {
+        const int slot = wv + kMxWaves * k;
+        const int ti = tile_of(slot);
+        if (ti >= ntiles) return;
+        const bool is_w1 = ti < a.tile_begin[1];
+        const int var = var_of(ti);
+        const bool live = (ti - a.tile_begin[var]) * kTile + cc < a.n[var];
+        const int pos = slot * kTile + cc;
+        const float sc = scL[pos], xj = xL[pos];
+        const float gv = live ? gL[pos] * sc : 0.0f;
+        float in0, in1;
+        if (PRE == L2O_PRE_FC_ELU) {
+          float m = mL[pos], v = vL[pos];
+          rnnprop_inputs(gv, m, v, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, om1, om2, in0, in1);
+          if (!live) { in0 = 0.0f; in1 = 0.0f; }
+          if (q == 0) { mL[pos] = m; vL[pos] = v; }
+        } else {
+          preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
+        }
+        float d = bx::tile_step_w<PRE, true, bx::NetWBLF<PRE>>(core.w, s, in0, in1, q);
+        if (a.np.tanh_output) d = tanhf_(d);
+        const float xn = __builtin_fmaf(d, a.np.scale, xj);
+        if (live && q == 0) {
+          xL[pos] = xn;
+          if (is_w1) xw[pos] = xn * sc;
+        }
+      };
+      static_for<0, kTPW>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        do_tile(k, sr[k]);
+      });
+    } else {                                                 // a lone wave per SIMD: two tiles per step (bx::tile_step2_w)
+    // what a tile's lanes bring to / take from its step: gradient -> the net's two inputs (the moments ride in LDS), and
+    // the update of x / x s behind it
+    struct TileIo { int pos; bool live, is_w1, real; float sc, xj, in0, in1; };
+    auto tile_in = [&](int k) __attribute__((always_inline)) {
+      TileIo io;
       const int slot = wv + kMxWaves * k;
       const int ti = tile_of(slot);
-      if (ti >= ntiles) return;
-      const bool is_w1 = ti < a.tile_begin[1];
-      const int var = var_of(ti);
-      const bool live = (ti - a.tile_begin[var]) * kTile + cc < a.n[var];
-      const int pos = slot * kTile + cc;
-      const float sc = scL[pos], xj = xL[pos];
-      const float gv = live ? gL[pos] * sc : 0.0f;
-      float in0, in1;
+      io.real = ti < ntiles;
+      io.is_w1 = ti < a.tile_begin[1];
+      const int var = io.real ? var_of(ti) : 0;
+      io.live = io.real && (ti - a.tile_begin[var]) * kTile + cc < a.n[var];
+      io.pos = slot * kTile + cc;
+      io.sc = scL[io.pos];
+      io.xj = xL[io.pos];
+      const float gv = io.live ? gL[io.pos] * io.sc : 0.0f;
       if (PRE == L2O_PRE_FC_ELU) {
-        float m = mL[pos], v = vL[pos];
-        rnnprop_inputs(gv, m, v, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, om1, om2, in0, in1);
-        if (!live) { in0 = 0.0f; in1 = 0.0f; }
-        if (q == 0) { mL[pos] = m; vL[pos] = v; }
+        float m = mL[io.pos], v = vL[io.pos];
+        rnnprop_inputs(gv, m, v, a.np.beta1, a.np.beta2, a.np.omb1, a.np.omb2, om1, om2, io.in0, io.in1);
+        if (!io.live) { io.in0 = 0.0f; io.in1 = 0.0f; }
+        if (q == 0 && io.real) { mL[io.pos] = m; vL[io.pos] = v; }
       } else {
-        preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
+        preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, io.in0, io.in1);
       }
-      float d = bx::tile_step_w<PRE, true, bx::NetWBLF<PRE>>(core.w, s, in0, in1, q);
+      return io;
+    };
+    auto tile_out = [&](const TileIo& io, float d) __attribute__((always_inline)) {
       if (a.np.tanh_output) d = tanhf_(d);
-      const float xn = __builtin_fmaf(d, a.np.scale, xj);
-      if (live && q == 0) {
-        xL[pos] = xn;
-        if (is_w1) xw[pos] = xn * sc;
+      const float xn = __builtin_fmaf(d, a.np.scale, io.xj);
+      if (io.live && q == 0) {
+        xL[io.pos] = xn;
+        if (io.is_w1) xw[io.pos] = xn * io.sc;
       }
     };
-    static_for<0, 4>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      do_tile(k, sr[k]);
-    });
+      static_for<0, kTPW / 2>([&](auto kc) {
+        constexpr int k = 2 * decltype(kc)::value;
+        if (tile_of(wv + kMxWaves * k) < ntiles) {           // (a wave's tiles are real from slot 0 up: k real or neither)
+          const TileIo ia = tile_in(k), ib = tile_in(k + 1);
+          float da, db;
+          bx::tile_step2_w<PRE, bx::NetWBLF<PRE>>(core.w, sr[k], sr[k + 1], ia.in0, ia.in1, ib.in0, ib.in1, q, da, db);
+          tile_out(ia, da);
+          if (ib.real) tile_out(ib, db);
+        }
+      });
+    }
     if (PRE == L2O_PRE_FC_ELU) {                            // beta^k as a float-float running product
       float hi = p1h * a.np.beta1, er = __builtin_fmaf(p1h, a.np.beta1, -hi);
       float lo = __builtin_fmaf(p1l, a.np.beta1, er), sum = hi + lo;
@@ -605,8 +687,9 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
   if (inst == 0 && mem == 0 && tid == 0) a.ws->ticks = __builtin_readcyclecounter() - loop_t0;
 
   // ---- write back: x, moments, LSTM state -------------------------------------------------------
-  {
-    const int pos = tid;
+#pragma unroll
+  for (int pi = 0; pi < kMxCoords / kThreads; ++pi) {      // (static trip count: 1 | 2)
+    const int pos = tid + kThreads * pi;
     const int ti = tile_of(pos >> 4);
     if (ti < ntiles) {
       const int var = var_of(ti);
@@ -618,7 +701,7 @@ __global__ __launch_bounds__(kMxThreads) void k_mlp_xcd(MlpXcdArgs a) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < kTPW; ++k) {
     const int ti = tile_of(wv + kMxWaves * k);
     if (ti < ntiles) {
       const int var = var_of(ti);

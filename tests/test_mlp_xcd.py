@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from helpers import make_params, rel_err
+from helpers import lib_option, make_params, rel_err
 from open_l2o_amd import _abi, _engine, meta, meta_rnnprop_eval, problems
 from open_l2o_amd.replicas import Replicas
 from test_meta_api import _net_config
@@ -46,8 +46,15 @@ def _replicas(cfg, params, data, idxs, T, activation="sigmoid", seed=9):
     return Replicas(opt, probs, T)
 
 
+@pytest.fixture(params=[1, 2], ids=["eight_waves", "four_waves_tile_pairs"])
+def waves(request):
+    """L2O_OPT_MLP_XCD_WAVES: both forms of k_mlp_xcd run every test of this file."""
+    with lib_option(_abi.OPT_MLP_XCD_WAVES, request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize("netname", ["dm_logsign", "dm"])
-def test_config5_shape_vs_oracle_T200(hip, netname):
+def test_config5_shape_vs_oracle_T200(hip, waves, netname):
     """Minibatch 64, T = 200 (BASELINE config 5's optimizee): TWO instances in one launch (XCDs 0 and 1), each against
     O.unroll_multi on its own minibatch sequence and its own initial weights: the whole loss trajectory and x_T."""
     data = problems.synthetic_mnist(512, seed=3)
@@ -73,7 +80,7 @@ def test_config5_shape_vs_oracle_T200(hip, netname):
 
 
 @pytest.mark.parametrize("activation,n", [("sigmoid", 8), ("relu", 3), ("sigmoid", 11)])
-def test_rnnprop_instances_equal_the_whole_chip_kernel(hip, activation, n):
+def test_rnnprop_instances_equal_the_whole_chip_kernel(hip, waves, activation, n):
     """RNNProp (moments in LDS, bias corrections beta^(step0 + t)): n instances through k_mlp_xcd (n = 8: every XCD; 3: five
     XCDs exit at once; 11: two launches) against the same n instances stepped one after the other by k_mlp_unroll, on the
     same minibatches; two chained unrolls (carry of x, LSTM state, m, v across launches; step0 = 1 and 1 + T)."""
@@ -100,7 +107,7 @@ def test_rnnprop_instances_equal_the_whole_chip_kernel(hip, activation, n):
     assert not np.allclose(res["xcd"][0][0][0], res["xcd"][0][0][1])       # (different instances)
 
 
-def test_a_team_that_does_not_assemble_is_recovered(hip):
+def test_a_team_that_does_not_assemble_is_recovered(hip, waves):
     """The injected timeout (workspace fault word): no member waits for anybody, the status word is raised -- Replicas.run
     restores every replica's inputs and re-runs them on the step-granular kernels, same minibatches."""
     data = problems.synthetic_mnist(256, seed=6)
@@ -143,7 +150,7 @@ def test_unsupported_shapes_say_so(hip):
 
 
 @pytest.mark.parametrize("netname", ["rnnprop", "dm"])
-def test_soak_a_thousand_launches(hip, netname):
+def test_soak_a_thousand_launches(hip, waves, netname):
     """1 000 back-to-back launches of eight instances (T = 3) with no host sync in between, for the net whose first build hung
     depending on unrelated code: no member ever gives up waiting, and the loss of every instance stays
     what the SAME sequence gives on a second pass (the launches are deterministic: fixed summation orders everywhere)."""
