@@ -535,7 +535,7 @@ def roofline_block(case, args, counters):
             # (measured, not assumed: the same kernel with 32 of the 256 problems -- 32 busy CUs, everything cache-resident
             #  -- takes 0.93 of the full launch's time; non-temporal loads on the stream are 21 % SLOWER)
             out["bound_note"] = ("hbm is the byte roofline this row is priced against; the streaming unroll itself is paced by the "
-                                 "CU's instruction stream, not by the bytes (profiles/r05w_c3_problem_count_sweep.txt, "
+                                 "CU's instruction stream, not by the bytes (profiles/archive_r05/r05w_c3_problem_count_sweep.txt, "
                                  "r05v_c3_nontemporal_stream_ab.txt; DESIGN.md 3.1c)")
     else:
         wb = work_block(case, issue, args, clock_hz)

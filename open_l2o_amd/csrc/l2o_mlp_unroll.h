@@ -173,7 +173,7 @@ __device__ __forceinline__ void mu_wait_loads() { asm volatile("s_waitcnt vmcnt(
 //  clocks so that it arrives behind the granules -- +-0.3 .. +3.5 %, the waiting is for partners that really are late;
 //  LDS-only workgroup barriers in the step loop -- 1 % slower; the next minibatch's indices requested a step ahead and passed
 //  through LDS -- 2 % slower; the forward tail on the VALU -- the matrix-core tail is 14 % faster.  Both memory-side ideas
-//  were measured AGAIN on the spill-free kernel (profiles/r05j_c5_prefetch_barriers_ab.txt): indices staged a step ahead in
+//  were measured AGAIN on the spill-free kernel (profiles/archive_r05/r05j_c5_prefetch_barriers_ab.txt): indices staged a step ahead in
 //  registers, all gathers issued back to back -- the phase clock's 1.8 k-cycle wait at the head of the tail goes, the kernel
 //  is 1 % SLOWER (1.830 vs 1.813 ms); LDS-only barriers on top -- 2.6 % slower (1.877 ms).  Vector memory returns in order
 //  and every poll ends in vmcnt(0): a minibatch gather (HBM / MALL latency) that is in flight when a hop starts sits in

@@ -5,7 +5,7 @@
 //
 // Why: k_mlp_unroll puts ONE instance on the whole chip -- 996 tiles on 996 SIMDs of 249 workgroups on 8 XCDs -- and its
 // step is three exchange hops (local reduce, fabric, local gather) around 670 cycles of LSTM work per tile: 54 % of the wave
-// cycles are parked in polls (profiles/r05_counters_c5.json), roofline.frac 0.08.  That decomposition buys the lowest
+// cycles are parked in polls (profiles/archive_r05/r05_counters_c5.json), roofline.frac 0.08.  That decomposition buys the lowest
 // LATENCY of one unroll; it is the wrong one for THROUGHPUT (a meta-training batch of optimizees, BASELINE config 5's
 // replicas), because a replica needs no partner outside its own L2:
 //
