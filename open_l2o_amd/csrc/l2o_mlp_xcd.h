@@ -593,6 +593,9 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV == 4
       if (q == 0) gL[slot * kTile + cc] = gv;
     }
     if constexpr (WV == 8) {                                 // one tile step at a time, two waves per SIMD fill each other's stalls
+      // (measured and removed, profiles/r06_c5_xcd_forms_ab.txt: starting waves 4-7 of a member 0.9 / 1.8 / 2.7 k cycles late --
+      //  the two waves of a SIMD leave the barrier together and run the same sequence -- costs exactly the delay: 4.68 / 4.71 /
+      //  4.82 ms against 4.57)
       auto do_tile = [&](int k, TileState& s) __attribute__((always_inline)) {
         const int slot = wv + kMxWaves * k;
         const int ti = tile_of(slot);
