@@ -35,6 +35,12 @@ bench_args() { # CFG -> the bench.py arguments of that BASELINE configuration
     *) echo "--config $1" ;;
   esac
 }
+prof_args() { # CFG -> the same workload with a SHORT timed region, for the rocprofv3 passes (counters are per launch)
+  case $1 in
+    2) echo "--steps 20 --warmup 5 --unrolls-per-step 16" ;;
+    *) echo "$(bench_args $1) --min-timed-seconds 0.2" ;;
+  esac
+}
 workload_json() { # the `workload` key scripts/counters_to_json.py stores and bench.py matches
   case $1 in
     2) echo '["quadratic", "dm", 128, 128, 100]' ;;
@@ -75,15 +81,15 @@ for job in "$@"; do
       timeout 600 python bench.py $(bench_args $a1) $extra $(words "$a2") 2>>$O/bench.err | tee $out | cut -c1-300 ;;
     trace)
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_c$a1 -o t -- \
-         python $R/bench.py $(bench_args $a1) --no-cpu-baseline --no-also $(words "$a2") > $O/trace_c$a1.json 2> $O/trace_c$a1.err)
+         python $R/bench.py $(prof_args $a1) --no-cpu-baseline --no-also $(words "$a2") > $O/trace_c$a1.json 2> $O/trace_c$a1.err)
       db=$(ls $O/trace_c$a1/*.db $O/trace_c$a1/*/*.db 2>/dev/null | head -1)
       [ -n "$db" ] && python scripts/rocprof_summary.py $db $O/kernel_trace_c$a1.txt | head -8
       rm -rf $O/trace_c$a1 ;;
     counters)
-      bash scripts/gpu_counters.sh $O c$a1 "$(kernel_of $a1)" "$(workload_json $a1)" $(bench_args $a1) $(words "$a2") ;;
+      bash scripts/gpu_counters.sh $O c$a1 "$(kernel_of $a1)" "$(workload_json $a1)" $(prof_args $a1) $(words "$a2") ;;
     final)
       extra=$([ "$a1" = 2 ] || echo --no-cpu-baseline)
-      bash scripts/gpu_counters.sh $O c$a1 "$(kernel_of $a1)" "$(workload_json $a1)" $(bench_args $a1) $(words "$a2")
+      bash scripts/gpu_counters.sh $O c$a1 "$(kernel_of $a1)" "$(workload_json $a1)" $(prof_args $a1) $(words "$a2")
       # the bench line AFTER the counters exist in this lease: its roofline block reads gpurun_out/TAG/counters_cN.json
       L2O_COUNTERS_DIR=$O timeout 600 python bench.py $(bench_args $a1) $extra $(words "$a2") 2>>$O/bench.err | tee $O/bench_c$a1.json | cut -c1-300 ;;
     train)
