@@ -1122,7 +1122,7 @@ def main(argv=None):
         # ---- flat copies of the other configurations' headline figures (they survive a consumer that keeps top-level
         # scalars only: VERDICT r05 item 4)
         for name, pre in (("config3", "c3"), ("config4_one_gpu", "c4"), ("config4_shard_of_8", "c4s8"), ("config5", "c5"),
-                          ("config5_replicas8", "c5x8"), ("config5_one_xcd", "c5xcd1")):
+                          ("config4_shard_of_8_rccl", "c4s8rccl"), ("config5_replicas8", "c5x8"), ("config5_one_xcd", "c5xcd1")):
             e = also.get(name) or {}
             if "value" in e:
                 out[pre + "_value"] = e["value"]
