@@ -357,9 +357,14 @@ class ReplicaGraph(object):
         self._x0 = [[v.value.clone() for v in g.x] for g in self.reps.graphs]
 
     def launch(self, feed, commit=True, events=None, use_graph=False, restart=None):
-        if restart is not None:                              # every replica from ITS initial weights, zero state / moments
+        if restart is not None:                              # every replica from ITS initial weights, zero state / moments:
+            import torch                                     # one multi-tensor copy for all of them
+            dst, src = [], []
             for g, x0 in zip(self.reps.graphs, self._x0):
-                g.rewind(x0)
+                d_, s_ = g.rewind_lists(x0)
+                dst += d_
+                src += s_
+            torch._foreach_copy_(dst, src)
         if events is not None:
             events[0].record()
         fx = self.reps.launch(feed)

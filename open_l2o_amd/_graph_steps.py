@@ -132,11 +132,12 @@ class StepPlanMixin(object):
                 return 0
         return int(eng.mlp_unroll_supported(net.spec, self._mlp_desc(self.terms[0])))   # 2: the kernel's FAST form
 
-    def mlp_instance(self, feed=None, dry=False):
+    def mlp_instance(self, feed=None, dry=False, draw=True):
         """What this graph contributes to a launch of several optimizee instances (replicas.Replicas ->
         l2o_mlp_unroll_multi): its minibatch indices (drawn here, like a launch of its own would), the live x / LSTM
         state / moment buffers of the four variables in the order w1, b1, w2, b2 and its loss buffer -- or None when
-        the fused MLP unroll does not apply to it.  dry: no draw, no buffers -- only whether it applies."""
+        the fused MLP unroll does not apply to it.  dry: no draw, no buffers -- only whether it applies.  draw=False: the
+        caller has filled self._mlp_idx[0] itself (Replicas draws the minibatches of all its replicas in one call)."""
         self._ensure_init()
         T = self.len_unroll
         feed = feed or {}
@@ -153,7 +154,8 @@ class StepPlanMixin(object):
             return dict(net=net, desc=desc)
         if self.rnnprop and self.step not in feed:
             raise ValueError("You must feed a value for placeholder 'step' (DM/util.py:59-60)")
-        self._draw_minibatches(T)
+        if draw:
+            self._draw_minibatches(T)
         index_of = {v.decl.name: j for j, v in enumerate(self.x)}
         js = [index_of[tv.name] for tv in _term_vars(term)]               # w1, b1, w2, b2 -> variable index
         slot_of = {s.var_index: si for si, s in enumerate(slots)}

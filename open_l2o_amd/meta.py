@@ -728,6 +728,16 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
     def rewind(self, x0):
         """Device-side restart of the SAME problem instance: x <- x0 (list of device tensors),
         LSTM state / moments <- 0, without re-sampling the problem data (bench.py)."""
+        dst, src = self.rewind_lists(x0)
+        if hasattr(torch, "_foreach_copy_") and len(dst) > 1:
+            torch._foreach_copy_(dst, src)                  # ONE launch for x, LSTM state and moments
+        else:
+            for d_, s_ in zip(dst, src):
+                d_.copy_(s_)
+
+    def rewind_lists(self, x0):
+        """(destinations, sources) of rewind(x0): a caller that rewinds several graphs at once (bench.py's replicas) passes
+        the concatenated lists to ONE multi-tensor copy."""
         self._ensure_init()
         dst, src = [v.value for v in self.x], list(x0)
         zeros = self.__dict__.setdefault("_rewind_zeros", {})
@@ -743,11 +753,7 @@ class UnrollGraph(BpttMixin, AdamMixin, StepPlanMixin, object):
                     z = zeros[tuple(t.shape)] = torch.zeros_like(t)
                 dst.append(t)
                 src.append(z)
-        if hasattr(torch, "_foreach_copy_") and len(dst) > 1:
-            torch._foreach_copy_(dst, src)                  # ONE launch for x, LSTM state and moments
-        else:
-            for d_, s_ in zip(dst, src):
-                d_.copy_(s_)
+        return dst, src
 
     def _local_shape(self, var):
         if self.sharded:

@@ -82,13 +82,33 @@ class Replicas(object):
         inst = g.mlp_instance(None, dry=True)
         return inst is not None and eng.mlp_unroll_multi_supported(inst["net"].spec, inst["desc"], min(8, len(self.graphs)))
 
+    def _draw_all(self):
+        """The minibatch indices of ALL replicas in one device draw (one torch generator call instead of one per replica;
+        every replica still gets its own independent index sequence) -- when no replica has a host `sampler` and the engine
+        draws on the device.  Returns False when the replicas must draw for themselves."""
+        graphs = self.graphs
+        eng = graphs[0].engine
+        if not hasattr(eng, "sample_int") or any(t.hyper.get("sampler") is not None for g in graphs for t in g.terms):
+            return False
+        from ._graph_core import rng
+        d = graphs[0]._mlp_desc(graphs[0].terms[0])
+        shape = (len(graphs), self.len_unroll + 1, d.batch)
+        big = self.__dict__.get("_idx_all")
+        if big is None or tuple(big.shape) != shape:
+            big = self._idx_all = eng.empty_int(*shape)
+        for j, g in enumerate(graphs):                       # (a graph's reset() drops its index buffers)
+            g._mlp_idx = {0: big[j]}
+        eng.sample_int(big, d.images.shape[0], int(rng().integers(0, 2 ** 62)))
+        return True
+
     def launch(self, feed=None):
         """ENQUEUE one committed unroll of every replica on the one-instance-per-XCD kernel (launches of up to eight) without
         synchronising the host, without a recovery snapshot and without a status check -- the caller syncs and calls
         engine.check_unroll_status() itself (bench.py's timed region).  Returns the replicas' loss buffers (device, [T + 1])."""
         graphs = self.graphs
         eng = graphs[0].engine
-        insts = [g.mlp_instance(self._feed(g, feed)) for g in graphs]
+        drew = self._draw_all()
+        insts = [g.mlp_instance(self._feed(g, feed), draw=not drew) for g in graphs]
         if any(i is None for i in insts):
             raise _abi.L2OUnsupported(_abi.L2O_ERR_UNSUPPORTED, "Replicas.launch: l2o_mlp_unroll_multi does not apply")
         net, desc = insts[0]["net"], insts[0]["desc"]
@@ -123,8 +143,9 @@ class Replicas(object):
         step0 = int(feed[graphs[0].step]) if graphs[0].rnnprop else 1
         recover = not os.environ.get("L2O_NO_RECOVERY")
         insts = []
+        drew = self._draw_all()
         for g in graphs:
-            inst = g.mlp_instance(self._feed(g, feed))
+            inst = g.mlp_instance(self._feed(g, feed), draw=not drew)
             if inst is None or (insts and (inst["desc"] is not insts[0]["desc"] or inst["net"] is not insts[0]["net"])):
                 raise ValueError("Replicas.run: the replicas must be problems.mnist instances over ONE data set, stepped by "
                                  "one (20, 20) LSTM network")
