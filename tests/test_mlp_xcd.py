@@ -212,3 +212,23 @@ def test_trained_rnnprop_replicas_vs_oracle_T200(hip):
         # past the prefix the two trajectories are two samples of a chaotic system (per-step rounding differences act like a
         # perturbation larger than one ulp of x_0): both still optimize to the same level
         assert abs(float(reps.fx_arrays[j][-1]) - float(fx_ref[-1])) < 0.1 * float(fx_ref[-1]), (j, reps.fx_arrays[j][-1], fx_ref[-1])
+
+
+def test_evaluate_rnnprop_driver_with_replicas(tmp_path):
+    """scripts/evaluate_rnnprop.py --problem mnist --replicas 8: the re-hosted evaluation driver evaluates eight instances of
+    the optimizee together on the one-instance-per-XCD kernel and writes one loss record per instance."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    trained = os.path.join(root, "tests", "golden", "trained", "rnnprop_mnist_mlp", "rp.l2l-0")   # (--path IS the net file: DM/util.py:108)
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "evaluate_rnnprop.py"), "--problem", "mnist",
+                        "--synthetic_mnist", "1024", "--batch_size", "64", "--num_steps", "60", "--replicas", "8", "--seed", "3",
+                        "--path", trained, "--output_path", str(tmp_path)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "kernel form: xcd" in p.stdout, p.stdout[-1500:]
+    rec = pickle.load(open(os.path.join(str(tmp_path), "L2L_eval_loss_record.pickle-mnist"), "rb"))
+    assert len(rec) == 8 and all(len(r) == 60 for r in rec)
+    assert all(r[-1] < 0.8 * r[0] for r in rec)                          # the trained optimizer optimizes every instance
+    assert len({round(r[-1], 6) for r in rec}) == 8                       # ... and they are eight different instances
