@@ -69,6 +69,24 @@ int main(int argc, char** argv) {
   CHECK(l2o_state_floats(B, D) == (size_t)B * 1 * 4 * H * 16, "l2o_state_floats");
   CHECK(l2o_unroll(NULL, NULL, NULL, NULL, NULL, NULL, NULL, 1, 1, NULL, NULL, NULL) != L2O_OK && strlen(l2o_last_error()) > 0,
         "NULL arguments are rejected with a message");
+  {
+    /* ABI v13, host-side contracts of the multi-instance MLP unroll and the deep-MLP evaluation (no launches) */
+    l2o_mlp mlp;
+    memset(&mlp, 0, sizeof mlp);
+    mlp.n_in = 784; mlp.n_hidden = 20; mlp.n_out = 10; mlp.batch = 64;
+    CHECK(l2o_mlp_unroll_multi_workspace_bytes(&mlp, 8) > 8 * l2o_mlp_unroll_multi_workspace_bytes(&mlp, 1) / 2 &&
+          l2o_mlp_unroll_multi_workspace_bytes(&mlp, 1) > 0, "l2o_mlp_unroll_multi_workspace_bytes grows with the instances");
+    CHECK(l2o_mlp_unroll_multi_workspace_bytes(&mlp, 9) == 0, "more than eight instances per launch are refused");
+    mlp.batch = 32;
+    CHECK(l2o_mlp_unroll_multi_workspace_bytes(&mlp, 1) == 0, "other minibatch sizes have no one-XCD kernel");
+    CHECK(l2o_mlp_unroll_multi(&cfg, wpack, &mlp, NULL, 1, 1, 1, NULL, NULL) != L2O_OK, "NULL instances are rejected");
+    l2o_mlp_deep deep;
+    memset(&deep, 0, sizeof deep);
+    deep.n_in = 784; deep.n_out = 10; deep.batch = 128; deep.n_hidden_layers = 2; deep.hidden[0] = 20; deep.hidden[1] = 20;
+    CHECK(l2o_mlp_deep_scratch_floats(&deep) == (size_t)128 * 32 * 5 + 128, "l2o_mlp_deep_scratch_floats");
+    deep.n_hidden_layers = 4;
+    CHECK(l2o_mlp_deep_scratch_floats(&deep) == 0, "four hidden layers are refused");
+  }
   if (host_only) {
     printf("abi_smoke: host-only checks passed (ABI v%d, wpack %zu floats)\n", l2o_abi_version(), nw);
     return 0;
