@@ -191,6 +191,7 @@ struct NetWB {
   const __attribute__((address_space(3))) f32x4* bias;   // LDS: this lane group's [layer][t] accumulator inits (set_bias)
   static constexpr bool kLdsFrags = false;               // (NetWBL: the A operands are read from LDS at issue time)
   static constexpr int kFragFence = 0;
+  static constexpr int kFragDepth = 0;                   // (LDS fragments: reads kept in flight ahead of their MFMA, issue_pipelined)
   static constexpr bool kLdsWin = false;                 // (NetWBLF: win0 / win1 are read from LDS where they are used)
   static constexpr int kLdsChunk = -1;                   // (NetWBH: ONE chunk's A operands are read from LDS)
 };
@@ -210,9 +211,21 @@ struct NetWBH : NetWB<PRE, false> {
 // (256 registers each) where the register-resident form needs 240 AGPRs per wave.  lfr points at this lane's 16 bytes of
 // fragment 0; fragment (chunk, M-tile, MFMA j) sits at a compile-time offset (ds_read_b128 immediate, < 64 KB).
 template <int PRE>
+// Measured (profiles/r06_frag_pipeline_ab.txt; results bit-identical at every depth):
+//   k_mlp_xcd     depth 0 / 2 / 3 / 4: 5.66 / 6.32 / 6.28 / 6.39 G (config 5, 8 replicas)       -> 4 (L2O_MX_FRAG_DEPTH, l2o_mlp_xcd.h)
+//   k_unroll_cu8  depth 0 / 2 / 3:     5.69 / 6.05 / 6.03 G (config 3)                          -> 2
+//   k_unroll_lds  depth 0 / 2 / 4 / 6: 8.28 / 7.23 / 7.47 / 7.60 G (config 4 on one GPU)         -> 0: there hipcc's own schedule
+//                 (the reads interleaved with the GEMV passes' LDS traffic) beats the pinned alternation
+#ifndef L2O_LDS_FRAG_DEPTH
+#define L2O_LDS_FRAG_DEPTH 0      // k_unroll_lds (NetWBL)
+#endif
+#ifndef L2O_CU8_FRAG_DEPTH
+#define L2O_CU8_FRAG_DEPTH 2      // k_unroll_cu8 (NetWBLF)
+#endif
 struct NetWBL : NetWB<PRE, true> {
   static constexpr bool kLdsFrags = true;
   static constexpr int kFragFence = 0;
+  static constexpr int kFragDepth = L2O_LDS_FRAG_DEPTH;
   const __attribute__((address_space(3))) u32x4* lfr;
 };
 
@@ -288,8 +301,46 @@ __device__ __forceinline__ void preload_bias(const W& w, f32x4 (&acc)[kNT]) {
 
 // MFMAs [LO, HI) of chunk CH (index n: packed MFMA | product n / 5, M-tile n % 5 -- consecutive MFMAs hit
 // different accumulators).  ZERO: the first one starts the accumulator (C = the layer's bias, see bias_off).
+// LDS-resident fragments, software-pipelined (round 6): W::kFragDepth > 0 keeps that many fragment reads IN FLIGHT ahead of
+// the MFMA that consumes them.  Left to itself hipcc -- in a kernel near its register limit -- reuses ONE register quad for
+// every fragment: `ds_read_b128 v[114:117]; s_waitcnt lgkmcnt(0); v_mfma ... v[114:117]`, eighty times per tile step, i.e.
+// every MFMA pays an LDS round trip (found in k_mlp_xcd's ISA: 55 % of its wave cycles in s_waitcnt).  A rotating set of
+// kFragDepth quads, the read of fragment n + depth issued right behind MFMA n (which has read its operand by then), and
+// sched_group_barriers that pin the (MFMA, DS read) alternation.
+template <int PRE, int CH, int LO, int HI, bool ZERO, bool PK, class W>
+__device__ __forceinline__ void issue_pipelined(const W& w, const BOp<PK>& b, f32x4 (&acc)[kNT]) {
+  static_assert(PK && W::kLdsFrags, "issue_pipelined: the packed LDS-resident fragments");
+  constexpr int DEP = W::kFragDepth;
+  u32x4 f[DEP];
+  static_for<0, DEP>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (LO + i < HI) {
+      constexpr int n = LO + i;
+      f[i] = w.lfr[((CH * kNT + n % kNT) * kPack + n / kNT) * 64];
+    }
+  });
+  // (the first `depth` reads go out TOGETHER, ahead of the first MFMA: without this group the scheduler sinks each of them
+  //  into the read slot of a later iteration and the depth collapses to one)
+  __builtin_amdgcn_sched_group_barrier(0x100, (HI - LO) < DEP ? (HI - LO) : DEP, 0);
+  static_for<LO, HI>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    constexpr int p = n / kNT, t = n % kNT, slot = (n - LO) % DEP;
+    acc[t] = mfma_bf(f[slot], b.m[p], acc[t]);
+    if constexpr (n + DEP < HI) {
+      constexpr int m = n + DEP;
+      f[slot] = w.lfr[((CH * kNT + m % kNT) * kPack + m / kNT) * 64];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ... then the read that refills its quad
+  });
+}
+
 template <int PRE, int CH, int LO, int HI, bool ZERO, bool PK, class W>
 __device__ __forceinline__ void issue(const W& w, const BOp<PK>& b, f32x4 (&acc)[kNT]) {
+  if constexpr (W::kLdsFrags && W::kFragDepth > 0) {
+    issue_pipelined<PRE, CH, LO, HI, ZERO, PK, W>(w, b, acc);
+    return;
+  }
   static_for<LO, HI>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
     constexpr int p = n / kNT, t = n % kNT;
@@ -742,20 +793,21 @@ namespace bx {
 #ifndef L2O_CU8_LDS_WIN
 #define L2O_CU8_LDS_WIN 1
 #endif
-template <int PRE>
-struct NetWBLF : NetWBL<PRE> {                                                            // (k_unroll_cu8)
+template <int PRE, int DEPTH = L2O_CU8_FRAG_DEPTH>
+struct NetWBLF : NetWBL<PRE> {                                                            // (k_unroll_cu8, k_mlp_xcd)
   static constexpr int kFragFence = L2O_CU8_FRAG_FENCE;
+  static constexpr int kFragDepth = DEPTH;               // fragment reads in flight ahead of their MFMA (issue_pipelined)
   static constexpr bool kLdsWin = L2O_CU8_LDS_WIN && PRE != L2O_PRE_FC_ELU;
   const __attribute__((address_space(3))) f32x4* lwin;   // LDS: this lane's 16 bytes of input-weight row 0 ([rows][64 lanes][4])
   static constexpr int kWinFloats = PRE == L2O_PRE_FC_ELU ? 0 : (PRE == L2O_PRE_LOGSIGN ? 2 : 1) * kNT * 256;
 };
 // every thread copies its share of the input-weight rows of wpack into LDS; the caller's barrier follows
-template <int PRE>
-__device__ __forceinline__ void stage_win(NetWBLF<PRE>& w, float* lds, const float* __restrict__ wp, int tid, int nthreads, int lane) {
-  if constexpr (NetWBLF<PRE>::kLdsWin) {
+template <int PRE, int DEPTH>
+__device__ __forceinline__ void stage_win(NetWBLF<PRE, DEPTH>& w, float* lds, const float* __restrict__ wp, int tid, int nthreads, int lane) {
+  if constexpr (NetWBLF<PRE, DEPTH>::kLdsWin) {
     const f32x4* src = reinterpret_cast<const f32x4*>(wp + win_off(PRE));
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    for (int i = tid; i < NetWBLF<PRE>::kWinFloats / 4; i += nthreads) dst[i] = src[i];
+    for (int i = tid; i < NetWBLF<PRE, DEPTH>::kWinFloats / 4; i += nthreads) dst[i] = src[i];
     w.lwin = reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const __attribute__((address_space(3))) float*)lds) + lane;
   }
 }

@@ -139,9 +139,15 @@ __device__ __forceinline__ void mx_store2(unsigned long long* p, float v0, float
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 }
 
+#ifndef L2O_MX_FRAG_DEPTH
+#define L2O_MX_FRAG_DEPTH 4    // fragment reads in flight ahead of their MFMA (bx::issue_pipelined; 238-249 registers, no spills)
+#endif
+template <int PRE>
+using MxW = bx::NetWBLF<PRE, L2O_MX_FRAG_DEPTH>;
+
 template <int PRE>
 static size_t mlp_xcd_lds_bytes() {
-  return sizeof(float) * (size_t)mlp_xcd_lds(LstmCoreLds<PRE, bx::NetWBLF<PRE>>::kFragWords, bx::NetWBLF<PRE>::kWinFloats).total;
+  return sizeof(float) * (size_t)mlp_xcd_lds(LstmCoreLds<PRE, MxW<PRE>>::kFragWords, MxW<PRE>::kWinFloats).total;
 }
 
 // WV = waves per member: 8 (two per SIMD, four tiles each, one tile step at a time) or 4 (one per SIMD, eight tiles each,
@@ -152,8 +158,8 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV == 4
   constexpr int kThreads = 64 * WV, kMxWaves = WV, kTPW = kMxSlots / WV;
   const long long kernel_t0 = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) float mx_smem[];
-  using Core = LstmCoreLds<PRE, bx::NetWBLF<PRE>>;
-  constexpr MlpXcdLds LY = mlp_xcd_lds(Core::kFragWords, bx::NetWBLF<PRE>::kWinFloats);
+  using Core = LstmCoreLds<PRE, MxW<PRE>>;
+  constexpr MlpXcdLds LY = mlp_xcd_lds(Core::kFragWords, MxW<PRE>::kWinFloats);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV == 4
   core.stage_frags(frs, a.np.wpack, tid, kThreads, lane);
   __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];
   core.stage_bias(bias_s, a.np.wpack, tid, kThreads, q);
-  bx::stage_win<PRE>(core.w, winL, a.np.wpack, tid, kThreads, lane);
+  bx::stage_win(core.w, winL, a.np.wpack, tid, kThreads, lane);
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   float om1 = 1.0f, om2 = 1.0f;
   bool dead = false;
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV == 4
         } else {
           preprocess_grad<PRE>(gv, a.np.k_inv_ln2, a.np.exp_k, in0, in1);
         }
-        float d = bx::tile_step_w<PRE, true, bx::NetWBLF<PRE>>(core.w, s, in0, in1, q);
+        float d = bx::tile_step_w<PRE, true, MxW<PRE>>(core.w, s, in0, in1, q);
         if (a.np.tanh_output) d = tanhf_(d);
         const float xn = __builtin_fmaf(d, a.np.scale, xj);
         if (live && q == 0) {
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV == 4
         if (tile_of(wv + kMxWaves * k) < ntiles) {           // (a wave's tiles are real from slot 0 up: k real or neither)
           const TileIo ia = tile_in(k), ib = tile_in(k + 1);
           float da, db;
-          bx::tile_step2_w<PRE, bx::NetWBLF<PRE>>(core.w, sr[k], sr[k + 1], ia.in0, ia.in1, ib.in0, ib.in1, q, da, db);
+          bx::tile_step2_w<PRE, MxW<PRE>>(core.w, sr[k], sr[k + 1], ia.in0, ia.in1, ib.in0, ib.in1, q, da, db);
           tile_out(ia, da);
           if (ib.real) tile_out(ib, db);
         }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kCu8Threads) void k_unroll_cu8(UnrollArgs a) {
   core.stage_frags(frs, a.np.wpack, tid, kCu8Threads, lane);
   __shared__ __attribute__((aligned(16))) float bias_s[Core::kBiasFloats];
   core.stage_bias(bias_s, a.np.wpack, tid, kCu8Threads, q);
-  bx::stage_win<PRE>(core.w, winL, a.np.wpack, tid, kCu8Threads, lane);
+  bx::stage_win(core.w, winL, a.np.wpack, tid, kCu8Threads, lane);
   float p1h = a.p1_hi, p1l = a.p1_lo, p2h = a.p2_hi, p2l = a.p2_lo;
   float om1 = 1.0f, om2 = 1.0f;
   __syncthreads();
