@@ -121,6 +121,39 @@ __device__ __forceinline__ void tgemm(const unsigned* fr, int lane, const float 
 // written per launch, 3.1 TB/s; kept because it removes a cross-wave dependency the data flow does not have.)
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// A wave's staging block -> global memory, NF floats (a multiple of 4), both contiguous.  The rolled
+// `for (i = lane; i < n / 4; i += 64)` this replaces compiled to ds_read_b128; s_waitcnt lgkmcnt(0); global_store_dwordx4
+// per trip -- eleven LDS round trips in a row for the 10 KB Bm block of every step -- and so does the unrolled C++ form, with or
+// without sched_group_barriers (the scheduler pairs every read with its store through ONE register quad).  Hence one asm
+// statement per FIVE reads, wait included (a load and its wait in separate statements is the hazard l2o_mlp_xcd.h describes).
+template <int OFF0, int CNT>
+__device__ __forceinline__ void lds_read5_wait(unsigned addr, f32x4 (&v)[5]) {
+  static_assert(CNT >= 1 && CNT <= 5 && OFF0 + 4096 < 65536, "ds offset field");
+  // (the reads past CNT repeat the last valid one: one asm string for every group size)
+  asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %5 offset:%7\n\tds_read_b128 %2, %5 offset:%8\n\t"
+               "ds_read_b128 %3, %5 offset:%9\n\tds_read_b128 %4, %5 offset:%10\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+               : "v"(addr), "n"(OFF0), "n"(OFF0 + 1024 * (CNT > 1 ? 1 : CNT - 1)), "n"(OFF0 + 1024 * (CNT > 2 ? 2 : CNT - 1)),
+                 "n"(OFF0 + 1024 * (CNT > 3 ? 3 : CNT - 1)), "n"(OFF0 + 1024 * (CNT > 4 ? 4 : CNT - 1))
+               : "memory");
+}
+template <int NF>
+__device__ __forceinline__ void stage_block_out(float* __restrict__ dst, const float* stg, int lane) {
+  static_assert(NF % 4 == 0, "whole float4s");
+  constexpr int N4 = NF / 4, FULL = N4 / 64;                // trips in which every lane has a float4
+  asm volatile("" : "+v"(lane));                            // (offsets recomputed here, not hoisted out of the step loop and kept live)
+  const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)stg + 16u * (unsigned)lane;
+  f32x4* const d4 = reinterpret_cast<f32x4*>(dst) + lane;
+  static_for<0, (FULL + 4) / 5>([&](auto gc) {
+    constexpr int k0 = decltype(gc)::value * 5, cnt = FULL - k0 < 5 ? FULL - k0 : 5;
+    f32x4 v[5];
+    lds_read5_wait<1024 * k0, cnt>(addr, v);
+#pragma unroll
+    for (int k = 0; k < cnt; ++k) d4[64 * (k0 + k)] = v[k];
+  });
+  if (N4 % 64 != 0 && lane < N4 % 64) d4[64 * FULL] = reinterpret_cast<const f32x4*>(stg)[lane + 64 * FULL];
+}
+
 template <int PRE>
 struct BwdMfmaGeom {
   using Geo = BwdTileGeom<PRE>;
@@ -335,12 +368,7 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
       }
       if (q == 0) { for (int e = P + 2 * kH; e < KAC; ++e) arow[e] = 0.0f; }
       wave_lds_fence();
-      if (valid) {
-        float* const a0 = p.act1 + n0 * KAC;
-        const int na = NC * KAC;
-        for (int i = lane; i < na / 4; i += 64) reinterpret_cast<float4*>(a0)[i] = reinterpret_cast<const float4*>(stg)[i];
-        for (int e = (na & ~3) + lane; e < na; e += 64) a0[e] = stg[e];
-      }
+      if (valid) stage_block_out<NC * KAC>(p.act1 + n0 * KAC, stg, lane);
       wave_lds_fence();
     }
     {
@@ -374,9 +402,14 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     }
     wave_lds_fence();
     if (valid) {
-      const int na = (p.T > 0 ? NC : nv) * (compact ? KAC : KA);
-      for (int i = lane; i < na / 4; i += 64) reinterpret_cast<float4*>(a_t)[i] = reinterpret_cast<const float4*>(stg)[i];
-      for (int e = (na & ~3) + lane; e < na; e += 64) a_t[e] = stg[e];
+      if (p.T > 0) {                                        // whole tiles (padding rows as zeros): 16 rows = whole float4s
+        if (compact) stage_block_out<NC * KAC>(a_t, stg, lane);
+        else stage_block_out<NC * KA>(a_t, stg, lane);
+      } else {
+        const int na = nv * KA;
+        for (int i = lane; i < na / 4; i += 64) reinterpret_cast<float4*>(a_t)[i] = reinterpret_cast<const float4*>(stg)[i];
+        for (int e = (na & ~3) + lane; e < na; e += 64) a_t[e] = stg[e];
+      }
     }
     wave_lds_fence();                                       // the staging block is free for Bm
     MCK();                                                  // 5: A block out
@@ -429,9 +462,13 @@ __global__ __launch_bounds__(256) void k_cwlstm_bwd_mfma(BwdParams p) {
     MCK();                                                  // 7: layer-1 backward
     // ---- coalesced store of the Bm row block ------------------------------------------------------------
     if (valid) {
-      const int nb = (p.T > 0 ? NC : nv) * KB;
-      for (int i = lane; i < nb / 4; i += 64) reinterpret_cast<float4*>(b_t)[i] = reinterpret_cast<const float4*>(stg)[i];
-      for (int e = (nb & ~3) + lane; e < nb; e += 64) b_t[e] = stg[e];
+      if (p.T > 0) {
+        stage_block_out<NC * KB>(b_t, stg, lane);
+      } else {
+        const int nb = nv * KB;
+        for (int i = lane; i < nb / 4; i += 64) reinterpret_cast<float4*>(b_t)[i] = reinterpret_cast<const float4*>(stg)[i];
+        for (int e = (nb & ~3) + lane; e < nb; e += 64) b_t[e] = stg[e];
+      }
     }
     MCK();                                                  // 8: Bm block out
     cur = nxt;
