@@ -232,11 +232,12 @@ class L2OPartnerTimeout(L2OError):
 
 def source_build_id():
     """What l2o_build_id() of a library built from the sources in this tree returns (csrc/Makefile: sha256 over
-    l2o_kernels.hip, the headers and the Makefile in make's $(sort) order), or None without the sources."""
+    the two .hip translation units, the headers and the Makefile in make's $(sort) order), or None without the sources."""
     import glob
     import hashlib
     csrc = os.path.join(_HERE, "csrc")
-    names = ["l2o_kernels.hip", "Makefile", "../../include/l2o_abi.h"] + [os.path.basename(p) for p in glob.glob(os.path.join(csrc, "*.h"))]
+    names = ["l2o_kernels.hip", "l2o_kernels_ilp.hip", "Makefile", "../../include/l2o_abi.h"] + [
+        os.path.basename(p) for p in glob.glob(os.path.join(csrc, "*.h"))]
     h = hashlib.sha256()
     try:
         for n in sorted(set(names)):

@@ -856,6 +856,9 @@ __global__ __launch_bounds__(CH <= 4 ? 256 : 512) void k_unroll(UnrollArgs a) {
 #include "l2o_unroll_cu.h"
 #include "l2o_unroll_cu8.h"
 
+#include "l2o_ilp_kernels.h"   // the plain two-CU / eight-wave unrolls: code in l2o_kernels_ilp.hip, `extern template` here
+#ifndef L2O_TU_ILP             // (everything below belongs to the main translation unit only)
+
 #include "l2o_mlp.h"
 
 #include "l2o_mlp_unroll.h"
@@ -2640,3 +2643,5 @@ int l2o_rnnprop_input_adjoint(const float* Bm, int64_t ldb, int32_t du_col, int3
 }
 
 }  // extern "C"
+
+#endif  // L2O_TU_ILP

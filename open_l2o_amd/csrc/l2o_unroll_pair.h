@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void k_unroll_pair(UnrollPairArgs pa) {
 //   fx[t]         = (sum_b fx_part[t][b]) / B_global, the summation order of k_reduce_fx (optional)
 //   the exchange granules are zeroed for the NEXT launch (tag 0 is never valid; no memset launch per unroll)
 //   the launch sequence word the next launch salts its tags with advances
+#ifndef L2O_TU_ILP       // (not a template: defined in the main translation unit only, see l2o_ilp_kernels.h)
 __global__ __launch_bounds__(256) void k_combine_halves(const float* __restrict__ fx_half, float* __restrict__ fx_part,
                                                         int nb, int nparts, float inv_bg, float* __restrict__ fx,
                                                         unsigned long long* __restrict__ xbuf, long xwords, PairWs* ws,
@@ -523,3 +524,4 @@ __global__ __launch_bounds__(256) void k_combine_halves(const float* __restrict_
   for (long e = lo + tid; e < hi; e += 256) xbuf[e] = 0ull;
   if (t == 0 && tid == 0) ws->seq = ws->seq + 1u;
 }
+#endif
