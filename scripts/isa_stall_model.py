@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where does one wave's step go?  An in-order scoreboard model of a kernel's main loop, read from its ISA.
 
-    bash scripts/tu_regs.sh l2o_unroll_pair.h 'k_unroll_pair<0, 1, 8, false, false>(UnrollPairArgs)'
+    bash scripts/tu_regs.sh l2o_unroll_pair.h 'k_unroll_pair<0, 1, 8, false, false>(UnrollPairArgs)' -- -mllvm -amdgpu-sched-strategy=max-ilp
     python scripts/isa_stall_model.py build/tu_regs.s _Z13k_unroll_pairILi0ELi1ELi8ELb0ELb0EEv14UnrollPairArgs
 
 One wave per SIMD issues in order.  Every instruction of the step loop (the backward-branch region with the most MFMAs;
