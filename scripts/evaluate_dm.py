@@ -36,6 +36,10 @@ def main():
     flags.add_argument("--num_dims", type=int, default=None)
     flags.add_argument("--synthetic_mnist", type=int, default=0,
                        help="problems.mnist on N synthetic MNIST-shaped examples (no dataset ships offline)")
+    flags.add_argument("--replicas", type=int, default=1,
+                       help="(ours) evaluate this many independent instances of the optimizee TOGETHER (own initial weights, "
+                            "own minibatches; problems.mnist on the MI355X: eight per launch, one per XCD -- "
+                            "open_l2o_amd.replicas.Replicas); the loss record holds one list per instance")
     FLAGS = flags.parse_args()
 
     num_unrolls = FLAGS.num_steps // FLAGS.unroll_len
@@ -51,6 +55,9 @@ def main():
         if FLAGS.path is None:
             logging.warning("Evaluating untrained L2L optimizer")
         optimizer = meta.MetaOptimizer(**net_config)
+        if FLAGS.replicas > 1:
+            from _eval_common import evaluate_replicas
+            return evaluate_replicas(FLAGS, optimizer, problem, net_assignments, num_unrolls)
         meta_loss = optimizer.meta_loss(problem, FLAGS.unroll_len, net_assignments=net_assignments)
         _, update, reset, cost_op, _ = meta_loss
     else:

@@ -232,3 +232,22 @@ def test_evaluate_rnnprop_driver_with_replicas(tmp_path):
     assert len(rec) == 8 and all(len(r) == 60 for r in rec)
     assert all(r[-1] < 0.8 * r[0] for r in rec)                          # the trained optimizer optimizes every instance
     assert len({round(r[-1], 6) for r in rec}) == 8                       # ... and they are eight different instances
+
+
+def test_evaluate_dm_driver_with_replicas(tmp_path):
+    """scripts/evaluate_dm.py --problem mnist --replicas 8 (an untrained L2O-DM optimizer: DM/evaluate_dm.py:74-75 warns and goes
+    on): eight instances together on the one-instance-per-XCD kernel, one finite loss record per instance."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "evaluate_dm.py"), "--problem", "mnist",
+                        "--synthetic_mnist", "1024", "--batch_size", "64", "--num_steps", "40", "--replicas", "8", "--seed", "5",
+                        "--output_path", str(tmp_path)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "kernel form: xcd" in p.stdout, p.stdout[-1500:]
+    rec = pickle.load(open(os.path.join(str(tmp_path), "L2L_eval_loss_record.pickle-mnist"), "rb"))
+    assert len(rec) == 8 and all(len(r) == 40 for r in rec)
+    assert all(np.isfinite(r).all() for r in rec)
+    assert len({round(r[-1], 6) for r in rec}) == 8                       # eight different instances
