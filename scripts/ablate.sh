@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   for v in $VARS; do
     defs=""
     for d in ${v//_/ }; do [ "$d" != BASE ] && defs="$defs -DL2O_ABLATE_$d"; done
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize $defs -shared open_l2o_amd/csrc/l2o_kernels.hip -o build/ablate/lib_$v.so &
+    bash scripts/build_lib.sh build/ablate/lib_$v.so $defs &
   done
   wait; ls -la build/ablate
 else
