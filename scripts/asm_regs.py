@@ -1,4 +1,5 @@
-"""Register / spill summary of every kernel in build/asm (make -C open_l2o_amd/csrc asm)."""
+"""Register / spill summary of every kernel in build/asm (make -C open_l2o_amd/csrc asm: the MAIN translation unit; the kernels of
+csrc/l2o_ilp_kernels.h: scripts/tu_regs.sh ... -- -mllvm -amdgpu-sched-strategy=max-ilp, or scripts/so_regs.py on the built library)."""
 import re, sys
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 s = open(args[0] if args else 'build/asm/l2o_kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read()
